@@ -1,0 +1,139 @@
+/* vtgs.h -- C ABI of the MI355X-native differentiable Gaussian-splat rasterizer (libvtgs.so).
+ *
+ * Drop-in boundary.  The reference reaches its rasterizer through the Python module
+ * `diff_gaussian_rasterization` (src/vtgaussian_slam.py:38, utils/recon_helpers.py:2), whose
+ * autograd.Function binds three native entry points of an un-vendored CUDA extension
+ * (requirements.txt:19): `_C.rasterize_gaussians`, `_C.rasterize_gaussians_backward`, `_C.mark_visible`.
+ * Those pybind/torch-typed entry points are what this header replaces: plain pointers, sizes and a
+ * HIP stream, no torch types, no C++ exceptions.  Call sites served:
+ *   src/vtgaussian_slam.py:461,466,747      GaussianRasterizer(raster_settings=cam)(**rendervar)
+ *   utils/eval_helpers.py:240,247,431,443,728,733   forward-only renders
+ *   utils/recon_helpers.py:14-26            the 11-field settings record (-> VtgsCamera)
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it says "host"; all arrays are contiguous row-major
+ *     float32 (radii int32); N = number of Gaussians; images are CHW.
+ *   - the caller owns all memory: inputs, outputs, the forward workspace (kept alive until backward,
+ *     like the geom/binning/image buffers the replaced extension hands back to Python) and the
+ *     backward scratch.  The library never allocates device memory, never frees, keeps no pointer
+ *     after a call returns, and enqueues everything on `stream`.
+ *   - outputs are fully overwritten (gradient arrays are written for every row, zeros included).
+ *   - the only host synchronisation is in vtgs_forward (it reads back 32 bytes of counters to
+ *     report overflow and statistics); vtgs_backward never synchronises.
+ *   - all functions return a VtgsStatus; vtgs_strerror() gives a static message.
+ */
+#ifndef VTGS_H
+#define VTGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VTGS_ABI_VERSION 1
+
+typedef enum VtgsStatus {
+  VTGS_OK = 0,
+  VTGS_ERR_INVALID_ARGUMENT = 1,   /* null pointer, negative size, bad band, bad rule            */
+  VTGS_ERR_WORKSPACE_TOO_SMALL = 2,/* workspace_bytes < vtgs_workspace_bytes(...)                */
+  VTGS_ERR_INSTANCE_OVERFLOW = 3,  /* more (Gaussian,tile) instances than instance_capacity;      */
+                                   /* VtgsForwardInfo.instances_needed says how many; re-allocate  */
+                                   /* and call again (outputs of the failed call are undefined)    */
+  VTGS_ERR_HIP = 4,                /* a HIP runtime call failed (see vtgs_last_hip_error)          */
+  VTGS_ERR_STALE_WORKSPACE = 5     /* reserved                                                     */
+} VtgsStatus;
+
+/* radius_rule: how the screen-space extent of a splat is derived from its 2-D covariance.      */
+#define VTGS_RADIUS_3SIGMA  0      /* ceil(3 sqrt(lambda_max)) -- the published rule (default)  */
+#define VTGS_RADIUS_OPACITY 1      /* min(3 sigma, ceil(sqrt(2 ln(255 o) lambda_max)))          */
+
+/* Mirrors GaussianRasterizationSettings (utils/recon_helpers.py:14-26).  `sh_degree`, `campos`
+ * and `prefiltered` of that record do not influence a colors_precomp render and are not passed.   */
+typedef struct VtgsCamera {
+  int32_t image_width;
+  int32_t image_height;
+  float   tanfovx;
+  float   tanfovy;
+  float   scale_modifier;
+  int32_t radius_rule;       /* VTGS_RADIUS_*                                                       */
+  int32_t tile_row_begin;    /* band of 16-pixel tile rows this call renders (tile-row multi-GPU     */
+  int32_t tile_row_end;      /* partition); begin == end == 0 means the whole image                  */
+  const float* bg;           /* [3]  background colour                                               */
+  const float* viewmatrix;   /* [16] w2c transposed, as stored at utils/recon_helpers.py:8           */
+  const float* projmatrix;   /* [16] full projection, as stored at utils/recon_helpers.py:13         */
+} VtgsCamera;
+
+/* Filled by vtgs_forward on the host. */
+typedef struct VtgsForwardInfo {
+  uint64_t instances;        /* (Gaussian, 8x8 tile) instances binned by this call                   */
+  uint64_t instances_needed; /* == instances, or the count that did not fit on overflow              */
+  uint64_t tiles16_touched;  /* R of SURVEY 8(d): sum over Gaussians of 16x16 tiles in their rect    */
+  uint32_t visible;          /* Gaussians with radii > 0                                             */
+  uint32_t max_tile_list;    /* longest per-tile list                                                */
+} VtgsForwardInfo;
+
+uint32_t    vtgs_abi_version(void);
+const char* vtgs_strerror(int status);
+const char* vtgs_last_hip_error(void);   /* message of the last failed HIP call on this host thread */
+
+/* Bytes of forward workspace for N Gaussians, a width x height image and room for
+ * `instance_capacity` (Gaussian,tile) instances.  A safe first guess is 8*N; vtgs_forward reports
+ * the exact need on overflow.                                                                        */
+size_t vtgs_workspace_bytes(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity);
+
+/* Bytes of backward scratch for a forward that binned `instances` instances.                        */
+size_t vtgs_backward_scratch_bytes(int32_t n, uint64_t instances);
+
+/* Forward.  Replaces `_C.rasterize_gaussians` for the colors_precomp + scales/rotations signature
+ * the reference uses (shs / cov3D_precomp are rejected in the Python layer).
+ *   means3D[N,3] opacities[N,1] colors[N,3] scales[N,3] rotations[N,4](w,x,y,z)
+ *   out_color[3,H,W] out_depth[1,H,W] out_radii[N] (0 = culled)
+ * `info` (host, may be NULL).                                                                        */
+int vtgs_forward(const VtgsCamera* cam, int32_t n,
+                 const float* means3D, const float* colors, const float* opacities,
+                 const float* scales, const float* rotations,
+                 float* out_color, float* out_depth, int32_t* out_radii,
+                 void* workspace, size_t workspace_bytes, uint64_t instance_capacity,
+                 VtgsForwardInfo* info, void* stream);
+
+/* Second render over the SAME geometry (identical cam/means3D/opacities/scales/rotations as the
+ * vtgs_forward that filled `workspace`) with other per-Gaussian colours -- the depth/silhouette pass
+ * at src/vtgaussian_slam.py:466 right after the RGB pass at :461.  Skips projection, binning and
+ * sorting; writes its per-pixel state to `image_state` ([H*W] floats, caller-owned) so both renders
+ * can be differentiated.                                                                             */
+int vtgs_forward_shared(const VtgsCamera* cam, int32_t n, const float* colors,
+                        float* out_color, float* out_depth,
+                        const void* workspace, size_t workspace_bytes, uint64_t instance_capacity,
+                        float* image_state, void* stream);
+
+/* Backward.  Replaces `_C.rasterize_gaussians_backward`.
+ *   grad_color[3,H,W] = dL/d out_color;  out_color = what the forward wrote (the gradient of the
+ *   depth image is not propagated -- the reference discards that output, src/vtgaussian_slam.py:461).
+ *   workspace / instance_capacity: exactly what the forward was given (the capacity fixes the layout).
+ *   image_state: NULL to use the state stored in the workspace by vtgs_forward, or the buffer a
+ *   vtgs_forward_shared call filled.
+ *   scratch: vtgs_backward_scratch_bytes(n, info.instances) bytes, contents undefined on entry and exit.
+ *   In band mode (tile_row_begin/end) the gradients are this band's partial sums; pixels outside the
+ *   band are written as zero by the forward and ignored by the backward.
+ *   g_means2D[N,3] holds the NDC-scaled screen-space gradient in [:, :2] (what means2D.grad shows at
+ *   utils/slam_external.py:100-103), zeros in [:, 2].                                                */
+int vtgs_backward(const VtgsCamera* cam, int32_t n,
+                  const float* means3D, const float* colors, const float* opacities,
+                  const float* scales, const float* rotations,
+                  const float* out_color, const float* grad_color,
+                  const void* workspace, size_t workspace_bytes, uint64_t instance_capacity,
+                  const float* image_state, void* scratch, size_t scratch_bytes,
+                  float* g_means3D, float* g_means2D, float* g_colors, float* g_opacities,
+                  float* g_scales, float* g_rotations, void* stream);
+
+/* Replaces `_C.mark_visible` (GaussianRasterizer.markVisible; unused by the reference driver).
+ * out_visible[N] bytes: 1 when the point passes the near-plane test of the forward.                 */
+int vtgs_mark_visible(const VtgsCamera* cam, int32_t n, const float* means3D,
+                      uint8_t* out_visible, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTGS_H */

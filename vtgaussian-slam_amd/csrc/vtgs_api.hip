@@ -1,0 +1,250 @@
+// vtgs_api.hip -- the extern "C" surface declared in include/vtgs.h: argument checks, workspace carving,
+// kernel launches on the caller's stream.  No device allocation, no retained pointers.
+#include "../../include/vtgs.h"
+#include "vtgs_internal.h"
+
+#include <stdio.h>
+#include <string.h>
+
+namespace vtgs {
+// kernels (vtgs_binning.hip / vtgs_composite.hip)
+__global__ void project_and_bin(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
+                                const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, InstTmp*, Counters*,
+                                unsigned long long);
+__global__ void scan_tiles(const uint32_t*, uint32_t*, uint32_t, Counters*, unsigned long long);
+__global__ void scatter_instances(const InstTmp*, const uint32_t*, unsigned long long*, uint32_t*, const Counters*);
+__global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
+                           const Counters*);
+__global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*,
+                                  const float*, float*, float*, float*, const Counters*);
+__global__ void composite_backward(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
+                                   const GeomRec*, const float*, const float*, const float*, const float*, float*);
+__global__ void gather_splat_grads(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
+                                   const float*, const GaussAux*, const float*, float*, float*, float*, float*, float*,
+                                   float*);
+__global__ void mark_visible_kernel(const float*, int, const float*, uint8_t*);
+}  // namespace vtgs
+
+using namespace vtgs;
+
+static thread_local char g_hip_err[256] = "";
+
+static int hip_fail(hipError_t e, const char* what) {
+  snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", what, hipGetErrorString(e));
+  return VTGS_ERR_HIP;
+}
+#define VTGS_HIP(call)                                        \
+  do {                                                        \
+    hipError_t e__ = (call);                                  \
+    if (e__ != hipSuccess) return hip_fail(e__, #call);       \
+  } while (0)
+
+static bool band_of(const VtgsCamera* cam, int* row8_begin, int* row8_end, int* rows16, int* row16_0) {
+  const int gy16 = (cam->image_height + kBinTile - 1) / kBinTile;
+  const int gy8 = (cam->image_height + kSubTile - 1) / kSubTile;
+  int b = cam->tile_row_begin, e = cam->tile_row_end;
+  if (b == 0 && e == 0) e = gy16;
+  if (b < 0 || e > gy16 || b >= e) return false;
+  *row8_begin = 2 * b;
+  *row8_end = (2 * e < gy8) ? 2 * e : gy8;
+  *rows16 = e - b;
+  *row16_0 = b;
+  return true;
+}
+
+static bool cam_ok(const VtgsCamera* cam) {
+  return cam && cam->image_width > 0 && cam->image_height > 0 && cam->tanfovx > 0.f && cam->tanfovy > 0.f &&
+         cam->bg && cam->viewmatrix && cam->projmatrix &&
+         (cam->radius_rule == VTGS_RADIUS_3SIGMA || cam->radius_rule == VTGS_RADIUS_OPACITY);
+}
+
+static CamScalars scalars_of(const VtgsCamera* cam, int row8_begin, int row8_end) {
+  CamScalars cs;
+  cs.W = cam->image_width; cs.H = cam->image_height;
+  cs.tanfovx = cam->tanfovx; cs.tanfovy = cam->tanfovy; cs.mod = cam->scale_modifier;
+  cs.radius_rule = cam->radius_rule;
+  cs.row8_begin = row8_begin; cs.row8_end = row8_end;
+  return cs;
+}
+
+extern "C" {
+
+uint32_t vtgs_abi_version(void) { return VTGS_ABI_VERSION; }
+
+const char* vtgs_strerror(int status) {
+  switch (status) {
+    case VTGS_OK: return "ok";
+    case VTGS_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case VTGS_ERR_WORKSPACE_TOO_SMALL: return "workspace too small";
+    case VTGS_ERR_INSTANCE_OVERFLOW: return "more (Gaussian,tile) instances than instance_capacity";
+    case VTGS_ERR_HIP: return "HIP runtime error";
+    case VTGS_ERR_STALE_WORKSPACE: return "workspace holds no completed forward for these sizes";
+    default: return "unknown status";
+  }
+}
+
+const char* vtgs_last_hip_error(void) { return g_hip_err; }
+
+size_t vtgs_workspace_bytes(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity) {
+  if (n < 0 || width <= 0 || height <= 0) return 0;
+  return make_layout(n, width, height, instance_capacity).total;
+}
+
+size_t vtgs_backward_scratch_bytes(int32_t n, uint64_t instances) {
+  (void)n;
+  return align256((size_t)(instances ? instances : 1) * kGradRec * sizeof(float));
+}
+
+static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs, int rows16, const WsLayout& L,
+                                    char* ws, const float* colors, float* out_color, float* out_depth,
+                                    float* image_state, hipStream_t st) {
+  const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
+  const uint32_t nblk16 = (uint32_t)(gx16 * rows16);
+  hipLaunchKernelGGL(composite_forward, dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
+                     (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid),
+                     (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
+                     (const Counters*)(ws + L.counters));
+  VTGS_HIP(hipGetLastError());
+  return VTGS_OK;
+}
+
+int vtgs_forward(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* opacities,
+                 const float* scales, const float* rotations, float* out_color, float* out_depth, int32_t* out_radii,
+                 void* workspace, size_t workspace_bytes, uint64_t instance_capacity, VtgsForwardInfo* info,
+                 void* stream) {
+  if (!cam_ok(cam) || n < 0 || !out_color || !out_depth || !workspace || instance_capacity == 0 ||
+      instance_capacity > 0xFFFFFFFFull)
+    return VTGS_ERR_INVALID_ARGUMENT;
+  if (n > 0 && (!means3D || !colors || !opacities || !scales || !rotations || !out_radii)) return VTGS_ERR_INVALID_ARGUMENT;
+  int r8b, r8e, rows16, row16_0;
+  if (!band_of(cam, &r8b, &r8e, &rows16, &row16_0)) return VTGS_ERR_INVALID_ARGUMENT;
+  const WsLayout L = make_layout(n, cam->image_width, cam->image_height, instance_capacity);
+  if (workspace_bytes < L.total) return VTGS_ERR_WORKSPACE_TOO_SMALL;
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  const CamScalars cs = scalars_of(cam, r8b, r8e);
+  Counters* ctr = (Counters*)(ws + L.counters);
+
+  VTGS_HIP(hipMemsetAsync(ws + L.counters, 0, 256, st));
+  VTGS_HIP(hipMemsetAsync(ws + L.tile_cnt, 0, ((size_t)L.tiles8 + 1) * 4, st));
+  if (rows16 * kBinTile < cam->image_height || cam->tile_row_begin != 0) {
+    // band mode: pixels outside the band are written as zero (include/vtgs.h); the caller keeps only
+    // its own rows when it assembles the bands
+    const size_t P = (size_t)cam->image_width * cam->image_height;
+    VTGS_HIP(hipMemsetAsync(out_color, 0, 3 * P * sizeof(float), st));
+    VTGS_HIP(hipMemsetAsync(out_depth, 0, P * sizeof(float), st));
+  }
+  if (n > 0) {
+    hipLaunchKernelGGL(project_and_bin, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+                       means3D, opacities, scales, rotations, out_radii, (GeomRec*)(ws + L.geom),
+                       (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt), (InstTmp*)(ws + L.inst_tmp), ctr,
+                       (unsigned long long)instance_capacity);
+    VTGS_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(scan_tiles, dim3(1), dim3(1024), 0, st, (const uint32_t*)(ws + L.tile_cnt),
+                     (uint32_t*)(ws + L.tile_off), L.tiles8, ctr, (unsigned long long)instance_capacity);
+  VTGS_HIP(hipGetLastError());
+  hipLaunchKernelGGL(scatter_instances, dim3(2048), dim3(256), 0, st, (const InstTmp*)(ws + L.inst_tmp),
+                     (const uint32_t*)(ws + L.tile_off), (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals),
+                     (const Counters*)ctr);
+  VTGS_HIP(hipGetLastError());
+  hipLaunchKernelGGL(sort_tiles, dim3(L.tiles8), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_off),
+                     (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
+                     (uint32_t*)(ws + L.sorted_inst), L.tiles8, (const Counters*)ctr);
+  VTGS_HIP(hipGetLastError());
+  int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st);
+  if (rc != VTGS_OK) return rc;
+
+  // stamp the workspace and read the counters back (the only host synchronisation of the library)
+  Counters stamp;
+  memset(&stamp, 0, sizeof(stamp));
+  stamp.magic = kMagicDone; stamp.n = (uint32_t)n;
+  stamp.width = (uint32_t)cam->image_width; stamp.height = (uint32_t)cam->image_height;
+  stamp.capacity_lo = (uint32_t)instance_capacity; stamp.capacity_hi = (uint32_t)(instance_capacity >> 32);
+  stamp.row8_begin = (uint32_t)r8b; stamp.row8_end = (uint32_t)r8e;
+  const size_t tail = offsetof(Counters, magic);
+  VTGS_HIP(hipMemcpyAsync((char*)ctr + tail, (char*)&stamp + tail, sizeof(Counters) - tail, hipMemcpyHostToDevice, st));
+  Counters host;
+  VTGS_HIP(hipMemcpyAsync(&host, ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+  VTGS_HIP(hipStreamSynchronize(st));
+  if (info) {
+    info->instances = host.overflow ? 0 : host.inst_total;
+    info->instances_needed = host.inst_total;
+    info->tiles16_touched = host.r16;
+    info->visible = host.visible;
+    info->max_tile_list = host.max_list;
+  }
+  if (host.overflow) {
+    uint32_t zero = 0;   // a failed forward must not look complete
+    VTGS_HIP(hipMemcpyAsync((char*)ctr + tail, &zero, 4, hipMemcpyHostToDevice, st));
+    VTGS_HIP(hipStreamSynchronize(st));
+    return VTGS_ERR_INSTANCE_OVERFLOW;
+  }
+  return VTGS_OK;
+}
+
+int vtgs_forward_shared(const VtgsCamera* cam, int32_t n, const float* colors, float* out_color, float* out_depth,
+                        const void* workspace, size_t workspace_bytes, uint64_t instance_capacity, float* image_state,
+                        void* stream) {
+  if (!cam_ok(cam) || n < 0 || !colors || !out_color || !out_depth || !workspace || !image_state ||
+      instance_capacity == 0 || instance_capacity > 0xFFFFFFFFull)
+    return VTGS_ERR_INVALID_ARGUMENT;
+  int r8b, r8e, rows16, row16_0;
+  if (!band_of(cam, &r8b, &r8e, &rows16, &row16_0)) return VTGS_ERR_INVALID_ARGUMENT;
+  const WsLayout L = make_layout(n, cam->image_width, cam->image_height, instance_capacity);
+  if (workspace_bytes < L.total) return VTGS_ERR_WORKSPACE_TOO_SMALL;
+  hipStream_t st = (hipStream_t)stream;
+  const CamScalars cs = scalars_of(cam, r8b, r8e);
+  if (rows16 * kBinTile < cam->image_height || cam->tile_row_begin != 0) {
+    const size_t P = (size_t)cam->image_width * cam->image_height;
+    VTGS_HIP(hipMemsetAsync(out_color, 0, 3 * P * sizeof(float), st));
+    VTGS_HIP(hipMemsetAsync(out_depth, 0, P * sizeof(float), st));
+  }
+  return launch_composite_forward(cam, cs, rows16, L, (char*)workspace, colors, out_color, out_depth, image_state, st);
+}
+
+int vtgs_backward(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* opacities,
+                  const float* scales, const float* rotations, const float* out_color, const float* grad_color,
+                  const void* workspace, size_t workspace_bytes, uint64_t instance_capacity, const float* image_state,
+                  void* scratch, size_t scratch_bytes, float* g_means3D, float* g_means2D, float* g_colors,
+                  float* g_opacities, float* g_scales, float* g_rotations, void* stream) {
+  if (!cam_ok(cam) || n < 0 || !out_color || !grad_color || !workspace || !scratch || instance_capacity == 0 ||
+      instance_capacity > 0xFFFFFFFFull)
+    return VTGS_ERR_INVALID_ARGUMENT;
+  if (n > 0 && (!means3D || !colors || !opacities || !scales || !rotations || !g_means3D || !g_means2D || !g_colors ||
+                !g_opacities || !g_scales || !g_rotations))
+    return VTGS_ERR_INVALID_ARGUMENT;
+  int r8b, r8e, rows16, row16_0;
+  if (!band_of(cam, &r8b, &r8e, &rows16, &row16_0)) return VTGS_ERR_INVALID_ARGUMENT;
+  if (n == 0) return VTGS_OK;
+  const WsLayout L = make_layout(n, cam->image_width, cam->image_height, instance_capacity);
+  if (workspace_bytes < L.total) return VTGS_ERR_WORKSPACE_TOO_SMALL;
+  if (scratch_bytes < kGradRec * sizeof(float)) return VTGS_ERR_INVALID_ARGUMENT;
+  hipStream_t st = (hipStream_t)stream;
+  const char* ws = (const char*)workspace;
+  const CamScalars cs = scalars_of(cam, r8b, r8e);
+  const float* state = image_state ? image_state : (const float*)(ws + L.final_T);
+  const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
+  const uint32_t nblk16 = (uint32_t)(gx16 * rows16);
+  hipLaunchKernelGGL(composite_backward, dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
+                     (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid),
+                     (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color, grad_color,
+                     state, (float*)scratch);
+  VTGS_HIP(hipGetLastError());
+  hipLaunchKernelGGL(gather_splat_grads, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+                     means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch,
+                     g_means3D, g_means2D, g_colors, g_opacities, g_scales, g_rotations);
+  VTGS_HIP(hipGetLastError());
+  return VTGS_OK;
+}
+
+int vtgs_mark_visible(const VtgsCamera* cam, int32_t n, const float* means3D, uint8_t* out_visible, void* stream) {
+  if (!cam || !cam->viewmatrix || n < 0 || (n > 0 && (!means3D || !out_visible))) return VTGS_ERR_INVALID_ARGUMENT;
+  if (n == 0) return VTGS_OK;
+  hipLaunchKernelGGL(mark_visible_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, cam->viewmatrix, n,
+                     means3D, out_visible);
+  VTGS_HIP(hipGetLastError());
+  return VTGS_OK;
+}
+
+}  // extern "C"

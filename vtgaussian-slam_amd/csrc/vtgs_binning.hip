@@ -1,0 +1,254 @@
+// vtgs_binning.hip -- projection, per-tile bucketing and per-tile depth sort (gfx950, wave64).
+//
+// Pipeline (all on the caller's stream, no host round trip):
+//   project_and_bin   one thread per Gaussian: EWA projection (vtgs_math.h), then walks the 8x8 tiles
+//                     under its 16x16-tile rectangle, keeps those the splat's alpha>=1/255 ellipse can
+//                     reach, and reserves a slot in each tile with run-aggregated atomics (Gaussians of a
+//                     view-tied map are stored in raster order, so neighbouring lanes hit the same tile
+//                     and one atomic serves a whole run of lanes).
+//   scan_tiles        exclusive scan of the per-tile counts (<= ~33 k tiles: one workgroup).
+//   scatter_instances instance -> (tile offset + slot): 64-bit key (depth bits | Gaussian id) + instance id.
+//   sort_tiles        per-tile bitonic sort of (key, value) in LDS; key order == the stable
+//                     (tile, depth) order of the published algorithm because ties fall back to Gaussian id.
+//
+// The replaced implementation [UPSTREAM-PUBLIC] sorts all (tile|depth) keys with a global radix sort
+// (several passes over 12 B x R) and reads the total back to the host to size it.  Here the tile is
+// resolved by bucketing (one pass) and only the short per-tile lists are sorted, on chip.
+#include "vtgs_internal.h"
+
+namespace vtgs {
+
+// Reserve one slot per active lane in counters[tile]; lanes of a run (consecutive active lanes with the
+// same tile) share one atomic.  Returns the slot.  All 64 lanes must call it.
+__device__ __forceinline__ uint32_t run_aggregated_reserve(uint32_t* __restrict__ counters, int tile, bool act) {
+  const int l = lane_id();
+  const int prev_tile = __shfl_up(tile, 1, 64);
+  const int prev_act = __shfl_up((int)act, 1, 64);
+  const bool head = act && (l == 0 || !prev_act || prev_tile != tile);
+  const unsigned long long H = __ballot(head);
+  const unsigned long long A = __ballot(act);
+  const unsigned long long stops = H | ~A;                       // lanes where a run cannot continue
+  const unsigned long long le_mask = (l == 63) ? ~0ull : ((2ull << l) - 1ull);   // bits <= l
+  const unsigned long long heads_le = H & le_mask;
+  const int hl = heads_le ? (63 - __builtin_clzll(heads_le)) : 0;   // head lane of my run
+  uint32_t base = 0;
+  if (head) {
+    const unsigned long long above = stops & ~le_mask;            // bits > l
+    const int e = above ? __builtin_ctzll(above) : 64;
+    base = atomicAdd(&counters[tile], (uint32_t)(e - l));
+  }
+  base = __shfl(base, hl, 64);
+  return base + (uint32_t)(l - hl);
+}
+
+struct TileWalk {       // candidate 8x8 tiles of one splat: those under its 16x16-tile rectangle, in the band
+  int cx0, cy0, cw, ch;
+};
+
+__device__ __forceinline__ TileWalk make_walk(const CamParams& cam, const Splat& sp, bool reach) {
+  TileWalk w{0, 0, 0, 0};
+  if (!reach) return w;
+  const int x0 = 2 * sp.x0, x1 = min(2 * sp.x1, cam.gx8);
+  const int y0 = max(2 * sp.y0, cam.row8_begin), y1 = min(min(2 * sp.y1, cam.gy8), cam.row8_end);
+  if (x1 > x0 && y1 > y0) { w.cx0 = x0; w.cy0 = y0; w.cw = x1 - x0; w.ch = y1 - y0; }
+  return w;
+}
+
+// does the splat's alpha >= 1/255 region reach the pixel centres of 8x8 tile (tx,ty)?
+__device__ __forceinline__ bool tile_reached(const CamParams& cam, const Splat& sp, float tau, int tx, int ty) {
+  const float px0 = (float)(tx * kSubTile), py0 = (float)(ty * kSubTile);
+  const float px1 = fminf(px0 + (float)(kSubTile - 1), (float)(cam.W - 1));
+  const float py1 = fminf(py0 + (float)(kSubTile - 1), (float)(cam.H - 1));
+  const float q = min_quadratic_over_rect(sp.A, sp.B, sp.C, sp.u, sp.v, px0, py0, px1, py1);
+  return q <= tau;
+}
+
+__global__ __launch_bounds__(256) void project_and_bin(
+    CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
+    const float* __restrict__ means3D, const float* __restrict__ opacities,
+    const float* __restrict__ scales, const float* __restrict__ rotations,
+    int32_t* __restrict__ radii, GeomRec* __restrict__ geom, GaussAux* __restrict__ gaux,
+    uint32_t* __restrict__ tile_cnt, InstTmp* __restrict__ inst_tmp, Counters* __restrict__ ctr,
+    unsigned long long capacity) {
+  const CamParams cam = load_cam(cs, Vp, PVp);
+  const int gid = (int)(blockIdx.x * 256u + threadIdx.x);
+  const int l = lane_id();
+  const bool valid = gid < n;
+
+  Splat sp; SplatAux aux;
+  float op = 0.f;
+  bool vis = false;
+  if (valid) {
+    const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
+    const float sc[3] = {scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
+    const float4 q4 = reinterpret_cast<const float4*>(rotations)[gid];
+    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+    op = opacities[gid];
+    vis = project_splat(cam, mean, sc, q, op, sp, aux);
+    radii[gid] = vis ? sp.radius : 0;
+  }
+  // alpha = o*G >= 1/255 somewhere  <=>  q <= ln(255 o); slack keeps the test conservative
+  float tau = -1.f;
+  if (vis && op * 255.f >= 1.f) { tau = logf(255.f * op); tau += 1e-4f * tau + 1e-4f; }
+  const bool reach = vis && tau >= 0.f;
+  const TileWalk w = make_walk(cam, sp, reach);
+  const int area = w.cw * w.ch;
+
+  // pass 1: how many tiles does this splat really reach
+  uint32_t cnt = 0;
+  for (int i = 0, tx = 0, ty = 0; i < area; ++i) {
+    cnt += tile_reached(cam, sp, tau, w.cx0 + tx, w.cy0 + ty) ? 1u : 0u;
+    if (++tx == w.cw) { tx = 0; ++ty; }
+  }
+  // instances of one splat are contiguous: reserve [base, base+cnt) with one atomic per wavefront
+  const uint32_t incl = wave_incl_scan(cnt);
+  const uint32_t wave_total = (uint32_t)bcast_i((int)incl, 63);
+  uint32_t wave_base = 0;
+  if (l == 0 && wave_total) wave_base = atomicAdd(&ctr->inst_total, wave_total);
+  wave_base = (uint32_t)bcast_i((int)wave_base, 0);
+  const uint32_t inst_base = wave_base + incl - cnt;
+
+  if (valid) {
+    GeomRec g;
+    g.u = sp.u; g.v = sp.v; g.A = sp.A; g.B = sp.B; g.C = sp.C; g.opacity = op; g.depth = sp.depth; g.pad = 0.f;
+    if (!vis) { g.u = g.v = g.A = g.B = g.C = g.depth = 0.f; }
+    geom[gid] = g;
+    gaux[gid] = GaussAux{inst_base, cnt};
+  }
+  // statistics: one atomic per wavefront
+  {
+    const unsigned long long vb = __ballot(vis);
+    const uint32_t r16 = vis ? (uint32_t)((sp.x1 - sp.x0) * (sp.y1 - sp.y0)) : 0u;
+    const uint32_t r16_incl = wave_incl_scan(r16);
+    if (l == 63) {
+      if (vb) atomicAdd(&ctr->visible, (uint32_t)__popcll(vb));
+      if (r16_incl) atomicAdd(&ctr->r16, (unsigned long long)r16_incl);
+    }
+  }
+
+  // pass 2: reserve a slot in every reached tile, lanes in lock-step so runs can share atomics
+  const int max_area = wave_max_i(area);
+  const uint32_t zbits = __float_as_uint(sp.depth);
+  uint32_t ord = 0;
+  for (int i = 0, tx = 0, ty = 0; i < max_area; ++i) {
+    const bool in = i < area;
+    const int ttx = w.cx0 + tx, tty = w.cy0 + ty;
+    const bool act = in && tile_reached(cam, sp, tau, ttx, tty);
+    const int tile = act ? (tty * cam.gx8 + ttx) : -1;
+    const uint32_t slot = run_aggregated_reserve(tile_cnt, tile, act);
+    if (act) {
+      const unsigned long long id = (unsigned long long)inst_base + ord;
+      if (id < capacity) inst_tmp[id] = InstTmp{(uint32_t)tile, slot, (uint32_t)gid, zbits};
+      ++ord;
+    }
+    if (in && ++tx == w.cw) { tx = 0; ++ty; }
+  }
+}
+
+// exclusive scan of tile_cnt[0..tiles) -> tile_off[0..tiles]; one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void scan_tiles(const uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ tile_off,
+                                                   uint32_t tiles, Counters* __restrict__ ctr, unsigned long long capacity) {
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t wmax[16];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (tiles + 1023u) / 1024u;
+  const uint32_t b = t * per, e = min(b + per, tiles);
+  uint32_t s = 0, mx = 0;
+  for (uint32_t i = b; i < e; ++i) { const uint32_t c = tile_cnt[i]; s += c; mx = max(mx, c); }
+  part[t] = s;
+  mx = (uint32_t)wave_max_i((int)mx);
+  if ((t & 63u) == 0) wmax[t >> 6] = mx;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {           // Hillis-Steele inclusive scan
+    const uint32_t v = (t >= d) ? part[t - d] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - s;
+  for (uint32_t i = b; i < e; ++i) { tile_off[i] = run; run += tile_cnt[i]; }
+  if (t == 1023) tile_off[tiles] = part[1023];
+  if (t == 0) {
+    uint32_t m = 0;
+    for (int i = 0; i < 16; ++i) m = max(m, wmax[i]);
+    ctr->max_list = m;
+    ctr->overflow = ((unsigned long long)ctr->inst_total > capacity) ? 1u : 0u;
+  }
+}
+
+__global__ __launch_bounds__(256) void scatter_instances(const InstTmp* __restrict__ inst_tmp, const uint32_t* __restrict__ tile_off,
+                                                         unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                         const Counters* __restrict__ ctr) {
+  if (ctr->overflow) return;
+  const uint32_t total = ctr->inst_total;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const InstTmp it = inst_tmp[i];
+    const uint32_t pos = tile_off[it.tile] + it.rank;
+    keys[pos] = ((unsigned long long)it.zbits << 32) | (unsigned long long)it.gid;
+    vals[pos] = i;
+  }
+}
+
+// One workgroup per 8x8 tile.  Lists up to kSortLds entries are sorted in LDS; longer ones in place in
+// global memory (L2-resident) with the same network.
+//
+// Network: the all-ascending form of the bitonic sorter -- each merge level starts with a mirror step
+// (i <-> block_end-1-offset) followed by half-cleaners (i <-> i+j).  Every comparator puts the smaller key
+// at the lower index, so a list of any length L behaves as if padded with +inf up to the next power of
+// two: comparators whose upper index is >= L are no-ops and are simply skipped.
+constexpr int kSortLds = 4096;
+
+__device__ __forceinline__ void order_pair(unsigned long long* k, uint32_t* v, uint32_t i, uint32_t p) {
+  const unsigned long long a = k[i], b = k[p];
+  if (a > b) {
+    k[i] = b; k[p] = a;
+    const uint32_t va = v[i], vb = v[p];
+    v[i] = vb; v[p] = va;
+  }
+}
+
+__device__ __forceinline__ void sort_network(unsigned long long* k, uint32_t* v, uint32_t L, uint32_t n2, uint32_t t) {
+  for (uint32_t k2 = 2; k2 <= n2; k2 <<= 1) {
+    const uint32_t half = k2 >> 1;
+    for (uint32_t q = t; q < (n2 >> 1); q += 256u) {                 // mirror step
+      const uint32_t blk = q / half, off = q - blk * half;
+      const uint32_t i = blk * k2 + off, p = blk * k2 + (k2 - 1u - off);
+      if (p < L) order_pair(k, v, i, p);
+    }
+    __syncthreads();
+    for (uint32_t j = half >> 1; j > 0; j >>= 1) {                    // half-cleaners
+      for (uint32_t q = t; q < (n2 >> 1); q += 256u) {
+        const uint32_t i = 2u * q - (q & (j - 1u)), p = i + j;
+        if (p < L) order_pair(k, v, i, p);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ tile_off, unsigned long long* __restrict__ keys,
+                                                  uint32_t* __restrict__ vals, uint32_t* __restrict__ sorted_gid,
+                                                  uint32_t* __restrict__ sorted_inst, uint32_t tiles,
+                                                  const Counters* __restrict__ ctr) {
+  __shared__ unsigned long long sk[kSortLds];
+  __shared__ uint32_t sv[kSortLds];
+  if (ctr->overflow) return;
+  const uint32_t tile = xcd_swizzle(blockIdx.x, tiles);
+  const uint32_t s = tile_off[tile], e = tile_off[tile + 1];
+  const uint32_t L = e - s;
+  if (L == 0) return;
+  const uint32_t t = threadIdx.x;
+  uint32_t n2 = 1;
+  while (n2 < L) n2 <<= 1;
+  if (L <= (uint32_t)kSortLds) {
+    for (uint32_t i = t; i < L; i += 256u) { sk[i] = keys[s + i]; sv[i] = vals[s + i]; }
+    __syncthreads();
+    sort_network(sk, sv, L, n2, t);
+    for (uint32_t i = t; i < L; i += 256u) { sorted_gid[s + i] = (uint32_t)sk[i]; sorted_inst[s + i] = sv[i]; }
+  } else {
+    sort_network(keys + s, vals + s, L, n2, t);   // __syncthreads() orders the workgroup's global accesses
+    for (uint32_t i = t; i < L; i += 256u) { sorted_gid[s + i] = (uint32_t)keys[s + i]; sorted_inst[s + i] = vals[s + i]; }
+  }
+}
+
+}  // namespace vtgs

@@ -1,0 +1,144 @@
+// vtgs_internal.h -- workspace layout, device-side records and wavefront helpers (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "vtgs_math.h"
+
+namespace vtgs {
+
+// ------------------------------------------------------------------------------------------------
+// HBM layout.  One caller-owned byte buffer, carved deterministically from (N, W, H, capacity) so
+// that backward finds what forward wrote.  All regions 256-byte aligned.
+//
+//   counters     256 B     Counters (zeroed per forward)
+//   geom         N x 32 B  GeomRec: what the composite needs per splat; read by gather, L2/MALL resident
+//   gaux         N x 8 B   first instance id + instance count (instances of a splat are contiguous)
+//   tile_cnt     (T8+1)x4  per 8x8-tile instance counters (zeroed per forward)
+//   tile_off     (T8+1)x4  exclusive scan of tile_cnt
+//   inst_tmp     cap x 16  {tile, rank in tile, gaussian, depth bits} written by the projection kernel
+//   keys         cap x 8   (depth bits << 32 | gaussian) bucketed by tile, then sorted in place per tile
+//   vals         cap x 4   instance id travelling with the key
+//   sorted_gid   cap x 4   per-tile front-to-back Gaussian ids
+//   sorted_inst  cap x 4   per-tile instance ids (address of the per-instance gradient record)
+//   final_T      P x 4     per-pixel transmittance after the last contributor
+// ------------------------------------------------------------------------------------------------
+struct Counters {
+  uint32_t inst_total;      // instances requested (keeps counting past capacity)
+  uint32_t overflow;        // set by the tile scan when inst_total > capacity
+  uint32_t visible;
+  uint32_t max_list;
+  unsigned long long r16;   // sum of 16x16 tiles in the splat rectangles (statistic, SURVEY 8d "R")
+  uint32_t magic;           // kMagicDone once a forward has completed on this workspace
+  uint32_t n;
+  uint32_t width, height;
+  uint32_t capacity_lo, capacity_hi;
+  uint32_t row8_begin, row8_end;
+};
+constexpr uint32_t kMagicDone = 0x56544753u;  // "VTGS"
+
+struct alignas(16) GeomRec {   // 32 bytes
+  float u, v;                  // pixel centre
+  float A, B, C;               // conic
+  float opacity;
+  float depth;
+  float pad;
+};
+
+struct alignas(8) GaussAux { uint32_t inst_base, inst_cnt; };
+
+struct alignas(16) InstTmp { uint32_t tile, rank, gid, zbits; };
+
+constexpr int kGradRec = 12;   // floats per instance gradient record (9 used, 48-byte stride)
+
+struct WsLayout {
+  size_t counters, geom, gaux, tile_cnt, tile_off, inst_tmp, keys, vals, sorted_gid, sorted_inst, final_T, total;
+  uint32_t tiles8;
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+inline WsLayout make_layout(int32_t n, int32_t w, int32_t h, uint64_t cap) {
+  WsLayout L;
+  const uint32_t gx8 = (uint32_t)(w + kSubTile - 1) / kSubTile, gy8 = (uint32_t)(h + kSubTile - 1) / kSubTile;
+  L.tiles8 = gx8 * gy8;
+  size_t o = 0;
+  L.counters = o;    o += 256;
+  L.geom = o;        o += align256((size_t)n * sizeof(GeomRec));
+  L.gaux = o;        o += align256((size_t)n * sizeof(GaussAux));
+  L.tile_cnt = o;    o += align256(((size_t)L.tiles8 + 1) * 4);
+  L.tile_off = o;    o += align256(((size_t)L.tiles8 + 1) * 4);
+  L.inst_tmp = o;    o += align256((size_t)cap * sizeof(InstTmp));
+  L.keys = o;        o += align256((size_t)cap * 8);
+  L.vals = o;        o += align256((size_t)cap * 4);
+  L.sorted_gid = o;  o += align256((size_t)cap * 4);
+  L.sorted_inst = o; o += align256((size_t)cap * 4);
+  L.final_T = o;     o += align256((size_t)w * h * 4);
+  L.total = o;
+  return L;
+}
+
+// camera scalars passed by value to kernels; the two matrices stay behind device pointers and are
+// fetched with scalar loads (wave-uniform addresses)
+struct CamScalars {
+  int W, H;
+  float tanfovx, tanfovy, mod;
+  int radius_rule;
+  int row8_begin, row8_end;
+};
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ CamParams load_cam(const CamScalars& cs, const float* __restrict__ V,
+                                              const float* __restrict__ PV) {
+  CamParams c;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { c.V[i] = V[i]; c.PV[i] = PV[i]; }
+  c.W = cs.W; c.H = cs.H;
+  c.fx = (float)cs.W / (2.f * cs.tanfovx);
+  c.fy = (float)cs.H / (2.f * cs.tanfovy);
+  c.limx = kFovClamp * cs.tanfovx; c.limy = kFovClamp * cs.tanfovy;
+  c.mod = cs.mod;
+  c.gx16 = (cs.W + kBinTile - 1) / kBinTile; c.gy16 = (cs.H + kBinTile - 1) / kBinTile;
+  c.gx8 = (cs.W + kSubTile - 1) / kSubTile;  c.gy8 = (cs.H + kSubTile - 1) / kSubTile;
+  c.row8_begin = cs.row8_begin; c.row8_end = cs.row8_end;
+  c.radius_rule = cs.radius_rule;
+  return c;
+}
+
+// ---------------------------------------------------------------- wavefront (64-lane) helpers ----
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+__device__ __forceinline__ float bcast_f(float v, int src_lane) {   // src_lane must be wave-uniform
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+__device__ __forceinline__ int bcast_i(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
+
+__device__ __forceinline__ float wave_sum(float v) {   // butterfly; every lane ends with the total
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = max(v, __shfl_xor(v, m, 64));
+  return v;
+}
+// inclusive prefix sum over lanes
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  const int l = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(v, d, 64);
+    if (l >= d) v += t;
+  }
+  return v;
+}
+
+// XCD-aware block remap (8 XCDs, blocks dealt round-robin): gives each XCD a contiguous chunk of
+// the index space so neighbouring tiles share an L2.  Bijective for any nblk.
+__device__ __forceinline__ uint32_t xcd_swizzle(uint32_t bid, uint32_t nblk) {
+  const uint32_t q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, idx = bid >> 3;
+  return xcd * q + (xcd < r ? xcd : r) + idx;
+}
+#endif  // __HIPCC__
+
+}  // namespace vtgs

@@ -1,0 +1,328 @@
+"""Drop-in `diff_gaussian_rasterization` for PyTorch-ROCm on MI355X.
+
+Same operator surface the reference imports (src/vtgaussian_slam.py:38, utils/recon_helpers.py:2,
+utils/eval_helpers.py:17):
+
+    from diff_gaussian_rasterization import GaussianRasterizer, GaussianRasterizationSettings
+    color, radii, depth = GaussianRasterizer(raster_settings=cam)(means3D=..., means2D=..., opacities=...,
+                                                                  colors_precomp=..., scales=..., rotations=...)
+
+backed by the hand-written HIP library `libvtgs.so` through its C ABI (include/vtgs.h).  There is no
+CPU or PyTorch fallback: importing this package without the built library raises.
+
+Put the directory that contains this package (`vtgaussian-slam_amd/`) on PYTHONPATH / sys.path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import NamedTuple, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_forward_info"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.environ.get("VTGS_LIBRARY", os.path.join(_HERE, "..", "lib", "libvtgs.so"))
+
+
+# ------------------------------------------------------------------------------------------------
+# C ABI binding (include/vtgs.h)
+# ------------------------------------------------------------------------------------------------
+class _VtgsCamera(ctypes.Structure):
+    _fields_ = [("image_width", ctypes.c_int32), ("image_height", ctypes.c_int32),
+                ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
+                ("radius_rule", ctypes.c_int32), ("tile_row_begin", ctypes.c_int32), ("tile_row_end", ctypes.c_int32),
+                ("bg", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p), ("projmatrix", ctypes.c_void_p)]
+
+
+class _VtgsForwardInfo(ctypes.Structure):
+    _fields_ = [("instances", ctypes.c_uint64), ("instances_needed", ctypes.c_uint64),
+                ("tiles16_touched", ctypes.c_uint64), ("visible", ctypes.c_uint32), ("max_tile_list", ctypes.c_uint32)]
+
+
+VTGS_OK, VTGS_ERR_INSTANCE_OVERFLOW = 0, 3
+ABI_VERSION = 1
+_P, _U64, _I32, _SZ = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
+
+_SIGNATURES = {
+    "vtgs_abi_version": (ctypes.c_uint32, []),
+    "vtgs_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "vtgs_last_hip_error": (ctypes.c_char_p, []),
+    "vtgs_workspace_bytes": (_SZ, [_I32, _I32, _I32, _U64]),
+    "vtgs_backward_scratch_bytes": (_SZ, [_I32, _U64]),
+    "vtgs_forward": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _U64,
+                                    ctypes.POINTER(_VtgsForwardInfo), _P]),
+    "vtgs_forward_shared": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _SZ, _U64, _P, _P]),
+    "vtgs_backward": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _U64, _P,
+                                     _P, _SZ, _P, _P, _P, _P, _P, _P, _P]),
+    "vtgs_mark_visible": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P]),
+}
+
+
+def _load_library() -> ctypes.CDLL:
+    path = os.path.abspath(_LIB_PATH)
+    if not os.path.exists(path):
+        raise ImportError(
+            f"libvtgs.so not found at {path}: the HIP rasterizer is not built. Run "
+            f"`python vtgaussian-slam_amd/build.py` (or `__graft_entry__.build()`); there is no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError here == ABI mismatch, fail loudly
+        fn.restype, fn.argtypes = res, args
+    if lib.vtgs_abi_version() != ABI_VERSION:
+        raise ImportError(f"libvtgs.so ABI {lib.vtgs_abi_version()} != expected {ABI_VERSION}; rebuild it")
+    return lib
+
+
+_lib = _load_library()
+
+
+def _check(status: int, what: str) -> None:
+    if status != VTGS_OK:
+        msg = _lib.vtgs_strerror(status).decode()
+        hip = _lib.vtgs_last_hip_error().decode()
+        raise RuntimeError(f"{what} failed: {msg}" + (f" ({hip})" if hip and status == 4 else ""))
+
+
+# ------------------------------------------------------------------------------------------------
+# Settings record: the 11 fields, in order, constructed at utils/recon_helpers.py:14-26
+# ------------------------------------------------------------------------------------------------
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+
+
+_RADIUS_RULES = {"3sigma": 0, "opacity": 1}
+_capacity_hint = {}          # (device index, N, W, H, band) -> instances seen last time
+_last_info = {}
+
+
+def last_forward_info() -> dict:
+    """Statistics of the most recent forward on this process (instances, 16x16 tile count R, ...)."""
+    return dict(_last_info)
+
+
+def _dev_f32(t, device) -> torch.Tensor:
+    t = torch.as_tensor(t)
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class _Camera:
+    """Device-side copies of the three small camera tensors + the ctypes record pointing at them."""
+
+    def __init__(self, settings: GaussianRasterizationSettings, device, radius_rule: int, tile_rows):
+        self.bg = _dev_f32(settings.bg, device).reshape(-1)
+        self.view = _dev_f32(settings.viewmatrix, device).reshape(-1)
+        self.proj = _dev_f32(settings.projmatrix, device).reshape(-1)
+        if self.bg.numel() != 3 or self.view.numel() != 16 or self.proj.numel() != 16:
+            raise ValueError("bg must have 3 elements, viewmatrix/projmatrix 16 (a leading batch dim of 1 is fine)")
+        b, e = (0, 0) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
+        self.c = _VtgsCamera(int(settings.image_width), int(settings.image_height), float(settings.tanfovx),
+                             float(settings.tanfovy), float(settings.scale_modifier), radius_rule, b, e,
+                             self.bg.data_ptr(), self.view.data_ptr(), self.proj.data_ptr())
+        self.H, self.W = int(settings.image_height), int(settings.image_width)
+        self.band = (b, e)
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require(t: torch.Tensor, name: str, shape_tail: int, n: int, device) -> torch.Tensor:
+    if t.device != device:
+        raise ValueError(f"{name} is on {t.device}, expected {device}")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if t.numel() != n * shape_tail:
+        raise ValueError(f"{name} must have {n}x{shape_tail} elements, got shape {tuple(t.shape)}")
+    return t.contiguous()
+
+
+class _ForwardState:
+    __slots__ = ("cam", "n", "workspace", "capacity", "instances", "image_state")
+
+
+def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations):
+    device = means3D.device
+    n = means3D.shape[0]
+    H, W = cam.H, cam.W
+    color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+    depth = torch.empty((1, H, W), dtype=torch.float32, device=device)
+    radii = torch.empty((n,), dtype=torch.int32, device=device)
+    key = (device.index, n, W, H, cam.band)
+    hint = _capacity_hint.get(key, 0)
+    capacity = max(int(hint * 1.25) + 4096, 4 * n + 4096) if hint else 8 * n + 65536
+    info = _VtgsForwardInfo()
+    for _attempt in range(3):
+        nbytes = _lib.vtgs_workspace_bytes(n, W, H, capacity)
+        workspace = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        st = _lib.vtgs_forward(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
+                               scales.data_ptr(), rotations.data_ptr(), color.data_ptr(), depth.data_ptr(),
+                               radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, ctypes.byref(info),
+                               _stream_ptr(device))
+        if st == VTGS_ERR_INSTANCE_OVERFLOW:
+            capacity = int(info.instances_needed * 1.25) + 4096
+            continue
+        _check(st, "vtgs_forward")
+        break
+    else:
+        raise RuntimeError("vtgs_forward: instance capacity kept overflowing")
+    _capacity_hint[key] = int(info.instances)
+    _last_info.update(instances=int(info.instances), tiles16_touched=int(info.tiles16_touched),
+                      visible=int(info.visible), max_tile_list=int(info.max_tile_list), n=n, width=W, height=H,
+                      capacity=int(capacity))
+    fs = _ForwardState()
+    fs.cam, fs.n, fs.workspace, fs.capacity, fs.instances, fs.image_state = cam, n, workspace, capacity, int(info.instances), None
+    return color, radii, depth, fs
+
+
+def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotations, out_color, grad_color):
+    device = means3D.device
+    n = fs.n
+    g_means3D = torch.empty((n, 3), dtype=torch.float32, device=device)
+    g_means2D = torch.empty((n, 3), dtype=torch.float32, device=device)
+    g_colors = torch.empty((n, 3), dtype=torch.float32, device=device)
+    g_opac = torch.empty((n, 1), dtype=torch.float32, device=device)
+    g_scales = torch.empty((n, 3), dtype=torch.float32, device=device)
+    g_rot = torch.empty((n, 4), dtype=torch.float32, device=device)
+    if n == 0:
+        return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
+    sbytes = _lib.vtgs_backward_scratch_bytes(n, fs.instances)
+    scratch = torch.empty((sbytes,), dtype=torch.uint8, device=device)
+    state_ptr = fs.image_state.data_ptr() if fs.image_state is not None else None
+    st = _lib.vtgs_backward(ctypes.byref(fs.cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
+                            scales.data_ptr(), rotations.data_ptr(), out_color.data_ptr(), grad_color.data_ptr(),
+                            fs.workspace.data_ptr(), fs.workspace.numel(), fs.capacity, state_ptr,
+                            scratch.data_ptr(), sbytes, g_means3D.data_ptr(), g_means2D.data_ptr(), g_colors.data_ptr(),
+                            g_opac.data_ptr(), g_scales.data_ptr(), g_rot.data_ptr(), _stream_ptr(device))
+    _check(st, "vtgs_backward")
+    return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """Argument order and gradient arity follow the replaced extension's autograd.Function
+    [UPSTREAM-PUBLIC]: (means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+    cov3Ds_precomp, raster_settings) -> (color, radii, depth); nine gradients back."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, cam: _Camera,
+                shared_from: Optional[_ForwardState]):
+        device = means3D.device
+        n = means3D.shape[0]
+        means3D = _require(means3D, "means3D", 3, n, device)
+        colors = _require(colors_precomp, "colors_precomp", 3, n, device)
+        opac = _require(opacities, "opacities", 1, n, device)
+        scales_c = _require(scales, "scales", 3, n, device)
+        rot = _require(rotations, "rotations", 4, n, device)
+        if shared_from is None:
+            color, radii, depth, fs = _run_forward(cam, means3D, colors, opac, scales_c, rot)
+        else:
+            base = shared_from
+            H, W = cam.H, cam.W
+            color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+            depth = torch.empty((1, H, W), dtype=torch.float32, device=device)
+            state = torch.empty((H * W,), dtype=torch.float32, device=device)
+            st = _lib.vtgs_forward_shared(ctypes.byref(base.cam.c), n, colors.data_ptr(), color.data_ptr(),
+                                          depth.data_ptr(), base.workspace.data_ptr(), base.workspace.numel(),
+                                          base.capacity, state.data_ptr(), _stream_ptr(device))
+            _check(st, "vtgs_forward_shared")
+            fs = _ForwardState()
+            fs.cam, fs.n, fs.workspace, fs.capacity, fs.instances, fs.image_state = (
+                base.cam, base.n, base.workspace, base.capacity, base.instances, state)
+            radii = None
+        ctx.fs = fs
+        ctx.save_for_backward(means3D, colors, opac, scales_c, rot, color)
+        ctx.mark_non_differentiable(depth)
+        if radii is not None:
+            ctx.mark_non_differentiable(radii)
+            return color, radii, depth, fs
+        return color, depth, fs
+
+    @staticmethod
+    def backward(ctx, grad_color, *unused):
+        means3D, colors, opac, scales_c, rot, color = ctx.saved_tensors
+        if grad_color is None:
+            grad_color = torch.zeros_like(color)
+        grad_color = grad_color.to(torch.float32).contiguous()
+        g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot = _run_backward(
+            ctx.fs, means3D, colors, opac, scales_c, rot, color, grad_color)
+        return g_means3D, g_means2D, None, g_colors, g_opac, g_scales, g_rot, None, None, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings, *, radius_rule: Optional[str] = None, tile_rows=None):
+    rast = GaussianRasterizer(raster_settings, radius_rule=radius_rule, tile_rows=tile_rows)
+    return rast(means3D, means2D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
+
+
+class GaussianRasterizer(nn.Module):
+    """`GaussianRasterizer(raster_settings=cam)(...)`; a new, stateless module per call is fine
+    (the reference builds one per render: src/vtgaussian_slam.py:461,466,747).
+
+    Extras that the reference does not use and that default to its behaviour:
+      radius_rule : "3sigma" (published rule, default; env VTGS_RADIUS_RULE) or "opacity".
+      tile_rows   : (begin, end) band of 16-pixel tile rows to render (tile-row multi-GPU partition).
+    """
+
+    def __init__(self, raster_settings, radius_rule: Optional[str] = None, tile_rows: Optional[Tuple[int, int]] = None):
+        super().__init__()
+        self.raster_settings = raster_settings
+        rule = radius_rule or os.environ.get("VTGS_RADIUS_RULE", "3sigma")
+        if rule not in _RADIUS_RULES:
+            raise ValueError(f"radius_rule must be one of {sorted(_RADIUS_RULES)}")
+        self._rule = _RADIUS_RULES[rule]
+        self._tile_rows = tile_rows
+        self._last_state: Optional[_ForwardState] = None
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            p = positions.detach().to(torch.float32).contiguous()
+            cam = _Camera(self.raster_settings, p.device, self._rule, self._tile_rows)
+            out = torch.empty((p.shape[0],), dtype=torch.uint8, device=p.device)
+            _check(_lib.vtgs_mark_visible(ctypes.byref(cam.c), p.shape[0], p.data_ptr(), out.data_ptr(),
+                                          _stream_ptr(p.device)), "vtgs_mark_visible")
+            return out.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if shs is not None:
+            raise NotImplementedError("spherical-harmonics colours are outside this build's scope: the reference "
+                                      "only ever passes colors_precomp (utils/slam_helpers.py:152-159)")
+        if cov3D_precomp is not None:
+            raise NotImplementedError("cov3D_precomp is outside this build's scope: the reference passes "
+                                      "scales + rotations (utils/slam_helpers.py:152-159)")
+        if not means3D.is_cuda:
+            raise RuntimeError("GaussianRasterizer needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
+        cam = _Camera(self.raster_settings, means3D.device, self._rule, self._tile_rows)
+        color, radii, depth, fs = _RasterizeGaussians.apply(means3D, means2D, None, colors_precomp, opacities, scales,
+                                                            rotations, None, cam, None)
+        self._last_state = fs
+        return color, radii, depth
+
+    def render_shared(self, colors_precomp: torch.Tensor, like: Tuple[torch.Tensor, ...]):
+        """Second render over the geometry of the previous `forward` of THIS module with other colours
+        (the depth/silhouette pass of src/vtgaussian_slam.py:466): skips projection, binning and sorting.
+        `like` = (means3D, means2D, opacities, scales, rotations) -- the same tensors the first call got,
+        so that gradients reach them.  Opt-in; the plain call-by-call path stays the default."""
+        if self._last_state is None:
+            raise RuntimeError("render_shared needs a preceding forward() on the same module")
+        means3D, means2D, opacities, scales, rotations = like
+        color, depth, _ = _RasterizeGaussians.apply(means3D, means2D, None, colors_precomp, opacities, scales, rotations,
+                                                    None, self._last_state.cam, self._last_state)
+        return color, depth
