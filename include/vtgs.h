@@ -133,6 +133,12 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n,
 int vtgs_mark_visible(const VtgsCamera* cam, int32_t n, const float* means3D,
                       uint8_t* out_visible, void* stream);
 
+/* Introspection for tests: byte offsets of the workspace regions for (n, width, height, capacity).
+ * out[0..7] = counters, geom (N x 8 f32: u v A B C opacity depth pad), gaux (N x {first instance, count}),
+ * tile_offsets ((tiles8+1) x u32), sorted_gid (cap x u32), sorted_inst (cap x u32), final_T (P x f32),
+ * tiles8 (count, not an offset).  8x8 tiles are numbered row-major over ceil(W/8) x ceil(H/8).          */
+int vtgs_debug_layout(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity, uint64_t out[8]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,8 @@ anywhere (the fork's "smaller radii") is isolated in `splat_radius()` behind `ra
 Semantics restated:
   preprocess  : view transform, cull z <= 0.2, EWA covariance J W S W^T J^T with the 1.3*tanfov clamp,
                 +0.3 dilation, conic, eigen-radius, pixel centre ((ndc+1)*S-1)/2, 16x16 tile rectangle.
-  binning     : key = (tile, float32 depth bits), stable => ties keep Gaussian index order.
+  binning     : key = (tile, float32 depth bits), stable => ties keep Gaussian index order.  The tile
+                rectangle floor() is taken RECT_EPS above its argument (lattice-aligned splats, see RECT_EPS).
   composite   : front-to-back; skip power>0; alpha=min(.99, o*exp(power)); skip alpha<1/255;
                 stop before adding when T*(1-alpha) < 1e-4; C += c*alpha*T; D += z*alpha*T; out = C + T*bg.
   backward    : torch autograd through the forward above, with the two places where the published
@@ -45,6 +46,7 @@ T_STOP = 1e-4
 NEAR_CULL = 0.2
 DILATION = 0.3
 FOV_CLAMP = 1.3
+RECT_EPS = 1e-4           # tile units; see kRectEps in vtgaussian-slam_amd/csrc/vtgs_math.h
 
 
 class OracleCamera(NamedTuple):
@@ -183,10 +185,10 @@ def preprocess(means3D, means2D, opacities, scales, rotations, cam, radius_rule=
     ud, vd, rd = u.detach(), v.detach(), radius
     finite = torch.isfinite(ud) & torch.isfinite(vd) & torch.isfinite(rd)
     ud, vd, rd = [torch.where(finite, q, torch.zeros_like(q)) for q in (ud, vd, rd)]
-    x0 = torch.clamp(torch.floor((ud - rd) / TILE), 0, gx).long()
-    x1 = torch.clamp(torch.floor((ud + rd + TILE - 1) / TILE), 0, gx).long()
-    y0 = torch.clamp(torch.floor((vd - rd) / TILE), 0, gy).long()
-    y1 = torch.clamp(torch.floor((vd + rd + TILE - 1) / TILE), 0, gy).long()
+    x0 = torch.clamp(torch.floor((ud - rd) / TILE + RECT_EPS), 0, gx).long()
+    x1 = torch.clamp(torch.floor((ud + rd + TILE - 1) / TILE + RECT_EPS), 0, gx).long()
+    y0 = torch.clamp(torch.floor((vd - rd) / TILE + RECT_EPS), 0, gy).long()
+    y1 = torch.clamp(torch.floor((vd + rd + TILE - 1) / TILE + RECT_EPS), 0, gy).long()
     area = (x1 - x0) * (y1 - y0)
     visible = (tz.detach() > NEAR_CULL) & det_ok & (area > 0) & finite
     radii = torch.where(visible, radius, torch.zeros_like(radius)).to(torch.int32)

@@ -139,8 +139,12 @@ def test_known_answers_on_device(gpu_device):
     # opacity 1: alpha saturates at 0.99 at the centre
     c, r, d = render(torch.tensor([[0.0, 0, z]]), torch.full((1, 3), s), torch.tensor([[1.0]]), torch.ones(1, 3))
     assert abs(float(c[0, H // 2 - 1, W // 2 - 1]) - 0.99) < 1e-6
-    # two stacked opaque splats: the front one hides 99 % of the back one, order = depth
+    # two stacked splats: the opaque front one (alpha .99) leaves T = .01 for the back one (alpha .5); order = depth
     m = torch.tensor([[0.0, 0, 3.0], [0.0, 0, 2.0]])
-    c, r, d = render(m, torch.full((2, 3), 0.2), torch.ones(2, 1), torch.tensor([[1.0, 0, 0], [0.0, 1.0, 0]]))
+    c, r, d = render(m, torch.full((2, 3), 0.2), torch.tensor([[0.5], [1.0]]), torch.tensor([[1.0, 0, 0], [0.0, 1.0, 0]]))
     cy, cx = H // 2 - 1, W // 2 - 1
-    assert abs(float(c[1, cy, cx]) - 0.99) < 1e-6 and abs(float(c[0, cy, cx]) - 0.01 * 0.99) < 1e-6
+    assert abs(float(c[1, cy, cx]) - 0.99) < 1e-6 and abs(float(c[0, cy, cx]) - 0.01 * 0.5) < 1e-6
+    # T-stop: behind two alpha-.99 splats T(1-alpha) = 1e-6 < 1e-4, so a third splat is never added
+    m = torch.tensor([[0.0, 0, 2.0], [0.0, 0, 2.5], [0.0, 0, 3.0]])
+    c, r, d = render(m, torch.full((3, 3), 0.2), torch.ones(3, 1), torch.tensor([[1.0, 0, 0], [0.0, 1.0, 0], [0.0, 0, 1.0]]))
+    assert float(c[2, cy, cx]) == 0.0 and abs(float(c[1, cy, cx]) - 0.0099) < 1e-6

@@ -238,6 +238,14 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n, const float* means3D, const 
   return VTGS_OK;
 }
 
+int vtgs_debug_layout(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity, uint64_t out[8]) {
+  if (n < 0 || width <= 0 || height <= 0 || !out) return VTGS_ERR_INVALID_ARGUMENT;
+  const WsLayout L = make_layout(n, width, height, instance_capacity);
+  out[0] = L.counters; out[1] = L.geom; out[2] = L.gaux; out[3] = L.tile_off; out[4] = L.sorted_gid;
+  out[5] = L.sorted_inst; out[6] = L.final_T; out[7] = L.tiles8;
+  return VTGS_OK;
+}
+
 int vtgs_mark_visible(const VtgsCamera* cam, int32_t n, const float* means3D, uint8_t* out_visible, void* stream) {
   if (!cam || !cam->viewmatrix || n < 0 || (n > 0 && (!means3D || !out_visible))) return VTGS_ERR_INVALID_ARGUMENT;
   if (n == 0) return VTGS_OK;

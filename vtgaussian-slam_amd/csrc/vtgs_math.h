@@ -25,6 +25,11 @@ constexpr float kAlphaMax   = 0.99f;
 constexpr float kTStop      = 1e-4f;
 constexpr int   kBinTile    = 16;   // granularity that decides which pixels a splat may reach
 constexpr int   kSubTile    = 8;    // granularity of the composite (one wavefront = 8x8 pixels)
+// View-tied splats sit exactly on pixel centres in their own base frame (src/vtgaussian_slam.py:87-88
+// back-projects (x - cx + 0.5)/fx), so (u +- r)/16 is an exact integer for 1 splat in 16 and float32
+// rounding noise (~1e-7 tile) would decide the tile rectangle at random.  The floor is therefore taken
+// 1e-4 tile (1.6e-3 px) above the value: the lattice case resolves to the exact-arithmetic answer.
+constexpr float kRectEps    = 1e-4f;
 
 struct CamParams {          // scalar camera state broadcast to every thread
   float V[16];              // viewmatrix memory order: t_j = sum_i p_i V[4*i+j]
@@ -152,10 +157,11 @@ VTGS_HD bool project_splat(const CamParams& cam, const float mean[3], const floa
   const int radius = splat_radius(lam, opacity, cam.radius_rule);
   const float rf = (float)radius;
   if (!(fabsf(out.u) < 1e9f) || !(fabsf(out.v) < 1e9f) || !(rf < 1e9f)) return false;
-  out.x0 = clampi((int)floorf((out.u - rf) / (float)kBinTile), 0, cam.gx16);
-  out.x1 = clampi((int)floorf((out.u + rf + (float)(kBinTile - 1)) / (float)kBinTile), 0, cam.gx16);
-  out.y0 = clampi((int)floorf((out.v - rf) / (float)kBinTile), 0, cam.gy16);
-  out.y1 = clampi((int)floorf((out.v + rf + (float)(kBinTile - 1)) / (float)kBinTile), 0, cam.gy16);
+  const float it = 1.f / (float)kBinTile;
+  out.x0 = clampi((int)floorf((out.u - rf) * it + kRectEps), 0, cam.gx16);
+  out.x1 = clampi((int)floorf((out.u + rf + (float)(kBinTile - 1)) * it + kRectEps), 0, cam.gx16);
+  out.y0 = clampi((int)floorf((out.v - rf) * it + kRectEps), 0, cam.gy16);
+  out.y1 = clampi((int)floorf((out.v + rf + (float)(kBinTile - 1)) * it + kRectEps), 0, cam.gy16);
   if ((out.x1 - out.x0) * (out.y1 - out.y0) <= 0) return false;
   out.radius = radius;
   return true;

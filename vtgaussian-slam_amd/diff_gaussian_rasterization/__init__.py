@@ -58,6 +58,7 @@ _SIGNATURES = {
     "vtgs_backward": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _U64, _P,
                                      _P, _SZ, _P, _P, _P, _P, _P, _P, _P]),
     "vtgs_mark_visible": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P]),
+    "vtgs_debug_layout": (ctypes.c_int, [_I32, _I32, _I32, _U64, ctypes.POINTER(ctypes.c_uint64)]),
 }
 
 
@@ -208,6 +209,21 @@ def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotatio
                             g_opac.data_ptr(), g_scales.data_ptr(), g_rot.data_ptr(), _stream_ptr(device))
     _check(st, "vtgs_backward")
     return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
+
+
+def debug_tile_lists(rasterizer: "GaussianRasterizer"):
+    """Test hook: (tile_offsets [tiles8+1] int64, sorted_gid [R] int64, geom [N,8] float32) of the last forward
+    of `rasterizer`, copied to the CPU.  8x8 tiles, row-major."""
+    fs = rasterizer._last_state
+    out = (ctypes.c_uint64 * 8)()
+    _check(_lib.vtgs_debug_layout(fs.n, fs.cam.W, fs.cam.H, fs.capacity, out), "vtgs_debug_layout")
+    ws = fs.workspace
+    tiles8 = int(out[7])
+    offs = ws[int(out[3]): int(out[3]) + 4 * (tiles8 + 1)].view(torch.int32).cpu().long()
+    total = int(offs[-1])
+    gid = ws[int(out[4]): int(out[4]) + 4 * total].view(torch.int32).cpu().long()
+    geom = ws[int(out[1]): int(out[1]) + 32 * fs.n].view(torch.float32).reshape(fs.n, 8).cpu()
+    return offs, gid, geom
 
 
 class _RasterizeGaussians(torch.autograd.Function):
