@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rasterize forward+backward throughput (Mgaussians*pixels/s), BASELINE.json metric.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One step = one full pass of the hot path through the drop-in operator: GaussianRasterizer forward
+(projection, tile bucketing, per-tile sort, composite of colour+depth) and backward (gradients to all six
+tensor inputs) on the synthetic view-tied scene of SURVEY.md 8(d): N = 1 M isotropic Gaussians, 1200x680,
+inputs resident in HBM.  With N > 1 GPUs the image is partitioned into bands of 16-pixel tile rows (one band
+per rank, Gaussians replicated) and the 7-float pose gradient is all-reduced over RCCL each step (strong
+scaling: the total work is fixed).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel, timed live with HIP events on the
+stream it runs on (vtgs_profile_*); `cpu_baseline` is the float32 oracle on a bounded band of the same scene.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "vtgaussian-slam_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def kernel_algorithmic_bytes(n, p, r16):
+    """B_alg = 180 N + 28 P + 52 R per fwd+bwd call, split over the kernels that own each term
+    (DESIGN.md section 4).  R = 16x16 tiles touched, counted by the op."""
+    return {
+        "project_and_bin": 44 * n + 12 * r16,            # means/scales/rot/opacity read + key/value emit
+        "scan_tiles": 8 * r16,                           # range scan
+        "scatter_instances": 12 * r16,                   # sort read
+        "sort_tiles": 12 * r16,                          # sort write
+        "composite_forward": 12 * n + 4 * r16 + 16 * p,  # colours read + id read + colour/depth out
+        "composite_backward": 12 * n + 4 * r16 + 12 * p, # colours re-read + id read + grad_color in
+        "gather_splat_grads": 44 * n + 68 * n,           # params re-read + six gradients written
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1200)
+    ap.add_argument("--height", type=int, default=680)
+    ap.add_argument("--cpu-rows", type=int, default=1000, help="16-px tile rows rendered by the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import diff_gaussian_rasterization as dgr
+    from oracle import gs_oracle as go           # scene generator + CPU baseline (checker side only)
+    from parity_util import to_settings
+
+    N, W, H = args.n, args.width, args.height
+    P = W * H
+    scene, cam = go.view_tied_scene(N, W, H, seed=0)
+    settings = to_settings(cam, dev)
+    leaves = {k: v.to(dev).requires_grad_(True) for k, v in scene.items()}
+    g = torch.Generator().manual_seed(1)
+    grad_color = (torch.rand(3, H, W, generator=g) * 2 - 1).to(dev)
+
+    from diff_gaussian_rasterization.partition import band_for_rank
+    gy16 = (H + 15) // 16
+    tile_rows = band_for_rank(H, world, rank) if world > 1 else None
+    rast = dgr.GaussianRasterizer(raster_settings=settings, tile_rows=tile_rows)
+
+    def step():
+        for t in leaves.values():
+            t.grad = None
+        color, radii, depth = rast(**leaves)
+        color.backward(grad_color)
+        if dist is not None:
+            # tracking: dL/dpose is a 7-float reduction of dL/dmeans3D; all-reduce it
+            gm, m = leaves["means3D"].grad, leaves["means3D"].detach()
+            pose = torch.cat([gm.sum(0), torch.cross(m, gm, dim=1).sum(0), gm[:, 2:3].sum(0)])
+            dist.all_reduce(pose)
+        return color
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        print(f"[bench] scene ready: N={N} {W}x{H}, world={world}", file=sys.stderr, flush=True)
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    if rank == 0:
+        print(f"[bench] timed region done: {ms_per_step:.3f} ms/step", file=sys.stderr, flush=True)
+    value = N * P / (dt / args.steps) / 1e6
+
+    # ---- per-kernel phase (not part of the timed region above): HIP events around every kernel ----------
+    info = dgr.last_forward_info()
+    r16 = info["tiles16_touched"]
+    dgr.profile_enable(True)
+    prof_steps = max(5, min(20, args.steps))
+    for _ in range(prof_steps):
+        step()
+    prof = dgr.profile_collect()
+    dgr.profile_enable(False)
+    kern = {k: {"avg_us": v[0] / v[1] * 1e3, "launches": v[1]} for k, v in prof.items()}
+    alg = kernel_algorithmic_bytes(N, P, r16) if world == 1 else None
+    roofline = None
+    if kern:
+        dom = max(kern, key=lambda k: kern[k]["avg_us"])
+        if alg is not None:
+            achieved = alg[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
+            call_bytes = 180 * N + 28 * P + 52 * r16
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "kernel_avg_us": round(kern[dom]["avg_us"], 2), "algorithmic_bytes": alg[dom],
+                        "call_algorithmic_bytes": call_bytes,
+                        "call_frac": round(call_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "note": "composite kernels are VALU/exp-bound, not HBM-bound (SURVEY 8d); see DESIGN.md"}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        rows = (0, min(args.cpu_rows, gy16))
+        cpu_scene = {k: v.clone().requires_grad_(True) for k, v in scene.items()}
+        # the box's CPU share, not the host's core count (oversubscribed OpenMP spins for minutes)
+        torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+        print(f"[bench] cpu baseline on {torch.get_num_threads()} threads ...", file=sys.stderr, flush=True)
+        tc0 = time.perf_counter()
+        c_cpu, _, _ = go.rasterize(cam=cam, tile_rows=rows, **cpu_scene)
+        c_cpu.backward(grad_color.cpu())
+        tcpu = time.perf_counter() - tc0
+        p_band = W * min(rows[1] * 16, H)
+        cpu_baseline = {"value": round(N * p_band / tcpu / 1e6, 1), "unit": "Mgaussians*pixels/s",
+                        "cores": torch.get_num_threads(), "kind": "port",
+                        "sample": f"float32 PyTorch oracle fwd+bwd, same scene, tile rows {rows[0]}..{rows[1]} "
+                                  f"({p_band} of {P} pixels; projection+binning of all N included), {tcpu:.1f} s"}
+
+    if rank == 0:
+        out = {
+            "metric": "Mgaussians*pixels/s rasterize fwd+bwd", "value": round(value, 1), "unit": "Mgaussians*pixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"view-tied synthetic scene (SURVEY 8d), N={N} isotropic Gaussians, {W}x{H}, "
+                                   f"3-channel render, grads to all six inputs",
+                       "gaussians": N, "width": W, "height": H, "instances_8x8": info["instances"],
+                       "tiles16_touched_R": r16, "max_tile_list": info["max_tile_list"],
+                       "partition": "none" if world == 1 else f"tile-row bands x{world} + all-reduce(7 floats)"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "kernels_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["avg_us"])},
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -133,6 +133,19 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n,
 int vtgs_mark_visible(const VtgsCamera* cam, int32_t n, const float* means3D,
                       uint8_t* out_visible, void* stream);
 
+/* Per-kernel timing with HIP events recorded on the stream each kernel is launched on (used by bench.py for
+ * the roofline of the dominant kernel).  While enabled, every kernel launch of the library is bracketed by two
+ * events; vtgs_profile_collect synchronises the device, sums elapsed time per kernel name since enabling and
+ * clears the log.  Not thread-safe; meant for a measurement phase, not for production calls.               */
+typedef struct VtgsProfileEntry {
+  char     name[40];
+  double   total_ms;
+  uint32_t launches;
+  uint32_t pad;
+} VtgsProfileEntry;
+int vtgs_profile_enable(int on);
+int vtgs_profile_collect(VtgsProfileEntry* out, int32_t max_entries, int32_t* n_entries);
+
 /* Introspection for tests: byte offsets of the workspace regions for (n, width, height, capacity).
  * out[0..7] = counters, geom (N x 8 f32: u v A B C opacity depth pad), gaux (N x {first instance, count}),
  * tile_offsets ((tiles8+1) x u32), sorted_gid (cap x u32), sorted_inst (cap x u32), final_T (P x f32),

@@ -40,10 +40,16 @@ from typing import NamedTuple, Optional, Tuple
 import torch
 
 TILE = 16                 # binning granularity that defines which pixels a splat may reach
-ALPHA_MIN = 1.0 / 255.0
-ALPHA_MAX = 0.99
-T_STOP = 1e-4
-NEAR_CULL = 0.2
+def _f32(x: float) -> float:
+    """Thresholds are the float32 constants of the kernels (1.f/255.f, 0.99f, 1e-4f, 0.2f), so a float32 input
+    sitting exactly on one of them resolves the same way whatever dtype the oracle runs in."""
+    return float(torch.tensor(x, dtype=torch.float32))
+
+
+ALPHA_MIN = _f32(1.0 / 255.0)
+ALPHA_MAX = _f32(0.99)
+T_STOP = _f32(1e-4)
+NEAR_CULL = _f32(0.2)
 DILATION = 0.3
 FOV_CLAMP = 1.3
 RECT_EPS = 1e-4           # tile units; see kRectEps in vtgaussian-slam_amd/csrc/vtgs_math.h

@@ -1,0 +1,83 @@
+"""The C-ABI library loads and exports every function include/vtgs.h declares; argument validation that
+needs no GPU.  (No compute calls here.)"""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, "include", "vtgs.h")
+LIB = os.path.join(ROOT, "vtgaussian-slam_amd", "lib", "libvtgs.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        pytest.fail("libvtgs.so missing: run `python vtgaussian-slam_amd/build.py` (build() does)")
+    return ctypes.CDLL(LIB)
+
+
+def _declared():
+    src = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(vtgs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared()
+    assert {"vtgs_forward", "vtgs_backward", "vtgs_forward_shared", "vtgs_mark_visible", "vtgs_workspace_bytes",
+            "vtgs_backward_scratch_bytes", "vtgs_strerror", "vtgs_abi_version", "vtgs_last_hip_error",
+            "vtgs_debug_layout", "vtgs_profile_enable", "vtgs_profile_collect"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vtgs.h but not exported"
+
+
+def test_version_strings_and_sizes(lib):
+    lib.vtgs_abi_version.restype = ctypes.c_uint32
+    assert lib.vtgs_abi_version() == 1
+    lib.vtgs_strerror.restype = ctypes.c_char_p
+    assert lib.vtgs_strerror(0) == b"ok" and b"instance" in lib.vtgs_strerror(3)
+    lib.vtgs_workspace_bytes.restype = ctypes.c_size_t
+    lib.vtgs_workspace_bytes.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_uint64]
+    a = lib.vtgs_workspace_bytes(1000, 640, 480, 8000)
+    b = lib.vtgs_workspace_bytes(1000, 640, 480, 16000)
+    c = lib.vtgs_workspace_bytes(2000, 640, 480, 8000)
+    assert 0 < a < b and a < c and a % 256 == 0
+    assert lib.vtgs_workspace_bytes(-1, 640, 480, 8) == 0 and lib.vtgs_workspace_bytes(10, 0, 480, 8) == 0
+    lib.vtgs_backward_scratch_bytes.restype = ctypes.c_size_t
+    lib.vtgs_backward_scratch_bytes.argtypes = [ctypes.c_int32, ctypes.c_uint64]
+    assert lib.vtgs_backward_scratch_bytes(10, 100) >= 100 * 48
+
+
+def test_invalid_arguments_are_rejected_before_any_device_work(lib):
+    assert lib.vtgs_forward(None, 0, *([None] * 9), ctypes.c_size_t(0), ctypes.c_uint64(1), None, None) == 1
+    assert lib.vtgs_mark_visible(None, 0, None, None, None) == 1
+    out = (ctypes.c_uint64 * 8)()
+    lib.vtgs_debug_layout.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+    assert lib.vtgs_debug_layout(5, 33, 17, 64, out) == 0
+    assert out[7] == 5 * 3 and out[1] == 256            # ceil(33/8) x ceil(17/8) tiles; geom right after counters
+
+
+def test_python_surface_matches_reference_call_sites():
+    import inspect
+
+    import diff_gaussian_rasterization as dgr
+    assert dgr.GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+        "sh_degree", "campos", "prefiltered")                              # utils/recon_helpers.py:14-26
+    sig = inspect.signature(dgr.GaussianRasterizer.forward)
+    assert list(sig.parameters)[1:] == ["means3D", "means2D", "opacities", "shs", "colors_precomp", "scales",
+                                        "rotations", "cov3D_precomp"]
+    import torch
+    st = dgr.GaussianRasterizationSettings(8, 8, 1.0, 1.0, torch.zeros(3), 1.0, torch.eye(4)[None], torch.eye(4)[None],
+                                           0, torch.zeros(3), False)
+    r = dgr.GaussianRasterizer(raster_settings=st)
+    z = torch.zeros(2, 3)
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(z, z, z[:, :1], scales=z, rotations=torch.zeros(2, 4))
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(z, z, z[:, :1], colors_precomp=z)
+    with pytest.raises(RuntimeError, match="no CPU path"):                 # product path never falls back to CPU
+        r(z, z, z[:, :1], colors_precomp=z, scales=z, rotations=torch.zeros(2, 4))
+    with pytest.raises(ValueError):
+        dgr.GaussianRasterizer(raster_settings=st, radius_rule="bogus")

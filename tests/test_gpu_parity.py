@@ -144,7 +144,8 @@ def test_known_answers_on_device(gpu_device):
     c, r, d = render(m, torch.full((2, 3), 0.2), torch.tensor([[0.5], [1.0]]), torch.tensor([[1.0, 0, 0], [0.0, 1.0, 0]]))
     cy, cx = H // 2 - 1, W // 2 - 1
     assert abs(float(c[1, cy, cx]) - 0.99) < 1e-6 and abs(float(c[0, cy, cx]) - 0.01 * 0.5) < 1e-6
-    # T-stop: behind two alpha-.99 splats T(1-alpha) = 1e-6 < 1e-4, so a third splat is never added
+    # T-stop: alpha .99 then .9 leave T = 1e-3; a third alpha-.99 splat would make T(1-alpha) = 1e-5 < 1e-4: never added
     m = torch.tensor([[0.0, 0, 2.0], [0.0, 0, 2.5], [0.0, 0, 3.0]])
-    c, r, d = render(m, torch.full((3, 3), 0.2), torch.ones(3, 1), torch.tensor([[1.0, 0, 0], [0.0, 1.0, 0], [0.0, 0, 1.0]]))
-    assert float(c[2, cy, cx]) == 0.0 and abs(float(c[1, cy, cx]) - 0.0099) < 1e-6
+    c, r, d = render(m, torch.full((3, 3), 0.2), torch.tensor([[1.0], [0.9], [1.0]]),
+                     torch.tensor([[1.0, 0, 0], [0.0, 1.0, 0], [0.0, 0, 1.0]]))
+    assert float(c[2, cy, cx]) == 0.0 and abs(float(c[1, cy, cx]) - 0.009) < 1e-6

@@ -39,6 +39,27 @@ static int hip_fail(hipError_t e, const char* what) {
     if (e__ != hipSuccess) return hip_fail(e__, #call);       \
   } while (0)
 
+// ---- optional per-kernel event timing (vtgs_profile_*) -------------------------------------------------
+struct ProfSlot { const char* name; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static ProfSlot g_prof[8192];
+static int g_prof_n = 0, g_prof_created = 0;
+
+struct ProfScope {
+  hipStream_t st; int idx;
+  ProfScope(const char* name, hipStream_t s) : st(s), idx(-1) {
+    if (!g_prof_on || g_prof_n >= 8192) return;
+    idx = g_prof_n++;
+    if (idx >= g_prof_created) {
+      if (hipEventCreate(&g_prof[idx].a) != hipSuccess || hipEventCreate(&g_prof[idx].b) != hipSuccess) { idx = -1; --g_prof_n; return; }
+      g_prof_created = idx + 1;
+    }
+    g_prof[idx].name = name;
+    (void)hipEventRecord(g_prof[idx].a, st);
+  }
+  ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, st); }
+};
+
 static bool band_of(const VtgsCamera* cam, int* row8_begin, int* row8_end, int* rows16, int* row16_0) {
   const int gy16 = (cam->image_height + kBinTile - 1) / kBinTile;
   const int gy8 = (cam->image_height + kSubTile - 1) / kSubTile;
@@ -100,10 +121,10 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
                                     float* image_state, hipStream_t st) {
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   const uint32_t nblk16 = (uint32_t)(gx16 * rows16);
-  hipLaunchKernelGGL(composite_forward, dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
+  { ProfScope ps__("composite_forward", st); hipLaunchKernelGGL(composite_forward, dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
                      (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid),
                      (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
-                     (const Counters*)(ws + L.counters));
+                     (const Counters*)(ws + L.counters)); }
   VTGS_HIP(hipGetLastError());
   return VTGS_OK;
 }
@@ -135,22 +156,22 @@ int vtgs_forward(const VtgsCamera* cam, int32_t n, const float* means3D, const f
     VTGS_HIP(hipMemsetAsync(out_depth, 0, P * sizeof(float), st));
   }
   if (n > 0) {
-    hipLaunchKernelGGL(project_and_bin, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+    { ProfScope ps__("project_and_bin", st); hipLaunchKernelGGL(project_and_bin, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
                        means3D, opacities, scales, rotations, out_radii, (GeomRec*)(ws + L.geom),
                        (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt), (InstTmp*)(ws + L.inst_tmp), ctr,
-                       (unsigned long long)instance_capacity);
+                       (unsigned long long)instance_capacity); }
     VTGS_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(scan_tiles, dim3(1), dim3(1024), 0, st, (const uint32_t*)(ws + L.tile_cnt),
-                     (uint32_t*)(ws + L.tile_off), L.tiles8, ctr, (unsigned long long)instance_capacity);
+  { ProfScope ps__("scan_tiles", st); hipLaunchKernelGGL(scan_tiles, dim3(1), dim3(1024), 0, st, (const uint32_t*)(ws + L.tile_cnt),
+                     (uint32_t*)(ws + L.tile_off), L.tiles8, ctr, (unsigned long long)instance_capacity); }
   VTGS_HIP(hipGetLastError());
-  hipLaunchKernelGGL(scatter_instances, dim3(2048), dim3(256), 0, st, (const InstTmp*)(ws + L.inst_tmp),
+  { ProfScope ps__("scatter_instances", st); hipLaunchKernelGGL(scatter_instances, dim3(2048), dim3(256), 0, st, (const InstTmp*)(ws + L.inst_tmp),
                      (const uint32_t*)(ws + L.tile_off), (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals),
-                     (const Counters*)ctr);
+                     (const Counters*)ctr); }
   VTGS_HIP(hipGetLastError());
-  hipLaunchKernelGGL(sort_tiles, dim3(L.tiles8), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_off),
+  { ProfScope ps__("sort_tiles", st); hipLaunchKernelGGL(sort_tiles, dim3(L.tiles8), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_off),
                      (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
-                     (uint32_t*)(ws + L.sorted_inst), L.tiles8, (const Counters*)ctr);
+                     (uint32_t*)(ws + L.sorted_inst), L.tiles8, (const Counters*)ctr); }
   VTGS_HIP(hipGetLastError());
   int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st);
   if (rc != VTGS_OK) return rc;
@@ -226,15 +247,44 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n, const float* means3D, const 
   const float* state = image_state ? image_state : (const float*)(ws + L.final_T);
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   const uint32_t nblk16 = (uint32_t)(gx16 * rows16);
-  hipLaunchKernelGGL(composite_backward, dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
+  { ProfScope ps__("composite_backward", st); hipLaunchKernelGGL(composite_backward, dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
                      (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid),
                      (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color, grad_color,
-                     state, (float*)scratch);
+                     state, (float*)scratch); }
   VTGS_HIP(hipGetLastError());
-  hipLaunchKernelGGL(gather_splat_grads, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+  { ProfScope ps__("gather_splat_grads", st); hipLaunchKernelGGL(gather_splat_grads, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
                      means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch,
-                     g_means3D, g_means2D, g_colors, g_opacities, g_scales, g_rotations);
+                     g_means3D, g_means2D, g_colors, g_opacities, g_scales, g_rotations); }
   VTGS_HIP(hipGetLastError());
+  return VTGS_OK;
+}
+
+int vtgs_profile_enable(int on) {
+  g_prof_on = on != 0;
+  g_prof_n = 0;
+  return VTGS_OK;
+}
+
+int vtgs_profile_collect(VtgsProfileEntry* out, int32_t max_entries, int32_t* n_entries) {
+  if (!out || !n_entries || max_entries <= 0) return VTGS_ERR_INVALID_ARGUMENT;
+  VTGS_HIP(hipDeviceSynchronize());
+  int n = 0;
+  for (int i = 0; i < g_prof_n; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_prof[i].a, g_prof[i].b) != hipSuccess) continue;
+    int k = 0;
+    for (; k < n; ++k) if (strncmp(out[k].name, g_prof[i].name, sizeof(out[k].name)) == 0) break;
+    if (k == n) {
+      if (n == max_entries) continue;
+      memset(&out[n], 0, sizeof(out[n]));
+      strncpy(out[n].name, g_prof[i].name, sizeof(out[n].name) - 1);
+      ++n;
+    }
+    out[k].total_ms += ms;
+    out[k].launches += 1;
+  }
+  *n_entries = n;
+  g_prof_n = 0;
   return VTGS_OK;
 }
 

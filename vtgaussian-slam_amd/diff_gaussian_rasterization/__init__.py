@@ -42,6 +42,11 @@ class _VtgsForwardInfo(ctypes.Structure):
                 ("tiles16_touched", ctypes.c_uint64), ("visible", ctypes.c_uint32), ("max_tile_list", ctypes.c_uint32)]
 
 
+class _VtgsProfileEntry(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 40), ("total_ms", ctypes.c_double), ("launches", ctypes.c_uint32),
+                ("pad", ctypes.c_uint32)]
+
+
 VTGS_OK, VTGS_ERR_INSTANCE_OVERFLOW = 0, 3
 ABI_VERSION = 1
 _P, _U64, _I32, _SZ = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
@@ -59,6 +64,8 @@ _SIGNATURES = {
                                      _P, _SZ, _P, _P, _P, _P, _P, _P, _P]),
     "vtgs_mark_visible": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P]),
     "vtgs_debug_layout": (ctypes.c_int, [_I32, _I32, _I32, _U64, ctypes.POINTER(ctypes.c_uint64)]),
+    "vtgs_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "vtgs_profile_collect": (ctypes.c_int, [ctypes.POINTER(_VtgsProfileEntry), _I32, ctypes.POINTER(_I32)]),
 }
 
 
@@ -112,6 +119,19 @@ _last_info = {}
 def last_forward_info() -> dict:
     """Statistics of the most recent forward on this process (instances, 16x16 tile count R, ...)."""
     return dict(_last_info)
+
+
+def profile_enable(on: bool) -> None:
+    """Bracket every kernel launch of the library with HIP events on its stream (measurement phases only)."""
+    _check(_lib.vtgs_profile_enable(1 if on else 0), "vtgs_profile_enable")
+
+
+def profile_collect() -> dict:
+    """{kernel name: (total ms, launches)} since profile_enable(True); synchronises the device."""
+    buf = (_VtgsProfileEntry * 32)()
+    n = _I32(0)
+    _check(_lib.vtgs_profile_collect(buf, 32, ctypes.byref(n)), "vtgs_profile_collect")
+    return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches) for i in range(n.value)}
 
 
 def _dev_f32(t, device) -> torch.Tensor:
