@@ -15,10 +15,10 @@
 // and the running prefix P_k = sum_{j<=k} (g.c_j) alpha_j T_j,
 //     dL/dalpha_k = T_k (g.c_k) - (Cg - P_k + T_final (g.bg)) / (1 - alpha_k)
 // so the list is replayed in the SAME order as the forward (identical skip/stop decisions by construction,
-// no per-pixel contributor count to store) and the per-pixel state is two scalars (T, P).  Per splat the
-// wavefront reduces nine sums over its 64 pixels (SplatMoments, vtgs_math.h) and stores them as one
-// 48-byte record per (splat, tile) instance -- plain stores, no float atomics, bitwise reproducible.
-// gather_splat_grads then sums each splat's contiguous run of records and runs splat_backward.
+// no per-pixel contributor count to store) and the per-pixel state is two scalars (T, P).  Per splat the nine
+// sums over the tile's 64 pixels are formed by an f32 MFMA (see composite_backward) and stored as one 48-byte
+// record per (splat, tile) instance -- plain stores, no float atomics, bitwise reproducible.
+// gather_splat_grads then re-centres and sums each splat's contiguous run of records and runs splat_backward.
 #include "vtgs_internal.h"
 
 namespace vtgs {
@@ -116,29 +116,72 @@ __global__ __launch_bounds__(256) void composite_forward(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Backward composite.  Pixel-major replay produces, per (splat k, pixel p), two scalars:
+//     u_kp = G_kp * dL/dalpha_kp      and      w_kp = alpha_kp * T_kp
+// and the nine per-splat sums are a contraction over the 64 pixels of the tile:
+//     S[k][0..5] = sum_p u_kp * phi_j(p),  phi = (1, X, Y, X^2, XY, Y^2),  X,Y = pixel - tile centre
+//     S[k][6..8] = sum_p w_kp * g_ch(p)                                   (g = dL/dcolor)
+// i.e. [16 splats x 64 px] x [64 px x 9] per batch of 16 splats -- run on the matrix cores with the exact-f32
+// MFMA (v_mfma_f32_16x16x4_f32), which is otherwise idle and issues beside the VALU work of the co-resident
+// wavefronts.  The lane<->pixel layout of the replay is transposed into the MFMA A-operand layout
+// (lane = splat row i + 16 * k-slot) through a per-wavefront LDS image [16][65] (stride 65: conflict-free for
+// both the row-wise ds_write_b32 and the column-wise ds_read_b32).  B (phi | g) lives in 16 VGPRs per lane for the
+// whole tile.  The tile-local moments are re-centred on the splat in gather_splat_grads (the record carries the
+// tile id), so nothing here depends on the splat position and there is no cross-lane reduction at all.
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kRowStride = 65;
+
 __global__ __launch_bounds__(256) void composite_backward(
     CamScalars cs, const float* __restrict__ bg, uint32_t nblk16,
     const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ sorted_gid,
     const uint32_t* __restrict__ sorted_inst, const GeomRec* __restrict__ geom, const float* __restrict__ colors,
     const float* __restrict__ out_color, const float* __restrict__ grad_color, const float* __restrict__ final_T,
     float* __restrict__ grad_inst) {
+  __shared__ float lds[4][2][16 * kRowStride];
   const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
   const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
   const TileCoord tc = tile_coord(cs, nblk16, gx16, gx8, gy8);
   if (!tc.tile_ok) return;
   const int l = lane_id();
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float* __restrict__ Us = lds[wv][0];
+  float* __restrict__ Ws = lds[wv][1];
   const float pxf = (float)tc.px, pyf = (float)tc.py;
   const uint32_t s = tile_off[tc.tile], e = tile_off[tc.tile + 1];
+  if (s == e) return;
+  const size_t P = (size_t)cs.W * cs.H;
 
   float g0 = 0.f, g1 = 0.f, g2 = 0.f, Cg = 0.f, Bg = 0.f;
   if (tc.inside) {
-    const size_t P = (size_t)cs.W * cs.H, pix = (size_t)tc.py * cs.W + tc.px;
+    const size_t pix = (size_t)tc.py * cs.W + tc.px;
     g0 = grad_color[pix]; g1 = grad_color[P + pix]; g2 = grad_color[2 * P + pix];
     const float Tf = final_T[pix];
     const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
     Cg = g0 * (out_color[pix] - Tf * b0) + g1 * (out_color[P + pix] - Tf * b1) + g2 * (out_color[2 * P + pix] - Tf * b2);
     Bg = Tf * (g0 * b0 + g1 * b1 + g2 * b2);
   }
+  // B operand: lane (j = l&15, kk = l>>4), step t  <->  pixel p = 16*kk + t of the tile (p = lane index of the replay)
+  const int bj = l & 15, bk = l >> 4;
+  const int tx0 = tc.px - (l & 7), ty0 = tc.py - (l >> 3);          // tile origin
+  float Bv[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int p = 16 * bk + t;
+    const float X = (float)(p & 7) - 3.5f, Y = (float)(p >> 3) - 3.5f;
+    float v = 0.f;
+    v = (bj == 0) ? 1.f : v; v = (bj == 1) ? X : v; v = (bj == 2) ? Y : v;
+    v = (bj == 3) ? X * X : v; v = (bj == 4) ? X * Y : v; v = (bj == 5) ? Y * Y : v;
+    if (bj >= 6 && bj <= 8) {
+      const int qx = tx0 + (p & 7), qy = ty0 + (p >> 3);
+      if (qx < cs.W && qy < cs.H) v = grad_color[(size_t)(bj - 6) * P + (size_t)qy * cs.W + qx];
+    }
+    Bv[t] = v;
+  }
+  const int a_off = bj * kRowStride + 16 * bk;                         // A operand: row = splat bj, k-slot bk
+  const uint32_t tile_bits = (uint32_t)tc.tile;
+
   float T = 1.f, Pfx = 0.f;
   bool done = !tc.inside;
   uint32_t base = s;
@@ -147,40 +190,52 @@ __global__ __launch_bounds__(256) void composite_backward(
     const int n = (int)min(64u, e - base);
     const ChunkRec r = gather_chunk(sorted_gid, geom, colors, base + (uint32_t)l, l < n);
     const uint32_t my_inst = (l < n) ? sorted_inst[base + (uint32_t)l] : 0u;
-    for (int j = 0; j < n; ++j) {
-      const float su = bcast_f(r.u, j), sv = bcast_f(r.v, j);
-      const float sa = bcast_f(r.qa, j), sb = bcast_f(r.qb, j), sc = bcast_f(r.qc, j);
-      const float so = bcast_f(r.op, j);
-      const float dx = su - pxf, dy = sv - pyf;
-      const float p2 = dx * (sa * dx + sb * dy) + sc * dy * dy;
-      const float G = __builtin_amdgcn_exp2f(p2);
-      const float alpha = fminf(kAlphaMax, so * G);
-      const float Tn = T * (1.f - alpha);
-      bool hit = !done && p2 <= 0.f && alpha >= kAlphaMin;
-      if (hit && Tn < kTStop) { done = true; hit = false; }
-      float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f, m6 = 0.f, m7 = 0.f, m8 = 0.f;
-      if (__ballot(hit) != 0ull) {
-        const float c0 = bcast_f(r.c0, j), c1 = bcast_f(r.c1, j), c2 = bcast_f(r.c2, j);
-        if (hit) {
+    for (int jb = 0; jb < n; jb += 16) {
+      const int nb = min(16, n - jb);
+      for (int jj = 0; jj < nb; ++jj) {
+        const int j = jb + jj;
+        const float su = bcast_f(r.u, j), sv = bcast_f(r.v, j);
+        const float sa = bcast_f(r.qa, j), sb = bcast_f(r.qb, j), sc = bcast_f(r.qc, j);
+        const float so = bcast_f(r.op, j);
+        const float dx = su - pxf, dy = sv - pyf;
+        const float p2 = dx * (sa * dx + sb * dy) + sc * dy * dy;
+        const float G = __builtin_amdgcn_exp2f(p2);
+        const float alpha = fminf(kAlphaMax, so * G);
+        const float Tn = T * (1.f - alpha);
+        bool hit = !done && p2 <= 0.f && alpha >= kAlphaMin;
+        if (hit && Tn < kTStop) { done = true; hit = false; }
+        float uu = 0.f, ww = 0.f;
+        if (__ballot(hit) != 0ull) {
+          const float c0 = bcast_f(r.c0, j), c1 = bcast_f(r.c1, j), c2 = bcast_f(r.c2, j);
           const float gc = g0 * c0 + g1 * c1 + g2 * c2;
           const float wgt = alpha * T;
-          Pfx = fmaf(gc, wgt, Pfx);
-          const float dLda = T * gc - (Cg - Pfx + Bg) / (1.f - alpha);
-          const float uu = G * dLda;                 // clamp at 0.99 passes the gradient through
-          m0 = uu; m1 = uu * dx; m2 = uu * dy; m3 = m1 * dx; m4 = m1 * dy; m5 = m2 * dy;
-          m6 = wgt * g0; m7 = wgt * g1; m8 = wgt * g2;
-          T = Tn;
+          const float Pn = fmaf(gc, wgt, Pfx);
+          const float dLda = T * gc - (Cg - Pn + Bg) * __builtin_amdgcn_rcpf(1.f - alpha);
+          uu = hit ? G * dLda : 0.f;            // clamp at 0.99 passes the gradient through
+          ww = hit ? wgt : 0.f;
+          Pfx = hit ? Pn : Pfx;
+          T = hit ? Tn : T;
         }
-        m0 = wave_sum(m0); m1 = wave_sum(m1); m2 = wave_sum(m2); m3 = wave_sum(m3); m4 = wave_sum(m4);
-        m5 = wave_sum(m5); m6 = wave_sum(m6); m7 = wave_sum(m7); m8 = wave_sum(m8);
+        Us[jj * kRowStride + l] = uu;
+        Ws[jj * kRowStride + l] = ww;
       }
-      // lane k < 12 stores float k of this instance's record
-      const uint32_t inst = (uint32_t)bcast_i((int)my_inst, j);
-      float val = 0.f;
-      val = (l == 0) ? m0 : val; val = (l == 1) ? m1 : val; val = (l == 2) ? m2 : val;
-      val = (l == 3) ? m3 : val; val = (l == 4) ? m4 : val; val = (l == 5) ? m5 : val;
-      val = (l == 6) ? m6 : val; val = (l == 7) ? m7 : val; val = (l == 8) ? m8 : val;
-      if (l < kGradRec) grad_inst[(size_t)inst * kGradRec + l] = val;
+      // contraction over the 64 pixels on the matrix cores
+      f32x4 D1 = {0.f, 0.f, 0.f, 0.f}, D2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Us[a_off + t], Bv[t], D1, 0, 0, 0);
+        D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws[a_off + t], Bv[t], D2, 0, 0, 0);
+      }
+      // D: col = l&15, row = 4*(l>>4) + reg.  Column j<6 from D1 (u x phi), 6..8 from D2 (w x g), 9 = tile id.
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = 4 * bk + rr;
+        const uint32_t inst = (uint32_t)__shfl((int)my_inst, jb + row, 64);
+        float val = (bj < 6) ? D1[rr] : D2[rr];
+        val = (bj == 9) ? __uint_as_float(tile_bits) : val;
+        val = (bj > 9) ? 0.f : val;
+        if (row < nb && bj < kGradRec) grad_inst[(size_t)inst * kGradRec + bj] = val;
+      }
     }
   }
   // every pixel finished before the end of the list: the remaining instances contribute nothing
@@ -189,12 +244,13 @@ __global__ __launch_bounds__(256) void composite_backward(
     if (l < n) {
       const uint32_t inst = sorted_inst[base + (uint32_t)l];
       float4* p = reinterpret_cast<float4*>(grad_inst + (size_t)inst * kGradRec);
-      p[0] = p[1] = p[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+      p[0] = p[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      p[2] = make_float4(0.f, __uint_as_float(tile_bits), 0.f, 0.f);
     }
   }
 }
 
-// one thread per Gaussian: sum its instance records (fixed order), then the projection backward
+// one thread per Gaussian: re-centre and sum its instance records (fixed order), then the projection backward
 __global__ __launch_bounds__(256) void gather_splat_grads(
     CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
     const float* __restrict__ means3D, const float* __restrict__ opacities,
@@ -210,22 +266,33 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
   g.opacity = 0.f; g.rot[0] = g.rot[1] = g.rot[2] = g.rot[3] = 0.f;
   const GaussAux ga = gaux[gid];
   if (ga.inst_cnt) {
-    SplatMoments mo;
-    for (int k = 0; k < 9; ++k) mo.m[k] = 0.f;
-    const float4* rec = reinterpret_cast<const float4*>(grad_inst + (size_t)ga.inst_base * kGradRec);
-    for (uint32_t i = 0; i < ga.inst_cnt; ++i) {
-      const float4 a = rec[3 * i], b = rec[3 * i + 1], c = rec[3 * i + 2];
-      mo.m[0] += a.x; mo.m[1] += a.y; mo.m[2] += a.z; mo.m[3] += a.w;
-      mo.m[4] += b.x; mo.m[5] += b.y; mo.m[6] += b.z; mo.m[7] += b.w;
-      mo.m[8] += c.x;
-    }
     const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
     const float sc[3] = {scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
     const float4 q4 = reinterpret_cast<const float4*>(rotations)[gid];
     const float q[4] = {q4.x, q4.y, q4.z, q4.w};
     const float op = opacities[gid];
     Splat sp; SplatAux aux;
-    if (project_splat(cam, mean, sc, q, op, sp, aux)) splat_backward(cam, sc, q, op, sp, aux, mo, g);
+    if (project_splat(cam, mean, sc, q, op, sp, aux)) {
+      SplatMoments mo;
+      for (int k = 0; k < 9; ++k) mo.m[k] = 0.f;
+      const float4* rec = reinterpret_cast<const float4*>(grad_inst + (size_t)ga.inst_base * kGradRec);
+      for (uint32_t i = 0; i < ga.inst_cnt; ++i) {
+        const float4 a = rec[3 * i], b = rec[3 * i + 1], c = rec[3 * i + 2];
+        // record = tile-local moments (U0, UX, UY, UXX, UXY, UYY), colour sums, tile id
+        const uint32_t tile = __float_as_uint(c.y);
+        const int ty = (int)(tile / (uint32_t)cam.gx8), tx = (int)(tile - (uint32_t)ty * (uint32_t)cam.gx8);
+        const float sx = sp.u - ((float)(tx * kSubTile) + 3.5f), sy = sp.v - ((float)(ty * kSubTile) + 3.5f);
+        const float U0 = a.x, UX = a.y, UY = a.z, UXX = a.w, UXY = b.x, UYY = b.y;
+        mo.m[0] += U0;
+        mo.m[1] += sx * U0 - UX;                                     // d = centre - pixel = s - X
+        mo.m[2] += sy * U0 - UY;
+        mo.m[3] += sx * sx * U0 - 2.f * sx * UX + UXX;
+        mo.m[4] += sx * sy * U0 - sx * UY - sy * UX + UXY;
+        mo.m[5] += sy * sy * U0 - 2.f * sy * UY + UYY;
+        mo.m[6] += b.z; mo.m[7] += b.w; mo.m[8] += c.x;
+      }
+      splat_backward(cam, sc, q, op, sp, aux, mo, g);
+    }
   }
   for (int i = 0; i < 3; ++i) {
     g_means3D[3 * gid + i] = g.mean3D[i];
