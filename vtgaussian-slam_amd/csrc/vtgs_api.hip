@@ -10,8 +10,8 @@ namespace vtgs {
 // kernels (vtgs_binning.hip / vtgs_composite.hip)
 __global__ void project_and_bin(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
                                 const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, InstTmp*, Counters*,
-                                unsigned long long);
-__global__ void scan_tiles(const uint32_t*, uint32_t*, uint32_t, Counters*, unsigned long long);
+                                BlockStats*, unsigned long long);
+__global__ void scan_tiles(const uint32_t*, uint32_t*, uint32_t, Counters*, unsigned long long, const BlockStats*, uint32_t);
 __global__ void scatter_instances(const InstTmp*, const uint32_t*, unsigned long long*, uint32_t*, const Counters*);
 __global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
                            const Counters*);
@@ -159,11 +159,12 @@ int vtgs_forward(const VtgsCamera* cam, int32_t n, const float* means3D, const f
     { ProfScope ps__("project_and_bin", st); hipLaunchKernelGGL(project_and_bin, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
                        means3D, opacities, scales, rotations, out_radii, (GeomRec*)(ws + L.geom),
                        (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt), (InstTmp*)(ws + L.inst_tmp), ctr,
-                       (unsigned long long)instance_capacity); }
+                       (BlockStats*)(ws + L.block_stats), (unsigned long long)instance_capacity); }
     VTGS_HIP(hipGetLastError());
   }
   { ProfScope ps__("scan_tiles", st); hipLaunchKernelGGL(scan_tiles, dim3(1), dim3(1024), 0, st, (const uint32_t*)(ws + L.tile_cnt),
-                     (uint32_t*)(ws + L.tile_off), L.tiles8, ctr, (unsigned long long)instance_capacity); }
+                     (uint32_t*)(ws + L.tile_off), L.tiles8, ctr, (unsigned long long)instance_capacity,
+                     (const BlockStats*)(ws + L.block_stats), (uint32_t)((n + 255) / 256)); }
   VTGS_HIP(hipGetLastError());
   { ProfScope ps__("scatter_instances", st); hipLaunchKernelGGL(scatter_instances, dim3(2048), dim3(256), 0, st, (const InstTmp*)(ws + L.inst_tmp),
                      (const uint32_t*)(ws + L.tile_off), (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals),

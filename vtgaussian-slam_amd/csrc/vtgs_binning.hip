@@ -69,13 +69,13 @@ __global__ __launch_bounds__(256) void project_and_bin(
     const float* __restrict__ scales, const float* __restrict__ rotations,
     int32_t* __restrict__ radii, GeomRec* __restrict__ geom, GaussAux* __restrict__ gaux,
     uint32_t* __restrict__ tile_cnt, InstTmp* __restrict__ inst_tmp, Counters* __restrict__ ctr,
-    unsigned long long capacity) {
+    BlockStats* __restrict__ block_stats, unsigned long long capacity) {
   const CamParams cam = load_cam(cs, Vp, PVp);
   const int gid = (int)(blockIdx.x * 256u + threadIdx.x);
   const int l = lane_id();
   const bool valid = gid < n;
 
-  Splat sp; SplatAux aux;
+  Splat sp{}; SplatAux aux;
   float op = 0.f;
   bool vis = false;
   if (valid) {
@@ -100,12 +100,29 @@ __global__ __launch_bounds__(256) void project_and_bin(
     cnt += tile_reached(cam, sp, tau, w.cx0 + tx, w.cy0 + ty) ? 1u : 0u;
     if (++tx == w.cw) { tx = 0; ++ty; }
   }
-  // instances of one splat are contiguous: reserve [base, base+cnt) with one atomic per wavefront
+  // Instances of one splat are contiguous: reserve [base, base+cnt).  ONE atomic per workgroup on the
+  // global counter: same-address atomics serialise at the memory side (~14 ns each measured), so per-wavefront
+  // atomics on one cache line cost more than the whole projection.
+  __shared__ uint32_t s_wave_cnt[4], s_wave_vis[4], s_wave_r16[4], s_block_base;
+  const int wv = (int)(threadIdx.x >> 6);
   const uint32_t incl = wave_incl_scan(cnt);
-  const uint32_t wave_total = (uint32_t)bcast_i((int)incl, 63);
-  uint32_t wave_base = 0;
-  if (l == 0 && wave_total) wave_base = atomicAdd(&ctr->inst_total, wave_total);
-  wave_base = (uint32_t)bcast_i((int)wave_base, 0);
+  const uint32_t r16 = vis ? (uint32_t)((sp.x1 - sp.x0) * (sp.y1 - sp.y0)) : 0u;
+  const uint32_t r16_incl = wave_incl_scan(r16);
+  const unsigned long long vb = __ballot(vis);
+  if (l == 63) { s_wave_cnt[wv] = incl; s_wave_vis[wv] = (uint32_t)__popcll(vb); s_wave_r16[wv] = r16_incl; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+    s_block_base = tot ? atomicAdd(&ctr->inst_total, tot) : 0u;
+    BlockStats bs;
+    bs.visible = s_wave_vis[0] + s_wave_vis[1] + s_wave_vis[2] + s_wave_vis[3];
+    bs.pad = 0;
+    bs.r16 = (unsigned long long)s_wave_r16[0] + s_wave_r16[1] + s_wave_r16[2] + s_wave_r16[3];
+    block_stats[blockIdx.x] = bs;
+  }
+  __syncthreads();
+  uint32_t wave_base = s_block_base;
+  for (int k = 0; k < wv; ++k) wave_base += s_wave_cnt[k];
   const uint32_t inst_base = wave_base + incl - cnt;
 
   if (valid) {
@@ -114,16 +131,6 @@ __global__ __launch_bounds__(256) void project_and_bin(
     if (!vis) { g.u = g.v = g.A = g.B = g.C = g.depth = 0.f; }
     geom[gid] = g;
     gaux[gid] = GaussAux{inst_base, cnt};
-  }
-  // statistics: one atomic per wavefront
-  {
-    const unsigned long long vb = __ballot(vis);
-    const uint32_t r16 = vis ? (uint32_t)((sp.x1 - sp.x0) * (sp.y1 - sp.y0)) : 0u;
-    const uint32_t r16_incl = wave_incl_scan(r16);
-    if (l == 63) {
-      if (vb) atomicAdd(&ctr->visible, (uint32_t)__popcll(vb));
-      if (r16_incl) atomicAdd(&ctr->r16, (unsigned long long)r16_incl);
-    }
   }
 
   // pass 2: reserve a slot in every reached tile, lanes in lock-step so runs can share atomics
@@ -147,9 +154,12 @@ __global__ __launch_bounds__(256) void project_and_bin(
 
 // exclusive scan of tile_cnt[0..tiles) -> tile_off[0..tiles]; one workgroup of 1024 threads
 __global__ __launch_bounds__(1024) void scan_tiles(const uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ tile_off,
-                                                   uint32_t tiles, Counters* __restrict__ ctr, unsigned long long capacity) {
+                                                   uint32_t tiles, Counters* __restrict__ ctr, unsigned long long capacity,
+                                                   const BlockStats* __restrict__ block_stats, uint32_t nblocks) {
   __shared__ uint32_t part[1024];
   __shared__ uint32_t wmax[16];
+  __shared__ uint32_t svis[16];
+  __shared__ unsigned long long sr16[16];
   const uint32_t t = threadIdx.x;
   const uint32_t per = (tiles + 1023u) / 1024u;
   const uint32_t b = t * per, e = min(b + per, tiles);
@@ -157,7 +167,14 @@ __global__ __launch_bounds__(1024) void scan_tiles(const uint32_t* __restrict__ 
   for (uint32_t i = b; i < e; ++i) { const uint32_t c = tile_cnt[i]; s += c; mx = max(mx, c); }
   part[t] = s;
   mx = (uint32_t)wave_max_i((int)mx);
-  if ((t & 63u) == 0) wmax[t >> 6] = mx;
+  // statistics: sum of the per-workgroup partials written by project_and_bin
+  uint32_t vis = 0; unsigned long long r16 = 0;
+  for (uint32_t i = t; i < nblocks; i += 1024u) { vis += block_stats[i].visible; r16 += block_stats[i].r16; }
+  for (int m = 1; m < 64; m <<= 1) {
+    vis += (uint32_t)__shfl_xor((int)vis, m, 64);
+    r16 += (unsigned long long)__shfl_xor((long long)r16, m, 64);
+  }
+  if ((t & 63u) == 0) { wmax[t >> 6] = mx; svis[t >> 6] = vis; sr16[t >> 6] = r16; }
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {           // Hillis-Steele inclusive scan
     const uint32_t v = (t >= d) ? part[t - d] : 0u;
@@ -169,9 +186,9 @@ __global__ __launch_bounds__(1024) void scan_tiles(const uint32_t* __restrict__ 
   for (uint32_t i = b; i < e; ++i) { tile_off[i] = run; run += tile_cnt[i]; }
   if (t == 1023) tile_off[tiles] = part[1023];
   if (t == 0) {
-    uint32_t m = 0;
-    for (int i = 0; i < 16; ++i) m = max(m, wmax[i]);
-    ctr->max_list = m;
+    uint32_t m = 0, v = 0; unsigned long long r = 0;
+    for (int i = 0; i < 16; ++i) { m = max(m, wmax[i]); v += svis[i]; r += sr16[i]; }
+    ctr->max_list = m; ctr->visible = v; ctr->r16 = r;
     ctr->overflow = ((unsigned long long)ctr->inst_total > capacity) ? 1u : 0u;
   }
 }

@@ -13,6 +13,7 @@ namespace vtgs {
 //   counters     256 B     Counters (zeroed per forward)
 //   geom         N x 32 B  GeomRec: what the composite needs per splat; read by gather, L2/MALL resident
 //   gaux         N x 8 B   first instance id + instance count (instances of a splat are contiguous)
+//   block_stats  ceil(N/256) x 16 B  per-workgroup {visible, 16x16 tiles touched} partials (no same-address atomics)
 //   tile_cnt     (T8+1)x4  per 8x8-tile instance counters (zeroed per forward)
 //   tile_off     (T8+1)x4  exclusive scan of tile_cnt
 //   inst_tmp     cap x 16  {tile, rank in tile, gaussian, depth bits} written by the projection kernel
@@ -46,12 +47,14 @@ struct alignas(16) GeomRec {   // 32 bytes
 
 struct alignas(8) GaussAux { uint32_t inst_base, inst_cnt; };
 
+struct alignas(16) BlockStats { uint32_t visible, pad; unsigned long long r16; };
+
 struct alignas(16) InstTmp { uint32_t tile, rank, gid, zbits; };
 
 constexpr int kGradRec = 12;   // floats per instance gradient record (9 used, 48-byte stride)
 
 struct WsLayout {
-  size_t counters, geom, gaux, tile_cnt, tile_off, inst_tmp, keys, vals, sorted_gid, sorted_inst, final_T, total;
+  size_t counters, geom, gaux, block_stats, tile_cnt, tile_off, inst_tmp, keys, vals, sorted_gid, sorted_inst, final_T, total;
   uint32_t tiles8;
 };
 
@@ -65,6 +68,7 @@ inline WsLayout make_layout(int32_t n, int32_t w, int32_t h, uint64_t cap) {
   L.counters = o;    o += 256;
   L.geom = o;        o += align256((size_t)n * sizeof(GeomRec));
   L.gaux = o;        o += align256((size_t)n * sizeof(GaussAux));
+  L.block_stats = o; o += align256(((size_t)(n + 255) / 256 + 1) * sizeof(BlockStats));
   L.tile_cnt = o;    o += align256(((size_t)L.tiles8 + 1) * 4);
   L.tile_off = o;    o += align256(((size_t)L.tiles8 + 1) * 4);
   L.inst_tmp = o;    o += align256((size_t)cap * sizeof(InstTmp));
