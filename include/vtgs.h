@@ -18,8 +18,8 @@
  *     backward scratch.  The library never allocates device memory, never frees, keeps no pointer
  *     after a call returns, and enqueues everything on `stream`.
  *   - outputs are fully overwritten (gradient arrays are written for every row, zeros included).
- *   - the only host synchronisation is in vtgs_forward (it reads back 32 bytes of counters to
- *     report overflow and statistics); vtgs_backward never synchronises.
+ *   - the only host synchronisation is in vtgs_forward with VTGS_FORWARD_SYNC (it waits for the result
+ *     record to report overflow and statistics); VTGS_FORWARD_ASYNC and vtgs_backward never synchronise.
  *   - all functions return a VtgsStatus; vtgs_strerror() gives a static message.
  */
 #ifndef VTGS_H
@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VTGS_ABI_VERSION 1
+#define VTGS_ABI_VERSION 2
 
 typedef enum VtgsStatus {
   VTGS_OK = 0,
@@ -65,14 +65,22 @@ typedef struct VtgsCamera {
   const float* projmatrix;   /* [16] full projection, as stored at utils/recon_helpers.py:13         */
 } VtgsCamera;
 
-/* Filled by vtgs_forward on the host. */
+/* Result record of a forward.  Assembled on the device and copied to `info` (host). */
 typedef struct VtgsForwardInfo {
-  uint64_t instances;        /* (Gaussian, 8x8 tile) instances binned by this call                   */
+  uint64_t instances;        /* (Gaussian, 8x8 tile) instances binned by this call (0 on overflow)    */
   uint64_t instances_needed; /* == instances, or the count that did not fit on overflow              */
   uint64_t tiles16_touched;  /* R of SURVEY 8(d): sum over Gaussians of 16x16 tiles in their rect    */
   uint32_t visible;          /* Gaussians with radii > 0                                             */
   uint32_t max_tile_list;    /* longest per-tile list                                                */
+  uint32_t overflow;         /* 1: instance_capacity was too small, outputs are invalid              */
+  uint32_t complete;         /* 1 once the record has been written (async mode: poll / wait on it)   */
 } VtgsForwardInfo;
+
+/* vtgs_forward flags */
+#define VTGS_FORWARD_SYNC  0u   /* wait for the forward, fill `info`, return VTGS_ERR_INSTANCE_OVERFLOW on overflow  */
+#define VTGS_FORWARD_ASYNC 1u   /* do not synchronise: `info` must be PINNED host memory that stays valid until the  */
+                                /* stream reaches the copy; the caller synchronises (event / stream) before reading */
+                                /* it and must treat info->overflow == 1 as VTGS_ERR_INSTANCE_OVERFLOW               */
 
 uint32_t    vtgs_abi_version(void);
 const char* vtgs_strerror(int status);
@@ -90,13 +98,13 @@ size_t vtgs_backward_scratch_bytes(int32_t n, uint64_t instances);
  * the reference uses (shs / cov3D_precomp are rejected in the Python layer).
  *   means3D[N,3] opacities[N,1] colors[N,3] scales[N,3] rotations[N,4](w,x,y,z)
  *   out_color[3,H,W] out_depth[1,H,W] out_radii[N] (0 = culled)
- * `info` (host, may be NULL).                                                                        */
+ * `info`: host record (may be NULL with VTGS_FORWARD_SYNC); `flags`: VTGS_FORWARD_*.                    */
 int vtgs_forward(const VtgsCamera* cam, int32_t n,
                  const float* means3D, const float* colors, const float* opacities,
                  const float* scales, const float* rotations,
                  float* out_color, float* out_depth, int32_t* out_radii,
                  void* workspace, size_t workspace_bytes, uint64_t instance_capacity,
-                 VtgsForwardInfo* info, void* stream);
+                 VtgsForwardInfo* info, uint32_t flags, void* stream);
 
 /* Second render over the SAME geometry (identical cam/means3D/opacities/scales/rotations as the
  * vtgs_forward that filled `workspace`) with other per-Gaussian colours -- the depth/silhouette pass

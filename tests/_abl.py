@@ -4,12 +4,22 @@ from oracle import gs_oracle as go
 from parity_util import to_settings
 import diff_gaussian_rasterization as dgr
 dev=torch.device('cuda:0')
-scene,cam=go.view_tied_scene(1_000_000,1200,680,seed=0)
-leaves={k:v.to(dev) for k,v in scene.items()}
+N=int(os.environ.get('ABL_N','1000000'))
+scene,cam=go.view_tied_scene(N,1200,680,seed=0)
+leaves={k:v.to(dev).requires_grad_(True) for k,v in scene.items()}
 rast=dgr.GaussianRasterizer(raster_settings=to_settings(cam,dev))
+g=torch.rand(3,680,1200,device=dev)
+bwd=os.environ.get('ABL_BWD','1')=='1'
+def step():
+    c,r,d=rast(**leaves)
+    if bwd: c.backward(g)
+for it in range(5): step()
+torch.cuda.synchronize()
 dgr.profile_enable(True)
-for it in range(6):
-    try: rast(**leaves)
-    except Exception as ex: print('err',ex); break
+for it in range(20): step()
 p=dgr.profile_collect()
-print(os.environ.get('VTGS_LIBRARY','base').split('/')[-1], {k:round(v[0]/v[1]*1e3,1) for k,v in p.items()}, flush=True)
+torch.cuda.synchronize(); t=time.time()
+dgr.profile_enable(False)
+for it in range(20): step()
+torch.cuda.synchronize(); dt=(time.time()-t)/20*1e3
+print(os.environ.get('ABL_TAG',''), 'step %.3f ms'%dt, {k:round(v[0]/v[1]*1e3,1) for k,v in p.items()}, flush=True)

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_version_strings_and_sizes(lib):
     lib.vtgs_abi_version.restype = ctypes.c_uint32
-    assert lib.vtgs_abi_version() == 1
+    assert lib.vtgs_abi_version() == 2
     lib.vtgs_strerror.restype = ctypes.c_char_p
     assert lib.vtgs_strerror(0) == b"ok" and b"instance" in lib.vtgs_strerror(3)
     lib.vtgs_workspace_bytes.restype = ctypes.c_size_t
@@ -50,7 +50,7 @@ def test_version_strings_and_sizes(lib):
 
 
 def test_invalid_arguments_are_rejected_before_any_device_work(lib):
-    assert lib.vtgs_forward(None, 0, *([None] * 9), ctypes.c_size_t(0), ctypes.c_uint64(1), None, None) == 1
+    assert lib.vtgs_forward(None, 0, *([None] * 9), ctypes.c_size_t(0), ctypes.c_uint64(1), None, 0, None) == 1
     assert lib.vtgs_mark_visible(None, 0, None, None, None) == 1
     out = (ctypes.c_uint64 * 8)()
     lib.vtgs_debug_layout.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]

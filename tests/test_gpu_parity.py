@@ -149,3 +149,32 @@ def test_known_answers_on_device(gpu_device):
     c, r, d = render(m, torch.full((3, 3), 0.2), torch.tensor([[1.0], [0.9], [1.0]]),
                      torch.tensor([[1.0, 0, 0], [0.0, 1.0, 0], [0.0, 0, 1.0]]))
     assert float(c[2, cy, cx]) == 0.0 and abs(float(c[1, cy, cx]) - 0.009) < 1e-6
+
+
+def test_capacity_overflow_sync_retry_and_async_detection(gpu_device):
+    """Big splats => far more (Gaussian, tile) instances than the first capacity guess.  The synchronous forward
+    retries transparently; an asynchronous forward whose capacity was too small must fail LOUDLY at backward."""
+    import diff_gaussian_rasterization as dgr
+    from parity_util import to_settings
+    n, W, H = 200, 320, 240
+    scene, cam = go.random_scene(n, W, H, seed=31, anisotropic=False)
+    scene["scales"] = torch.full((n, 3), 0.6)                       # ~100 px radius at z ~ 3
+    scene["means3D"][:, 2] = scene["means3D"][:, 2].abs() + 1.0
+    ref_c, _, ref_d, _, aux = run_oracle(scene, cam)
+    dev = gpu_device
+    leaves = {k: v.to(dev).requires_grad_(True) for k, v in scene.items()}
+    st = to_settings(cam, dev)
+    dgr._capacity_hint.clear()
+    c, r, d = dgr.GaussianRasterizer(raster_settings=st)(**leaves)             # first call: synchronous, retries
+    info = dgr.last_forward_info()
+    assert info["instances"] > 8 * n + 65536 or info["instances"] > 4 * n + 4096
+    _check_images(ref_c, ref_d, c.detach().cpu(), d.detach().cpu())
+    key = next(iter(dgr._capacity_hint))
+    dgr._capacity_hint[key] = 10                                                  # poison the hint -> capacity too small
+    c2, _, _ = dgr.GaussianRasterizer(raster_settings=st)(**leaves)             # asynchronous: returns without checking
+    with pytest.raises(RuntimeError, match="did not fit"):
+        c2.sum().backward()
+    assert dgr._capacity_hint[key] == info["instances"]                          # hint repaired from the result record
+    c3, _, _ = dgr.GaussianRasterizer(raster_settings=st)(**leaves)
+    c3.sum().backward()
+    _check_images(ref_c, ref_d, c3.detach().cpu(), d.detach().cpu())

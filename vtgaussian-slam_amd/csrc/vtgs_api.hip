@@ -15,6 +15,7 @@ __global__ void scan_tiles(const uint32_t*, uint32_t*, uint32_t, Counters*, unsi
 __global__ void scatter_instances(const InstTmp*, const uint32_t*, unsigned long long*, uint32_t*, const Counters*);
 __global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
                            const Counters*);
+template <int WAVES, int UNROLL>
 __global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*,
                                   const float*, float*, float*, float*, const Counters*);
 __global__ void composite_backward(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
@@ -116,15 +117,35 @@ size_t vtgs_backward_scratch_bytes(int32_t n, uint64_t instances) {
   return align256((size_t)(instances ? instances : 1) * kGradRec * sizeof(float));
 }
 
+#include <stdlib.h>
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs, int rows16, const WsLayout& L,
                                     char* ws, const float* colors, float* out_color, float* out_depth,
                                     float* image_state, hipStream_t st) {
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   const uint32_t nblk16 = (uint32_t)(gx16 * rows16);
-  { ProfScope ps__("composite_forward", st); hipLaunchKernelGGL(composite_forward, dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
-                     (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid),
-                     (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
-                     (const Counters*)(ws + L.counters)); }
+  static const int waves = env_int("VTGS_FWD_WAVES", 4), unroll = env_int("VTGS_FWD_UNROLL", 1);
+#define VTGS_FWD_ARGS cs, cam->bg, nblk, (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid), \
+                      (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state, (const Counters*)(ws + L.counters)
+  {
+    ProfScope ps__("composite_forward", st);
+    if (waves == 4) {
+      const uint32_t nblk = nblk16;
+      if (unroll == 4) hipLaunchKernelGGL((composite_forward<4, 4>), dim3(nblk), dim3(256), 0, st, VTGS_FWD_ARGS);
+      else if (unroll == 2) hipLaunchKernelGGL((composite_forward<4, 2>), dim3(nblk), dim3(256), 0, st, VTGS_FWD_ARGS);
+      else hipLaunchKernelGGL((composite_forward<4, 1>), dim3(nblk), dim3(256), 0, st, VTGS_FWD_ARGS);
+    } else {
+      const uint32_t nblk = nblk16 * 4u;
+      if (unroll == 4) hipLaunchKernelGGL((composite_forward<1, 4>), dim3(nblk), dim3(64), 0, st, VTGS_FWD_ARGS);
+      else if (unroll == 2) hipLaunchKernelGGL((composite_forward<1, 2>), dim3(nblk), dim3(64), 0, st, VTGS_FWD_ARGS);
+      else hipLaunchKernelGGL((composite_forward<1, 1>), dim3(nblk), dim3(64), 0, st, VTGS_FWD_ARGS);
+    }
+  }
+#undef VTGS_FWD_ARGS
   VTGS_HIP(hipGetLastError());
   return VTGS_OK;
 }
@@ -132,7 +153,7 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
 int vtgs_forward(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* opacities,
                  const float* scales, const float* rotations, float* out_color, float* out_depth, int32_t* out_radii,
                  void* workspace, size_t workspace_bytes, uint64_t instance_capacity, VtgsForwardInfo* info,
-                 void* stream) {
+                 uint32_t flags, void* stream) {
   if (!cam_ok(cam) || n < 0 || !out_color || !out_depth || !workspace || instance_capacity == 0 ||
       instance_capacity > 0xFFFFFFFFull)
     return VTGS_ERR_INVALID_ARGUMENT;
@@ -177,32 +198,19 @@ int vtgs_forward(const VtgsCamera* cam, int32_t n, const float* means3D, const f
   int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st);
   if (rc != VTGS_OK) return rc;
 
-  // stamp the workspace and read the counters back (the only host synchronisation of the library)
-  Counters stamp;
-  memset(&stamp, 0, sizeof(stamp));
-  stamp.magic = kMagicDone; stamp.n = (uint32_t)n;
-  stamp.width = (uint32_t)cam->image_width; stamp.height = (uint32_t)cam->image_height;
-  stamp.capacity_lo = (uint32_t)instance_capacity; stamp.capacity_hi = (uint32_t)(instance_capacity >> 32);
-  stamp.row8_begin = (uint32_t)r8b; stamp.row8_end = (uint32_t)r8e;
-  const size_t tail = offsetof(Counters, magic);
-  VTGS_HIP(hipMemcpyAsync((char*)ctr + tail, (char*)&stamp + tail, sizeof(Counters) - tail, hipMemcpyHostToDevice, st));
-  Counters host;
-  VTGS_HIP(hipMemcpyAsync(&host, ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+  // result record: assembled on the device by scan_tiles at byte 64 of the counters block
+  static_assert(sizeof(VtgsForwardInfo) == 40, "VtgsForwardInfo layout is mirrored in Counters");
+  const char* image = (const char*)ctr + offsetof(Counters, info_instances);
+  if (flags & VTGS_FORWARD_ASYNC) {
+    if (!info) return VTGS_ERR_INVALID_ARGUMENT;
+    VTGS_HIP(hipMemcpyAsync(info, image, sizeof(VtgsForwardInfo), hipMemcpyDeviceToHost, st));
+    return VTGS_OK;
+  }
+  VtgsForwardInfo host;
+  VTGS_HIP(hipMemcpyAsync(&host, image, sizeof(VtgsForwardInfo), hipMemcpyDeviceToHost, st));
   VTGS_HIP(hipStreamSynchronize(st));
-  if (info) {
-    info->instances = host.overflow ? 0 : host.inst_total;
-    info->instances_needed = host.inst_total;
-    info->tiles16_touched = host.r16;
-    info->visible = host.visible;
-    info->max_tile_list = host.max_list;
-  }
-  if (host.overflow) {
-    uint32_t zero = 0;   // a failed forward must not look complete
-    VTGS_HIP(hipMemcpyAsync((char*)ctr + tail, &zero, 4, hipMemcpyHostToDevice, st));
-    VTGS_HIP(hipStreamSynchronize(st));
-    return VTGS_ERR_INSTANCE_OVERFLOW;
-  }
-  return VTGS_OK;
+  if (info) *info = host;
+  return host.overflow ? VTGS_ERR_INSTANCE_OVERFLOW : VTGS_OK;
 }
 
 int vtgs_forward_shared(const VtgsCamera* cam, int32_t n, const float* colors, float* out_color, float* out_depth,

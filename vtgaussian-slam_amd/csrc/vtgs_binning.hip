@@ -188,8 +188,12 @@ __global__ __launch_bounds__(1024) void scan_tiles(const uint32_t* __restrict__ 
   if (t == 0) {
     uint32_t m = 0, v = 0; unsigned long long r = 0;
     for (int i = 0; i < 16; ++i) { m = max(m, wmax[i]); v += svis[i]; r += sr16[i]; }
-    ctr->max_list = m; ctr->visible = v; ctr->r16 = r;
-    ctr->overflow = ((unsigned long long)ctr->inst_total > capacity) ? 1u : 0u;
+    const uint32_t total = ctr->inst_total;
+    const uint32_t ovf = ((unsigned long long)total > capacity) ? 1u : 0u;
+    ctr->overflow = ovf;
+    ctr->info_instances = ovf ? 0ull : (unsigned long long)total;
+    ctr->info_needed = total; ctr->info_r16 = r;
+    ctr->info_visible = v; ctr->info_max_list = m; ctr->info_overflow = ovf; ctr->info_complete = 1u;
   }
 }
 

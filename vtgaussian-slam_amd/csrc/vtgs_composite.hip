@@ -49,13 +49,23 @@ __device__ __forceinline__ ChunkRec gather_chunk(const uint32_t* __restrict__ so
 // tile -> wavefront mapping shared by forward and backward
 struct TileCoord { int tile, px, py; bool tile_ok, inside; };
 
-__device__ __forceinline__ TileCoord tile_coord(const CamScalars& cs, uint32_t nblk16, int gx16, int gx8, int gy8) {
-  const uint32_t b = xcd_swizzle(blockIdx.x, nblk16);
-  const int row16_0 = cs.row8_begin >> 1;
-  const int t16x = (int)(b % (uint32_t)gx16), t16y = row16_0 + (int)(b / (uint32_t)gx16);
-  // the wavefront index is wave-uniform; saying so keeps list bounds and readlane selects in SGPRs
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = lane_id();
-  const int t8x = 2 * t16x + (w & 1), t8y = 2 * t16y + (w >> 1);
+template <int WAVES>
+__device__ __forceinline__ TileCoord tile_coord(const CamScalars& cs, uint32_t nblk, int gx16, int gx8, int gy8) {
+  const uint32_t b = xcd_swizzle(blockIdx.x, nblk);
+  const int l = lane_id();
+  int t8x, t8y;
+  if (WAVES == 4) {          // workgroup = the 2x2 tiles of one 16x16 block
+    const int row16_0 = cs.row8_begin >> 1;
+    const int t16x = (int)(b % (uint32_t)gx16), t16y = row16_0 + (int)(b / (uint32_t)gx16);
+    // the wavefront index is wave-uniform; saying so keeps list bounds and readlane selects in SGPRs
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    t8x = 2 * t16x + (w & 1); t8y = 2 * t16y + (w >> 1);
+  } else {                   // workgroup = one wavefront = one 8x8 tile; blocks walk 2x2 groups so neighbours stay close
+    const uint32_t g = b >> 2, q = b & 3u;
+    const int row16_0 = cs.row8_begin >> 1;
+    const int t16x = (int)(g % (uint32_t)gx16), t16y = row16_0 + (int)(g / (uint32_t)gx16);
+    t8x = 2 * t16x + (int)(q & 1u); t8y = 2 * t16y + (int)(q >> 1);
+  }
   TileCoord tc;
   tc.tile_ok = t8x < gx8 && t8y < gy8 && t8y >= cs.row8_begin && t8y < cs.row8_end;
   tc.tile = t8y * gx8 + t8x;
@@ -65,8 +75,9 @@ __device__ __forceinline__ TileCoord tile_coord(const CamScalars& cs, uint32_t n
   return tc;
 }
 
-__global__ __launch_bounds__(256) void composite_forward(
-    CamScalars cs, const float* __restrict__ bg, uint32_t nblk16,
+template <int WAVES, int UNROLL>
+__global__ __launch_bounds__(64 * WAVES) void composite_forward(
+    CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
     const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ sorted_gid,
     const GeomRec* __restrict__ geom, const float* __restrict__ colors,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
@@ -74,7 +85,7 @@ __global__ __launch_bounds__(256) void composite_forward(
   if (ctr->overflow) return;
   const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
   const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
-  const TileCoord tc = tile_coord(cs, nblk16, gx16, gx8, gy8);
+  const TileCoord tc = tile_coord<WAVES>(cs, nblk, gx16, gx8, gy8);
   if (!tc.tile_ok) return;                       // wave-uniform
   const int l = lane_id();
   const float pxf = (float)tc.px, pyf = (float)tc.py;
@@ -85,24 +96,34 @@ __global__ __launch_bounds__(256) void composite_forward(
   for (uint32_t base = s; base < e; base += 64u) {
     if (__ballot(!done) == 0ull) break;
     const int n = (int)min(64u, e - base);
-    const ChunkRec r = gather_chunk(sorted_gid, geom, colors, base + (uint32_t)l, l < n);
-    for (int j = 0; j < n; ++j) {
-      const float su = bcast_f(r.u, j), sv = bcast_f(r.v, j);
-      const float sa = bcast_f(r.qa, j), sb = bcast_f(r.qb, j), sc = bcast_f(r.qc, j);
-      const float so = bcast_f(r.op, j);
-      const float dx = su - pxf, dy = sv - pyf;
-      const float p2 = dx * (sa * dx + sb * dy) + sc * dy * dy;
-      const float alpha = fminf(kAlphaMax, so * __builtin_amdgcn_exp2f(p2));
-      const float Tn = T * (1.f - alpha);
-      bool hit = !done && p2 <= 0.f && alpha >= kAlphaMin;
-      if (hit && Tn < kTStop) { done = true; hit = false; }
-      if (__ballot(hit) != 0ull) {               // wave-uniform: nobody adds this splat -> skip colour reads
-        const float wgt = hit ? alpha * T : 0.f;
-        C0 = fmaf(bcast_f(r.c0, j), wgt, C0);
-        C1 = fmaf(bcast_f(r.c1, j), wgt, C1);
-        C2 = fmaf(bcast_f(r.c2, j), wgt, C2);
-        D = fmaf(bcast_f(r.depth, j), wgt, D);
-        T = hit ? Tn : T;
+    const ChunkRec r = gather_chunk(sorted_gid, geom, colors, base + (uint32_t)l, l < n);   // lanes >= n hold op = 0
+    for (int j = 0; j < n; j += UNROLL) {
+      // phase 1: alpha of UNROLL splats -- independent chains (readlane -> exp), no dependence on T
+      float alpha[UNROLL];
+      bool pm[UNROLL];
+#pragma unroll
+      for (int q = 0; q < UNROLL; ++q) {
+        const int jq = min(j + q, 63);          // past-the-end slots read a zero-opacity record
+        const float dx = bcast_f(r.u, jq) - pxf, dy = bcast_f(r.v, jq) - pyf;
+        const float p2 = dx * (bcast_f(r.qa, jq) * dx + bcast_f(r.qb, jq) * dy) + bcast_f(r.qc, jq) * dy * dy;
+        alpha[q] = fminf(kAlphaMax, bcast_f(r.op, jq) * __builtin_amdgcn_exp2f(p2));
+        pm[q] = p2 <= 0.f && alpha[q] >= kAlphaMin && (UNROLL == 1 || j + q < n);
+      }
+      // phase 2: transmittance is sequential
+#pragma unroll
+      for (int q = 0; q < UNROLL; ++q) {
+        const int jq = min(j + q, 63);
+        const float Tn = T * (1.f - alpha[q]);
+        bool hit = !done && pm[q];
+        if (hit && Tn < kTStop) { done = true; hit = false; }
+        if (__ballot(hit) != 0ull) {             // wave-uniform: nobody adds this splat -> skip colour reads
+          const float wgt = hit ? alpha[q] * T : 0.f;
+          C0 = fmaf(bcast_f(r.c0, jq), wgt, C0);
+          C1 = fmaf(bcast_f(r.c1, jq), wgt, C1);
+          C2 = fmaf(bcast_f(r.c2, jq), wgt, C2);
+          D = fmaf(bcast_f(r.depth, jq), wgt, D);
+          T = hit ? Tn : T;
+        }
       }
     }
   }
@@ -115,6 +136,12 @@ __global__ __launch_bounds__(256) void composite_forward(
     final_T[pix] = T;
   }
 }
+template __global__ void composite_forward<4, 1>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
+template __global__ void composite_forward<4, 2>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
+template __global__ void composite_forward<4, 4>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
+template __global__ void composite_forward<1, 1>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
+template __global__ void composite_forward<1, 2>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
+template __global__ void composite_forward<1, 4>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
 
 // ---------------------------------------------------------------------------------------------------
 // Backward composite.  Pixel-major replay produces, per (splat k, pixel p), two scalars:
@@ -142,7 +169,7 @@ __global__ __launch_bounds__(256) void composite_backward(
   __shared__ float lds[4][2][16 * kRowStride];
   const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
   const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
-  const TileCoord tc = tile_coord(cs, nblk16, gx16, gx8, gy8);
+  const TileCoord tc = tile_coord<4>(cs, nblk16, gx16, gx8, gy8);
   if (!tc.tile_ok) return;
   const int l = lane_id();
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -26,16 +26,12 @@ namespace vtgs {
 struct Counters {
   uint32_t inst_total;      // instances requested (keeps counting past capacity)
   uint32_t overflow;        // set by the tile scan when inst_total > capacity
-  uint32_t visible;
-  uint32_t max_list;
-  unsigned long long r16;   // sum of 16x16 tiles in the splat rectangles (statistic, SURVEY 8d "R")
-  uint32_t magic;           // kMagicDone once a forward has completed on this workspace
-  uint32_t n;
-  uint32_t width, height;
-  uint32_t capacity_lo, capacity_hi;
-  uint32_t row8_begin, row8_end;
+  uint32_t pad[14];
+  // byte 64: image of the public VtgsForwardInfo, written by scan_tiles, copied to the host by vtgs_forward
+  unsigned long long info_instances, info_needed, info_r16;
+  uint32_t info_visible, info_max_list, info_overflow, info_complete;
 };
-constexpr uint32_t kMagicDone = 0x56544753u;  // "VTGS"
+static_assert(sizeof(Counters) <= 256, "counters block");
 
 struct alignas(16) GeomRec {   // 32 bytes
   float u, v;                  // pixel centre

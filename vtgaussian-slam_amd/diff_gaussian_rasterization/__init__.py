@@ -39,7 +39,8 @@ class _VtgsCamera(ctypes.Structure):
 
 class _VtgsForwardInfo(ctypes.Structure):
     _fields_ = [("instances", ctypes.c_uint64), ("instances_needed", ctypes.c_uint64),
-                ("tiles16_touched", ctypes.c_uint64), ("visible", ctypes.c_uint32), ("max_tile_list", ctypes.c_uint32)]
+                ("tiles16_touched", ctypes.c_uint64), ("visible", ctypes.c_uint32), ("max_tile_list", ctypes.c_uint32),
+                ("overflow", ctypes.c_uint32), ("complete", ctypes.c_uint32)]
 
 
 class _VtgsProfileEntry(ctypes.Structure):
@@ -48,7 +49,8 @@ class _VtgsProfileEntry(ctypes.Structure):
 
 
 VTGS_OK, VTGS_ERR_INSTANCE_OVERFLOW = 0, 3
-ABI_VERSION = 1
+ABI_VERSION = 2
+VTGS_FORWARD_SYNC, VTGS_FORWARD_ASYNC = 0, 1
 _P, _U64, _I32, _SZ = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
 
 _SIGNATURES = {
@@ -58,7 +60,7 @@ _SIGNATURES = {
     "vtgs_workspace_bytes": (_SZ, [_I32, _I32, _I32, _U64]),
     "vtgs_backward_scratch_bytes": (_SZ, [_I32, _U64]),
     "vtgs_forward": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _U64,
-                                    ctypes.POINTER(_VtgsForwardInfo), _P]),
+                                    _P, ctypes.c_uint32, _P]),
     "vtgs_forward_shared": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _SZ, _U64, _P, _P]),
     "vtgs_backward": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _U64, _P,
                                      _P, _SZ, _P, _P, _P, _P, _P, _P, _P]),
@@ -171,10 +173,63 @@ def _require(t: torch.Tensor, name: str, shape_tail: int, n: int, device) -> tor
 
 
 class _ForwardState:
-    __slots__ = ("cam", "n", "workspace", "capacity", "instances", "image_state")
+    __slots__ = ("cam", "n", "workspace", "capacity", "instances", "image_state", "pending", "key")
 
 
-def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations):
+class _PinnedInfoRing:
+    """Pinned host slots for the asynchronous result record of vtgs_forward (one 64-byte slot per in-flight
+    forward) + the HIP event that says the record has landed."""
+    SLOTS = 64
+
+    def __init__(self):
+        self.buf = torch.zeros((self.SLOTS, 64), dtype=torch.uint8).pin_memory()
+        self.events = [None] * self.SLOTS
+        self.next = 0
+
+    def take(self):
+        i = self.next
+        self.next = (i + 1) % self.SLOTS
+        if self.events[i] is not None:           # a slot is only reused once its previous record has landed
+            self.events[i].synchronize()
+        self.buf[i].zero_()
+        return i
+
+    def info(self, i) -> _VtgsForwardInfo:
+        return _VtgsForwardInfo.from_buffer_copy(bytes(self.buf[i][:ctypes.sizeof(_VtgsForwardInfo)].numpy()))
+
+
+_ring = None
+_ASYNC_DEFAULT = os.environ.get("VTGS_SYNC_FORWARD", "0") != "1"
+
+
+def _record_info(key, n, W, H, capacity, info):
+    _capacity_hint[key] = max(int(info.instances_needed), 1)
+    _last_info.update(instances=int(info.instances), tiles16_touched=int(info.tiles16_touched),
+                      visible=int(info.visible), max_tile_list=int(info.max_tile_list), n=n, width=W, height=H,
+                      capacity=int(capacity))
+
+
+def _resolve_pending(fs: "_ForwardState") -> None:
+    """Wait for the asynchronous result record of a forward and act on it (called before its backward)."""
+    if fs.pending is None:
+        return
+    slot, event = fs.pending
+    event.synchronize()
+    info = _ring.info(slot)
+    fs.pending = None
+    if not info.complete:
+        raise RuntimeError("vtgs_forward: result record never arrived (stream error?)")
+    _record_info(fs.key, fs.n, fs.cam.W, fs.cam.H, fs.capacity, info)
+    if info.overflow:
+        raise RuntimeError(
+            f"vtgs_forward (asynchronous mode): {info.instances_needed} (Gaussian,tile) instances did not fit the "
+            f"workspace capacity {fs.capacity}; the outputs of that forward are invalid. The capacity hint has been "
+            f"raised -- re-run the step (or set VTGS_SYNC_FORWARD=1 to check inside every forward).")
+    fs.instances = int(info.instances)
+
+
+def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, want_async: bool):
+    global _ring
     device = means3D.device
     n = means3D.shape[0]
     H, W = cam.H, cam.W
@@ -184,14 +239,34 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations):
     key = (device.index, n, W, H, cam.band)
     hint = _capacity_hint.get(key, 0)
     capacity = max(int(hint * 1.25) + 4096, 4 * n + 4096) if hint else 8 * n + 65536
+    # the first forward of a shape has no instance-count history: check it synchronously
+    use_async = want_async and _ASYNC_DEFAULT and hint > 0
+    fs = _ForwardState()
+    fs.cam, fs.n, fs.image_state, fs.pending, fs.key = cam, n, None, None, key
+    if use_async:
+        if _ring is None:
+            _ring = _PinnedInfoRing()
+        nbytes = _lib.vtgs_workspace_bytes(n, W, H, capacity)
+        workspace = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        slot = _ring.take()
+        st = _lib.vtgs_forward(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
+                               scales.data_ptr(), rotations.data_ptr(), color.data_ptr(), depth.data_ptr(),
+                               radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, _ring.buf[slot].data_ptr(),
+                               VTGS_FORWARD_ASYNC, _stream_ptr(device))
+        _check(st, "vtgs_forward")
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        _ring.events[slot] = ev
+        fs.workspace, fs.capacity, fs.instances, fs.pending = workspace, capacity, None, (slot, ev)
+        return color, radii, depth, fs
     info = _VtgsForwardInfo()
     for _attempt in range(3):
         nbytes = _lib.vtgs_workspace_bytes(n, W, H, capacity)
         workspace = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         st = _lib.vtgs_forward(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
                                scales.data_ptr(), rotations.data_ptr(), color.data_ptr(), depth.data_ptr(),
-                               radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, ctypes.byref(info),
-                               _stream_ptr(device))
+                               radii.data_ptr(), workspace.data_ptr(), nbytes, capacity,
+                               ctypes.addressof(info), VTGS_FORWARD_SYNC, _stream_ptr(device))
         if st == VTGS_ERR_INSTANCE_OVERFLOW:
             capacity = int(info.instances_needed * 1.25) + 4096
             continue
@@ -199,12 +274,8 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations):
         break
     else:
         raise RuntimeError("vtgs_forward: instance capacity kept overflowing")
-    _capacity_hint[key] = int(info.instances)
-    _last_info.update(instances=int(info.instances), tiles16_touched=int(info.tiles16_touched),
-                      visible=int(info.visible), max_tile_list=int(info.max_tile_list), n=n, width=W, height=H,
-                      capacity=int(capacity))
-    fs = _ForwardState()
-    fs.cam, fs.n, fs.workspace, fs.capacity, fs.instances, fs.image_state = cam, n, workspace, capacity, int(info.instances), None
+    _record_info(key, n, W, H, capacity, info)
+    fs.workspace, fs.capacity, fs.instances = workspace, capacity, int(info.instances)
     return color, radii, depth, fs
 
 
@@ -219,6 +290,7 @@ def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotatio
     g_rot = torch.empty((n, 4), dtype=torch.float32, device=device)
     if n == 0:
         return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
+    _resolve_pending(fs)                 # asynchronous forward: its result record is needed (and checked) now
     sbytes = _lib.vtgs_backward_scratch_bytes(n, fs.instances)
     scratch = torch.empty((sbytes,), dtype=torch.uint8, device=device)
     state_ptr = fs.image_state.data_ptr() if fs.image_state is not None else None
@@ -235,6 +307,7 @@ def debug_tile_lists(rasterizer: "GaussianRasterizer"):
     """Test hook: (tile_offsets [tiles8+1] int64, sorted_gid [R] int64, geom [N,8] float32) of the last forward
     of `rasterizer`, copied to the CPU.  8x8 tiles, row-major."""
     fs = rasterizer._last_state
+    _resolve_pending(fs)
     out = (ctypes.c_uint64 * 8)()
     _check(_lib.vtgs_debug_layout(fs.n, fs.cam.W, fs.cam.H, fs.capacity, out), "vtgs_debug_layout")
     ws = fs.workspace
@@ -253,7 +326,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, cam: _Camera,
-                shared_from: Optional[_ForwardState]):
+                shared_from: Optional[_ForwardState], want_async: bool = False):
         device = means3D.device
         n = means3D.shape[0]
         means3D = _require(means3D, "means3D", 3, n, device)
@@ -262,9 +335,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         scales_c = _require(scales, "scales", 3, n, device)
         rot = _require(rotations, "rotations", 4, n, device)
         if shared_from is None:
-            color, radii, depth, fs = _run_forward(cam, means3D, colors, opac, scales_c, rot)
+            color, radii, depth, fs = _run_forward(cam, means3D, colors, opac, scales_c, rot, want_async=want_async)
         else:
             base = shared_from
+            _resolve_pending(base)
             H, W = cam.H, cam.W
             color = torch.empty((3, H, W), dtype=torch.float32, device=device)
             depth = torch.empty((1, H, W), dtype=torch.float32, device=device)
@@ -274,8 +348,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                           base.capacity, state.data_ptr(), _stream_ptr(device))
             _check(st, "vtgs_forward_shared")
             fs = _ForwardState()
-            fs.cam, fs.n, fs.workspace, fs.capacity, fs.instances, fs.image_state = (
-                base.cam, base.n, base.workspace, base.capacity, base.instances, state)
+            fs.cam, fs.n, fs.workspace, fs.capacity, fs.instances, fs.image_state, fs.pending, fs.key = (
+                base.cam, base.n, base.workspace, base.capacity, base.instances, state, None, base.key)
             radii = None
         ctx.fs = fs
         ctx.save_for_backward(means3D, colors, opac, scales_c, rot, color)
@@ -293,7 +367,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         grad_color = grad_color.to(torch.float32).contiguous()
         g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot = _run_backward(
             ctx.fs, means3D, colors, opac, scales_c, rot, color, grad_color)
-        return g_means3D, g_means2D, None, g_colors, g_opac, g_scales, g_rot, None, None, None
+        return g_means3D, g_means2D, None, g_colors, g_opac, g_scales, g_rot, None, None, None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -346,8 +420,12 @@ class GaussianRasterizer(nn.Module):
         if not means3D.is_cuda:
             raise RuntimeError("GaussianRasterizer needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
         cam = _Camera(self.raster_settings, means3D.device, self._rule, self._tile_rows)
+        # Asynchronous forward only when a backward will follow (that is where its result record is checked);
+        # grad mode is off inside autograd.Function.forward, so this is decided here.
+        want_async = torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (means3D, means2D, colors_precomp, opacities, scales, rotations))
         color, radii, depth, fs = _RasterizeGaussians.apply(means3D, means2D, None, colors_precomp, opacities, scales,
-                                                            rotations, None, cam, None)
+                                                            rotations, None, cam, None, want_async)
         self._last_state = fs
         return color, radii, depth
 
