@@ -178,3 +178,29 @@ def test_capacity_overflow_sync_retry_and_async_detection(gpu_device):
     c3, _, _ = dgr.GaussianRasterizer(raster_settings=st)(**leaves)
     c3.sum().backward()
     _check_images(ref_c, ref_d, c3.detach().cpu(), d.detach().cpu())
+
+
+@pytest.mark.parametrize("n,w,h", [(3000, 160, 120), (60000, 152, 104), (40000, 64, 48), (120000, 40, 32)])
+def test_tile_lists_are_exactly_depth_sorted(gpu_device, n, w, h):
+    """Index work is bit-exact: every 8x8 tile's list is ordered by (float32 depth bits, Gaussian id), holds no
+    duplicate, and every (Gaussian, tile) instance is accounted for.  The four shapes walk the sort paths:
+    registers (E = 1..16), LDS (<= 2048) and in-place global (> 2048)."""
+    import diff_gaussian_rasterization as dgr
+    from parity_util import to_settings
+    scene, cam = go.view_tied_scene(n, w, h, seed=n % 97)
+    m = (n // 7 - 1) * 7
+    scene["means3D"][0:m:7, 2] = scene["means3D"][3:m + 3:7, 2]                      # inject exact depth ties
+    dev = gpu_device
+    rast = dgr.GaussianRasterizer(raster_settings=to_settings(cam, dev))
+    with torch.no_grad():
+        rast(**{k: v.to(dev) for k, v in scene.items()})
+    offs, gid, geom = dgr.debug_tile_lists(rast)
+    info = dgr.last_forward_info()
+    assert int(offs[-1]) == info["instances"]
+    lens = offs[1:] - offs[:-1]
+    assert int(lens.max()) == info["max_tile_list"]
+    zbits = geom[:, 6].view(torch.int32).long()
+    key = (zbits[gid] << 32) | gid
+    tile_of = torch.repeat_interleave(torch.arange(lens.numel()), lens)
+    same_tile = tile_of[1:] == tile_of[:-1]
+    assert bool(((key[1:] > key[:-1]) | ~same_tile).all()), "a tile list is not strictly (depth, id)-ordered"

@@ -191,7 +191,7 @@ int vtgs_forward(const VtgsCamera* cam, int32_t n, const float* means3D, const f
                      (const uint32_t*)(ws + L.tile_off), (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals),
                      (const Counters*)ctr); }
   VTGS_HIP(hipGetLastError());
-  { ProfScope ps__("sort_tiles", st); hipLaunchKernelGGL(sort_tiles, dim3(L.tiles8), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_off),
+  { ProfScope ps__("sort_tiles", st); hipLaunchKernelGGL(sort_tiles, dim3((L.tiles8 + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_off),
                      (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
                      (uint32_t*)(ws + L.sorted_inst), L.tiles8, (const Counters*)ctr); }
   VTGS_HIP(hipGetLastError());

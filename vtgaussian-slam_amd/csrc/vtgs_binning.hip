@@ -210,14 +210,96 @@ __global__ __launch_bounds__(256) void scatter_instances(const InstTmp* __restri
   }
 }
 
-// One workgroup per 8x8 tile.  Lists up to kSortLds entries are sorted in LDS; longer ones in place in
-// global memory (L2-resident) with the same network.
+// Per-tile depth sort.  Network: the all-ascending form of the bitonic sorter -- each merge level starts with a
+// mirror step (e <-> e ^ (k2-1)) followed by half-cleaners (e <-> e ^ j).  Every comparator puts the smaller key at
+// the lower index, so a list of any length behaves as if padded with +inf up to the next power of two.
 //
-// Network: the all-ascending form of the bitonic sorter -- each merge level starts with a mirror step
-// (i <-> block_end-1-offset) followed by half-cleaners (i <-> i+j).  Every comparator puts the smaller key
-// at the lower index, so a list of any length L behaves as if padded with +inf up to the next power of
-// two: comparators whose upper index is >= L are no-ops and are simply skipped.
-constexpr int kSortLds = 4096;
+// Fast path (lists <= 1024, i.e. practically all of them): ONE WAVEFRONT PER TILE, keys in registers.  Blocked
+// layout, element e = lane*E + r with E = n2/64 registers per lane: strides below E are in-lane compare-exchanges,
+// strides >= E are lane-xor exchanges (DPP / ds_bpermute), no LDS traffic and no barriers.
+// Slow path (longer lists): the whole workgroup cooperates, in LDS up to kSortLds entries, else in place in global
+// memory (L2-resident) with the same network.
+constexpr int kSortLds = 2048;
+constexpr int kWaveSortMax = 1024;
+
+template <int E>
+__device__ __forceinline__ void wave_sort_regs(unsigned long long (&k)[E], uint32_t (&v)[E], int lane) {
+#pragma unroll
+  for (int k2 = 2; k2 <= 64 * E; k2 <<= 1) {
+    // ---- mirror step: partner = e ^ (k2 - 1)
+    if (k2 <= E) {
+#pragma unroll
+      for (int r = 0; r < E; ++r) {
+        const int p = r ^ (k2 - 1);
+        if (r < p) {
+          const bool sw = k[r] > k[p];
+          const unsigned long long a = k[r], b = k[p];
+          const uint32_t va = v[r], vb = v[p];
+          k[r] = sw ? b : a; k[p] = sw ? a : b; v[r] = sw ? vb : va; v[p] = sw ? va : vb;
+        }
+      }
+    } else {
+      const int M = k2 / E - 1;                                  // lane mask; in-lane index mirrors (E-1-r)
+      const bool lower = (lane & ((M + 1) >> 1)) == 0;
+      unsigned long long pk[E]; uint32_t pv[E];
+#pragma unroll
+      for (int r = 0; r < E; ++r) {
+        pk[r] = (unsigned long long)__shfl_xor((long long)k[E - 1 - r], M, 64);
+        pv[r] = (uint32_t)__shfl_xor((int)v[E - 1 - r], M, 64);
+      }
+#pragma unroll
+      for (int r = 0; r < E; ++r) {
+        const bool take = lower ? (pk[r] < k[r]) : (pk[r] > k[r]);
+        k[r] = take ? pk[r] : k[r]; v[r] = take ? pv[r] : v[r];
+      }
+    }
+    // ---- half-cleaners: partner = e ^ j
+#pragma unroll
+    for (int j = k2 >> 2; j > 0; j >>= 1) {
+      if (j < E) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          if (!(r & j)) {
+            const int p = r | j;
+            const bool sw = k[r] > k[p];
+            const unsigned long long a = k[r], b = k[p];
+            const uint32_t va = v[r], vb = v[p];
+            k[r] = sw ? b : a; k[p] = sw ? a : b; v[r] = sw ? vb : va; v[p] = sw ? va : vb;
+          }
+        }
+      } else {
+        const int m = j / E;
+        const bool lower = (lane & m) == 0;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const unsigned long long pk = (unsigned long long)__shfl_xor((long long)k[r], m, 64);
+          const uint32_t pv = (uint32_t)__shfl_xor((int)v[r], m, 64);
+          const bool take = lower ? (pk < k[r]) : (pk > k[r]);
+          k[r] = take ? pk : k[r]; v[r] = take ? pv : v[r];
+        }
+      }
+    }
+  }
+}
+
+template <int E>
+__device__ __forceinline__ void wave_sort_tile(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                               uint32_t* __restrict__ sorted_gid, uint32_t* __restrict__ sorted_inst,
+                                               uint32_t s, uint32_t L, int lane) {
+  unsigned long long k[E]; uint32_t v[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const uint32_t e = (uint32_t)lane * E + r;
+    k[r] = (e < L) ? keys[s + e] : ~0ull;
+    v[r] = (e < L) ? vals[s + e] : 0u;
+  }
+  wave_sort_regs<E>(k, v, lane);
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const uint32_t e = (uint32_t)lane * E + r;
+    if (e < L) { sorted_gid[s + e] = (uint32_t)k[r]; sorted_inst[s + e] = v[r]; }
+  }
+}
 
 __device__ __forceinline__ void order_pair(unsigned long long* k, uint32_t* v, uint32_t i, uint32_t p) {
   const unsigned long long a = k[i], b = k[p];
@@ -247,6 +329,7 @@ __device__ __forceinline__ void sort_network(unsigned long long* k, uint32_t* v,
   }
 }
 
+// grid = ceil(tiles/4) workgroups of 4 wavefronts; wavefront w of workgroup b owns tile 4*b' + w (b' XCD-swizzled)
 __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ tile_off, unsigned long long* __restrict__ keys,
                                                   uint32_t* __restrict__ vals, uint32_t* __restrict__ sorted_gid,
                                                   uint32_t* __restrict__ sorted_inst, uint32_t tiles,
@@ -254,21 +337,43 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
   __shared__ unsigned long long sk[kSortLds];
   __shared__ uint32_t sv[kSortLds];
   if (ctr->overflow) return;
-  const uint32_t tile = xcd_swizzle(blockIdx.x, tiles);
-  const uint32_t s = tile_off[tile], e = tile_off[tile + 1];
-  const uint32_t L = e - s;
-  if (L == 0) return;
+  const uint32_t nblk = (tiles + 3u) >> 2;
+  const uint32_t b = xcd_swizzle(blockIdx.x, nblk);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = lane_id();
+  {
+    const uint32_t tile = 4u * b + (uint32_t)wv;
+    if (tile < tiles) {
+      const uint32_t s = tile_off[tile], L = tile_off[tile + 1] - s;
+      if (L == 1u) {
+        if (lane == 0) { sorted_gid[s] = (uint32_t)keys[s]; sorted_inst[s] = vals[s]; }
+      } else if (L <= 64u) {
+        if (L) wave_sort_tile<1>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
+      } else if (L <= 128u) wave_sort_tile<2>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
+      else if (L <= 256u) wave_sort_tile<4>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
+      else if (L <= 512u) wave_sort_tile<8>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
+      else if (L <= (uint32_t)kWaveSortMax) wave_sort_tile<16>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
+    }
+  }
+  // long lists: the whole workgroup takes them one at a time (workgroup-uniform control flow)
   const uint32_t t = threadIdx.x;
-  uint32_t n2 = 1;
-  while (n2 < L) n2 <<= 1;
-  if (L <= (uint32_t)kSortLds) {
-    for (uint32_t i = t; i < L; i += 256u) { sk[i] = keys[s + i]; sv[i] = vals[s + i]; }
+  for (uint32_t q = 0; q < 4u; ++q) {
+    const uint32_t tile = 4u * b + q;
+    if (tile >= tiles) break;
+    const uint32_t s = tile_off[tile], L = tile_off[tile + 1] - s;
+    if (L <= (uint32_t)kWaveSortMax) continue;
+    uint32_t n2 = 1;
+    while (n2 < L) n2 <<= 1;
     __syncthreads();
-    sort_network(sk, sv, L, n2, t);
-    for (uint32_t i = t; i < L; i += 256u) { sorted_gid[s + i] = (uint32_t)sk[i]; sorted_inst[s + i] = sv[i]; }
-  } else {
-    sort_network(keys + s, vals + s, L, n2, t);   // __syncthreads() orders the workgroup's global accesses
-    for (uint32_t i = t; i < L; i += 256u) { sorted_gid[s + i] = (uint32_t)keys[s + i]; sorted_inst[s + i] = vals[s + i]; }
+    if (L <= (uint32_t)kSortLds) {
+      for (uint32_t i = t; i < L; i += 256u) { sk[i] = keys[s + i]; sv[i] = vals[s + i]; }
+      __syncthreads();
+      sort_network(sk, sv, L, n2, t);
+      for (uint32_t i = t; i < L; i += 256u) { sorted_gid[s + i] = (uint32_t)sk[i]; sorted_inst[s + i] = sv[i]; }
+    } else {
+      sort_network(keys + s, vals + s, L, n2, t);   // __syncthreads() orders the workgroup's global accesses
+      for (uint32_t i = t; i < L; i += 256u) { sorted_gid[s + i] = (uint32_t)keys[s + i]; sorted_inst[s + i] = vals[s + i]; }
+    }
   }
 }
 
