@@ -15,6 +15,9 @@ __global__ void scan_tiles(const uint32_t*, uint32_t*, uint32_t, Counters*, unsi
 __global__ void scatter_instances(const InstTmp*, const uint32_t*, unsigned long long*, uint32_t*, const Counters*);
 __global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
                            const Counters*);
+template <int WAVES>
+__global__ void composite_forward_mx(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*,
+                                     const float*, float*, float*, float*, const Counters*);
 template <int WAVES, int UNROLL>
 __global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*,
                                   const float*, float*, float*, float*, const Counters*);
@@ -129,11 +132,15 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   const uint32_t nblk16 = (uint32_t)(gx16 * rows16);
   static const int waves = env_int("VTGS_FWD_WAVES", 4), unroll = env_int("VTGS_FWD_UNROLL", 1);
+  static const int impl = env_int("VTGS_FWD_IMPL", 1);     // 1 = matrix-core form, 0 = scalar (readlane) form
 #define VTGS_FWD_ARGS cs, cam->bg, nblk, (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid), \
                       (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state, (const Counters*)(ws + L.counters)
   {
     ProfScope ps__("composite_forward", st);
-    if (waves == 4) {
+    if (impl == 1) {
+      if (waves == 4) { const uint32_t nblk = nblk16; hipLaunchKernelGGL((composite_forward_mx<4>), dim3(nblk), dim3(256), 0, st, VTGS_FWD_ARGS); }
+      else { const uint32_t nblk = nblk16 * 4u; hipLaunchKernelGGL((composite_forward_mx<1>), dim3(nblk), dim3(64), 0, st, VTGS_FWD_ARGS); }
+    } else if (waves == 4) {
       const uint32_t nblk = nblk16;
       if (unroll == 4) hipLaunchKernelGGL((composite_forward<4, 4>), dim3(nblk), dim3(256), 0, st, VTGS_FWD_ARGS);
       else if (unroll == 2) hipLaunchKernelGGL((composite_forward<4, 2>), dim3(nblk), dim3(256), 0, st, VTGS_FWD_ARGS);

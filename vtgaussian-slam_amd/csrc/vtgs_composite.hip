@@ -144,6 +144,227 @@ template __global__ void composite_forward<1, 2>(CamScalars, const float*, uint3
 template __global__ void composite_forward<1, 4>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
 
 // ---------------------------------------------------------------------------------------------------
+// Forward composite, matrix-core form ("mx").
+//
+// exponent[pixel p, splat k] = log2(alpha_unclamped) = sum_m K_m(k) * Phi_m(p) is bilinear of rank 6:
+//     Phi = (1, X, Y, X^2, XY, Y^2)  with X,Y = pixel - tile centre
+//     K   = (qa sx^2 + qb sx sy + qc sy^2 + log2 o,  -2 qa sx - qb sy,  -2 qc sy - qb sx,  qa, qb, qc),  s = splat centre - tile centre
+// so 64 pixels x 16 splats come out of SIX v_mfma_f32_16x16x1_4b_f32 (4 blocks of 16x16, exact f32 fma chains).
+// With cbsz=2/abid=b the A operand of all four blocks is taken from lanes 16b..16b+15: those lanes' OWN coefficient
+// registers (lane L of the wavefront gathered splat L of the 64-chunk) -- no broadcast instruction at all.
+// B is each lane's own pixel monomials (lane L <-> pixel L of the 8x8 tile), constant for the tile.
+// Result layout (measured, tests/micro/mfma_layout.hip): lane (j = L&15, q = L>>4), register 4*blk + r holds
+//     pixel 16*blk + j,  splat 16*b + 4*q + r.
+// Each lane therefore owns 4 pixels x 4 splats per batch; the per-splat payload (colour, depth) is read per quad
+// from LDS, the transmittance is chained across the four quad-lanes of a pixel with one LDS exchange per batch
+// (T_in = T_batch * prod of the earlier quads' local products), colour sums stay per lane and are reduced across
+// the quad-lanes once per tile.  The stop rule T(1-alpha) < 1e-4 is evaluated exactly on a wave-uniform slow path
+// that is taken only for batches in which some pixel's transmittance actually crosses 1e-4.
+// The `power > 0` skip of the scalar form cannot trigger for a positive-definite conic and is not evaluated here
+// (the exponent carries ~1e-5 absolute rounding from the expansion; alpha is still clamped to 0.99).
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct MxSplat {           // what lane L holds for splat L of the current 64-chunk
+  float K[6];
+  float4 pay;              // c0 c1 c2 depth
+};
+
+__device__ __forceinline__ MxSplat mx_gather(const uint32_t* __restrict__ sorted_gid, const GeomRec* __restrict__ geom,
+                                             const float* __restrict__ colors, uint32_t pos, bool in, float cx, float cy) {
+  MxSplat m;
+  m.K[0] = -1e30f; m.K[1] = m.K[2] = m.K[3] = m.K[4] = m.K[5] = 0.f;
+  m.pay = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (in) {
+    const uint32_t gid = sorted_gid[pos];
+    const float4* gp = reinterpret_cast<const float4*>(geom + gid);
+    const float4 g0 = gp[0], g1 = gp[1];
+    const float sx = g0.x - cx, sy = g0.y - cy;
+    const float qa = -0.5f * kLog2e * g0.z, qb = -kLog2e * g0.w, qc = -0.5f * kLog2e * g1.x;
+    m.K[0] = qa * sx * sx + qb * sx * sy + qc * sy * sy + __log2f(g1.y);
+    m.K[1] = -2.f * qa * sx - qb * sy;
+    m.K[2] = -2.f * qc * sy - qb * sx;
+    m.K[3] = qa; m.K[4] = qb; m.K[5] = qc;
+    m.pay = make_float4(colors[3 * gid], colors[3 * gid + 1], colors[3 * gid + 2], g1.z);
+  }
+  return m;
+}
+
+template <int B>
+__device__ __forceinline__ f32x16 mx_exponents(const float (&K)[6], const float (&Phi)[6]) {
+  f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < 6; ++m) d = __builtin_amdgcn_mfma_f32_16x16x1f32(K[m], Phi[m], d, 2, B, 0);
+  return d;
+}
+
+struct MxFwdState {
+  float Tb[4];             // transmittance of pixel (blk, j) at the start of the batch; 0 = finished (replicated over q)
+  float Tfin[4];           // set by the lane that stopped the pixel: T before the stopping splat
+  float C[4][4];           // this lane's share of colour (3) + depth sums of pixel (blk, j)
+};
+
+template <int B>
+__device__ __forceinline__ void mx_forward_batch(MxFwdState& st, const float (&K)[6], const float (&Phi)[6],
+                                                 const float4* __restrict__ lds_pay, float4* __restrict__ lds_xch,
+                                                 int l) {
+  const int j = l & 15, q = l >> 4;
+  const f32x16 d = mx_exponents<B>(K, Phi);
+  float4 pay[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pay[r] = lds_pay[16 * B + 4 * q + r];
+  float a[4][4], pl[4][4];
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float al = fminf(kAlphaMax, __builtin_amdgcn_exp2f(d[4 * blk + r]));
+      a[blk][r] = (al >= kAlphaMin) ? al : 0.f;
+    }
+    pl[blk][0] = 1.f - a[blk][0];
+    pl[blk][1] = pl[blk][0] * (1.f - a[blk][1]);
+    pl[blk][2] = pl[blk][1] * (1.f - a[blk][2]);
+    pl[blk][3] = pl[blk][2] * (1.f - a[blk][3]);
+  }
+  lds_xch[l] = make_float4(pl[0][3], pl[1][3], pl[2][3], pl[3][3]);
+  const float4 P0 = lds_xch[j], P1 = lds_xch[16 + j], P2 = lds_xch[32 + j], P3 = lds_xch[48 + j];
+  const float p0[4] = {P0.x, P0.y, P0.z, P0.w}, p1[4] = {P1.x, P1.y, P1.z, P1.w};
+  const float p2[4] = {P2.x, P2.y, P2.z, P2.w}, p3[4] = {P3.x, P3.y, P3.z, P3.w};
+  float Tin[4], Tend[4];
+  bool cross = false;
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    const float e1 = p0[blk], e2 = e1 * p1[blk], e3 = e2 * p2[blk];
+    const float pre = (q == 0) ? 1.f : (q == 1) ? e1 : (q == 2) ? e2 : e3;
+    Tin[blk] = st.Tb[blk] * pre;
+    Tend[blk] = st.Tb[blk] * (e3 * p3[blk]);
+    cross = cross || (st.Tb[blk] > 0.f && Tend[blk] < kTStop);
+  }
+  if (__ballot(cross) == 0ull) {
+    // no pixel of the tile reaches the stop threshold inside this batch
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      const float t0 = Tin[blk], t1 = t0 * pl[blk][0], t2 = t0 * pl[blk][1], t3 = t0 * pl[blk][2];
+      const float w[4] = {a[blk][0] * t0, a[blk][1] * t1, a[blk][2] * t2, a[blk][3] * t3};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st.C[blk][0] = fmaf(w[r], pay[r].x, st.C[blk][0]);
+        st.C[blk][1] = fmaf(w[r], pay[r].y, st.C[blk][1]);
+        st.C[blk][2] = fmaf(w[r], pay[r].z, st.C[blk][2]);
+        st.C[blk][3] = fmaf(w[r], pay[r].w, st.C[blk][3]);
+      }
+      st.Tb[blk] = Tend[blk];
+    }
+    return;
+  }
+  // exact stop rule: the first (quad, splat) in list order with T*(1-alpha) < 1e-4 ends the pixel, before adding
+  const unsigned long long lower_q = 0x0001000100010001ull & ((q == 0) ? 0ull : ((1ull << (16 * q)) - 1ull));
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    const float t0 = Tin[blk], t1 = t0 * pl[blk][0], t2 = t0 * pl[blk][1], t3 = t0 * pl[blk][2];
+    const float t[4] = {t0, t1, t2, t3};
+    bool stop[4], livep = true, any = false;
+    float tstop = 0.f;
+    float w[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      stop[r] = a[blk][r] > 0.f && Tin[blk] * pl[blk][r] < kTStop;
+      if (livep && stop[r]) { tstop = t[r]; any = true; }
+      livep = livep && !stop[r];
+      w[r] = livep ? a[blk][r] * t[r] : 0.f;
+    }
+    const bool was_alive = st.Tb[blk] > 0.f;
+    const unsigned long long bal = __ballot(any && was_alive) >> j;
+    const bool earlier = (bal & lower_q) != 0ull;              // a quad in front of mine already ended the pixel
+    const bool pixel_stopped = (bal & 0x0001000100010001ull) != 0ull;
+    const bool mine = was_alive && !earlier;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float wr = mine ? w[r] : 0.f;
+      st.C[blk][0] = fmaf(wr, pay[r].x, st.C[blk][0]);
+      st.C[blk][1] = fmaf(wr, pay[r].y, st.C[blk][1]);
+      st.C[blk][2] = fmaf(wr, pay[r].z, st.C[blk][2]);
+      st.C[blk][3] = fmaf(wr, pay[r].w, st.C[blk][3]);
+    }
+    if (mine && any) st.Tfin[blk] = tstop;
+    st.Tb[blk] = (was_alive && !pixel_stopped) ? Tend[blk] : 0.f;
+  }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void composite_forward_mx(
+    CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
+    const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ sorted_gid,
+    const GeomRec* __restrict__ geom, const float* __restrict__ colors,
+    float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
+    const Counters* __restrict__ ctr) {
+  __shared__ float4 lds_pay_all[WAVES][64];
+  __shared__ float4 lds_xch_all[WAVES][64];
+  __shared__ float lds_red_all[WAVES][5 * 64 * 4];          // [value 0..4][q][pixel 0..63]
+  if (ctr->overflow) return;
+  const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
+  const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
+  const TileCoord tc = tile_coord<WAVES>(cs, nblk, gx16, gx8, gy8);   // lane L <-> pixel L of the tile (x = L&7, y = L>>3)
+  if (!tc.tile_ok) return;
+  const int l = lane_id();
+  const int wv = (WAVES == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float4* lds_pay = lds_pay_all[wv];
+  float4* lds_xch = lds_xch_all[wv];
+  float* lds_red = lds_red_all[wv];
+  const int j = l & 15, q = l >> 4;
+  const int tx0 = tc.px - (l & 7), ty0 = tc.py - (l >> 3);
+  const float cx = (float)tx0 + 3.5f, cy = (float)ty0 + 3.5f;
+  const float X = (float)(l & 7) - 3.5f, Y = (float)(l >> 3) - 3.5f;
+  const float Phi[6] = {1.f, X, Y, X * X, X * Y, Y * Y};
+  const uint32_t s = tile_off[tc.tile], e = tile_off[tc.tile + 1];
+
+  MxFwdState st;
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    const int p = 16 * blk + j;                               // pixel (blk, j) of the tile
+    const bool in_img = (tx0 + (p & 7)) < cs.W && (ty0 + (p >> 3)) < cs.H;
+    st.Tb[blk] = in_img ? 1.f : 0.f;
+    st.Tfin[blk] = 0.f;
+    st.C[blk][0] = st.C[blk][1] = st.C[blk][2] = st.C[blk][3] = 0.f;
+  }
+  for (uint32_t base = s; base < e; base += 64u) {
+    const bool alive = st.Tb[0] > 0.f || st.Tb[1] > 0.f || st.Tb[2] > 0.f || st.Tb[3] > 0.f;
+    if (__ballot(alive) == 0ull) break;
+    const int n = (int)min(64u, e - base);
+    const MxSplat m = mx_gather(sorted_gid, geom, colors, base + (uint32_t)l, l < n, cx, cy);
+    lds_pay[l] = m.pay;
+    mx_forward_batch<0>(st, m.K, Phi, lds_pay, lds_xch, l);
+    if (n > 16) mx_forward_batch<1>(st, m.K, Phi, lds_pay, lds_xch, l);
+    if (n > 32) mx_forward_batch<2>(st, m.K, Phi, lds_pay, lds_xch, l);
+    if (n > 48) mx_forward_batch<3>(st, m.K, Phi, lds_pay, lds_xch, l);
+  }
+  // reduce the four quad-lanes of every pixel: lane L outputs pixel L = (blk = L>>4, j = L&15)
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    const int p = 16 * blk + j;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lds_red[(c * 4 + q) * 64 + p] = st.C[blk][c];
+    lds_red[(4 * 4 + q) * 64 + p] = st.Tfin[blk];
+  }
+  float out[5];
+#pragma unroll
+  for (int c = 0; c < 5; ++c)
+    out[c] = lds_red[(c * 4 + 0) * 64 + l] + lds_red[(c * 4 + 1) * 64 + l] + lds_red[(c * 4 + 2) * 64 + l] + lds_red[(c * 4 + 3) * 64 + l];
+  const float Tb_mine = (q == 0) ? st.Tb[0] : (q == 1) ? st.Tb[1] : (q == 2) ? st.Tb[2] : st.Tb[3];   // pixel L has blk == q
+  const float T = (Tb_mine > 0.f) ? Tb_mine : out[4];
+  if (tc.inside) {
+    const size_t P = (size_t)cs.W * cs.H, pix = (size_t)tc.py * cs.W + tc.px;
+    out_color[pix] = out[0] + T * bg[0];
+    out_color[P + pix] = out[1] + T * bg[1];
+    out_color[2 * P + pix] = out[2] + T * bg[2];
+    out_depth[pix] = out[3];
+    final_T[pix] = T;
+  }
+}
+template __global__ void composite_forward_mx<4>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
+template __global__ void composite_forward_mx<1>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
+
+// ---------------------------------------------------------------------------------------------------
 // Backward composite.  Pixel-major replay produces, per (splat k, pixel p), two scalars:
 //     u_kp = G_kp * dL/dalpha_kp      and      w_kp = alpha_kp * T_kp
 // and the nine per-splat sums are a contraction over the 64 pixels of the tile:
