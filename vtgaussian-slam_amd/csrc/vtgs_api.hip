@@ -23,8 +23,11 @@ __global__ void composite_forward(CamScalars, const float*, uint32_t, const uint
                                   const float*, float*, float*, float*, const Counters*);
 __global__ void composite_backward(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
                                    const GeomRec*, const float*, const float*, const float*, const float*, float*);
+template <int WAVES>
+__global__ void composite_backward_mx(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
+                                      const GeomRec*, const float*, const float*, const float*, const float*, float*);
 __global__ void gather_splat_grads(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
-                                   const float*, const GaussAux*, const float*, float*, float*, float*, float*, float*,
+                                   const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*,
                                    float*);
 __global__ void mark_visible_kernel(const float*, int, const float*, uint8_t*);
 }  // namespace vtgs
@@ -263,13 +266,20 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n, const float* means3D, const 
   const float* state = image_state ? image_state : (const float*)(ws + L.final_T);
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   const uint32_t nblk16 = (uint32_t)(gx16 * rows16);
-  { ProfScope ps__("composite_backward", st); hipLaunchKernelGGL(composite_backward, dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
-                     (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid),
-                     (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color, grad_color,
-                     state, (float*)scratch); }
+  static const int bwd_impl = env_int("VTGS_BWD_IMPL", 1), bwd_waves = env_int("VTGS_BWD_WAVES", 4);
+#define VTGS_BWD_ARGS cs, cam->bg, nblk, (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid), \
+                      (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color, grad_color, \
+                      state, (float*)scratch
+  {
+    ProfScope ps__("composite_backward", st);
+    if (bwd_impl == 1 && bwd_waves == 1) { const uint32_t nblk = nblk16 * 4u; hipLaunchKernelGGL((composite_backward_mx<1>), dim3(nblk), dim3(64), 0, st, VTGS_BWD_ARGS); }
+    else if (bwd_impl == 1) { const uint32_t nblk = nblk16; hipLaunchKernelGGL((composite_backward_mx<4>), dim3(nblk), dim3(256), 0, st, VTGS_BWD_ARGS); }
+    else { const uint32_t nblk = nblk16; hipLaunchKernelGGL(composite_backward, dim3(nblk), dim3(256), 0, st, VTGS_BWD_ARGS); }
+  }
+#undef VTGS_BWD_ARGS
   VTGS_HIP(hipGetLastError());
   { ProfScope ps__("gather_splat_grads", st); hipLaunchKernelGGL(gather_splat_grads, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
-                     means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch,
+                     means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, bwd_impl == 1 ? 1 : 0,
                      g_means3D, g_means2D, g_colors, g_opacities, g_scales, g_rotations); }
   VTGS_HIP(hipGetLastError());
   return VTGS_OK;

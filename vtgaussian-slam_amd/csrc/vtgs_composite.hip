@@ -498,12 +498,232 @@ __global__ __launch_bounds__(256) void composite_backward(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Backward composite, matrix-core form.  Same lane layout as composite_forward_mx (lane = pixel column j x splat
+// quad q, exponents from six 4-block MFMAs).  Besides the transmittance, the gradient prefix
+//     P_k = sum_{i<=k} (g.c_i) alpha_i T_i      is chained across the quad-lanes:  P_in(q) = P_batch + sum_{q'<q} T_in(q') S(q')
+// with S the T-free local sum.  Per (pixel, splat) the lane produces u' = alpha_unclamped * dL/dalpha (= o * u of the
+// scalar form; the gather kernel divides the six geometric sums by o) and w = alpha*T, writes them transposed into the
+// per-wavefront LDS images and the existing f32-MFMA contraction over the 64 pixels forms the nine per-splat sums.
+// ---------------------------------------------------------------------------------------------------
+struct MxBwdState {
+  float Tb[4], Pb[4];      // transmittance / gradient prefix of pixel (blk, j) at the start of the batch (replicated over q)
+  float g[4][3];           // dL/dcolor of pixel (blk, j)
+  float CB[4];             // g.(out - T_final bg) + T_final (g.bg)
+};
+
+template <int B>
+__device__ __forceinline__ void mx_backward_batch(MxBwdState& st, const float (&K)[6], const float (&Phi)[6],
+                                                  const float4* __restrict__ lds_pay, float4* __restrict__ lds_xch,
+                                                  float* __restrict__ Us, float* __restrict__ Ws, int l) {
+  const int j = l & 15, q = l >> 4;
+  const f32x16 d = mx_exponents<B>(K, Phi);
+  float4 pay[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pay[r] = lds_pay[16 * B + 4 * q + r];
+  const unsigned long long lower_q = 0x0001000100010001ull & ((q == 0) ? 0ull : ((1ull << (16 * q)) - 1ull));
+  // two half-passes over the pixel groups {0,1} and {2,3}: halves the number of live per-pair values
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float Gp[2][4], a[2][4], pl[2][4], gc[2][4], S[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int blk = 2 * h + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Gp[i][r] = __builtin_amdgcn_exp2f(d[4 * blk + r]);
+        const float al = fminf(kAlphaMax, Gp[i][r]);
+        a[i][r] = (al >= kAlphaMin) ? al : 0.f;
+        gc[i][r] = st.g[blk][0] * pay[r].x + st.g[blk][1] * pay[r].y + st.g[blk][2] * pay[r].z;
+      }
+      pl[i][0] = 1.f - a[i][0];
+      pl[i][1] = pl[i][0] * (1.f - a[i][1]);
+      pl[i][2] = pl[i][1] * (1.f - a[i][2]);
+      pl[i][3] = pl[i][2] * (1.f - a[i][3]);
+      S[i][0] = gc[i][0] * a[i][0];
+      S[i][1] = fmaf(gc[i][1] * a[i][1], pl[i][0], S[i][0]);
+      S[i][2] = fmaf(gc[i][2] * a[i][2], pl[i][1], S[i][1]);
+      S[i][3] = fmaf(gc[i][3] * a[i][3], pl[i][2], S[i][2]);
+    }
+    // exchange (local product, local T-free prefix sum) of both pixel groups among the four quad-lanes of a pixel
+    float4* xch = lds_xch + 64 * h;
+    xch[l] = make_float4(pl[0][3], pl[1][3], S[0][3], S[1][3]);
+    const float4 x0 = xch[j], x1 = xch[16 + j], x2 = xch[32 + j], x3 = xch[48 + j];
+    float Tin[2], Pin[2], Tend[2], Pend[2];
+    bool cross = false;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int blk = 2 * h + i;
+      const float P0 = i ? x0.y : x0.x, P1 = i ? x1.y : x1.x, P2 = i ? x2.y : x2.x, P3 = i ? x3.y : x3.x;
+      const float S0 = i ? x0.w : x0.z, S1 = i ? x1.w : x1.z, S2 = i ? x2.w : x2.z, S3 = i ? x3.w : x3.z;
+      const float T0 = st.Tb[blk];
+      const float T1 = T0 * P0, T2 = T1 * P1, T3 = T2 * P2;
+      const float Q0 = st.Pb[blk];
+      const float Q1 = fmaf(T0, S0, Q0), Q2 = fmaf(T1, S1, Q1), Q3 = fmaf(T2, S2, Q2);
+      Tin[i] = (q == 0) ? T0 : (q == 1) ? T1 : (q == 2) ? T2 : T3;
+      Pin[i] = (q == 0) ? Q0 : (q == 1) ? Q1 : (q == 2) ? Q2 : Q3;
+      Tend[i] = T3 * P3;
+      Pend[i] = fmaf(T3, S3, Q3);
+      cross = cross || (T0 > 0.f && Tend[i] < kTStop);
+    }
+    const bool slow = __ballot(cross) != 0ull;                 // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int blk = 2 * h + i;
+      const float t0 = Tin[i], t1 = t0 * pl[i][0], t2 = t0 * pl[i][1], t3 = t0 * pl[i][2];
+      const float t[4] = {t0, t1, t2, t3};
+      bool live[4] = {true, true, true, true};
+      const bool was_alive = st.Tb[blk] > 0.f;
+      bool mine = was_alive;
+      bool pixel_stopped = false;
+      if (slow) {
+        bool livep = true, any = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool stop = a[i][r] > 0.f && Tin[i] * pl[i][r] < kTStop;
+          any = any || (livep && stop);
+          livep = livep && !stop;
+          live[r] = livep;
+        }
+        const unsigned long long bal = __ballot(any && mine) >> j;
+        mine = mine && (bal & lower_q) == 0ull;
+        pixel_stopped = (bal & 0x0001000100010001ull) != 0ull;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float Pr = fmaf(Tin[i], S[i][r], Pin[i]);            // prefix including this splat
+        const float al = fminf(kAlphaMax, Gp[i][r]);
+        const float dLda = t[r] * gc[i][r] - (st.CB[blk] - Pr) * __builtin_amdgcn_rcpf(1.f - al);
+        const bool on = mine && live[r] && a[i][r] > 0.f;
+        Us[(4 * q + r) * kRowStride + 16 * blk + j] = on ? Gp[i][r] * dLda : 0.f;   // 0.99 clamp passes the gradient through
+        Ws[(4 * q + r) * kRowStride + 16 * blk + j] = on ? a[i][r] * t[r] : 0.f;
+      }
+      st.Tb[blk] = (was_alive && !pixel_stopped) ? Tend[i] : 0.f;
+      st.Pb[blk] = Pend[i];
+    }
+  }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
+    CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
+    const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ sorted_gid,
+    const uint32_t* __restrict__ sorted_inst, const GeomRec* __restrict__ geom, const float* __restrict__ colors,
+    const float* __restrict__ out_color, const float* __restrict__ grad_color, const float* __restrict__ final_T,
+    float* __restrict__ grad_inst) {
+  __shared__ float4 lds_pay_all[WAVES][64];
+  __shared__ float4 lds_xch_all[WAVES][128];
+  __shared__ float lds_uw[WAVES][2][16 * kRowStride];
+  const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
+  const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
+  const TileCoord tc = tile_coord<WAVES>(cs, nblk, gx16, gx8, gy8);
+  if (!tc.tile_ok) return;
+  const int l = lane_id();
+  const int wv = (WAVES == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float4* lds_pay = lds_pay_all[wv];
+  float4* lds_xch = lds_xch_all[wv];
+  float* __restrict__ Us = lds_uw[wv][0];
+  float* __restrict__ Ws = lds_uw[wv][1];
+  const uint32_t s = tile_off[tc.tile], e = tile_off[tc.tile + 1];
+  if (s == e) return;
+  const size_t P = (size_t)cs.W * cs.H;
+  const int j = l & 15, q = l >> 4;
+  const int tx0 = tc.px - (l & 7), ty0 = tc.py - (l >> 3);
+  const float cx = (float)tx0 + 3.5f, cy = (float)ty0 + 3.5f;
+  const float X = (float)(l & 7) - 3.5f, Y = (float)(l >> 3) - 3.5f;
+  const float Phi[6] = {1.f, X, Y, X * X, X * Y, Y * Y};
+  const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+
+  MxBwdState st;
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    const int p = 16 * blk + j;
+    const int qx = tx0 + (p & 7), qy = ty0 + (p >> 3);
+    const bool in_img = qx < cs.W && qy < cs.H;
+    st.Tb[blk] = in_img ? 1.f : 0.f;
+    st.Pb[blk] = 0.f;
+    st.g[blk][0] = st.g[blk][1] = st.g[blk][2] = 0.f;
+    st.CB[blk] = 0.f;
+    if (in_img) {
+      const size_t pix = (size_t)qy * cs.W + qx;
+      const float g0 = grad_color[pix], g1 = grad_color[P + pix], g2 = grad_color[2 * P + pix];
+      const float Tf = final_T[pix];
+      st.g[blk][0] = g0; st.g[blk][1] = g1; st.g[blk][2] = g2;
+      st.CB[blk] = g0 * (out_color[pix] - Tf * b0) + g1 * (out_color[P + pix] - Tf * b1) + g2 * (out_color[2 * P + pix] - Tf * b2)
+                   + Tf * (g0 * b0 + g1 * b1 + g2 * b2);
+    }
+  }
+  // B operand of the pixel contraction: lane (bj = l&15, bk = l>>4), step t <-> pixel p = 16*bk + t
+  const int bj = j, bk = q;
+  float Bv[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int p = 16 * bk + t;
+    const float PX = (float)(p & 7) - 3.5f, PY = (float)(p >> 3) - 3.5f;
+    float v = 0.f;
+    v = (bj == 0) ? 1.f : v; v = (bj == 1) ? PX : v; v = (bj == 2) ? PY : v;
+    v = (bj == 3) ? PX * PX : v; v = (bj == 4) ? PX * PY : v; v = (bj == 5) ? PY * PY : v;
+    if (bj >= 6 && bj <= 8) {
+      const int qx = tx0 + (p & 7), qy = ty0 + (p >> 3);
+      if (qx < cs.W && qy < cs.H) v = grad_color[(size_t)(bj - 6) * P + (size_t)qy * cs.W + qx];
+    }
+    Bv[t] = v;
+  }
+  const int a_off = bj * kRowStride + 16 * bk;
+  const uint32_t tile_bits = (uint32_t)tc.tile;
+
+  uint32_t base = s;
+  for (; base < e; base += 64u) {
+    const bool alive = st.Tb[0] > 0.f || st.Tb[1] > 0.f || st.Tb[2] > 0.f || st.Tb[3] > 0.f;
+    if (__ballot(alive) == 0ull) break;
+    const int n = (int)min(64u, e - base);
+    const MxSplat m = mx_gather(sorted_gid, geom, colors, base + (uint32_t)l, l < n, cx, cy);
+    const uint32_t my_inst = (l < n) ? sorted_inst[base + (uint32_t)l] : 0u;
+    lds_pay[l] = m.pay;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (16 * b >= n) break;                                 // wave-uniform
+      if (b == 0) mx_backward_batch<0>(st, m.K, Phi, lds_pay, lds_xch, Us, Ws, l);
+      if (b == 1) mx_backward_batch<1>(st, m.K, Phi, lds_pay, lds_xch, Us, Ws, l);
+      if (b == 2) mx_backward_batch<2>(st, m.K, Phi, lds_pay, lds_xch, Us, Ws, l);
+      if (b == 3) mx_backward_batch<3>(st, m.K, Phi, lds_pay, lds_xch, Us, Ws, l);
+      const int nb = min(16, n - 16 * b);
+      f32x4 D1 = {0.f, 0.f, 0.f, 0.f}, D2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Us[a_off + t], Bv[t], D1, 0, 0, 0);
+        D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws[a_off + t], Bv[t], D2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = 4 * bk + rr;
+        const uint32_t inst = (uint32_t)__shfl((int)my_inst, 16 * b + row, 64);
+        float val = (bj < 6) ? D1[rr] : D2[rr];
+        val = (bj == 9) ? __uint_as_float(tile_bits) : val;
+        val = (bj > 9) ? 0.f : val;
+        if (row < nb && bj < kGradRec) grad_inst[(size_t)inst * kGradRec + bj] = val;
+      }
+    }
+  }
+  for (; base < e; base += 64u) {
+    const int n = (int)min(64u, e - base);
+    if (l < n) {
+      const uint32_t inst = sorted_inst[base + (uint32_t)l];
+      float4* p = reinterpret_cast<float4*>(grad_inst + (size_t)inst * kGradRec);
+      p[0] = p[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      p[2] = make_float4(0.f, __uint_as_float(tile_bits), 0.f, 0.f);
+    }
+  }
+}
+template __global__ void composite_backward_mx<4>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*);
+template __global__ void composite_backward_mx<1>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*);
+
 // one thread per Gaussian: re-centre and sum its instance records (fixed order), then the projection backward
 __global__ __launch_bounds__(256) void gather_splat_grads(
     CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
     const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ scales, const float* __restrict__ rotations,
-    const GaussAux* __restrict__ gaux, const float* __restrict__ grad_inst,
+    const GaussAux* __restrict__ gaux, const float* __restrict__ grad_inst, int moments_scaled_by_opacity,
     float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_colors,
     float* __restrict__ g_opacities, float* __restrict__ g_scales, float* __restrict__ g_rotations) {
   const CamParams cam = load_cam(cs, Vp, PVp);
@@ -538,6 +758,10 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
         mo.m[4] += sx * sy * U0 - sx * UY - sy * UX + UXY;
         mo.m[5] += sy * sy * U0 - 2.f * sy * UY + UYY;
         mo.m[6] += b.z; mo.m[7] += b.w; mo.m[8] += c.x;
+      }
+      if (moments_scaled_by_opacity) {        // the matrix-core backward accumulates u' = o*u
+        const float io = 1.f / op;
+        for (int k = 0; k < 6; ++k) mo.m[k] *= io;
       }
       splat_backward(cam, sc, q, op, sp, aux, mo, g);
     }
