@@ -204,3 +204,81 @@ def test_tile_lists_are_exactly_depth_sorted(gpu_device, n, w, h):
     tile_of = torch.repeat_interleave(torch.arange(lens.numel()), lens)
     same_tile = tile_of[1:] == tile_of[:-1]
     assert bool(((key[1:] > key[:-1]) | ~same_tile).all()), "a tile list is not strictly (depth, id)-ordered"
+
+
+def test_tile_row_bands_reassemble_the_full_frame(gpu_device):
+    """Multi-GPU partition on one device: rendering the bands one after the other reproduces the
+    full-frame image exactly, and the band gradients sum to the full-frame gradients."""
+    from diff_gaussian_rasterization.partition import all_bands, pixel_rows
+    scene, cam = go.view_tied_scene(20000, 200, 136, seed=17)           # 9 tile rows -> bands of 3/2/2/2
+    H, W = cam.image_height, cam.image_width
+    g = torch.Generator().manual_seed(2)
+    grad_color = torch.rand(3, H, W, generator=g) * 2 - 1
+    full_c, full_r, full_d, full_g = run_hip(scene, cam, gpu_device, grad_color)
+    img = torch.zeros_like(full_c)
+    dep = torch.zeros_like(full_d)
+    acc = {k: torch.zeros_like(v) for k, v in full_g.items()}
+    for band in all_bands(H, 4):
+        y0, y1 = pixel_rows(band, H)
+        gc = torch.zeros_like(grad_color)
+        gc[:, y0:y1] = grad_color[:, y0:y1]
+        c, r, d, gr = run_hip(scene, cam, gpu_device, gc, tile_rows=band)
+        assert float(c[:, :y0].abs().max() if y0 else 0) == 0 and float(c[:, y1:].abs().max() if y1 < H else 0) == 0
+        assert torch.equal(r, full_r)                                   # radii do not depend on the band
+        img[:, y0:y1] = c[:, y0:y1]
+        dep[:, y0:y1] = d[:, y0:y1]
+        for k in acc:
+            acc[k] += gr[k]
+    assert torch.equal(img, full_c) and torch.equal(dep, full_d)
+    for k in GRAD_KEYS:
+        if k == "rotations":       # isotropic scene: exactly zero in exact arithmetic, float32 noise here
+            assert (full_g[k] - acc[k]).abs().max().item() <= 1e-5 * full_g["scales"].abs().max().item()
+            continue
+        mx, p999 = grad_error(full_g[k], acc[k])
+        assert mx <= 1e-4 and p999 <= 1e-4, (k, mx, p999)
+
+
+def test_shared_geometry_second_render(gpu_device):
+    """vtgs_forward_shared (the depth/silhouette pass over the RGB pass's geometry, src/vtgaussian_slam.py:461->466):
+    identical to an independent second forward, forward and backward."""
+    import diff_gaussian_rasterization as dgr
+    from parity_util import to_settings
+    scene, cam = go.view_tied_scene(8000, 160, 120, seed=23)
+    dev = gpu_device
+    z = scene["means3D"][:, 2:3]
+    dcol = torch.cat([z, torch.ones_like(z), z * z], dim=1)
+    g = torch.Generator().manual_seed(4)
+    g1 = (torch.rand(3, 120, 160, generator=g) * 2 - 1).to(dev)
+    g2 = (torch.rand(3, 120, 160, generator=g) * 2 - 1).to(dev)
+    st = to_settings(cam, dev)
+
+    def leaves():
+        return {k: v.to(dev).clone().requires_grad_(True) for k, v in scene.items()}
+    # reference: two independent renders
+    a = leaves()
+    dc_a = dcol.to(dev).clone().requires_grad_(True)
+    c1, _, _ = dgr.GaussianRasterizer(raster_settings=st)(**a)
+    c2, _, d2 = dgr.GaussianRasterizer(raster_settings=st)(**dict(a, colors_precomp=dc_a))
+    ((c1 * g1).sum() + (c2 * g2).sum()).backward()
+    # shared geometry
+    b = leaves()
+    dc_b = dcol.to(dev).clone().requires_grad_(True)
+    rast = dgr.GaussianRasterizer(raster_settings=st)
+    s1, _, _ = rast(**b)
+    s2, sd2 = rast.render_shared(dc_b, like=(b["means3D"], b["means2D"], b["opacities"], b["scales"], b["rotations"]))
+    ((s1 * g1).sum() + (s2 * g2).sum()).backward()
+    assert torch.equal(c1, s1) and torch.equal(c2, s2) and torch.equal(d2, sd2)
+    assert torch.equal(dc_a.grad, dc_b.grad)
+    for k in GRAD_KEYS:
+        assert torch.allclose(a[k].grad, b[k].grad, rtol=1e-5, atol=1e-7), k
+
+
+def test_mark_visible_and_scalar_kernels_agree(gpu_device):
+    import diff_gaussian_rasterization as dgr
+    from parity_util import to_settings
+    scene, cam = go.random_scene(5000, 200, 136, seed=9, anisotropic=True, w2c=_w2c(9))
+    st = to_settings(cam, gpu_device)
+    vis = dgr.GaussianRasterizer(raster_settings=st).markVisible(scene["means3D"].to(gpu_device)).cpu()
+    V = cam.viewmatrix.reshape(4, 4)
+    tz = (torch.cat([scene["means3D"], torch.ones(5000, 1)], 1) @ V)[:, 2]
+    assert (vis != (tz > 0.2)).sum().item() <= 1
