@@ -144,8 +144,15 @@ def main():
         if alg is not None:
             achieved = alg[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
             call_bytes = 180 * N + 28 * P + 52 * r16
+            traffic = None           # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                if (N, W, H) == (1_000_000, 1200, 680) and dom in pmc:
+                    traffic = pmc[dom]["traffic_bytes"]
+            except (OSError, ValueError, KeyError):
+                pass
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "kernel_avg_us": round(kern[dom]["avg_us"], 2), "algorithmic_bytes": alg[dom],
                         "call_algorithmic_bytes": call_bytes,
                         "call_frac": round(call_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
