@@ -91,7 +91,9 @@ const char* vtgs_last_hip_error(void);   /* message of the last failed HIP call 
  * the exact need on overflow.                                                                        */
 size_t vtgs_workspace_bytes(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity);
 
-/* Bytes of backward scratch for a forward that binned `instances` instances.                        */
+/* Bytes of backward scratch for a forward that binned `instances` instances.  When the count is not known
+ * yet (asynchronous forward), pass its instance_capacity: the scratch is indexed by instance id < capacity.
+ * If the forward overflowed, the backward kernels see the device-side flag and write nothing.            */
 size_t vtgs_backward_scratch_bytes(int32_t n, uint64_t instances);
 
 /* Forward.  Replaces `_C.rasterize_gaussians` for the colors_precomp + scales/rotations signature

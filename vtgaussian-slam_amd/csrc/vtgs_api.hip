@@ -22,13 +22,15 @@ template <int WAVES, int UNROLL>
 __global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*,
                                   const float*, float*, float*, float*, const Counters*);
 __global__ void composite_backward(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
-                                   const GeomRec*, const float*, const float*, const float*, const float*, float*);
+                                   const GeomRec*, const float*, const float*, const float*, const float*, float*,
+                                   const Counters*);
 template <int WAVES>
 __global__ void composite_backward_mx(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
-                                      const GeomRec*, const float*, const float*, const float*, const float*, float*);
+                                      const GeomRec*, const float*, const float*, const float*, const float*, float*,
+                                      const Counters*);
 __global__ void gather_splat_grads(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
                                    const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*,
-                                   float*);
+                                   float*, const Counters*);
 __global__ void mark_visible_kernel(const float*, int, const float*, uint8_t*);
 }  // namespace vtgs
 
@@ -187,7 +189,7 @@ int vtgs_forward(const VtgsCamera* cam, int32_t n, const float* means3D, const f
     VTGS_HIP(hipMemsetAsync(out_depth, 0, P * sizeof(float), st));
   }
   if (n > 0) {
-    { ProfScope ps__("project_and_bin", st); hipLaunchKernelGGL(project_and_bin, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+    { ProfScope ps__("project_and_bin", st); hipLaunchKernelGGL(project_and_bin, dim3((n + 1023) / 1024), dim3(1024), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
                        means3D, opacities, scales, rotations, out_radii, (GeomRec*)(ws + L.geom),
                        (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt), (InstTmp*)(ws + L.inst_tmp), ctr,
                        (BlockStats*)(ws + L.block_stats), (unsigned long long)instance_capacity); }
@@ -195,7 +197,7 @@ int vtgs_forward(const VtgsCamera* cam, int32_t n, const float* means3D, const f
   }
   { ProfScope ps__("scan_tiles", st); hipLaunchKernelGGL(scan_tiles, dim3(1), dim3(1024), 0, st, (const uint32_t*)(ws + L.tile_cnt),
                      (uint32_t*)(ws + L.tile_off), L.tiles8, ctr, (unsigned long long)instance_capacity,
-                     (const BlockStats*)(ws + L.block_stats), (uint32_t)((n + 255) / 256)); }
+                     (const BlockStats*)(ws + L.block_stats), (uint32_t)((n + 1023) / 1024)); }
   VTGS_HIP(hipGetLastError());
   { ProfScope ps__("scatter_instances", st); hipLaunchKernelGGL(scatter_instances, dim3(2048), dim3(256), 0, st, (const InstTmp*)(ws + L.inst_tmp),
                      (const uint32_t*)(ws + L.tile_off), (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals),
@@ -269,7 +271,7 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n, const float* means3D, const 
   static const int bwd_impl = env_int("VTGS_BWD_IMPL", 1), bwd_waves = env_int("VTGS_BWD_WAVES", 4);
 #define VTGS_BWD_ARGS cs, cam->bg, nblk, (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid), \
                       (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color, grad_color, \
-                      state, (float*)scratch
+                      state, (float*)scratch, (const Counters*)(ws + L.counters)
   {
     ProfScope ps__("composite_backward", st);
     if (bwd_impl == 1 && bwd_waves == 1) { const uint32_t nblk = nblk16 * 4u; hipLaunchKernelGGL((composite_backward_mx<1>), dim3(nblk), dim3(64), 0, st, VTGS_BWD_ARGS); }
@@ -280,7 +282,8 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n, const float* means3D, const 
   VTGS_HIP(hipGetLastError());
   { ProfScope ps__("gather_splat_grads", st); hipLaunchKernelGGL(gather_splat_grads, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
                      means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, bwd_impl == 1 ? 1 : 0,
-                     g_means3D, g_means2D, g_colors, g_opacities, g_scales, g_rotations); }
+                     g_means3D, g_means2D, g_colors, g_opacities, g_scales, g_rotations,
+                     (const Counters*)(ws + L.counters)); }
   VTGS_HIP(hipGetLastError());
   return VTGS_OK;
 }

@@ -18,9 +18,12 @@
 
 namespace vtgs {
 
-// Reserve one slot per active lane in counters[tile]; lanes of a run (consecutive active lanes with the
-// same tile) share one atomic.  Returns the slot.  All 64 lanes must call it.
-__device__ __forceinline__ uint32_t run_aggregated_reserve(uint32_t* __restrict__ counters, int tile, bool act) {
+// Reserve one slot per active lane in counters[tile]; lanes of a run (consecutive active lanes with the same tile)
+// share one atomic.  Split in two so the caller can overlap the atomic's round trip with other work:
+// reserve_issue() launches the atomic and returns what is needed later, reserve_resolve() turns it into the slot.
+struct Reservation { uint32_t base; int head_lane; int rank; bool act; int tile; };
+
+__device__ __forceinline__ Reservation reserve_issue(uint32_t* __restrict__ counters, int tile, bool act) {
   const int l = lane_id();
   const int prev_tile = __shfl_up(tile, 1, 64);
   const int prev_act = __shfl_up((int)act, 1, 64);
@@ -30,15 +33,20 @@ __device__ __forceinline__ uint32_t run_aggregated_reserve(uint32_t* __restrict_
   const unsigned long long stops = H | ~A;                       // lanes where a run cannot continue
   const unsigned long long le_mask = (l == 63) ? ~0ull : ((2ull << l) - 1ull);   // bits <= l
   const unsigned long long heads_le = H & le_mask;
-  const int hl = heads_le ? (63 - __builtin_clzll(heads_le)) : 0;   // head lane of my run
-  uint32_t base = 0;
+  Reservation r;
+  r.head_lane = heads_le ? (63 - __builtin_clzll(heads_le)) : 0;   // head lane of my run
+  r.rank = l - r.head_lane;
+  r.act = act; r.tile = tile;
+  r.base = 0;
   if (head) {
     const unsigned long long above = stops & ~le_mask;            // bits > l
     const int e = above ? __builtin_ctzll(above) : 64;
-    base = atomicAdd(&counters[tile], (uint32_t)(e - l));
+    r.base = atomicAdd(&counters[tile], (uint32_t)(e - l));
   }
-  base = __shfl(base, hl, 64);
-  return base + (uint32_t)(l - hl);
+  return r;
+}
+__device__ __forceinline__ uint32_t reserve_resolve(const Reservation& r) {   // all 64 lanes must call it
+  return (uint32_t)__shfl((int)r.base, r.head_lane, 64) + (uint32_t)r.rank;
 }
 
 struct TileWalk {       // candidate 8x8 tiles of one splat: those under its 16x16-tile rectangle, in the band
@@ -63,15 +71,18 @@ __device__ __forceinline__ bool tile_reached(const CamParams& cam, const Splat& 
   return q <= tau;
 }
 
-__global__ __launch_bounds__(256) void project_and_bin(
+constexpr int kProjBlock = 1024;     // threads per workgroup: one allocation atomic per 1024 Gaussians
+
+__global__ __launch_bounds__(kProjBlock) void project_and_bin(
     CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
     const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ scales, const float* __restrict__ rotations,
     int32_t* __restrict__ radii, GeomRec* __restrict__ geom, GaussAux* __restrict__ gaux,
     uint32_t* __restrict__ tile_cnt, InstTmp* __restrict__ inst_tmp, Counters* __restrict__ ctr,
     BlockStats* __restrict__ block_stats, unsigned long long capacity) {
+  constexpr int kWaves = kProjBlock / 64;
   const CamParams cam = load_cam(cs, Vp, PVp);
-  const int gid = (int)(blockIdx.x * 256u + threadIdx.x);
+  const int gid = (int)(blockIdx.x * (uint32_t)kProjBlock + threadIdx.x);
   const int l = lane_id();
   const bool valid = gid < n;
 
@@ -94,16 +105,19 @@ __global__ __launch_bounds__(256) void project_and_bin(
   const TileWalk w = make_walk(cam, sp, reach);
   const int area = w.cw * w.ch;
 
-  // pass 1: how many tiles does this splat really reach
+  // pass 1: which candidate tiles does this splat really reach (remembered as a bitmask for the first 64)
   uint32_t cnt = 0;
+  unsigned long long reach_mask = 0ull;
   for (int i = 0, tx = 0, ty = 0; i < area; ++i) {
-    cnt += tile_reached(cam, sp, tau, w.cx0 + tx, w.cy0 + ty) ? 1u : 0u;
+    const bool hit = tile_reached(cam, sp, tau, w.cx0 + tx, w.cy0 + ty);
+    cnt += hit ? 1u : 0u;
+    if (i < 64 && hit) reach_mask |= 1ull << i;
     if (++tx == w.cw) { tx = 0; ++ty; }
   }
   // Instances of one splat are contiguous: reserve [base, base+cnt).  ONE atomic per workgroup on the
   // global counter: same-address atomics serialise at the memory side (~14 ns each measured), so per-wavefront
   // atomics on one cache line cost more than the whole projection.
-  __shared__ uint32_t s_wave_cnt[4], s_wave_vis[4], s_wave_r16[4], s_block_base;
+  __shared__ uint32_t s_wave_cnt[kWaves], s_wave_vis[kWaves], s_wave_r16[kWaves], s_block_base;
   const int wv = (int)(threadIdx.x >> 6);
   const uint32_t incl = wave_incl_scan(cnt);
   const uint32_t r16 = vis ? (uint32_t)((sp.x1 - sp.x0) * (sp.y1 - sp.y0)) : 0u;
@@ -112,12 +126,11 @@ __global__ __launch_bounds__(256) void project_and_bin(
   if (l == 63) { s_wave_cnt[wv] = incl; s_wave_vis[wv] = (uint32_t)__popcll(vb); s_wave_r16[wv] = r16_incl; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t tot = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+    uint32_t tot = 0, v = 0; unsigned long long r = 0;
+    for (int k = 0; k < kWaves; ++k) { tot += s_wave_cnt[k]; v += s_wave_vis[k]; r += s_wave_r16[k]; }
     s_block_base = tot ? atomicAdd(&ctr->inst_total, tot) : 0u;
     BlockStats bs;
-    bs.visible = s_wave_vis[0] + s_wave_vis[1] + s_wave_vis[2] + s_wave_vis[3];
-    bs.pad = 0;
-    bs.r16 = (unsigned long long)s_wave_r16[0] + s_wave_r16[1] + s_wave_r16[2] + s_wave_r16[3];
+    bs.visible = v; bs.pad = 0; bs.r16 = r;
     block_stats[blockIdx.x] = bs;
   }
   __syncthreads();
@@ -133,22 +146,30 @@ __global__ __launch_bounds__(256) void project_and_bin(
     gaux[gid] = GaussAux{inst_base, cnt};
   }
 
-  // pass 2: reserve a slot in every reached tile, lanes in lock-step so runs can share atomics
+  // pass 2: reserve a slot in every reached tile, lanes in lock-step so runs can share atomics.  The returning
+  // atomic of step i is consumed in step i+1, so its round trip overlaps the next step's work.
   const int max_area = wave_max_i(area);
   const uint32_t zbits = __float_as_uint(sp.depth);
   uint32_t ord = 0;
-  for (int i = 0, tx = 0, ty = 0; i < max_area; ++i) {
-    const bool in = i < area;
-    const int ttx = w.cx0 + tx, tty = w.cy0 + ty;
-    const bool act = in && tile_reached(cam, sp, tau, ttx, tty);
-    const int tile = act ? (tty * cam.gx8 + ttx) : -1;
-    const uint32_t slot = run_aggregated_reserve(tile_cnt, tile, act);
-    if (act) {
+  Reservation pend;
+  pend.base = 0; pend.head_lane = 0; pend.rank = 0; pend.act = false; pend.tile = -1;
+  for (int i = 0, tx = 0, ty = 0; i <= max_area; ++i) {
+    Reservation cur;
+    cur.base = 0; cur.head_lane = 0; cur.rank = 0; cur.act = false; cur.tile = -1;
+    if (i < max_area) {                                      // wave-uniform
+      const bool in = i < area;
+      const int ttx = w.cx0 + tx, tty = w.cy0 + ty;
+      const bool act = in && ((i < 64) ? ((reach_mask >> i) & 1ull) != 0ull : tile_reached(cam, sp, tau, ttx, tty));
+      cur = reserve_issue(tile_cnt, act ? (tty * cam.gx8 + ttx) : -1, act);
+      if (in && ++tx == w.cw) { tx = 0; ++ty; }
+    }
+    const uint32_t slot = reserve_resolve(pend);
+    if (pend.act) {
       const unsigned long long id = (unsigned long long)inst_base + ord;
-      if (id < capacity) inst_tmp[id] = InstTmp{(uint32_t)tile, slot, (uint32_t)gid, zbits};
+      if (id < capacity) inst_tmp[id] = InstTmp{(uint32_t)pend.tile, slot, (uint32_t)gid, zbits};
       ++ord;
     }
-    if (in && ++tx == w.cw) { tx = 0; ++ty; }
+    pend = cur;
   }
 }
 

@@ -213,39 +213,67 @@ __device__ __forceinline__ void mx_forward_batch(MxFwdState& st, const float (&K
   float4 pay[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) pay[r] = lds_pay[16 * B + 4 * q + r];
-  float a[4][4], pl[4][4];
+  const unsigned long long lower_q = 0x0001000100010001ull & ((q == 0) ? 0ull : ((1ull << (16 * q)) - 1ull));
+  float2* xch2 = reinterpret_cast<float2*>(lds_xch);
+  // two half-passes over the pixel groups {0,1} and {2,3} (keeps the live register set small)
 #pragma unroll
-  for (int blk = 0; blk < 4; ++blk) {
+  for (int h = 0; h < 2; ++h) {
+    float a[2][4], pl[2][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float al = fminf(kAlphaMax, __builtin_amdgcn_exp2f(d[4 * blk + r]));
-      a[blk][r] = (al >= kAlphaMin) ? al : 0.f;
+    for (int i = 0; i < 2; ++i) {
+      const int blk = 2 * h + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float al = fminf(kAlphaMax, __builtin_amdgcn_exp2f(d[4 * blk + r]));
+        a[i][r] = (al >= kAlphaMin) ? al : 0.f;
+      }
+      pl[i][0] = 1.f - a[i][0];
+      pl[i][1] = pl[i][0] * (1.f - a[i][1]);
+      pl[i][2] = pl[i][1] * (1.f - a[i][2]);
+      pl[i][3] = pl[i][2] * (1.f - a[i][3]);
     }
-    pl[blk][0] = 1.f - a[blk][0];
-    pl[blk][1] = pl[blk][0] * (1.f - a[blk][1]);
-    pl[blk][2] = pl[blk][1] * (1.f - a[blk][2]);
-    pl[blk][3] = pl[blk][2] * (1.f - a[blk][3]);
-  }
-  lds_xch[l] = make_float4(pl[0][3], pl[1][3], pl[2][3], pl[3][3]);
-  const float4 P0 = lds_xch[j], P1 = lds_xch[16 + j], P2 = lds_xch[32 + j], P3 = lds_xch[48 + j];
-  const float p0[4] = {P0.x, P0.y, P0.z, P0.w}, p1[4] = {P1.x, P1.y, P1.z, P1.w};
-  const float p2[4] = {P2.x, P2.y, P2.z, P2.w}, p3[4] = {P3.x, P3.y, P3.z, P3.w};
-  float Tin[4], Tend[4];
-  bool cross = false;
+    float2* xch = xch2 + 64 * h;
+    xch[l] = make_float2(pl[0][3], pl[1][3]);
+    const float2 x0 = xch[j], x1 = xch[16 + j], x2 = xch[32 + j], x3 = xch[48 + j];
+    float Tin[2], Tend[2];
+    bool cross = false;
 #pragma unroll
-  for (int blk = 0; blk < 4; ++blk) {
-    const float e1 = p0[blk], e2 = e1 * p1[blk], e3 = e2 * p2[blk];
-    const float pre = (q == 0) ? 1.f : (q == 1) ? e1 : (q == 2) ? e2 : e3;
-    Tin[blk] = st.Tb[blk] * pre;
-    Tend[blk] = st.Tb[blk] * (e3 * p3[blk]);
-    cross = cross || (st.Tb[blk] > 0.f && Tend[blk] < kTStop);
-  }
-  if (__ballot(cross) == 0ull) {
-    // no pixel of the tile reaches the stop threshold inside this batch
+    for (int i = 0; i < 2; ++i) {
+      const int blk = 2 * h + i;
+      const float P0 = i ? x0.y : x0.x, P1 = i ? x1.y : x1.x, P2 = i ? x2.y : x2.x, P3 = i ? x3.y : x3.x;
+      const float e1 = P0, e2 = e1 * P1, e3 = e2 * P2;
+      const float pre = (q == 0) ? 1.f : (q == 1) ? e1 : (q == 2) ? e2 : e3;
+      Tin[i] = st.Tb[blk] * pre;
+      Tend[i] = st.Tb[blk] * (e3 * P3);
+      cross = cross || (st.Tb[blk] > 0.f && Tend[i] < kTStop);
+    }
+    const bool slow = __ballot(cross) != 0ull;                 // wave-uniform; rarely true
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk) {
-      const float t0 = Tin[blk], t1 = t0 * pl[blk][0], t2 = t0 * pl[blk][1], t3 = t0 * pl[blk][2];
-      const float w[4] = {a[blk][0] * t0, a[blk][1] * t1, a[blk][2] * t2, a[blk][3] * t3};
+    for (int i = 0; i < 2; ++i) {
+      const int blk = 2 * h + i;
+      const float t0 = Tin[i], t1 = t0 * pl[i][0], t2 = t0 * pl[i][1], t3 = t0 * pl[i][2];
+      const float t[4] = {t0, t1, t2, t3};
+      float w[4] = {a[i][0] * t0, a[i][1] * t1, a[i][2] * t2, a[i][3] * t3};
+      const bool was_alive = st.Tb[blk] > 0.f;
+      bool pixel_stopped = false;
+      if (slow) {
+        // exact stop rule: the first (quad, splat) in list order with T*(1-alpha) < 1e-4 ends the pixel, before adding
+        bool livep = true, any = false;
+        float tstop = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool stop = a[i][r] > 0.f && Tin[i] * pl[i][r] < kTStop;
+          if (livep && stop) { tstop = t[r]; any = true; }
+          livep = livep && !stop;
+          w[r] = livep ? w[r] : 0.f;
+        }
+        const unsigned long long bal = __ballot(any && was_alive) >> j;
+        const bool mine = was_alive && (bal & lower_q) == 0ull;    // no quad in front of mine ended the pixel
+        pixel_stopped = (bal & 0x0001000100010001ull) != 0ull;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = mine ? w[r] : 0.f;
+        if (mine && any) st.Tfin[blk] = tstop;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         st.C[blk][0] = fmaf(w[r], pay[r].x, st.C[blk][0]);
@@ -253,46 +281,13 @@ __device__ __forceinline__ void mx_forward_batch(MxFwdState& st, const float (&K
         st.C[blk][2] = fmaf(w[r], pay[r].z, st.C[blk][2]);
         st.C[blk][3] = fmaf(w[r], pay[r].w, st.C[blk][3]);
       }
-      st.Tb[blk] = Tend[blk];
+      st.Tb[blk] = (was_alive && !pixel_stopped) ? Tend[i] : 0.f;
     }
-    return;
-  }
-  // exact stop rule: the first (quad, splat) in list order with T*(1-alpha) < 1e-4 ends the pixel, before adding
-  const unsigned long long lower_q = 0x0001000100010001ull & ((q == 0) ? 0ull : ((1ull << (16 * q)) - 1ull));
-#pragma unroll
-  for (int blk = 0; blk < 4; ++blk) {
-    const float t0 = Tin[blk], t1 = t0 * pl[blk][0], t2 = t0 * pl[blk][1], t3 = t0 * pl[blk][2];
-    const float t[4] = {t0, t1, t2, t3};
-    bool stop[4], livep = true, any = false;
-    float tstop = 0.f;
-    float w[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      stop[r] = a[blk][r] > 0.f && Tin[blk] * pl[blk][r] < kTStop;
-      if (livep && stop[r]) { tstop = t[r]; any = true; }
-      livep = livep && !stop[r];
-      w[r] = livep ? a[blk][r] * t[r] : 0.f;
-    }
-    const bool was_alive = st.Tb[blk] > 0.f;
-    const unsigned long long bal = __ballot(any && was_alive) >> j;
-    const bool earlier = (bal & lower_q) != 0ull;              // a quad in front of mine already ended the pixel
-    const bool pixel_stopped = (bal & 0x0001000100010001ull) != 0ull;
-    const bool mine = was_alive && !earlier;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float wr = mine ? w[r] : 0.f;
-      st.C[blk][0] = fmaf(wr, pay[r].x, st.C[blk][0]);
-      st.C[blk][1] = fmaf(wr, pay[r].y, st.C[blk][1]);
-      st.C[blk][2] = fmaf(wr, pay[r].z, st.C[blk][2]);
-      st.C[blk][3] = fmaf(wr, pay[r].w, st.C[blk][3]);
-    }
-    if (mine && any) st.Tfin[blk] = tstop;
-    st.Tb[blk] = (was_alive && !pixel_stopped) ? Tend[blk] : 0.f;
   }
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void composite_forward_mx(
+__global__ __launch_bounds__(64 * WAVES, 4) void composite_forward_mx(
     CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
     const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ sorted_gid,
     const GeomRec* __restrict__ geom, const float* __restrict__ colors,
@@ -386,8 +381,9 @@ __global__ __launch_bounds__(256) void composite_backward(
     const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ sorted_gid,
     const uint32_t* __restrict__ sorted_inst, const GeomRec* __restrict__ geom, const float* __restrict__ colors,
     const float* __restrict__ out_color, const float* __restrict__ grad_color, const float* __restrict__ final_T,
-    float* __restrict__ grad_inst) {
+    float* __restrict__ grad_inst, const Counters* __restrict__ ctr) {
   __shared__ float lds[4][2][16 * kRowStride];
+  if (ctr->overflow) return;
   const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
   const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
   const TileCoord tc = tile_coord<4>(cs, nblk16, gx16, gx8, gy8);
@@ -610,9 +606,10 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ sorted_gid,
     const uint32_t* __restrict__ sorted_inst, const GeomRec* __restrict__ geom, const float* __restrict__ colors,
     const float* __restrict__ out_color, const float* __restrict__ grad_color, const float* __restrict__ final_T,
-    float* __restrict__ grad_inst) {
+    float* __restrict__ grad_inst, const Counters* __restrict__ ctr) {
   __shared__ float4 lds_pay_all[WAVES][64];
   __shared__ float4 lds_xch_all[WAVES][128];
+  if (ctr->overflow) return;
   __shared__ float lds_uw[WAVES][2][16 * kRowStride];
   const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
   const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
@@ -715,8 +712,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     }
   }
 }
-template __global__ void composite_backward_mx<4>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*);
-template __global__ void composite_backward_mx<1>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*);
+template __global__ void composite_backward_mx<4>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*);
+template __global__ void composite_backward_mx<1>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*);
 
 // one thread per Gaussian: re-centre and sum its instance records (fixed order), then the projection backward
 __global__ __launch_bounds__(256) void gather_splat_grads(
@@ -725,7 +722,9 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     const float* __restrict__ scales, const float* __restrict__ rotations,
     const GaussAux* __restrict__ gaux, const float* __restrict__ grad_inst, int moments_scaled_by_opacity,
     float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_colors,
-    float* __restrict__ g_opacities, float* __restrict__ g_scales, float* __restrict__ g_rotations) {
+    float* __restrict__ g_opacities, float* __restrict__ g_scales, float* __restrict__ g_rotations,
+    const Counters* __restrict__ ctr) {
+  if (ctr->overflow) return;                     // the forward did not complete: nothing valid to differentiate
   const CamParams cam = load_cam(cs, Vp, PVp);
   const int gid = (int)(blockIdx.x * 256u + threadIdx.x);
   if (gid >= n) return;

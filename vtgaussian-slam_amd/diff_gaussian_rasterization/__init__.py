@@ -290,8 +290,9 @@ def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotatio
     g_rot = torch.empty((n, 4), dtype=torch.float32, device=device)
     if n == 0:
         return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
-    _resolve_pending(fs)                 # asynchronous forward: its result record is needed (and checked) now
-    sbytes = _lib.vtgs_backward_scratch_bytes(n, fs.instances)
+    # Asynchronous forward: enqueue the backward first (scratch sized by capacity; the kernels check the device-side
+    # overflow flag themselves) and verify the result record afterwards, so the GPU never waits for the host.
+    sbytes = _lib.vtgs_backward_scratch_bytes(n, fs.instances if fs.pending is None else fs.capacity)
     scratch = torch.empty((sbytes,), dtype=torch.uint8, device=device)
     state_ptr = fs.image_state.data_ptr() if fs.image_state is not None else None
     st = _lib.vtgs_backward(ctypes.byref(fs.cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
@@ -300,6 +301,7 @@ def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotatio
                             scratch.data_ptr(), sbytes, g_means3D.data_ptr(), g_means2D.data_ptr(), g_colors.data_ptr(),
                             g_opac.data_ptr(), g_scales.data_ptr(), g_rot.data_ptr(), _stream_ptr(device))
     _check(st, "vtgs_backward")
+    _resolve_pending(fs)                 # raises if that forward had overflowed its capacity
     return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
 
 
