@@ -1,53 +1,61 @@
-// Micro-test: decode the A/B/D lane layout of v_mfma_f32_16x16x1_4b_f32 and its cbsz/abid A-broadcast.
+// Self-checking micro-test of the two MFMA facts composite_*_mx relies on (gfx950):
+//   v_mfma_f32_16x16x1_4b_f32 with cbsz=2/abid=b:  D[4*blk + r] of lane (j = L&15, q = L>>4)
+//        = A(lane 16*b + 4*q + r) * B(lane 16*blk + j)          (4 blocks in the 4 register groups, A broadcast from block b)
+//   v_mfma_f32_16x16x4_f32:                          D[r] of lane (j, q) = sum_k A(lane (4q + r) + 16 k) * B(lane j + 16 k)
+// Exit code 0 = layout as assumed.  Build: hipcc --offload-arch=gfx950 mfma_layout.hip -o mfma_layout.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int CBSZ, int ABID>
-__global__ void k16(float* out) {
+template <int ABID>
+__global__ void k16x1(float* out) {
   const int l = threadIdx.x;
   f32x16 d = {0};
-  // A = 100 + lane, B = 1 (so D tells which A lane fed each output), then A = 1, B = 1000 + lane
-  d = __builtin_amdgcn_mfma_f32_16x16x1f32(100.f + l, 1.f, d, CBSZ, ABID, 0);
-  for (int r = 0; r < 16; ++r) out[l * 32 + r] = d[r];
+  d = __builtin_amdgcn_mfma_f32_16x16x1f32(100.f + l, 1.f, d, 2, ABID, 0);
   f32x16 e = {0};
-  e = __builtin_amdgcn_mfma_f32_16x16x1f32(1.f, 1000.f + l, e, CBSZ, ABID, 0);
-  for (int r = 0; r < 16; ++r) out[l * 32 + 16 + r] = e[r];
+  e = __builtin_amdgcn_mfma_f32_16x16x1f32(1.f, 1000.f + l, e, 2, ABID, 0);
+  for (int r = 0; r < 16; ++r) { out[l * 32 + r] = d[r]; out[l * 32 + 16 + r] = e[r]; }
 }
-template <int CBSZ, int ABID>
-__global__ void k4(float* out) {
+__global__ void k16x4(float* out) {
   const int l = threadIdx.x;
   f32x4 d = {0, 0, 0, 0};
-  d = __builtin_amdgcn_mfma_f32_4x4x1f32(100.f + l, 1.f, d, CBSZ, ABID, 0);
-  for (int r = 0; r < 4; ++r) out[l * 8 + r] = d[r];
-  f32x4 e = {0, 0, 0, 0};
-  e = __builtin_amdgcn_mfma_f32_4x4x1f32(1.f, 1000.f + l, e, CBSZ, ABID, 0);
-  for (int r = 0; r < 4; ++r) out[l * 8 + 4 + r] = e[r];
+  // A(lane) = 1 + lane, B(lane) = 2^-(lane&15): the sum over the 4 k-slots identifies both operands
+  d = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(1 + l), (float)(l & 15) + 1.f, d, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) out[l * 4 + r] = d[r];
 }
-static void dump16(const char* name, float* h) {
-  printf("== %s: lane: D regs (A-source lanes) | D regs (B-source lanes)\n", name);
-  for (int l = 0; l < 64; l += 1) {
-    if (!(l < 20 || l % 16 == 0 || l == 63)) continue;
-    printf("lane %2d: A:", l);
-    for (int r = 0; r < 16; ++r) printf(" %3.0f", h[l * 32 + r] - 100.f);
-    printf(" | B:");
-    for (int r = 0; r < 16; ++r) printf(" %3.0f", h[l * 32 + 16 + r] - 1000.f);
-    printf("\n");
-  }
+#define CK(x) do { if ((x) != hipSuccess) { printf("HIP error line %d\n", __LINE__); return 2; } } while (0)
+
+template <int ABID>
+static int check16x1(float* d) {
+  float h[64 * 32];
+  k16x1<ABID><<<1, 64>>>(d);
+  CK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+  int bad = 0;
+  for (int l = 0; l < 64; ++l)
+    for (int blk = 0; blk < 4; ++blk)
+      for (int r = 0; r < 4; ++r) {
+        const int j = l & 15, q = l >> 4;
+        if (h[l * 32 + 4 * blk + r] != 100.f + 16 * ABID + 4 * q + r) ++bad;
+        if (h[l * 32 + 16 + 4 * blk + r] != 1000.f + 16 * blk + j) ++bad;
+      }
+  if (bad) printf("16x16x1_4b cbsz=2 abid=%d: %d mismatches\n", ABID, bad);
+  return bad;
 }
 int main() {
-  float *d, h[64 * 32];
-  hipMalloc(&d, sizeof(h));
-  k16<0, 0><<<1, 64>>>(d); hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost); dump16("16x16x1 cbsz=0", h);
-  k16<2, 1><<<1, 64>>>(d); hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost); dump16("16x16x1 cbsz=2 abid=1", h);
-  k16<2, 3><<<1, 64>>>(d); hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost); dump16("16x16x1 cbsz=2 abid=3", h);
-  float h4[64 * 8];
-  k4<0, 0><<<1, 64>>>(d); hipMemcpy(h4, d, sizeof(h4), hipMemcpyDeviceToHost);
-  printf("== 4x4x1 cbsz=0\n");
-  for (int l = 0; l < 12; ++l) { printf("lane %2d: A:", l); for (int r = 0; r < 4; ++r) printf(" %3.0f", h4[l*8+r]-100.f); printf(" | B:"); for (int r = 0; r < 4; ++r) printf(" %3.0f", h4[l*8+4+r]-1000.f); printf("\n"); }
-  k4<4, 5><<<1, 64>>>(d); hipMemcpy(h4, d, sizeof(h4), hipMemcpyDeviceToHost);
-  printf("== 4x4x1 cbsz=4 abid=5\n");
-  for (int l = 0; l < 12; ++l) { printf("lane %2d: A:", l); for (int r = 0; r < 4; ++r) printf(" %3.0f", h4[l*8+r]-100.f); printf(" | B:"); for (int r = 0; r < 4; ++r) printf(" %3.0f", h4[l*8+4+r]-1000.f); printf("\n"); }
-  return 0;
+  float* d;
+  CK(hipMalloc(&d, 64 * 32 * sizeof(float)));
+  int bad = check16x1<0>(d) + check16x1<1>(d) + check16x1<2>(d) + check16x1<3>(d);
+  float h[64 * 4];
+  k16x4<<<1, 64>>>(d);
+  CK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+  for (int l = 0; l < 64; ++l)
+    for (int r = 0; r < 4; ++r) {
+      const int j = l & 15, q = l >> 4, row = 4 * q + r;
+      float want = 0.f;
+      for (int k = 0; k < 4; ++k) want += (float)(1 + row + 16 * k) * ((float)j + 1.f);
+      if (h[l * 4 + r] != want) ++bad;
+    }
+  printf(bad ? "MFMA layout DIFFERS from what the kernels assume (%d)\n" : "mfma layouts ok\n", bad);
+  return bad ? 1 : 0;
 }

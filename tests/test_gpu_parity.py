@@ -282,3 +282,35 @@ def test_mark_visible_and_scalar_kernels_agree(gpu_device):
     V = cam.viewmatrix.reshape(4, 4)
     tz = (torch.cat([scene["means3D"], torch.ones(5000, 1)], 1) @ V)[:, 2]
     assert (vis != (tz > 0.2)).sum().item() <= 1
+
+
+def test_scalar_and_matrix_core_kernels_agree(gpu_device, monkeypatch):
+    """Two independent GPU implementations of the composite (lane = pixel scalar kernels vs matrix-core kernels)
+    must agree with each other as tightly as with the oracle."""
+    scene, cam = go.random_scene(6000, 200, 136, seed=41, anisotropic=True, w2c=_w2c(41))
+    g = torch.Generator().manual_seed(8)
+    grad_color = torch.rand(3, 136, 200, generator=g) * 2 - 1
+    monkeypatch.setenv("VTGS_FWD_IMPL", "1"); monkeypatch.setenv("VTGS_BWD_IMPL", "1")
+    c1, r1, d1, g1 = run_hip(scene, cam, gpu_device, grad_color)
+    monkeypatch.setenv("VTGS_FWD_IMPL", "0"); monkeypatch.setenv("VTGS_BWD_IMPL", "0")
+    c0, r0, d0, g0 = run_hip(scene, cam, gpu_device, grad_color)
+    assert torch.equal(r0, r1)
+    _check_images(c0.double(), d0.double(), c1, d1)
+    _check_grads({k: v.double() for k, v in g0.items()}, g1)
+    # mixed: matrix-core forward state feeding the scalar backward (the saved per-pixel state is interchangeable)
+    monkeypatch.setenv("VTGS_FWD_IMPL", "1"); monkeypatch.setenv("VTGS_BWD_IMPL", "0")
+    _, _, _, gm = run_hip(scene, cam, gpu_device, grad_color)
+    _check_grads({k: v.double() for k, v in g0.items()}, gm)
+
+
+def test_mfma_register_layout_assumptions(gpu_device, tmp_path):
+    """Measure, don't guess: the operand/result lane layout of the two MFMAs the matrix-core kernels are built on."""
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", "mfma_layout.hip")
+    exe = str(tmp_path / "mfma_layout.bin")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-Wno-unused-result", src, "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr

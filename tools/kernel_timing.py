@@ -1,5 +1,11 @@
+"""Per-kernel timing of the fwd+bwd step at the headline shape (HIP events inside the library).
+
+    python tools/kernel_timing.py            # env: ABL_N (Gaussians), ABL_BWD=0 forward only, ABL_TAG label,
+                                             #      VTGS_FWD_IMPL / VTGS_BWD_IMPL = 0 scalar kernels, 1 matrix-core kernels
+"""
 import sys, os, time, torch
-sys.path[:0]=['/root/repo','/root/repo/vtgaussian-slam_amd','/root/repo/tests']
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0]=[ROOT,os.path.join(ROOT,'vtgaussian-slam_amd'),os.path.join(ROOT,'tests')]
 from oracle import gs_oracle as go
 from parity_util import to_settings
 import diff_gaussian_rasterization as dgr

@@ -18,7 +18,6 @@ __global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint
 template <int WAVES>
 __global__ void composite_forward_mx(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*,
                                      const float*, float*, float*, float*, const Counters*);
-template <int WAVES, int UNROLL>
 __global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*,
                                   const float*, float*, float*, float*, const Counters*);
 __global__ void composite_backward(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
@@ -135,29 +134,21 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
                                     char* ws, const float* colors, float* out_color, float* out_depth,
                                     float* image_state, hipStream_t st) {
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
-  const uint32_t nblk16 = (uint32_t)(gx16 * rows16);
-  static const int waves = env_int("VTGS_FWD_WAVES", 4), unroll = env_int("VTGS_FWD_UNROLL", 1);
-  static const int impl = env_int("VTGS_FWD_IMPL", 1);     // 1 = matrix-core form, 0 = scalar (readlane) form
-#define VTGS_FWD_ARGS cs, cam->bg, nblk, (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid), \
-                      (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state, (const Counters*)(ws + L.counters)
+  const uint32_t nblk = (uint32_t)(gx16 * rows16);
+  const int impl = env_int("VTGS_FWD_IMPL", 1);            // 1 = matrix-core kernel, 0 = scalar kernel (read per call)
   {
     ProfScope ps__("composite_forward", st);
-    if (impl == 1) {
-      if (waves == 4) { const uint32_t nblk = nblk16; hipLaunchKernelGGL((composite_forward_mx<4>), dim3(nblk), dim3(256), 0, st, VTGS_FWD_ARGS); }
-      else { const uint32_t nblk = nblk16 * 4u; hipLaunchKernelGGL((composite_forward_mx<1>), dim3(nblk), dim3(64), 0, st, VTGS_FWD_ARGS); }
-    } else if (waves == 4) {
-      const uint32_t nblk = nblk16;
-      if (unroll == 4) hipLaunchKernelGGL((composite_forward<4, 4>), dim3(nblk), dim3(256), 0, st, VTGS_FWD_ARGS);
-      else if (unroll == 2) hipLaunchKernelGGL((composite_forward<4, 2>), dim3(nblk), dim3(256), 0, st, VTGS_FWD_ARGS);
-      else hipLaunchKernelGGL((composite_forward<4, 1>), dim3(nblk), dim3(256), 0, st, VTGS_FWD_ARGS);
-    } else {
-      const uint32_t nblk = nblk16 * 4u;
-      if (unroll == 4) hipLaunchKernelGGL((composite_forward<1, 4>), dim3(nblk), dim3(64), 0, st, VTGS_FWD_ARGS);
-      else if (unroll == 2) hipLaunchKernelGGL((composite_forward<1, 2>), dim3(nblk), dim3(64), 0, st, VTGS_FWD_ARGS);
-      else hipLaunchKernelGGL((composite_forward<1, 1>), dim3(nblk), dim3(64), 0, st, VTGS_FWD_ARGS);
-    }
+    if (impl == 1)
+      hipLaunchKernelGGL((composite_forward_mx<4>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
+                         (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid),
+                         (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
+                         (const Counters*)(ws + L.counters));
+    else
+      hipLaunchKernelGGL(composite_forward, dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
+                         (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid),
+                         (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
+                         (const Counters*)(ws + L.counters));
   }
-#undef VTGS_FWD_ARGS
   VTGS_HIP(hipGetLastError());
   return VTGS_OK;
 }
@@ -268,17 +259,20 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n, const float* means3D, const 
   const float* state = image_state ? image_state : (const float*)(ws + L.final_T);
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   const uint32_t nblk16 = (uint32_t)(gx16 * rows16);
-  static const int bwd_impl = env_int("VTGS_BWD_IMPL", 1), bwd_waves = env_int("VTGS_BWD_WAVES", 4);
-#define VTGS_BWD_ARGS cs, cam->bg, nblk, (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid), \
-                      (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color, grad_color, \
-                      state, (float*)scratch, (const Counters*)(ws + L.counters)
+  const int bwd_impl = env_int("VTGS_BWD_IMPL", 1);          // 1 = matrix-core kernel, 0 = scalar kernel (read per call)
   {
     ProfScope ps__("composite_backward", st);
-    if (bwd_impl == 1 && bwd_waves == 1) { const uint32_t nblk = nblk16 * 4u; hipLaunchKernelGGL((composite_backward_mx<1>), dim3(nblk), dim3(64), 0, st, VTGS_BWD_ARGS); }
-    else if (bwd_impl == 1) { const uint32_t nblk = nblk16; hipLaunchKernelGGL((composite_backward_mx<4>), dim3(nblk), dim3(256), 0, st, VTGS_BWD_ARGS); }
-    else { const uint32_t nblk = nblk16; hipLaunchKernelGGL(composite_backward, dim3(nblk), dim3(256), 0, st, VTGS_BWD_ARGS); }
+    if (bwd_impl == 1)
+      hipLaunchKernelGGL((composite_backward_mx<4>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
+                         (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid),
+                         (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
+                         grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters));
+    else
+      hipLaunchKernelGGL(composite_backward, dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
+                         (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid),
+                         (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
+                         grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters));
   }
-#undef VTGS_BWD_ARGS
   VTGS_HIP(hipGetLastError());
   { ProfScope ps__("gather_splat_grads", st); hipLaunchKernelGGL(gather_splat_grads, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
                      means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, bwd_impl == 1 ? 1 : 0,

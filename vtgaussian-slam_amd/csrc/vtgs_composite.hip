@@ -1,24 +1,27 @@
 // vtgs_composite.hip -- front-to-back alpha composite (forward) and its backward (gfx950, wave64).
 //
-// Work decomposition: ONE WAVEFRONT = ONE 8x8 PIXEL TILE, lane <-> pixel.  A workgroup is four
-// independent wavefronts (the 2x2 tiles of one 16x16 block, so they gather mostly the same splats from
-// the same L1/L2); there is no LDS and no barrier in the forward.  The tile's depth-sorted list is walked
-// in chunks of 64: each lane gathers one splat record (coalesced index read + 32-byte record gather),
-// then the chunk is replayed splat by splat with the record broadcast from its lane into scalar
-// registers (v_readlane), so the per-pixel arithmetic reads splat parameters as SGPR operands.
+// Work decomposition: ONE WAVEFRONT = ONE 8x8 PIXEL TILE; a workgroup is four independent wavefronts (the 2x2 tiles
+// of one 16x16 block, XCD-swizzled so neighbours gather the same splats from the same L2); no workgroup barriers.
+//
+// Two implementations of each direction live here:
+//   * matrix-core kernels (composite_forward_mx / composite_backward_mx, default): the exponent of 64 pixels x 16
+//     splats is a rank-6 bilinear form evaluated by six 4-block f32 MFMAs; see the block comments below.
+//   * scalar kernels (composite_forward / composite_backward, VTGS_FWD_IMPL=0 / VTGS_BWD_IMPL=0): lane = pixel, one
+//     splat at a time broadcast with v_readlane.  They are the first correct path of round 1 and stay as an
+//     independent implementation the GPU tests cross-check against.
 //
 // Semantics per pixel: skip power>0; alpha=min(.99,o*exp(power)); skip alpha<1/255;
-// stop before adding when T(1-alpha)<1e-4; C+=c*alpha*T; D+=z*alpha*T; out=C+T*bg.  exp is evaluated as
-// exp2 of a pre-scaled quadratic form (v_exp_f32).
+// stop before adding when T(1-alpha)<1e-4; C+=c*alpha*T; D+=z*alpha*T; out=C+T*bg.  exp is v_exp_f32 (exp2) of a
+// pre-scaled quadratic form.
 //
 // Backward (Appendix A4, restated front-to-back): with g = dL/dcolor at the pixel, Cg = g.(out - T_final*bg)
 // and the running prefix P_k = sum_{j<=k} (g.c_j) alpha_j T_j,
 //     dL/dalpha_k = T_k (g.c_k) - (Cg - P_k + T_final (g.bg)) / (1 - alpha_k)
 // so the list is replayed in the SAME order as the forward (identical skip/stop decisions by construction,
 // no per-pixel contributor count to store) and the per-pixel state is two scalars (T, P).  Per splat the nine
-// sums over the tile's 64 pixels are formed by an f32 MFMA (see composite_backward) and stored as one 48-byte
-// record per (splat, tile) instance -- plain stores, no float atomics, bitwise reproducible.
-// gather_splat_grads then re-centres and sums each splat's contiguous run of records and runs splat_backward.
+// sums over the tile's 64 pixels are formed by an f32 MFMA contraction and stored as one 48-byte record per
+// (splat, tile) instance -- plain stores, no float atomics, bitwise reproducible.  gather_splat_grads then
+// re-centres and sums each splat's contiguous run of records and runs splat_backward (vtgs_math.h).
 #include "vtgs_internal.h"
 
 namespace vtgs {
@@ -75,8 +78,9 @@ __device__ __forceinline__ TileCoord tile_coord(const CamScalars& cs, uint32_t n
   return tc;
 }
 
-template <int WAVES, int UNROLL>
-__global__ __launch_bounds__(64 * WAVES) void composite_forward(
+// Scalar ("readlane") forward composite: lane = pixel, splats broadcast one at a time.  Kept as an independent
+// second implementation (VTGS_FWD_IMPL=0) that the GPU tests cross-check against the matrix-core kernel.
+__global__ __launch_bounds__(256) void composite_forward(
     CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
     const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ sorted_gid,
     const GeomRec* __restrict__ geom, const float* __restrict__ colors,
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(64 * WAVES) void composite_forward(
   if (ctr->overflow) return;
   const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
   const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
-  const TileCoord tc = tile_coord<WAVES>(cs, nblk, gx16, gx8, gy8);
+  const TileCoord tc = tile_coord<4>(cs, nblk, gx16, gx8, gy8);
   if (!tc.tile_ok) return;                       // wave-uniform
   const int l = lane_id();
   const float pxf = (float)tc.px, pyf = (float)tc.py;
@@ -96,34 +100,21 @@ __global__ __launch_bounds__(64 * WAVES) void composite_forward(
   for (uint32_t base = s; base < e; base += 64u) {
     if (__ballot(!done) == 0ull) break;
     const int n = (int)min(64u, e - base);
-    const ChunkRec r = gather_chunk(sorted_gid, geom, colors, base + (uint32_t)l, l < n);   // lanes >= n hold op = 0
-    for (int j = 0; j < n; j += UNROLL) {
-      // phase 1: alpha of UNROLL splats -- independent chains (readlane -> exp), no dependence on T
-      float alpha[UNROLL];
-      bool pm[UNROLL];
-#pragma unroll
-      for (int q = 0; q < UNROLL; ++q) {
-        const int jq = min(j + q, 63);          // past-the-end slots read a zero-opacity record
-        const float dx = bcast_f(r.u, jq) - pxf, dy = bcast_f(r.v, jq) - pyf;
-        const float p2 = dx * (bcast_f(r.qa, jq) * dx + bcast_f(r.qb, jq) * dy) + bcast_f(r.qc, jq) * dy * dy;
-        alpha[q] = fminf(kAlphaMax, bcast_f(r.op, jq) * __builtin_amdgcn_exp2f(p2));
-        pm[q] = p2 <= 0.f && alpha[q] >= kAlphaMin && (UNROLL == 1 || j + q < n);
-      }
-      // phase 2: transmittance is sequential
-#pragma unroll
-      for (int q = 0; q < UNROLL; ++q) {
-        const int jq = min(j + q, 63);
-        const float Tn = T * (1.f - alpha[q]);
-        bool hit = !done && pm[q];
-        if (hit && Tn < kTStop) { done = true; hit = false; }
-        if (__ballot(hit) != 0ull) {             // wave-uniform: nobody adds this splat -> skip colour reads
-          const float wgt = hit ? alpha[q] * T : 0.f;
-          C0 = fmaf(bcast_f(r.c0, jq), wgt, C0);
-          C1 = fmaf(bcast_f(r.c1, jq), wgt, C1);
-          C2 = fmaf(bcast_f(r.c2, jq), wgt, C2);
-          D = fmaf(bcast_f(r.depth, jq), wgt, D);
-          T = hit ? Tn : T;
-        }
+    const ChunkRec r = gather_chunk(sorted_gid, geom, colors, base + (uint32_t)l, l < n);
+    for (int j = 0; j < n; ++j) {
+      const float dx = bcast_f(r.u, j) - pxf, dy = bcast_f(r.v, j) - pyf;
+      const float p2 = dx * (bcast_f(r.qa, j) * dx + bcast_f(r.qb, j) * dy) + bcast_f(r.qc, j) * dy * dy;
+      const float alpha = fminf(kAlphaMax, bcast_f(r.op, j) * __builtin_amdgcn_exp2f(p2));
+      const float Tn = T * (1.f - alpha);
+      bool hit = !done && p2 <= 0.f && alpha >= kAlphaMin;
+      if (hit && Tn < kTStop) { done = true; hit = false; }
+      if (__ballot(hit) != 0ull) {               // wave-uniform: nobody adds this splat -> skip colour reads
+        const float wgt = hit ? alpha * T : 0.f;
+        C0 = fmaf(bcast_f(r.c0, j), wgt, C0);
+        C1 = fmaf(bcast_f(r.c1, j), wgt, C1);
+        C2 = fmaf(bcast_f(r.c2, j), wgt, C2);
+        D = fmaf(bcast_f(r.depth, j), wgt, D);
+        T = hit ? Tn : T;
       }
     }
   }
@@ -136,12 +127,6 @@ __global__ __launch_bounds__(64 * WAVES) void composite_forward(
     final_T[pix] = T;
   }
 }
-template __global__ void composite_forward<4, 1>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
-template __global__ void composite_forward<4, 2>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
-template __global__ void composite_forward<4, 4>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
-template __global__ void composite_forward<1, 1>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
-template __global__ void composite_forward<1, 2>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
-template __global__ void composite_forward<1, 4>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
 
 // ---------------------------------------------------------------------------------------------------
 // Forward composite, matrix-core form ("mx").
@@ -357,7 +342,6 @@ __global__ __launch_bounds__(64 * WAVES, 4) void composite_forward_mx(
   }
 }
 template __global__ void composite_forward_mx<4>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
-template __global__ void composite_forward_mx<1>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
 
 // ---------------------------------------------------------------------------------------------------
 // Backward composite.  Pixel-major replay produces, per (splat k, pixel p), two scalars:
@@ -713,7 +697,6 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   }
 }
 template __global__ void composite_backward_mx<4>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*);
-template __global__ void composite_backward_mx<1>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*);
 
 // one thread per Gaussian: re-centre and sum its instance records (fixed order), then the projection backward
 __global__ __launch_bounds__(256) void gather_splat_grads(
