@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--height", type=int, default=680)
     ap.add_argument("--cpu-rows", type=int, default=1000, help="16-px tile rows rendered by the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                                                      "the multi-rank path with all ranks on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -65,14 +67,18 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; the gloo rehearsal mode puts every rank on device 0
+    dev = torch.device("cuda", local_rank if args.backend == "nccl" else 0)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import diff_gaussian_rasterization as dgr
     from oracle import gs_oracle as go           # scene generator + CPU baseline (checker side only)
@@ -137,17 +143,23 @@ def main():
     prof = dgr.profile_collect()
     dgr.profile_enable(False)
     kern = {k: {"avg_us": v[0] / v[1] * 1e3, "launches": v[1]} for k, v in prof.items()}
-    alg = kernel_algorithmic_bytes(N, P, r16) if world == 1 else None
+    # rank 0's share: all N Gaussians are projected on every rank, pixels and tile instances only for its band
+    if world == 1:
+        p_rank, r_rank = P, r16
+    else:
+        y0, y1 = tile_rows[0] * 16, min(tile_rows[1] * 16, H)
+        p_rank, r_rank = W * (y1 - y0), int(r16 * (tile_rows[1] - tile_rows[0]) / gy16)
+    alg = kernel_algorithmic_bytes(N, p_rank, r_rank)
     roofline = None
     if kern:
         dom = max(kern, key=lambda k: kern[k]["avg_us"])
         if alg is not None:
             achieved = alg[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
-            call_bytes = 180 * N + 28 * P + 52 * r16
+            call_bytes = 180 * N + 28 * p_rank + 52 * r_rank
             traffic = None           # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-                if (N, W, H) == (1_000_000, 1200, 680) and dom in pmc:
+                if world == 1 and (N, W, H) == (1_000_000, 1200, 680) and dom in pmc:
                     traffic = pmc[dom]["traffic_bytes"]
             except (OSError, ValueError, KeyError):
                 pass
@@ -156,7 +168,8 @@ def main():
                         "kernel_avg_us": round(kern[dom]["avg_us"], 2), "algorithmic_bytes": alg[dom],
                         "call_algorithmic_bytes": call_bytes,
                         "call_frac": round(call_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                        "note": "composite kernels are VALU/exp-bound, not HBM-bound (SURVEY 8d); see DESIGN.md"}
+                        "scope": "whole frame" if world == 1 else f"rank 0 band (tile rows {tile_rows[0]}..{tile_rows[1]})",
+                        "note": "composite kernels are VALU-bound, not HBM-bound (profiles/r1c_sq_counters.md, DESIGN.md 4)"}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
