@@ -33,12 +33,11 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 def kernel_algorithmic_bytes(n, p, r16):
     """B_alg = 180 N + 28 P + 52 R per fwd+bwd call, split over the kernels that own each term
-    (DESIGN.md section 4).  R = 16x16 tiles touched, counted by the op."""
+    (DESIGN.md section 3).  R = 16x16 tiles touched, counted by the op."""
     return {
         "project_and_bin": 44 * n + 12 * r16,            # means/scales/rot/opacity read + key/value emit
-        "scan_tiles": 8 * r16,                           # range scan
-        "scatter_instances": 12 * r16,                   # sort read
-        "sort_tiles": 12 * r16,                          # sort write
+        "finalize_forward": 8 * r16,                     # tile ranges
+        "sort_tiles": 24 * r16,                          # sort read + sort write
         "composite_forward": 12 * n + 4 * r16 + 16 * p,  # colours read + id read + colour/depth out
         "composite_backward": 12 * n + 4 * r16 + 12 * p, # colours re-read + id read + grad_color in
         "gather_splat_grads": 44 * n + 68 * n,           # params re-read + six gradients written

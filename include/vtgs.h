@@ -32,15 +32,16 @@
 extern "C" {
 #endif
 
-#define VTGS_ABI_VERSION 2
+#define VTGS_ABI_VERSION 3
 
 typedef enum VtgsStatus {
   VTGS_OK = 0,
   VTGS_ERR_INVALID_ARGUMENT = 1,   /* null pointer, negative size, bad band, bad rule            */
   VTGS_ERR_WORKSPACE_TOO_SMALL = 2,/* workspace_bytes < vtgs_workspace_bytes(...)                */
-  VTGS_ERR_INSTANCE_OVERFLOW = 3,  /* more (Gaussian,tile) instances than instance_capacity;      */
-                                   /* VtgsForwardInfo.instances_needed says how many; re-allocate  */
-                                   /* and call again (outputs of the failed call are undefined)    */
+  VTGS_ERR_INSTANCE_OVERFLOW = 3,  /* more (Gaussian,tile) instances than instance_capacity, or a    */
+                                   /* tile list longer than tile_capacity; VtgsForwardInfo says how  */
+                                   /* many (instances_needed, max_tile_list); re-allocate and call   */
+                                   /* again (outputs of the failed call are undefined)               */
   VTGS_ERR_HIP = 4,                /* a HIP runtime call failed (see vtgs_last_hip_error)          */
   VTGS_ERR_STALE_WORKSPACE = 5     /* reserved                                                     */
 } VtgsStatus;
@@ -72,7 +73,8 @@ typedef struct VtgsForwardInfo {
   uint64_t tiles16_touched;  /* R of SURVEY 8(d): sum over Gaussians of 16x16 tiles in their rect    */
   uint32_t visible;          /* Gaussians with radii > 0                                             */
   uint32_t max_tile_list;    /* longest per-tile list                                                */
-  uint32_t overflow;         /* 1: instance_capacity was too small, outputs are invalid              */
+  uint32_t overflow;         /* bit 0: instance_capacity too small; bit 1: tile_capacity too small.      */
+                             /* Non-zero: the outputs are invalid                                        */
   uint32_t complete;         /* 1 once the record has been written (async mode: poll / wait on it)   */
 } VtgsForwardInfo;
 
@@ -86,10 +88,12 @@ uint32_t    vtgs_abi_version(void);
 const char* vtgs_strerror(int status);
 const char* vtgs_last_hip_error(void);   /* message of the last failed HIP call on this host thread */
 
-/* Bytes of forward workspace for N Gaussians, a width x height image and room for
- * `instance_capacity` (Gaussian,tile) instances.  A safe first guess is 8*N; vtgs_forward reports
- * the exact need on overflow.                                                                        */
-size_t vtgs_workspace_bytes(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity);
+/* Bytes of forward workspace for N Gaussians, a width x height image, room for `instance_capacity`
+ * (Gaussian,tile) instances in total and for `tile_capacity` instances per 8x8 tile (every tile owns a
+ * fixed-capacity bin, so binning needs no prefix scan).  Safe first guesses: 8*N and 512; vtgs_forward
+ * reports the exact needs (instances_needed, max_tile_list) on overflow.                               */
+size_t vtgs_workspace_bytes(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity,
+                            uint32_t tile_capacity);
 
 /* Bytes of backward scratch for a forward that binned `instances` instances.  When the count is not known
  * yet (asynchronous forward), pass its instance_capacity: the scratch is indexed by instance id < capacity.
@@ -105,7 +109,7 @@ int vtgs_forward(const VtgsCamera* cam, int32_t n,
                  const float* means3D, const float* colors, const float* opacities,
                  const float* scales, const float* rotations,
                  float* out_color, float* out_depth, int32_t* out_radii,
-                 void* workspace, size_t workspace_bytes, uint64_t instance_capacity,
+                 void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
                  VtgsForwardInfo* info, uint32_t flags, void* stream);
 
 /* Second render over the SAME geometry (identical cam/means3D/opacities/scales/rotations as the
@@ -116,12 +120,12 @@ int vtgs_forward(const VtgsCamera* cam, int32_t n,
 int vtgs_forward_shared(const VtgsCamera* cam, int32_t n, const float* colors,
                         float* out_color, float* out_depth,
                         const void* workspace, size_t workspace_bytes, uint64_t instance_capacity,
-                        float* image_state, void* stream);
+                        uint32_t tile_capacity, float* image_state, void* stream);
 
 /* Backward.  Replaces `_C.rasterize_gaussians_backward`.
  *   grad_color[3,H,W] = dL/d out_color;  out_color = what the forward wrote (the gradient of the
  *   depth image is not propagated -- the reference discards that output, src/vtgaussian_slam.py:461).
- *   workspace / instance_capacity: exactly what the forward was given (the capacity fixes the layout).
+ *   workspace / instance_capacity / tile_capacity: exactly what the forward was given (they fix the layout).
  *   image_state: NULL to use the state stored in the workspace by vtgs_forward, or the buffer a
  *   vtgs_forward_shared call filled.
  *   scratch: vtgs_backward_scratch_bytes(n, info.instances) bytes, contents undefined on entry and exit.
@@ -133,7 +137,7 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n,
                   const float* means3D, const float* colors, const float* opacities,
                   const float* scales, const float* rotations,
                   const float* out_color, const float* grad_color,
-                  const void* workspace, size_t workspace_bytes, uint64_t instance_capacity,
+                  const void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
                   const float* image_state, void* scratch, size_t scratch_bytes,
                   float* g_means3D, float* g_means2D, float* g_colors, float* g_opacities,
                   float* g_scales, float* g_rotations, void* stream);
@@ -156,11 +160,13 @@ typedef struct VtgsProfileEntry {
 int vtgs_profile_enable(int on);
 int vtgs_profile_collect(VtgsProfileEntry* out, int32_t max_entries, int32_t* n_entries);
 
-/* Introspection for tests: byte offsets of the workspace regions for (n, width, height, capacity).
+/* Introspection for tests: byte offsets of the workspace regions for (n, width, height, capacities).
  * out[0..7] = counters, geom (N x 8 f32: u v A B C opacity depth pad), gaux (N x {first instance, count}),
- * tile_offsets ((tiles8+1) x u32), sorted_gid (cap x u32), sorted_inst (cap x u32), final_T (P x f32),
- * tiles8 (count, not an offset).  8x8 tiles are numbered row-major over ceil(W/8) x ceil(H/8).          */
-int vtgs_debug_layout(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity, uint64_t out[8]);
+ * tile_counts (tiles8 x u32), sorted_gid (tiles8 x tile_capacity x u32), sorted_inst (same), final_T (P x f32),
+ * tiles8 (count, not an offset).  8x8 tiles are numbered row-major over ceil(W/8) x ceil(H/8); tile t owns
+ * entries [t * tile_capacity, t * tile_capacity + count[t]).                                             */
+int vtgs_debug_layout(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity, uint32_t tile_capacity,
+                      uint64_t out[8]);
 
 #ifdef __cplusplus
 }

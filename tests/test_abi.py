@@ -34,27 +34,29 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_version_strings_and_sizes(lib):
     lib.vtgs_abi_version.restype = ctypes.c_uint32
-    assert lib.vtgs_abi_version() == 2
+    assert lib.vtgs_abi_version() == 3
     lib.vtgs_strerror.restype = ctypes.c_char_p
     assert lib.vtgs_strerror(0) == b"ok" and b"instance" in lib.vtgs_strerror(3)
     lib.vtgs_workspace_bytes.restype = ctypes.c_size_t
-    lib.vtgs_workspace_bytes.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_uint64]
-    a = lib.vtgs_workspace_bytes(1000, 640, 480, 8000)
-    b = lib.vtgs_workspace_bytes(1000, 640, 480, 16000)
-    c = lib.vtgs_workspace_bytes(2000, 640, 480, 8000)
+    lib.vtgs_workspace_bytes.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_uint64, ctypes.c_uint32]
+    a = lib.vtgs_workspace_bytes(1000, 640, 480, 8000, 256)
+    b = lib.vtgs_workspace_bytes(1000, 640, 480, 8000, 512)
+    c = lib.vtgs_workspace_bytes(2000, 640, 480, 8000, 256)
     assert 0 < a < b and a < c and a % 256 == 0
-    assert lib.vtgs_workspace_bytes(-1, 640, 480, 8) == 0 and lib.vtgs_workspace_bytes(10, 0, 480, 8) == 0
+    assert b - a >= 80 * 60 * 256 * 20                                   # 20 bytes per bin slot, 80x60 tiles
+    assert lib.vtgs_workspace_bytes(-1, 640, 480, 8, 64) == 0 and lib.vtgs_workspace_bytes(10, 0, 480, 8, 64) == 0
+    assert lib.vtgs_workspace_bytes(10, 640, 480, 8, 0) == 0
     lib.vtgs_backward_scratch_bytes.restype = ctypes.c_size_t
     lib.vtgs_backward_scratch_bytes.argtypes = [ctypes.c_int32, ctypes.c_uint64]
     assert lib.vtgs_backward_scratch_bytes(10, 100) >= 100 * 48
 
 
 def test_invalid_arguments_are_rejected_before_any_device_work(lib):
-    assert lib.vtgs_forward(None, 0, *([None] * 9), ctypes.c_size_t(0), ctypes.c_uint64(1), None, 0, None) == 1
+    assert lib.vtgs_forward(None, 0, *([None] * 9), ctypes.c_size_t(0), ctypes.c_uint64(1), 64, None, 0, None) == 1
     assert lib.vtgs_mark_visible(None, 0, None, None, None) == 1
     out = (ctypes.c_uint64 * 8)()
-    lib.vtgs_debug_layout.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
-    assert lib.vtgs_debug_layout(5, 33, 17, 64, out) == 0
+    lib.vtgs_debug_layout.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
+    assert lib.vtgs_debug_layout(5, 33, 17, 64, 32, out) == 0
     assert out[7] == 5 * 3 and out[1] == 256            # ceil(33/8) x ceil(17/8) tiles; geom right after counters
 
 

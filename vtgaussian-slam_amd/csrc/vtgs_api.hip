@@ -9,24 +9,24 @@
 namespace vtgs {
 // kernels (vtgs_binning.hip / vtgs_composite.hip)
 __global__ void project_and_bin(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
-                                const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, InstTmp*, Counters*,
-                                BlockStats*, unsigned long long);
-__global__ void scan_tiles(const uint32_t*, uint32_t*, uint32_t, Counters*, unsigned long long, const BlockStats*, uint32_t);
-__global__ void scatter_instances(const InstTmp*, const uint32_t*, unsigned long long*, uint32_t*, const Counters*);
-__global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
+                                const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*,
+                                Counters*, BlockStats*, unsigned long long, uint32_t);
+__global__ void finalize_forward(const uint32_t*, uint32_t, Counters*, unsigned long long, uint32_t, const BlockStats*,
+                                 uint32_t);
+__global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t,
                            const Counters*);
+__global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
+                                  const GeomRec*, const float*, float*, float*, float*, const Counters*);
 template <int WAVES>
-__global__ void composite_forward_mx(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*,
-                                     const float*, float*, float*, float*, const Counters*);
-__global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*,
-                                  const float*, float*, float*, float*, const Counters*);
-__global__ void composite_backward(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
-                                   const GeomRec*, const float*, const float*, const float*, const float*, float*,
-                                   const Counters*);
+__global__ void composite_forward_mx(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
+                                     const GeomRec*, const float*, float*, float*, float*, const Counters*);
+__global__ void composite_backward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
+                                   const uint32_t*, const GeomRec*, const float*, const float*, const float*,
+                                   const float*, float*, const Counters*);
 template <int WAVES>
-__global__ void composite_backward_mx(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
-                                      const GeomRec*, const float*, const float*, const float*, const float*, float*,
-                                      const Counters*);
+__global__ void composite_backward_mx(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
+                                      const uint32_t*, const GeomRec*, const float*, const float*, const float*,
+                                      const float*, float*, const Counters*);
 __global__ void gather_splat_grads(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
                                    const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*,
                                    float*, const Counters*);
@@ -105,7 +105,7 @@ const char* vtgs_strerror(int status) {
     case VTGS_OK: return "ok";
     case VTGS_ERR_INVALID_ARGUMENT: return "invalid argument";
     case VTGS_ERR_WORKSPACE_TOO_SMALL: return "workspace too small";
-    case VTGS_ERR_INSTANCE_OVERFLOW: return "more (Gaussian,tile) instances than instance_capacity";
+    case VTGS_ERR_INSTANCE_OVERFLOW: return "more (Gaussian,tile) instances than instance_capacity or a tile list longer than tile_capacity";
     case VTGS_ERR_HIP: return "HIP runtime error";
     case VTGS_ERR_STALE_WORKSPACE: return "workspace holds no completed forward for these sizes";
     default: return "unknown status";
@@ -114,9 +114,9 @@ const char* vtgs_strerror(int status) {
 
 const char* vtgs_last_hip_error(void) { return g_hip_err; }
 
-size_t vtgs_workspace_bytes(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity) {
-  if (n < 0 || width <= 0 || height <= 0) return 0;
-  return make_layout(n, width, height, instance_capacity).total;
+size_t vtgs_workspace_bytes(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity, uint32_t tile_capacity) {
+  if (n < 0 || width <= 0 || height <= 0 || tile_capacity == 0) return 0;
+  return make_layout(n, width, height, instance_capacity, tile_capacity).total;
 }
 
 size_t vtgs_backward_scratch_bytes(int32_t n, uint64_t instances) {
@@ -140,12 +140,12 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
     ProfScope ps__("composite_forward", st);
     if (impl == 1)
       hipLaunchKernelGGL((composite_forward_mx<4>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
-                         (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid),
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
                          (const Counters*)(ws + L.counters));
     else
       hipLaunchKernelGGL(composite_forward, dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
-                         (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid),
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
                          (const Counters*)(ws + L.counters));
   }
@@ -155,15 +155,15 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
 
 int vtgs_forward(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* opacities,
                  const float* scales, const float* rotations, float* out_color, float* out_depth, int32_t* out_radii,
-                 void* workspace, size_t workspace_bytes, uint64_t instance_capacity, VtgsForwardInfo* info,
-                 uint32_t flags, void* stream) {
+                 void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
+                 VtgsForwardInfo* info, uint32_t flags, void* stream) {
   if (!cam_ok(cam) || n < 0 || !out_color || !out_depth || !workspace || instance_capacity == 0 ||
-      instance_capacity > 0xFFFFFFFFull)
+      instance_capacity > 0xFFFFFFFFull || tile_capacity == 0)
     return VTGS_ERR_INVALID_ARGUMENT;
   if (n > 0 && (!means3D || !colors || !opacities || !scales || !rotations || !out_radii)) return VTGS_ERR_INVALID_ARGUMENT;
   int r8b, r8e, rows16, row16_0;
   if (!band_of(cam, &r8b, &r8e, &rows16, &row16_0)) return VTGS_ERR_INVALID_ARGUMENT;
-  const WsLayout L = make_layout(n, cam->image_width, cam->image_height, instance_capacity);
+  const WsLayout L = make_layout(n, cam->image_width, cam->image_height, instance_capacity, tile_capacity);
   if (workspace_bytes < L.total) return VTGS_ERR_WORKSPACE_TOO_SMALL;
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
@@ -182,26 +182,24 @@ int vtgs_forward(const VtgsCamera* cam, int32_t n, const float* means3D, const f
   if (n > 0) {
     { ProfScope ps__("project_and_bin", st); hipLaunchKernelGGL(project_and_bin, dim3((n + 1023) / 1024), dim3(1024), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
                        means3D, opacities, scales, rotations, out_radii, (GeomRec*)(ws + L.geom),
-                       (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt), (InstTmp*)(ws + L.inst_tmp), ctr,
-                       (BlockStats*)(ws + L.block_stats), (unsigned long long)instance_capacity); }
+                       (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt), (unsigned long long*)(ws + L.keys),
+                       (uint32_t*)(ws + L.vals), ctr, (BlockStats*)(ws + L.block_stats),
+                       (unsigned long long)instance_capacity, L.tile_cap); }
     VTGS_HIP(hipGetLastError());
   }
-  { ProfScope ps__("scan_tiles", st); hipLaunchKernelGGL(scan_tiles, dim3(1), dim3(1024), 0, st, (const uint32_t*)(ws + L.tile_cnt),
-                     (uint32_t*)(ws + L.tile_off), L.tiles8, ctr, (unsigned long long)instance_capacity,
-                     (const BlockStats*)(ws + L.block_stats), (uint32_t)((n + 1023) / 1024)); }
+  // overflow flags and statistics first: on overflow some bin slots were never written, so the consumers must bail
+  { ProfScope ps__("finalize_forward", st); hipLaunchKernelGGL(finalize_forward, dim3(1), dim3(1024), 0, st, (const uint32_t*)(ws + L.tile_cnt), L.tiles8, ctr,
+                     (unsigned long long)instance_capacity, L.tile_cap, (const BlockStats*)(ws + L.block_stats),
+                     (uint32_t)((n + 1023) / 1024)); }
   VTGS_HIP(hipGetLastError());
-  { ProfScope ps__("scatter_instances", st); hipLaunchKernelGGL(scatter_instances, dim3(2048), dim3(256), 0, st, (const InstTmp*)(ws + L.inst_tmp),
-                     (const uint32_t*)(ws + L.tile_off), (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals),
-                     (const Counters*)ctr); }
-  VTGS_HIP(hipGetLastError());
-  { ProfScope ps__("sort_tiles", st); hipLaunchKernelGGL(sort_tiles, dim3((L.tiles8 + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_off),
+
+  { ProfScope ps__("sort_tiles", st); hipLaunchKernelGGL(sort_tiles, dim3((L.tiles8 + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
                      (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
-                     (uint32_t*)(ws + L.sorted_inst), L.tiles8, (const Counters*)ctr); }
+                     (uint32_t*)(ws + L.sorted_inst), L.tiles8, L.tile_cap, (const Counters*)ctr); }
   VTGS_HIP(hipGetLastError());
   int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st);
   if (rc != VTGS_OK) return rc;
-
-  // result record: assembled on the device by scan_tiles at byte 64 of the counters block
+  // result record: assembled on the device by finalize_forward at byte 64 of the counters block
   static_assert(sizeof(VtgsForwardInfo) == 40, "VtgsForwardInfo layout is mirrored in Counters");
   const char* image = (const char*)ctr + offsetof(Counters, info_instances);
   if (flags & VTGS_FORWARD_ASYNC) {
@@ -217,14 +215,14 @@ int vtgs_forward(const VtgsCamera* cam, int32_t n, const float* means3D, const f
 }
 
 int vtgs_forward_shared(const VtgsCamera* cam, int32_t n, const float* colors, float* out_color, float* out_depth,
-                        const void* workspace, size_t workspace_bytes, uint64_t instance_capacity, float* image_state,
-                        void* stream) {
+                        const void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
+                        float* image_state, void* stream) {
   if (!cam_ok(cam) || n < 0 || !colors || !out_color || !out_depth || !workspace || !image_state ||
-      instance_capacity == 0 || instance_capacity > 0xFFFFFFFFull)
+      instance_capacity == 0 || instance_capacity > 0xFFFFFFFFull || tile_capacity == 0)
     return VTGS_ERR_INVALID_ARGUMENT;
   int r8b, r8e, rows16, row16_0;
   if (!band_of(cam, &r8b, &r8e, &rows16, &row16_0)) return VTGS_ERR_INVALID_ARGUMENT;
-  const WsLayout L = make_layout(n, cam->image_width, cam->image_height, instance_capacity);
+  const WsLayout L = make_layout(n, cam->image_width, cam->image_height, instance_capacity, tile_capacity);
   if (workspace_bytes < L.total) return VTGS_ERR_WORKSPACE_TOO_SMALL;
   hipStream_t st = (hipStream_t)stream;
   const CamScalars cs = scalars_of(cam, r8b, r8e);
@@ -238,11 +236,11 @@ int vtgs_forward_shared(const VtgsCamera* cam, int32_t n, const float* colors, f
 
 int vtgs_backward(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* opacities,
                   const float* scales, const float* rotations, const float* out_color, const float* grad_color,
-                  const void* workspace, size_t workspace_bytes, uint64_t instance_capacity, const float* image_state,
-                  void* scratch, size_t scratch_bytes, float* g_means3D, float* g_means2D, float* g_colors,
-                  float* g_opacities, float* g_scales, float* g_rotations, void* stream) {
+                  const void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
+                  const float* image_state, void* scratch, size_t scratch_bytes, float* g_means3D, float* g_means2D,
+                  float* g_colors, float* g_opacities, float* g_scales, float* g_rotations, void* stream) {
   if (!cam_ok(cam) || n < 0 || !out_color || !grad_color || !workspace || !scratch || instance_capacity == 0 ||
-      instance_capacity > 0xFFFFFFFFull)
+      instance_capacity > 0xFFFFFFFFull || tile_capacity == 0)
     return VTGS_ERR_INVALID_ARGUMENT;
   if (n > 0 && (!means3D || !colors || !opacities || !scales || !rotations || !g_means3D || !g_means2D || !g_colors ||
                 !g_opacities || !g_scales || !g_rotations))
@@ -250,7 +248,7 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n, const float* means3D, const 
   int r8b, r8e, rows16, row16_0;
   if (!band_of(cam, &r8b, &r8e, &rows16, &row16_0)) return VTGS_ERR_INVALID_ARGUMENT;
   if (n == 0) return VTGS_OK;
-  const WsLayout L = make_layout(n, cam->image_width, cam->image_height, instance_capacity);
+  const WsLayout L = make_layout(n, cam->image_width, cam->image_height, instance_capacity, tile_capacity);
   if (workspace_bytes < L.total) return VTGS_ERR_WORKSPACE_TOO_SMALL;
   if (scratch_bytes < kGradRec * sizeof(float)) return VTGS_ERR_INVALID_ARGUMENT;
   hipStream_t st = (hipStream_t)stream;
@@ -264,12 +262,12 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n, const float* means3D, const 
     ProfScope ps__("composite_backward", st);
     if (bwd_impl == 1)
       hipLaunchKernelGGL((composite_backward_mx<4>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
-                         (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid),
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
                          grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters));
     else
       hipLaunchKernelGGL(composite_backward, dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
-                         (const uint32_t*)(ws + L.tile_off), (const uint32_t*)(ws + L.sorted_gid),
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
                          grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters));
   }
@@ -311,10 +309,11 @@ int vtgs_profile_collect(VtgsProfileEntry* out, int32_t max_entries, int32_t* n_
   return VTGS_OK;
 }
 
-int vtgs_debug_layout(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity, uint64_t out[8]) {
-  if (n < 0 || width <= 0 || height <= 0 || !out) return VTGS_ERR_INVALID_ARGUMENT;
-  const WsLayout L = make_layout(n, width, height, instance_capacity);
-  out[0] = L.counters; out[1] = L.geom; out[2] = L.gaux; out[3] = L.tile_off; out[4] = L.sorted_gid;
+int vtgs_debug_layout(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity, uint32_t tile_capacity,
+                      uint64_t out[8]) {
+  if (n < 0 || width <= 0 || height <= 0 || !out || tile_capacity == 0) return VTGS_ERR_INVALID_ARGUMENT;
+  const WsLayout L = make_layout(n, width, height, instance_capacity, tile_capacity);
+  out[0] = L.counters; out[1] = L.geom; out[2] = L.gaux; out[3] = L.tile_cnt; out[4] = L.sorted_gid;
   out[5] = L.sorted_inst; out[6] = L.final_T; out[7] = L.tiles8;
   return VTGS_OK;
 }

@@ -1,19 +1,19 @@
-// vtgs_binning.hip -- projection, per-tile bucketing and per-tile depth sort (gfx950, wave64).
+// vtgs_binning.hip -- projection, per-tile binning and per-tile depth sort (gfx950, wave64).
 //
 // Pipeline (all on the caller's stream, no host round trip):
-//   project_and_bin   one thread per Gaussian: EWA projection (vtgs_math.h), then walks the 8x8 tiles
-//                     under its 16x16-tile rectangle, keeps those the splat's alpha>=1/255 ellipse can
-//                     reach, and reserves a slot in each tile with run-aggregated atomics (Gaussians of a
-//                     view-tied map are stored in raster order, so neighbouring lanes hit the same tile
-//                     and one atomic serves a whole run of lanes).
-//   scan_tiles        exclusive scan of the per-tile counts (<= ~33 k tiles: one workgroup).
-//   scatter_instances instance -> (tile offset + slot): 64-bit key (depth bits | Gaussian id) + instance id.
-//   sort_tiles        per-tile bitonic sort of (key, value) in LDS; key order == the stable
-//                     (tile, depth) order of the published algorithm because ties fall back to Gaussian id.
+//   project_and_bin   one thread per Gaussian: EWA projection (vtgs_math.h), then walks the 8x8 tiles under its
+//                     16x16-tile rectangle, keeps those the splat's alpha>=1/255 ellipse can reach, reserves a slot
+//                     in each tile's fixed-capacity bin with run-aggregated atomics (Gaussians of a view-tied map are
+//                     stored in raster order, so neighbouring lanes hit the same tile and one atomic serves a whole
+//                     run of lanes) and writes the 64-bit key (depth bits | Gaussian id) + instance id in place.
+//   sort_tiles        per-tile bitonic sort of (key, value): one wavefront per tile, keys in registers; key order ==
+//                     the stable (tile, depth) order of the published algorithm because ties fall back to Gaussian id.
+//   finalize_forward  one workgroup: longest list, statistics, overflow flags (the later kernels bail on them), the
+//                     host-visible result record.
 //
-// The replaced implementation [UPSTREAM-PUBLIC] sorts all (tile|depth) keys with a global radix sort
-// (several passes over 12 B x R) and reads the total back to the host to size it.  Here the tile is
-// resolved by bucketing (one pass) and only the short per-tile lists are sorted, on chip.
+// The replaced implementation [UPSTREAM-PUBLIC] sorts all (tile|depth) keys with a global radix sort (several passes
+// over 12 B x R) and reads the total back to the host to size it.  Here the tile is resolved by binning (one pass,
+// no prefix scan) and only the short per-tile lists are sorted, on chip.
 #include "vtgs_internal.h"
 
 namespace vtgs {
@@ -78,8 +78,8 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ scales, const float* __restrict__ rotations,
     int32_t* __restrict__ radii, GeomRec* __restrict__ geom, GaussAux* __restrict__ gaux,
-    uint32_t* __restrict__ tile_cnt, InstTmp* __restrict__ inst_tmp, Counters* __restrict__ ctr,
-    BlockStats* __restrict__ block_stats, unsigned long long capacity) {
+    uint32_t* __restrict__ tile_cnt, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
+    Counters* __restrict__ ctr, BlockStats* __restrict__ block_stats, unsigned long long capacity, uint32_t tile_cap) {
   constexpr int kWaves = kProjBlock / 64;
   const CamParams cam = load_cam(cs, Vp, PVp);
   const int gid = (int)(blockIdx.x * (uint32_t)kProjBlock + threadIdx.x);
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
   // pass 2: reserve a slot in every reached tile, lanes in lock-step so runs can share atomics.  The returning
   // atomic of step i is consumed in step i+1, so its round trip overlaps the next step's work.
   const int max_area = wave_max_i(area);
-  const uint32_t zbits = __float_as_uint(sp.depth);
+  const unsigned long long key = ((unsigned long long)__float_as_uint(sp.depth) << 32) | (unsigned long long)(uint32_t)gid;
   uint32_t ord = 0;
   Reservation pend;
   pend.base = 0; pend.head_lane = 0; pend.rank = 0; pend.act = false; pend.tile = -1;
@@ -166,29 +166,29 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     const uint32_t slot = reserve_resolve(pend);
     if (pend.act) {
       const unsigned long long id = (unsigned long long)inst_base + ord;
-      if (id < capacity) inst_tmp[id] = InstTmp{(uint32_t)pend.tile, slot, (uint32_t)gid, zbits};
+      if (id < capacity && slot < tile_cap) {                  // an overflowing bin / id is dropped and flagged later
+        const size_t pos = (size_t)pend.tile * tile_cap + slot;
+        keys[pos] = key;
+        vals[pos] = (uint32_t)id;
+      }
       ++ord;
     }
     pend = cur;
   }
 }
 
-// exclusive scan of tile_cnt[0..tiles) -> tile_off[0..tiles]; one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void scan_tiles(const uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ tile_off,
-                                                   uint32_t tiles, Counters* __restrict__ ctr, unsigned long long capacity,
-                                                   const BlockStats* __restrict__ block_stats, uint32_t nblocks) {
-  __shared__ uint32_t part[1024];
-  __shared__ uint32_t wmax[16];
-  __shared__ uint32_t svis[16];
+// One workgroup right after the binning: longest tile list, statistics, overflow flags and the image of the
+// host-visible VtgsForwardInfo.
+__global__ __launch_bounds__(1024) void finalize_forward(const uint32_t* __restrict__ tile_cnt, uint32_t tiles,
+                                                         Counters* __restrict__ ctr, unsigned long long capacity,
+                                                         uint32_t tile_cap, const BlockStats* __restrict__ block_stats,
+                                                         uint32_t nblocks) {
+  __shared__ uint32_t wmax[16], svis[16];
   __shared__ unsigned long long sr16[16];
   const uint32_t t = threadIdx.x;
-  const uint32_t per = (tiles + 1023u) / 1024u;
-  const uint32_t b = t * per, e = min(b + per, tiles);
-  uint32_t s = 0, mx = 0;
-  for (uint32_t i = b; i < e; ++i) { const uint32_t c = tile_cnt[i]; s += c; mx = max(mx, c); }
-  part[t] = s;
+  uint32_t mx = 0;
+  for (uint32_t i = t; i < tiles; i += 1024u) mx = max(mx, tile_cnt[i]);
   mx = (uint32_t)wave_max_i((int)mx);
-  // statistics: sum of the per-workgroup partials written by project_and_bin
   uint32_t vis = 0; unsigned long long r16 = 0;
   for (uint32_t i = t; i < nblocks; i += 1024u) { vis += block_stats[i].visible; r16 += block_stats[i].r16; }
   for (int m = 1; m < 64; m <<= 1) {
@@ -197,37 +197,15 @@ __global__ __launch_bounds__(1024) void scan_tiles(const uint32_t* __restrict__ 
   }
   if ((t & 63u) == 0) { wmax[t >> 6] = mx; svis[t >> 6] = vis; sr16[t >> 6] = r16; }
   __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {           // Hillis-Steele inclusive scan
-    const uint32_t v = (t >= d) ? part[t - d] : 0u;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  uint32_t run = part[t] - s;
-  for (uint32_t i = b; i < e; ++i) { tile_off[i] = run; run += tile_cnt[i]; }
-  if (t == 1023) tile_off[tiles] = part[1023];
   if (t == 0) {
     uint32_t m = 0, v = 0; unsigned long long r = 0;
     for (int i = 0; i < 16; ++i) { m = max(m, wmax[i]); v += svis[i]; r += sr16[i]; }
     const uint32_t total = ctr->inst_total;
-    const uint32_t ovf = ((unsigned long long)total > capacity) ? 1u : 0u;
+    const uint32_t ovf = (((unsigned long long)total > capacity) ? 1u : 0u) | ((m > tile_cap) ? 2u : 0u);
     ctr->overflow = ovf;
     ctr->info_instances = ovf ? 0ull : (unsigned long long)total;
     ctr->info_needed = total; ctr->info_r16 = r;
     ctr->info_visible = v; ctr->info_max_list = m; ctr->info_overflow = ovf; ctr->info_complete = 1u;
-  }
-}
-
-__global__ __launch_bounds__(256) void scatter_instances(const InstTmp* __restrict__ inst_tmp, const uint32_t* __restrict__ tile_off,
-                                                         unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                         const Counters* __restrict__ ctr) {
-  if (ctr->overflow) return;
-  const uint32_t total = ctr->inst_total;
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-    const InstTmp it = inst_tmp[i];
-    const uint32_t pos = tile_off[it.tile] + it.rank;
-    keys[pos] = ((unsigned long long)it.zbits << 32) | (unsigned long long)it.gid;
-    vals[pos] = i;
   }
 }
 
@@ -351,13 +329,13 @@ __device__ __forceinline__ void sort_network(unsigned long long* k, uint32_t* v,
 }
 
 // grid = ceil(tiles/4) workgroups of 4 wavefronts; wavefront w of workgroup b owns tile 4*b' + w (b' XCD-swizzled)
-__global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ tile_off, unsigned long long* __restrict__ keys,
+__global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ tile_cnt, unsigned long long* __restrict__ keys,
                                                   uint32_t* __restrict__ vals, uint32_t* __restrict__ sorted_gid,
-                                                  uint32_t* __restrict__ sorted_inst, uint32_t tiles,
+                                                  uint32_t* __restrict__ sorted_inst, uint32_t tiles, uint32_t tile_cap,
                                                   const Counters* __restrict__ ctr) {
   __shared__ unsigned long long sk[kSortLds];
   __shared__ uint32_t sv[kSortLds];
-  if (ctr->overflow) return;
+  if (ctr->overflow) return;                    // some bin slots were never written: nothing valid to sort
   const uint32_t nblk = (tiles + 3u) >> 2;
   const uint32_t b = xcd_swizzle(blockIdx.x, nblk);
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -365,7 +343,7 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
   {
     const uint32_t tile = 4u * b + (uint32_t)wv;
     if (tile < tiles) {
-      const uint32_t s = tile_off[tile], L = tile_off[tile + 1] - s;
+      const uint32_t s = tile * tile_cap, L = min(tile_cnt[tile], tile_cap);
       if (L == 1u) {
         if (lane == 0) { sorted_gid[s] = (uint32_t)keys[s]; sorted_inst[s] = vals[s]; }
       } else if (L <= 64u) {
@@ -381,7 +359,7 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
   for (uint32_t q = 0; q < 4u; ++q) {
     const uint32_t tile = 4u * b + q;
     if (tile >= tiles) break;
-    const uint32_t s = tile_off[tile], L = tile_off[tile + 1] - s;
+    const uint32_t s = tile * tile_cap, L = min(tile_cnt[tile], tile_cap);
     if (L <= (uint32_t)kWaveSortMax) continue;
     uint32_t n2 = 1;
     while (n2 < L) n2 <<= 1;

@@ -82,18 +82,18 @@ __device__ __forceinline__ TileCoord tile_coord(const CamScalars& cs, uint32_t n
 // second implementation (VTGS_FWD_IMPL=0) that the GPU tests cross-check against the matrix-core kernel.
 __global__ __launch_bounds__(256) void composite_forward(
     CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
-    const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ sorted_gid,
+    const uint32_t* __restrict__ tile_cnt, uint32_t tile_cap, const uint32_t* __restrict__ sorted_gid,
     const GeomRec* __restrict__ geom, const float* __restrict__ colors,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
     const Counters* __restrict__ ctr) {
-  if (ctr->overflow) return;
+  if (ctr->overflow) return;                     // bins hold unwritten slots after an overflow
   const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
   const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
   const TileCoord tc = tile_coord<4>(cs, nblk, gx16, gx8, gy8);
   if (!tc.tile_ok) return;                       // wave-uniform
   const int l = lane_id();
   const float pxf = (float)tc.px, pyf = (float)tc.py;
-  const uint32_t s = tile_off[tc.tile], e = tile_off[tc.tile + 1];
+  const uint32_t s = (uint32_t)tc.tile * tile_cap, e = s + min(tile_cnt[tc.tile], tile_cap);
 
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
   bool done = !tc.inside;
@@ -274,14 +274,14 @@ __device__ __forceinline__ void mx_forward_batch(MxFwdState& st, const float (&K
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 4) void composite_forward_mx(
     CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
-    const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ sorted_gid,
+    const uint32_t* __restrict__ tile_cnt, uint32_t tile_cap, const uint32_t* __restrict__ sorted_gid,
     const GeomRec* __restrict__ geom, const float* __restrict__ colors,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
     const Counters* __restrict__ ctr) {
   __shared__ float4 lds_pay_all[WAVES][64];
   __shared__ float4 lds_xch_all[WAVES][64];
   __shared__ float lds_red_all[WAVES][5 * 64 * 4];          // [value 0..4][q][pixel 0..63]
-  if (ctr->overflow) return;
+  if (ctr->overflow) return;                                // bins hold unwritten slots after an overflow
   const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
   const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
   const TileCoord tc = tile_coord<WAVES>(cs, nblk, gx16, gx8, gy8);   // lane L <-> pixel L of the tile (x = L&7, y = L>>3)
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void composite_forward_mx(
   const float cx = (float)tx0 + 3.5f, cy = (float)ty0 + 3.5f;
   const float X = (float)(l & 7) - 3.5f, Y = (float)(l >> 3) - 3.5f;
   const float Phi[6] = {1.f, X, Y, X * X, X * Y, Y * Y};
-  const uint32_t s = tile_off[tc.tile], e = tile_off[tc.tile + 1];
+  const uint32_t s = (uint32_t)tc.tile * tile_cap, e = s + min(tile_cnt[tc.tile], tile_cap);
 
   MxFwdState st;
 #pragma unroll
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void composite_forward_mx(
     final_T[pix] = T;
   }
 }
-template __global__ void composite_forward_mx<4>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
+template __global__ void composite_forward_mx<4>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
 
 // ---------------------------------------------------------------------------------------------------
 // Backward composite.  Pixel-major replay produces, per (splat k, pixel p), two scalars:
@@ -362,7 +362,7 @@ constexpr int kRowStride = 65;
 
 __global__ __launch_bounds__(256) void composite_backward(
     CamScalars cs, const float* __restrict__ bg, uint32_t nblk16,
-    const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ sorted_gid,
+    const uint32_t* __restrict__ tile_cnt, uint32_t tile_cap, const uint32_t* __restrict__ sorted_gid,
     const uint32_t* __restrict__ sorted_inst, const GeomRec* __restrict__ geom, const float* __restrict__ colors,
     const float* __restrict__ out_color, const float* __restrict__ grad_color, const float* __restrict__ final_T,
     float* __restrict__ grad_inst, const Counters* __restrict__ ctr) {
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void composite_backward(
   float* __restrict__ Us = lds[wv][0];
   float* __restrict__ Ws = lds[wv][1];
   const float pxf = (float)tc.px, pyf = (float)tc.py;
-  const uint32_t s = tile_off[tc.tile], e = tile_off[tc.tile + 1];
+  const uint32_t s = (uint32_t)tc.tile * tile_cap, e = s + min(tile_cnt[tc.tile], tile_cap);
   if (s == e) return;
   const size_t P = (size_t)cs.W * cs.H;
 
@@ -587,7 +587,7 @@ __device__ __forceinline__ void mx_backward_batch(MxBwdState& st, const float (&
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
-    const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ sorted_gid,
+    const uint32_t* __restrict__ tile_cnt, uint32_t tile_cap, const uint32_t* __restrict__ sorted_gid,
     const uint32_t* __restrict__ sorted_inst, const GeomRec* __restrict__ geom, const float* __restrict__ colors,
     const float* __restrict__ out_color, const float* __restrict__ grad_color, const float* __restrict__ final_T,
     float* __restrict__ grad_inst, const Counters* __restrict__ ctr) {
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   float4* lds_xch = lds_xch_all[wv];
   float* __restrict__ Us = lds_uw[wv][0];
   float* __restrict__ Ws = lds_uw[wv][1];
-  const uint32_t s = tile_off[tc.tile], e = tile_off[tc.tile + 1];
+  const uint32_t s = (uint32_t)tc.tile * tile_cap, e = s + min(tile_cnt[tc.tile], tile_cap);
   if (s == e) return;
   const size_t P = (size_t)cs.W * cs.H;
   const int j = l & 15, q = l >> 4;
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     }
   }
 }
-template __global__ void composite_backward_mx<4>(CamScalars, const float*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*);
+template __global__ void composite_backward_mx<4>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*);
 
 // one thread per Gaussian: re-centre and sum its instance records (fixed order), then the projection backward
 __global__ __launch_bounds__(256) void gather_splat_grads(

@@ -13,21 +13,23 @@ namespace vtgs {
 //   counters     256 B     Counters (zeroed per forward)
 //   geom         N x 32 B  GeomRec: what the composite needs per splat; read by gather, L2/MALL resident
 //   gaux         N x 8 B   first instance id + instance count (instances of a splat are contiguous)
-//   block_stats  ceil(N/256) x 16 B  per-workgroup {visible, 16x16 tiles touched} partials (no same-address atomics)
-//   tile_cnt     (T8+1)x4  per 8x8-tile instance counters (zeroed per forward)
-//   tile_off     (T8+1)x4  exclusive scan of tile_cnt
-//   inst_tmp     cap x 16  {tile, rank in tile, gaussian, depth bits} written by the projection kernel
-//   keys         cap x 8   (depth bits << 32 | gaussian) bucketed by tile, then sorted in place per tile
-//   vals         cap x 4   instance id travelling with the key
-//   sorted_gid   cap x 4   per-tile front-to-back Gaussian ids
-//   sorted_inst  cap x 4   per-tile instance ids (address of the per-instance gradient record)
+//   block_stats  ceil(N/1024) x 16 B  per-workgroup {visible, 16x16 tiles touched} partials (no same-address atomics)
+//   tile_cnt     T8 x 4    per 8x8-tile list length (zeroed per forward, filled by slot reservation)
+//   keys         T8 x cap_t x 8   tile bins: (depth bits << 32 | gaussian), written in place by the projection kernel
+//   vals         T8 x cap_t x 4   instance id travelling with the key
+//   sorted_gid   T8 x cap_t x 4   per-tile front-to-back Gaussian ids (tile t: [t*cap_t, t*cap_t + tile_cnt[t]))
+//   sorted_inst  T8 x cap_t x 4   per-tile instance ids (address of the per-instance gradient record)
 //   final_T      P x 4     per-pixel transmittance after the last contributor
+// Every tile owns a fixed-capacity bin (cap_t, a caller hint like the instance capacity), so binning is one
+// pass: no prefix scan over tiles and no scatter pass.  finalize_forward raises the overflow flags right after the
+// binning (a dropped instance leaves an unwritten bin slot, so sort and composite bail on the flag) and the caller
+// re-runs with the sizes reported in the result record.
 // ------------------------------------------------------------------------------------------------
 struct Counters {
   uint32_t inst_total;      // instances requested (keeps counting past capacity)
-  uint32_t overflow;        // set by the tile scan when inst_total > capacity
+  uint32_t overflow;        // bit 0: inst_total > instance capacity, bit 1: a tile list > tile capacity (finalize_forward)
   uint32_t pad[14];
-  // byte 64: image of the public VtgsForwardInfo, written by scan_tiles, copied to the host by vtgs_forward
+  // byte 64: image of the public VtgsForwardInfo, written by finalize_forward, copied to the host by vtgs_forward
   unsigned long long info_instances, info_needed, info_r16;
   uint32_t info_visible, info_max_list, info_overflow, info_complete;
 };
@@ -45,33 +47,32 @@ struct alignas(8) GaussAux { uint32_t inst_base, inst_cnt; };
 
 struct alignas(16) BlockStats { uint32_t visible, pad; unsigned long long r16; };
 
-struct alignas(16) InstTmp { uint32_t tile, rank, gid, zbits; };
-
 constexpr int kGradRec = 12;   // floats per instance gradient record (9 used, 48-byte stride)
 
 struct WsLayout {
-  size_t counters, geom, gaux, block_stats, tile_cnt, tile_off, inst_tmp, keys, vals, sorted_gid, sorted_inst, final_T, total;
-  uint32_t tiles8;
+  size_t counters, geom, gaux, block_stats, tile_cnt, keys, vals, sorted_gid, sorted_inst, final_T, total;
+  uint32_t tiles8, tile_cap;
 };
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-inline WsLayout make_layout(int32_t n, int32_t w, int32_t h, uint64_t cap) {
+inline WsLayout make_layout(int32_t n, int32_t w, int32_t h, uint64_t cap, uint32_t tile_cap) {
+  (void)cap;   // the instance capacity bounds instance ids (backward scratch); the bins are sized by tile_cap
   WsLayout L;
   const uint32_t gx8 = (uint32_t)(w + kSubTile - 1) / kSubTile, gy8 = (uint32_t)(h + kSubTile - 1) / kSubTile;
   L.tiles8 = gx8 * gy8;
+  L.tile_cap = tile_cap;
+  const size_t slots = (size_t)L.tiles8 * tile_cap;
   size_t o = 0;
   L.counters = o;    o += 256;
   L.geom = o;        o += align256((size_t)n * sizeof(GeomRec));
   L.gaux = o;        o += align256((size_t)n * sizeof(GaussAux));
-  L.block_stats = o; o += align256(((size_t)(n + 255) / 256 + 1) * sizeof(BlockStats));
+  L.block_stats = o; o += align256(((size_t)(n + 1023) / 1024 + 1) * sizeof(BlockStats));
   L.tile_cnt = o;    o += align256(((size_t)L.tiles8 + 1) * 4);
-  L.tile_off = o;    o += align256(((size_t)L.tiles8 + 1) * 4);
-  L.inst_tmp = o;    o += align256((size_t)cap * sizeof(InstTmp));
-  L.keys = o;        o += align256((size_t)cap * 8);
-  L.vals = o;        o += align256((size_t)cap * 4);
-  L.sorted_gid = o;  o += align256((size_t)cap * 4);
-  L.sorted_inst = o; o += align256((size_t)cap * 4);
+  L.keys = o;        o += align256(slots * 8);
+  L.vals = o;        o += align256(slots * 4);
+  L.sorted_gid = o;  o += align256(slots * 4);
+  L.sorted_inst = o; o += align256(slots * 4);
   L.final_T = o;     o += align256((size_t)w * h * 4);
   L.total = o;
   return L;

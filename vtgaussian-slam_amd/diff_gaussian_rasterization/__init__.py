@@ -49,7 +49,7 @@ class _VtgsProfileEntry(ctypes.Structure):
 
 
 VTGS_OK, VTGS_ERR_INSTANCE_OVERFLOW = 0, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 VTGS_FORWARD_SYNC, VTGS_FORWARD_ASYNC = 0, 1
 _P, _U64, _I32, _SZ = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
 
@@ -57,15 +57,16 @@ _SIGNATURES = {
     "vtgs_abi_version": (ctypes.c_uint32, []),
     "vtgs_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "vtgs_last_hip_error": (ctypes.c_char_p, []),
-    "vtgs_workspace_bytes": (_SZ, [_I32, _I32, _I32, _U64]),
+    "vtgs_workspace_bytes": (_SZ, [_I32, _I32, _I32, _U64, ctypes.c_uint32]),
     "vtgs_backward_scratch_bytes": (_SZ, [_I32, _U64]),
     "vtgs_forward": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _U64,
-                                    _P, ctypes.c_uint32, _P]),
-    "vtgs_forward_shared": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _SZ, _U64, _P, _P]),
-    "vtgs_backward": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _U64, _P,
-                                     _P, _SZ, _P, _P, _P, _P, _P, _P, _P]),
+                                    ctypes.c_uint32, _P, ctypes.c_uint32, _P]),
+    "vtgs_forward_shared": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _SZ, _U64,
+                                           ctypes.c_uint32, _P, _P]),
+    "vtgs_backward": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _U64,
+                                     ctypes.c_uint32, _P, _P, _SZ, _P, _P, _P, _P, _P, _P, _P]),
     "vtgs_mark_visible": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P]),
-    "vtgs_debug_layout": (ctypes.c_int, [_I32, _I32, _I32, _U64, ctypes.POINTER(ctypes.c_uint64)]),
+    "vtgs_debug_layout": (ctypes.c_int, [_I32, _I32, _I32, _U64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]),
     "vtgs_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "vtgs_profile_collect": (ctypes.c_int, [ctypes.POINTER(_VtgsProfileEntry), _I32, ctypes.POINTER(_I32)]),
 }
@@ -115,6 +116,7 @@ class GaussianRasterizationSettings(NamedTuple):
 
 _RADIUS_RULES = {"3sigma": 0, "opacity": 1}
 _capacity_hint = {}          # (device index, N, W, H, band) -> instances seen last time
+_tile_cap_hint = {}          # same key -> longest per-tile list seen last time
 _last_info = {}
 
 
@@ -173,7 +175,7 @@ def _require(t: torch.Tensor, name: str, shape_tail: int, n: int, device) -> tor
 
 
 class _ForwardState:
-    __slots__ = ("cam", "n", "workspace", "capacity", "instances", "image_state", "pending", "key")
+    __slots__ = ("cam", "n", "workspace", "capacity", "tile_cap", "instances", "image_state", "pending", "key")
 
 
 class _PinnedInfoRing:
@@ -202,8 +204,14 @@ _ring = None
 _ASYNC_DEFAULT = os.environ.get("VTGS_SYNC_FORWARD", "0") != "1"
 
 
+def _tile_capacity_for(max_list: int) -> int:
+    """Bin capacity for a longest list of `max_list`: 1.5x headroom, multiple of 64, at least 64."""
+    return max(64, (int(max_list * 1.5) + 63) // 64 * 64)
+
+
 def _record_info(key, n, W, H, capacity, info):
     _capacity_hint[key] = max(int(info.instances_needed), 1)
+    _tile_cap_hint[key] = max(int(info.max_tile_list), 1)
     _last_info.update(instances=int(info.instances), tiles16_touched=int(info.tiles16_touched),
                       visible=int(info.visible), max_tile_list=int(info.max_tile_list), n=n, width=W, height=H,
                       capacity=int(capacity))
@@ -222,9 +230,10 @@ def _resolve_pending(fs: "_ForwardState") -> None:
     _record_info(fs.key, fs.n, fs.cam.W, fs.cam.H, fs.capacity, info)
     if info.overflow:
         raise RuntimeError(
-            f"vtgs_forward (asynchronous mode): {info.instances_needed} (Gaussian,tile) instances did not fit the "
-            f"workspace capacity {fs.capacity}; the outputs of that forward are invalid. The capacity hint has been "
-            f"raised -- re-run the step (or set VTGS_SYNC_FORWARD=1 to check inside every forward).")
+            f"vtgs_forward (asynchronous mode): {info.instances_needed} (Gaussian,tile) instances / longest tile list "
+            f"{info.max_tile_list} did not fit the workspace capacities ({fs.capacity} instances, {fs.tile_cap} per "
+            f"tile); the outputs of that forward are invalid. The capacity hints have been raised -- re-run the step "
+            f"(or set VTGS_SYNC_FORWARD=1 to check inside every forward).")
     fs.instances = int(info.instances)
 
 
@@ -239,6 +248,7 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
     key = (device.index, n, W, H, cam.band)
     hint = _capacity_hint.get(key, 0)
     capacity = max(int(hint * 1.25) + 4096, 4 * n + 4096) if hint else 8 * n + 65536
+    tile_cap = _tile_capacity_for(_tile_cap_hint[key]) if key in _tile_cap_hint else 512
     # the first forward of a shape has no instance-count history: check it synchronously
     use_async = want_async and _ASYNC_DEFAULT and hint > 0
     fs = _ForwardState()
@@ -246,36 +256,39 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
     if use_async:
         if _ring is None:
             _ring = _PinnedInfoRing()
-        nbytes = _lib.vtgs_workspace_bytes(n, W, H, capacity)
+        nbytes = _lib.vtgs_workspace_bytes(n, W, H, capacity, tile_cap)
         workspace = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         slot = _ring.take()
         st = _lib.vtgs_forward(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
                                scales.data_ptr(), rotations.data_ptr(), color.data_ptr(), depth.data_ptr(),
-                               radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, _ring.buf[slot].data_ptr(),
-                               VTGS_FORWARD_ASYNC, _stream_ptr(device))
+                               radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, tile_cap,
+                               _ring.buf[slot].data_ptr(), VTGS_FORWARD_ASYNC, _stream_ptr(device))
         _check(st, "vtgs_forward")
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))
         _ring.events[slot] = ev
-        fs.workspace, fs.capacity, fs.instances, fs.pending = workspace, capacity, None, (slot, ev)
+        fs.workspace, fs.capacity, fs.tile_cap, fs.instances, fs.pending = workspace, capacity, tile_cap, None, (slot, ev)
         return color, radii, depth, fs
     info = _VtgsForwardInfo()
-    for _attempt in range(3):
-        nbytes = _lib.vtgs_workspace_bytes(n, W, H, capacity)
+    for _attempt in range(4):
+        nbytes = _lib.vtgs_workspace_bytes(n, W, H, capacity, tile_cap)
         workspace = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         st = _lib.vtgs_forward(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
                                scales.data_ptr(), rotations.data_ptr(), color.data_ptr(), depth.data_ptr(),
-                               radii.data_ptr(), workspace.data_ptr(), nbytes, capacity,
+                               radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, tile_cap,
                                ctypes.addressof(info), VTGS_FORWARD_SYNC, _stream_ptr(device))
-        if st == VTGS_ERR_INSTANCE_OVERFLOW:
-            capacity = int(info.instances_needed * 1.25) + 4096
+        if st == VTGS_ERR_INSTANCE_OVERFLOW:          # the record says what is needed: grow whichever was short
+            if info.overflow & 1:
+                capacity = int(info.instances_needed * 1.25) + 4096
+            if info.overflow & 2:
+                tile_cap = _tile_capacity_for(info.max_tile_list)
             continue
         _check(st, "vtgs_forward")
         break
     else:
         raise RuntimeError("vtgs_forward: instance capacity kept overflowing")
     _record_info(key, n, W, H, capacity, info)
-    fs.workspace, fs.capacity, fs.instances = workspace, capacity, int(info.instances)
+    fs.workspace, fs.capacity, fs.tile_cap, fs.instances = workspace, capacity, tile_cap, int(info.instances)
     return color, radii, depth, fs
 
 
@@ -297,7 +310,7 @@ def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotatio
     state_ptr = fs.image_state.data_ptr() if fs.image_state is not None else None
     st = _lib.vtgs_backward(ctypes.byref(fs.cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
                             scales.data_ptr(), rotations.data_ptr(), out_color.data_ptr(), grad_color.data_ptr(),
-                            fs.workspace.data_ptr(), fs.workspace.numel(), fs.capacity, state_ptr,
+                            fs.workspace.data_ptr(), fs.workspace.numel(), fs.capacity, fs.tile_cap, state_ptr,
                             scratch.data_ptr(), sbytes, g_means3D.data_ptr(), g_means2D.data_ptr(), g_colors.data_ptr(),
                             g_opac.data_ptr(), g_scales.data_ptr(), g_rot.data_ptr(), _stream_ptr(device))
     _check(st, "vtgs_backward")
@@ -307,16 +320,19 @@ def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotatio
 
 def debug_tile_lists(rasterizer: "GaussianRasterizer"):
     """Test hook: (tile_offsets [tiles8+1] int64, sorted_gid [R] int64, geom [N,8] float32) of the last forward
-    of `rasterizer`, copied to the CPU.  8x8 tiles, row-major."""
+    of `rasterizer`, copied to the CPU and compacted (tile t = sorted_gid[offsets[t]:offsets[t+1]]).  8x8 tiles, row-major."""
     fs = rasterizer._last_state
     _resolve_pending(fs)
     out = (ctypes.c_uint64 * 8)()
-    _check(_lib.vtgs_debug_layout(fs.n, fs.cam.W, fs.cam.H, fs.capacity, out), "vtgs_debug_layout")
+    _check(_lib.vtgs_debug_layout(fs.n, fs.cam.W, fs.cam.H, fs.capacity, fs.tile_cap, out), "vtgs_debug_layout")
     ws = fs.workspace
-    tiles8 = int(out[7])
-    offs = ws[int(out[3]): int(out[3]) + 4 * (tiles8 + 1)].view(torch.int32).cpu().long()
-    total = int(offs[-1])
-    gid = ws[int(out[4]): int(out[4]) + 4 * total].view(torch.int32).cpu().long()
+    tiles8, cap = int(out[7]), fs.tile_cap
+    cnt = ws[int(out[3]): int(out[3]) + 4 * tiles8].view(torch.int32).cpu().long()
+    bins = ws[int(out[4]): int(out[4]) + 4 * tiles8 * cap].view(torch.int32).reshape(tiles8, cap).cpu().long()
+    keep = torch.arange(cap)[None, :] < cnt[:, None]
+    gid = bins[keep]
+    offs = torch.zeros(tiles8 + 1, dtype=torch.long)
+    offs[1:] = torch.cumsum(cnt, 0)
     geom = ws[int(out[1]): int(out[1]) + 32 * fs.n].view(torch.float32).reshape(fs.n, 8).cpu()
     return offs, gid, geom
 
@@ -347,11 +363,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             state = torch.empty((H * W,), dtype=torch.float32, device=device)
             st = _lib.vtgs_forward_shared(ctypes.byref(base.cam.c), n, colors.data_ptr(), color.data_ptr(),
                                           depth.data_ptr(), base.workspace.data_ptr(), base.workspace.numel(),
-                                          base.capacity, state.data_ptr(), _stream_ptr(device))
+                                          base.capacity, base.tile_cap, state.data_ptr(), _stream_ptr(device))
             _check(st, "vtgs_forward_shared")
             fs = _ForwardState()
-            fs.cam, fs.n, fs.workspace, fs.capacity, fs.instances, fs.image_state, fs.pending, fs.key = (
-                base.cam, base.n, base.workspace, base.capacity, base.instances, state, None, base.key)
+            fs.cam, fs.n, fs.workspace, fs.capacity, fs.tile_cap, fs.instances, fs.image_state, fs.pending, fs.key = (
+                base.cam, base.n, base.workspace, base.capacity, base.tile_cap, base.instances, state, None, base.key)
             radii = None
         ctx.fs = fs
         ctx.save_for_backward(means3D, colors, opac, scales_c, rot, color)
