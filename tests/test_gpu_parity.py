@@ -7,6 +7,8 @@ other side in float32 for a handful of (pixel, splat) pairs, each worth <= 1/255
 bound the FRACTION of pixels above tolerance (<= 2e-4) and their magnitude (<= 1e-2) instead of demanding
 zero such pixels.
 """
+import os
+
 import pytest
 import torch
 
@@ -314,3 +316,24 @@ def test_mfma_register_layout_assumptions(gpu_device, tmp_path):
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-Wno-unused-result", src, "-o", exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("opacity_scale", [1.0, 0.35])
+def test_saturating_scene_exercises_the_stop_rule(gpu_device, opacity_scale):
+    """~13 splats per pixel centre (hundreds overlapping each pixel): every pixel reaches T < 1e-4 and stops
+    mid-list, in different batches and quad-lanes -- the exact stop rule's slow path in forward and backward."""
+    scene, cam = go.view_tied_scene(20000, 48, 32, seed=77)
+    scene["opacities"] = (scene["opacities"] * opacity_scale).clamp(max=0.999)
+    g = torch.Generator().manual_seed(6)
+    grad_color = torch.rand(3, 32, 48, generator=g) * 2 - 1
+    ref_c, ref_r, ref_d, ref_g, aux = run_oracle(scene, cam, grad_color)
+    assert (aux["T_final"] < 1.5e-4).double().mean().item() > 0.3     # a large share of the pixels does stop mid-list
+    for impl in ("1", "0"):
+        os.environ["VTGS_FWD_IMPL"] = impl
+        os.environ["VTGS_BWD_IMPL"] = impl
+        try:
+            got_c, got_r, got_d, got_g = run_hip(scene, cam, gpu_device, grad_color)
+        finally:
+            os.environ.pop("VTGS_FWD_IMPL"); os.environ.pop("VTGS_BWD_IMPL")
+        _check_images(ref_c, ref_d, got_c, got_d)
+        _check_grads(ref_g, got_g)

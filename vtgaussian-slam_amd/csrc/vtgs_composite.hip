@@ -505,15 +505,18 @@ __device__ __forceinline__ void mx_backward_batch(MxBwdState& st, const float (&
   // two half-passes over the pixel groups {0,1} and {2,3}: halves the number of live per-pair values
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    float Gp[2][4], a[2][4], pl[2][4], gc[2][4], S[2][4];
+    float Gm[2][4], a[2][4], pl[2][4], gc[2][4], S[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int blk = 2 * h + i;
+      const bool alive = st.Tb[blk] > 0.f;                   // pixel not finished at the start of the batch
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        Gp[i][r] = __builtin_amdgcn_exp2f(d[4 * blk + r]);
-        const float al = fminf(kAlphaMax, Gp[i][r]);
-        a[i][r] = (al >= kAlphaMin) ? al : 0.f;
+        const float Gp = __builtin_amdgcn_exp2f(d[4 * blk + r]);
+        const float al = fminf(kAlphaMax, Gp);
+        const bool valid = al >= kAlphaMin;
+        a[i][r] = valid ? al : 0.f;
+        Gm[i][r] = (valid && alive) ? Gp : 0.f;              // alpha_unclamped where this pair can contribute, else 0
         gc[i][r] = st.g[blk][0] * pay[r].x + st.g[blk][1] * pay[r].y + st.g[blk][2] * pay[r].z;
       }
       pl[i][0] = 1.f - a[i][0];
@@ -546,37 +549,39 @@ __device__ __forceinline__ void mx_backward_batch(MxBwdState& st, const float (&
       Pend[i] = fmaf(T3, S3, Q3);
       cross = cross || (T0 > 0.f && Tend[i] < kTStop);
     }
-    const bool slow = __ballot(cross) != 0ull;                 // wave-uniform
+    const bool slow = __ballot(cross) != 0ull;                 // wave-uniform; rarely true
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int blk = 2 * h + i;
       const float t0 = Tin[i], t1 = t0 * pl[i][0], t2 = t0 * pl[i][1], t3 = t0 * pl[i][2];
       const float t[4] = {t0, t1, t2, t3};
-      bool live[4] = {true, true, true, true};
       const bool was_alive = st.Tb[blk] > 0.f;
-      bool mine = was_alive;
       bool pixel_stopped = false;
       if (slow) {
+        // exact stop rule: the first (quad, splat) in list order with T*(1-alpha) < 1e-4 ends the pixel before adding;
+        // everything from there on (this quad and the quads behind it) contributes nothing
         bool livep = true, any = false;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool stop = a[i][r] > 0.f && Tin[i] * pl[i][r] < kTStop;
           any = any || (livep && stop);
           livep = livep && !stop;
-          live[r] = livep;
+          if (!livep) { Gm[i][r] = 0.f; a[i][r] = 0.f; }
         }
-        const unsigned long long bal = __ballot(any && mine) >> j;
-        mine = mine && (bal & lower_q) == 0ull;
+        const unsigned long long bal = __ballot(any && was_alive) >> j;
         pixel_stopped = (bal & 0x0001000100010001ull) != 0ull;
+        if ((bal & lower_q) != 0ull) {                          // a quad in front of mine already ended the pixel
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { Gm[i][r] = 0.f; a[i][r] = 0.f; }
+        }
       }
+      // fast path: no predicates -- Gm is 0 where the pair cannot contribute, a*t is 0 for invalid pairs and dead pixels
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float Pr = fmaf(Tin[i], S[i][r], Pin[i]);            // prefix including this splat
-        const float al = fminf(kAlphaMax, Gp[i][r]);
-        const float dLda = t[r] * gc[i][r] - (st.CB[blk] - Pr) * __builtin_amdgcn_rcpf(1.f - al);
-        const bool on = mine && live[r] && a[i][r] > 0.f;
-        Us[(4 * q + r) * kRowStride + 16 * blk + j] = on ? Gp[i][r] * dLda : 0.f;   // 0.99 clamp passes the gradient through
-        Ws[(4 * q + r) * kRowStride + 16 * blk + j] = on ? a[i][r] * t[r] : 0.f;
+        const float dLda = t[r] * gc[i][r] - (st.CB[blk] - Pr) * __builtin_amdgcn_rcpf(1.f - a[i][r]);
+        Us[(4 * q + r) * kRowStride + 16 * blk + j] = Gm[i][r] * dLda;   // 0.99 clamp passes the gradient through
+        Ws[(4 * q + r) * kRowStride + 16 * blk + j] = a[i][r] * t[r];
       }
       st.Tb[blk] = (was_alive && !pixel_stopped) ? Tend[i] : 0.f;
       st.Pb[blk] = Pend[i];
