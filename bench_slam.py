@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""SLAM-loop benchmark (metric 2, on the synthetic sequence): frames/s of the reference's per-frame
+tracking + mapping optimisation, driven through the drop-in operator exactly the way `get_loss` drives it
+(src/vtgaussian_slam.py:407-689): per iteration one RGB render and one [z,1,z^2] render, the Replica tracking /
+mapping losses, `loss.backward()`, Adam.  Iteration counts, loss weights and learning rates are those of
+configs/replica/room0.py (tracking 60 it, lrs 4e-4 / 2e-3; mapping 100 it, lrs 2.5e-3 / 5e-2 / 5e-3).
+
+The Replica data set is not available offline, so the sequence is synthetic: one view-tied submap
+(N Gaussians, one per pixel + edge splats) observed from a slowly moving camera; ground-truth colour and
+depth of every frame are rendered from the ground-truth pose.  Tracking starts each frame from the previous estimate
+and must recover the motion -- the reported pose error is an end-to-end check of the pose gradient.
+
+    python bench_slam.py --frames 3                        # one JSON line
+    python bench_slam.py --frames 3 --shared-geometry      # depth/silhouette pass reuses the RGB pass's binning (8f-2)
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "vtgaussian-slam_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+
+def pose_quat_trans(angle_deg: float, axis, trans):
+    a = math.radians(angle_deg) / 2
+    ax = torch.tensor(axis, dtype=torch.float32)
+    ax = ax / ax.norm()
+    return torch.cat([torch.tensor([math.cos(a)]), math.sin(a) * ax]), torch.tensor(trans, dtype=torch.float32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1200)
+    ap.add_argument("--height", type=int, default=680)
+    ap.add_argument("--tracking-iters", type=int, default=60)
+    ap.add_argument("--mapping-iters", type=int, default=100)
+    ap.add_argument("--shared-geometry", action="store_true", help="depth/silhouette pass reuses the RGB pass's binning (8f-2)")
+    ap.add_argument("--fused", action="store_true", help="fused pose transform + render variables + both renders (8f-1)")
+    args = ap.parse_args()
+    assert torch.cuda.is_available(), "bench_slam.py needs an MI355X"
+    dev = torch.device("cuda", 0)
+
+    import diff_gaussian_rasterization as dgr
+    import slam_callers as sc
+    from oracle import gs_oracle as go            # scene generator only
+    from parity_util import to_settings
+
+    N, W, H, T = args.n, args.width, args.height, args.frames + 1
+    scene, cam = go.view_tied_scene(N, W, H, seed=0)
+    settings = to_settings(cam, dev)
+    first_w2c = torch.eye(4, device=dev)
+    fx = W / 2.0
+    gt_params = {
+        "means3D": scene["means3D"].to(dev), "rgb_colors": scene["colors_precomp"].to(dev),
+        "unnorm_rotations": scene["rotations"].to(dev), "logit_opacities": torch.full((N, 1), 3.0, device=dev),
+        "log_scales": torch.log(scene["scales"][:, :1]).to(dev),
+    }
+    # ground-truth camera path: 0.15 deg and 4 mm per frame
+    gt_rots = torch.zeros(1, 4, T, device=dev)
+    gt_trans = torch.zeros(1, 3, T, device=dev)
+    for t in range(T):
+        q, tr = pose_quat_trans(0.15 * t, (0.3, 1.0, 0.1), (0.004 * t, -0.002 * t, 0.003 * t))
+        gt_rots[0, :, t], gt_trans[0, :, t] = q.to(dev), tr.to(dev)
+
+    from diff_gaussian_rasterization.fused import render_frame
+
+    def render_pair(params, t_idx, gaussians_grad, camera_grad):
+        if args.fused:
+            return render_frame(params, t_idx, settings, first_w2c, gaussians_grad, camera_grad)
+        tg = sc.transform_to_frame(params, t_idx, gaussians_grad=gaussians_grad, camera_grad=camera_grad)
+        rv = sc.transformed_params2rendervar(params, tg)
+        dv = sc.transformed_params2depthplussilhouette(params, first_w2c, tg)
+        rast = dgr.GaussianRasterizer(raster_settings=settings)
+        im, radius, _ = rast(**rv)
+        if args.shared_geometry:
+            depth_sil, _ = rast.render_shared(dv["colors_precomp"], like=(rv["means3D"], rv["means2D"], rv["opacities"],
+                                                                          rv["scales"], rv["rotations"]))
+        else:
+            depth_sil, _, _ = dgr.GaussianRasterizer(raster_settings=settings)(**dv)
+        return im, depth_sil, radius
+
+    # ground-truth observations
+    gts = []
+    with torch.no_grad():
+        for t in range(T):
+            p = dict(gt_params, cam_unnorm_rots=gt_rots, cam_trans=gt_trans)
+            im, ds, _ = render_pair(p, t, False, False)
+            sil = ds[1]
+            depth = torch.where(sil > 0.5, ds[0] / sil.clamp(min=1e-6), torch.zeros_like(sil))[None]
+            gts.append((im.clone(), depth.clone()))
+
+    # the map being optimised: same geometry, perturbed appearance; poses unknown except frame 0
+    g = torch.Generator().manual_seed(1)
+    params = {
+        "means3D": torch.nn.Parameter(gt_params["means3D"].clone()),
+        "rgb_colors": torch.nn.Parameter((gt_params["rgb_colors"] + 0.05 * torch.randn(N, 3, generator=g).to(dev)).clamp(0, 1)),
+        "unnorm_rotations": torch.nn.Parameter(gt_params["unnorm_rotations"].clone()),
+        "logit_opacities": torch.nn.Parameter(torch.full((N, 1), 2.0, device=dev)),
+        "log_scales": torch.nn.Parameter(gt_params["log_scales"].clone()),
+        "cam_unnorm_rots": torch.nn.Parameter(torch.tensor([1.0, 0, 0, 0], device=dev).reshape(1, 4, 1).repeat(1, 1, T)),
+        "cam_trans": torch.nn.Parameter(torch.zeros(1, 3, T, device=dev)),
+    }
+    track_lrs = dict(means3D=0.0, rgb_colors=0.0, unnorm_rotations=0.0, logit_opacities=0.0, log_scales=0.0,
+                     cam_unnorm_rots=0.0004, cam_trans=0.002)
+    map_lrs = dict(means3D=0.0, rgb_colors=0.0025, unnorm_rotations=0.0, logit_opacities=0.05, log_scales=0.005,
+                   cam_unnorm_rots=1e-8, cam_trans=1e-7)
+
+    def pose_error(t):
+        with torch.no_grad():
+            dt = (params["cam_trans"][0, :, t] - gt_trans[0, :, t]).norm().item() * 100          # cm
+            q1 = torch.nn.functional.normalize(params["cam_unnorm_rots"][0, :, t], dim=0)
+            dq = (q1 * gt_rots[0, :, t]).sum().abs().clamp(max=1.0)
+            return dt, math.degrees(2 * math.acos(dq.item()))
+
+    track_ms, map_ms, errs_before, errs_after = [], [], [], []
+    torch.cuda.synchronize()
+    t_all = time.perf_counter()
+    for t in range(1, T):
+        gt_im, gt_depth = gts[t]
+        with torch.no_grad():                     # forward-propagate the previous pose (constant-position prior)
+            params["cam_unnorm_rots"][..., t] = params["cam_unnorm_rots"][..., t - 1]
+            params["cam_trans"][..., t] = params["cam_trans"][..., t - 1]
+        errs_before.append(pose_error(t))
+        # ---- tracking
+        opt = torch.optim.Adam([{"params": [v], "name": k, "lr": track_lrs[k]} for k, v in params.items()])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        sil_thres, best = 0.99, (float("inf"), None, None)
+        for it in range(args.tracking_iters):
+            im, depth_sil, _ = render_pair(params, t, gaussians_grad=False, camera_grad=True)
+            if it == 0:
+                sil_thres = sc.best_silhouette_threshold(im, depth_sil[1], gt_im, gt_depth)
+            loss = sc.tracking_loss(im, depth_sil, gt_im, gt_depth, sil_thres)
+            loss.backward()
+            with torch.no_grad():
+                lv = loss.detach()
+                if it % 10 == 9 or it == 0:       # the reference keeps the best pose; checking it costs a host sync
+                    if lv.item() < best[0]:
+                        best = (lv.item(), params["cam_unnorm_rots"][..., t].clone(), params["cam_trans"][..., t].clone())
+            opt.step(); opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize(); track_ms.append((time.perf_counter() - t0) * 1e3 / args.tracking_iters)
+        errs_after.append(pose_error(t))
+        # ---- mapping
+        opt = torch.optim.Adam([{"params": [v], "name": k, "lr": map_lrs[k]} for k, v in params.items()], lr=0.0, eps=1e-15)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for it in range(args.mapping_iters):
+            im, depth_sil, _ = render_pair(params, t, gaussians_grad=True, camera_grad=False)
+            loss = sc.mapping_loss(im, depth_sil, gt_im, gt_depth)
+            loss.backward()
+            opt.step(); opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize(); map_ms.append((time.perf_counter() - t0) * 1e3 / args.mapping_iters)
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t_all
+    out = {
+        "metric": "SLAM frames/s, tracking+mapping loop (synthetic Replica-room0-like sequence)",
+        "value": round(args.frames / total, 3), "unit": "frames/s", "n_gpus": 1, "higher_is_better": True,
+        "data": "synthetic", "dtype": "f32",
+        "config": {"workload": f"view-tied submap N={N}, {W}x{H}; {args.tracking_iters} tracking + {args.mapping_iters} "
+                               f"mapping iterations per frame, 2 renders fwd+bwd per iteration (configs/replica/room0.py)",
+                   "frames": args.frames, "shared_geometry": bool(args.shared_geometry or args.fused), "fused_callers": bool(args.fused)},
+        "tracking_ms_per_iter": round(sum(track_ms) / len(track_ms), 3),
+        "mapping_ms_per_iter": round(sum(map_ms) / len(map_ms), 3),
+        "pose_error_before_tracking_cm_deg": [[round(a, 3), round(b, 4)] for a, b in errs_before],
+        "pose_error_after_tracking_cm_deg": [[round(a, 3), round(b, 4)] for a, b in errs_after],
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

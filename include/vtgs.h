@@ -147,6 +147,32 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n,
 int vtgs_mark_visible(const VtgsCamera* cam, int32_t n, const float* means3D,
                       uint8_t* out_visible, void* stream);
 
+/* ---- Fused caller chain, isotropic maps (log_scales [N,1], every reference config) -------------
+ * vtgs_prepare_frame replaces the element-wise PyTorch launches of utils/slam_helpers.py:323-385 (transform_to_frame),
+ * :127-160 (transformed_params2rendervar) and :217-287 (get_depth_and_silhouette / ...depthplussilhouette):
+ *   out_means_cam = R(q/|q|) means3D + t        out_opacities = sigmoid(logit_opacities)
+ *   out_scales    = exp(log_scales) tiled x3     out_rotations = normalize(unnorm_rotations)
+ *   out_depth_colors = [z, 1, z^2], z = row 2 of depth_w2c (row-major 4x4, the first-frame camera) applied to means_cam
+ * cam_q [4] (w,x,y,z, un-normalised), cam_t [3], depth_w2c [16] are DEVICE pointers (they are slices of parameters).
+ * vtgs_prepare_frame_backward is its adjoint for two renders over the same geometry (a = RGB pass, b = depth/silhouette
+ * pass): it takes the two sets of operator gradients plus dL/d(depth colours) and writes (flags bit 0) the gradients of
+ * means3D / unnorm_rotations, (flags bit 2) those of logit_opacities / log_scales -- the reference's gaussians_grad=False
+ * detaches only the former pair -- and (flags bit 1) per-workgroup partial sums of
+ * [dL/dt (3) | dL/dR (9, row-major)] into pose_partials[vtgs_pose_partial_rows(n)][12]; the caller sums the rows and
+ * takes the 12 -> 7 step through the quaternion.  No atomics: results are bitwise reproducible.                     */
+uint32_t vtgs_pose_partial_rows(int32_t n);
+int vtgs_prepare_frame(int32_t n, const float* means3D, const float* logit_opacities, const float* log_scales,
+                       const float* unnorm_rotations, const float* cam_q, const float* cam_t, const float* depth_w2c,
+                       float* out_means_cam, float* out_opacities, float* out_scales, float* out_rotations,
+                       float* out_depth_colors, void* stream);
+int vtgs_prepare_frame_backward(int32_t n, uint32_t flags, const float* means3D, const float* logit_opacities,
+                                const float* log_scales, const float* unnorm_rotations, const float* cam_q,
+                                const float* cam_t, const float* depth_w2c, const float* g_means_a, const float* g_means_b,
+                                const float* g_depth_colors, const float* g_opac_a, const float* g_opac_b,
+                                const float* g_scales_a, const float* g_scales_b, const float* g_rot_a, const float* g_rot_b,
+                                float* g_means3D, float* g_logit_opacities, float* g_log_scales, float* g_unnorm_rotations,
+                                float* pose_partials, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on (used by bench.py for
  * the roofline of the dominant kernel).  While enabled, every kernel launch of the library is bracketed by two
  * events; vtgs_profile_collect synchronises the device, sums elapsed time per kernel name since enabling and

@@ -166,13 +166,13 @@ def test_capacity_overflow_sync_retry_and_async_detection(gpu_device):
     dev = gpu_device
     leaves = {k: v.to(dev).requires_grad_(True) for k, v in scene.items()}
     st = to_settings(cam, dev)
-    dgr._capacity_hint.clear()
+    dgr._capacity_hint.clear(); dgr._caps_in_use.clear(); dgr._tile_cap_hint.clear()
     c, r, d = dgr.GaussianRasterizer(raster_settings=st)(**leaves)             # first call: synchronous, retries
     info = dgr.last_forward_info()
     assert info["instances"] > 8 * n + 65536 or info["instances"] > 4 * n + 4096
     _check_images(ref_c, ref_d, c.detach().cpu(), d.detach().cpu())
     key = next(iter(dgr._capacity_hint))
-    dgr._capacity_hint[key] = 10                                                  # poison the hint -> capacity too small
+    dgr._capacity_hint[key] = 10; dgr._caps_in_use.pop(key, None)                 # poison the hint -> capacity too small
     c2, _, _ = dgr.GaussianRasterizer(raster_settings=st)(**leaves)             # asynchronous: returns without checking
     with pytest.raises(RuntimeError, match="did not fit"):
         c2.sum().backward()

@@ -1,0 +1,160 @@
+// vtgs_frame.hip -- the reference's pose transform and render-variable builders as one kernel each way.
+//
+// Replaces, for isotropic maps (log_scales [N,1], every reference config), the ~20 element-wise PyTorch launches of
+//   utils/slam_helpers.py:323-385  transform_to_frame            means_cam = R(q/|q|) means + t
+//   utils/slam_helpers.py:127-160  transformed_params2rendervar  opacities = sigmoid, scales = exp(tile(log_s)), rot = normalize
+//   utils/slam_helpers.py:217-287  get_depth_and_silhouette      colours of the 2nd render = [z, 1, z^2], z in the first-frame camera
+// and their autograd backward, including the N -> 12 reduction that carries dL/dmeans_cam back to the pose
+// (dL/dt = sum g, dL/dR = sum g p^T; the 12 -> 7 step through the quaternion is done by the caller on 12 floats).
+#include "../../include/vtgs.h"
+#include "vtgs_internal.h"
+
+namespace vtgs {
+
+struct FramePose { float R[9]; float t[3]; float zr[4]; };   // rotation from the normalised quaternion, translation, depth row
+
+__device__ __forceinline__ FramePose load_pose(const float* __restrict__ q, const float* __restrict__ t,
+                                               const float* __restrict__ w2c) {
+  FramePose p;
+  const float n = rsqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float qq[4] = {q[0] * n, q[1] * n, q[2] * n, q[3] * n};
+  quat_to_R(qq, p.R);
+  p.t[0] = t[0]; p.t[1] = t[1]; p.t[2] = t[2];
+  p.zr[0] = w2c[8]; p.zr[1] = w2c[9]; p.zr[2] = w2c[10]; p.zr[3] = w2c[11];    // row 2 of the row-major 4x4
+  return p;
+}
+
+__global__ __launch_bounds__(256) void prepare_frame_kernel(
+    int n, const float* __restrict__ means3D, const float* __restrict__ logit_op, const float* __restrict__ log_scales,
+    const float* __restrict__ unnorm_rot, const float* __restrict__ cam_q, const float* __restrict__ cam_t,
+    const float* __restrict__ depth_w2c, float* __restrict__ means_cam, float* __restrict__ opac,
+    float* __restrict__ scales, float* __restrict__ rot, float* __restrict__ dcol) {
+  const FramePose P = load_pose(cam_q, cam_t, depth_w2c);
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (i >= n) return;
+  const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+  const float cx = P.R[0] * x + P.R[1] * y + P.R[2] * z + P.t[0];
+  const float cy = P.R[3] * x + P.R[4] * y + P.R[5] * z + P.t[1];
+  const float cz = P.R[6] * x + P.R[7] * y + P.R[8] * z + P.t[2];
+  means_cam[3 * i] = cx; means_cam[3 * i + 1] = cy; means_cam[3 * i + 2] = cz;
+  opac[i] = 1.f / (1.f + __expf(-logit_op[i]));
+  const float s = __expf(log_scales[i]);
+  scales[3 * i] = s; scales[3 * i + 1] = s; scales[3 * i + 2] = s;
+  const float4 u = reinterpret_cast<const float4*>(unnorm_rot)[i];
+  const float un = rsqrtf(fmaxf(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w, 1e-24f));
+  reinterpret_cast<float4*>(rot)[i] = make_float4(u.x * un, u.y * un, u.z * un, u.w * un);
+  const float zz = P.zr[0] * cx + P.zr[1] * cy + P.zr[2] * cz + P.zr[3];
+  dcol[3 * i] = zz; dcol[3 * i + 1] = 1.f; dcol[3 * i + 2] = zz * zz;
+}
+
+// flags: bit 0 = gradients to the Gaussian geometry (means3D, unnorm_rotations), bit 1 = to the pose,
+//        bit 2 = to the appearance (logit_opacities, log_scales; the colour gradient needs no kernel work)
+__global__ __launch_bounds__(256) void prepare_frame_backward_kernel(
+    int n, int flags, const float* __restrict__ means3D, const float* __restrict__ logit_op,
+    const float* __restrict__ log_scales, const float* __restrict__ unnorm_rot, const float* __restrict__ cam_q,
+    const float* __restrict__ cam_t, const float* __restrict__ depth_w2c,
+    const float* __restrict__ gm_a, const float* __restrict__ gm_b, const float* __restrict__ g_dcol,
+    const float* __restrict__ gop_a, const float* __restrict__ gop_b, const float* __restrict__ gsc_a,
+    const float* __restrict__ gsc_b, const float* __restrict__ grot_a, const float* __restrict__ grot_b,
+    float* __restrict__ g_means3D, float* __restrict__ g_logit, float* __restrict__ g_log_scales,
+    float* __restrict__ g_unnorm_rot, float* __restrict__ pose_partials) {
+  __shared__ float red[4][12];
+  const FramePose P = load_pose(cam_q, cam_t, depth_w2c);
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+  float acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+  if (i < n) {
+    const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+    const float cx = P.R[0] * x + P.R[1] * y + P.R[2] * z + P.t[0];
+    const float cy = P.R[3] * x + P.R[4] * y + P.R[5] * z + P.t[1];
+    const float cz = P.R[6] * x + P.R[7] * y + P.R[8] * z + P.t[2];
+    const float zz = P.zr[0] * cx + P.zr[1] * cy + P.zr[2] * cz + P.zr[3];
+    const float dz = g_dcol[3 * i] + 2.f * zz * g_dcol[3 * i + 2];
+    const float g0 = gm_a[3 * i] + gm_b[3 * i] + dz * P.zr[0];
+    const float g1 = gm_a[3 * i + 1] + gm_b[3 * i + 1] + dz * P.zr[1];
+    const float g2 = gm_a[3 * i + 2] + gm_b[3 * i + 2] + dz * P.zr[2];
+    if (flags & 1) {
+      g_means3D[3 * i] = P.R[0] * g0 + P.R[3] * g1 + P.R[6] * g2;
+      g_means3D[3 * i + 1] = P.R[1] * g0 + P.R[4] * g1 + P.R[7] * g2;
+      g_means3D[3 * i + 2] = P.R[2] * g0 + P.R[5] * g1 + P.R[8] * g2;
+      const float4 u = reinterpret_cast<const float4*>(unnorm_rot)[i];
+      const float4 ga = reinterpret_cast<const float4*>(grot_a)[i], gb = reinterpret_cast<const float4*>(grot_b)[i];
+      const float gr[4] = {ga.x + gb.x, ga.y + gb.y, ga.z + gb.z, ga.w + gb.w};
+      const float un = rsqrtf(fmaxf(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w, 1e-24f));
+      const float r[4] = {u.x * un, u.y * un, u.z * un, u.w * un};
+      const float dot = r[0] * gr[0] + r[1] * gr[1] + r[2] * gr[2] + r[3] * gr[3];
+      reinterpret_cast<float4*>(g_unnorm_rot)[i] = make_float4((gr[0] - r[0] * dot) * un, (gr[1] - r[1] * dot) * un,
+                                                                (gr[2] - r[2] * dot) * un, (gr[3] - r[3] * dot) * un);
+    }
+    if (flags & 4) {
+      const float o = 1.f / (1.f + __expf(-logit_op[i]));
+      g_logit[i] = (gop_a[i] + gop_b[i]) * o * (1.f - o);
+      const float s = __expf(log_scales[i]);
+      g_log_scales[i] = s * (gsc_a[3 * i] + gsc_a[3 * i + 1] + gsc_a[3 * i + 2] + gsc_b[3 * i] + gsc_b[3 * i + 1] + gsc_b[3 * i + 2]);
+    }
+    if (flags & 2) {
+      acc[0] = g0; acc[1] = g1; acc[2] = g2;                                   // dL/dt
+      acc[3] = g0 * x; acc[4] = g0 * y; acc[5] = g0 * z;                       // dL/dR row 0
+      acc[6] = g1 * x; acc[7] = g1 * y; acc[8] = g1 * z;
+      acc[9] = g2 * x; acc[10] = g2 * y; acc[11] = g2 * z;
+    }
+  }
+  if (flags & 2) {                                   // fixed-order block reduction: bitwise reproducible
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = wave_sum(acc[k]);
+    const int wv = (int)(threadIdx.x >> 6), l = lane_id();
+    if (l == 0)
+      for (int k = 0; k < 12; ++k) red[wv][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < 12) pose_partials[(size_t)blockIdx.x * 12 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  }
+}
+
+}  // namespace vtgs
+
+using namespace vtgs;
+
+extern "C" {
+
+uint32_t vtgs_pose_partial_rows(int32_t n) { return n > 0 ? (uint32_t)((n + 255) / 256) : 0u; }
+
+int vtgs_prepare_frame(int32_t n, const float* means3D, const float* logit_opacities, const float* log_scales,
+                       const float* unnorm_rotations, const float* cam_q, const float* cam_t, const float* depth_w2c,
+                       float* out_means_cam, float* out_opacities, float* out_scales, float* out_rotations,
+                       float* out_depth_colors, void* stream) {
+  if (n < 0 || !cam_q || !cam_t || !depth_w2c) return VTGS_ERR_INVALID_ARGUMENT;
+  if (n == 0) return VTGS_OK;
+  if (!means3D || !logit_opacities || !log_scales || !unnorm_rotations || !out_means_cam || !out_opacities || !out_scales ||
+      !out_rotations || !out_depth_colors)
+    return VTGS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(prepare_frame_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, means3D,
+                     logit_opacities, log_scales, unnorm_rotations, cam_q, cam_t, depth_w2c, out_means_cam, out_opacities,
+                     out_scales, out_rotations, out_depth_colors);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+int vtgs_prepare_frame_backward(int32_t n, uint32_t flags, const float* means3D, const float* logit_opacities,
+                                const float* log_scales, const float* unnorm_rotations, const float* cam_q,
+                                const float* cam_t, const float* depth_w2c, const float* g_means_a, const float* g_means_b,
+                                const float* g_depth_colors, const float* g_opac_a, const float* g_opac_b,
+                                const float* g_scales_a, const float* g_scales_b, const float* g_rot_a, const float* g_rot_b,
+                                float* g_means3D, float* g_logit_opacities, float* g_log_scales, float* g_unnorm_rotations,
+                                float* pose_partials, void* stream) {
+  if (n < 0 || !cam_q || !cam_t || !depth_w2c || (flags & ~7u)) return VTGS_ERR_INVALID_ARGUMENT;
+  if (n == 0 || flags == 0) return VTGS_OK;
+  if (!means3D || !logit_opacities || !log_scales || !unnorm_rotations || !g_means_a || !g_means_b || !g_depth_colors ||
+      !g_opac_a || !g_opac_b || !g_scales_a || !g_scales_b || !g_rot_a || !g_rot_b)
+    return VTGS_ERR_INVALID_ARGUMENT;
+  if ((flags & 1u) && (!g_means3D || !g_unnorm_rotations)) return VTGS_ERR_INVALID_ARGUMENT;
+  if ((flags & 4u) && (!g_logit_opacities || !g_log_scales)) return VTGS_ERR_INVALID_ARGUMENT;
+  if ((flags & 2u) && !pose_partials) return VTGS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(prepare_frame_backward_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, (int)flags,
+                     means3D, logit_opacities, log_scales, unnorm_rotations, cam_q, cam_t, depth_w2c, g_means_a, g_means_b,
+                     g_depth_colors, g_opac_a, g_opac_b, g_scales_a, g_scales_b, g_rot_a, g_rot_b, g_means3D,
+                     g_logit_opacities, g_log_scales, g_unnorm_rotations, pose_partials);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+}  // extern "C"

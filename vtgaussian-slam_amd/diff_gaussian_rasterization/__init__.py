@@ -117,6 +117,7 @@ class GaussianRasterizationSettings(NamedTuple):
 _RADIUS_RULES = {"3sigma": 0, "opacity": 1}
 _capacity_hint = {}          # (device index, N, W, H, band) -> instances seen last time
 _tile_cap_hint = {}          # same key -> longest per-tile list seen last time
+_caps_in_use = {}            # same key -> (instance capacity, tile capacity) of the previous forward
 _last_info = {}
 
 
@@ -209,6 +210,22 @@ def _tile_capacity_for(max_list: int) -> int:
     return max(64, (int(max_list * 1.5) + 63) // 64 * 64)
 
 
+def _choose_capacities(key, n):
+    """Capacities for the next forward.  They move with hysteresis -- only when the last observed need comes within
+    10 % of the capacity in use, or falls below a quarter of it -- so consecutive forwards ask the caching allocator
+    for identically sized workspaces (it can then recycle the blocks instead of calling hipMalloc/hipFree)."""
+    need_i, need_t = _capacity_hint.get(key, 0), _tile_cap_hint.get(key, 0)
+    if not need_i:
+        return 8 * n + 65536, 512
+    cap, tcap = _caps_in_use.get(key, (0, 0))
+    if need_i * 1.1 > cap or need_i * 4 < cap:
+        cap = max(int(need_i * 1.5) + 4096, 4 * n + 4096)
+    if need_t * 1.1 > tcap or need_t * 4 < tcap:
+        tcap = _tile_capacity_for(need_t)
+    _caps_in_use[key] = (cap, tcap)
+    return cap, tcap
+
+
 def _record_info(key, n, W, H, capacity, info):
     _capacity_hint[key] = max(int(info.instances_needed), 1)
     _tile_cap_hint[key] = max(int(info.max_tile_list), 1)
@@ -247,8 +264,7 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
     radii = torch.empty((n,), dtype=torch.int32, device=device)
     key = (device.index, n, W, H, cam.band)
     hint = _capacity_hint.get(key, 0)
-    capacity = max(int(hint * 1.25) + 4096, 4 * n + 4096) if hint else 8 * n + 65536
-    tile_cap = _tile_capacity_for(_tile_cap_hint[key]) if key in _tile_cap_hint else 512
+    capacity, tile_cap = _choose_capacities(key, n)
     # the first forward of a shape has no instance-count history: check it synchronously
     use_async = want_async and _ASYNC_DEFAULT and hint > 0
     fs = _ForwardState()

@@ -1,0 +1,135 @@
+"""Fused frame render (SURVEY.md 8f-1 + 8f-2): pose transform, render-variable builders and BOTH renders of one
+`get_loss` call (src/vtgaussian_slam.py:431-468) as one autograd node.
+
+    im, depth_sil, radii = render_frame(params, time_idx, raster_settings, first_frame_w2c,
+                                        gaussians_grad=..., camera_grad=...)
+
+is equivalent to the reference's
+
+    tg  = transform_to_frame(params, time_idx, gaussians_grad, camera_grad)          utils/slam_helpers.py:323-385
+    im, radii, _      = Renderer(cam)(**transformed_params2rendervar(params, tg))                       :127-160
+    depth_sil, _, _   = Renderer(cam)(**transformed_params2depthplussilhouette(params, w2c, tg))        :255-287
+
+for isotropic maps (log_scales [N,1], every reference config), but runs the element-wise chain as one HIP kernel
+each way (vtgs_prepare_frame / vtgs_prepare_frame_backward), projects / bins / sorts once for both renders
+(vtgs_forward + vtgs_forward_shared) and reduces dL/dmeans to the 7 pose scalars on the device.
+Opt-in: the unmodified driver keeps working through the plain GaussianRasterizer.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import (_Camera, _ForwardState, _RADIUS_RULES, _check, _lib, _run_backward, _run_forward, _resolve_pending,
+               _stream_ptr, _I32, _P)
+
+_lib.vtgs_pose_partial_rows.restype, _lib.vtgs_pose_partial_rows.argtypes = ctypes.c_uint32, [_I32]
+_lib.vtgs_prepare_frame.restype, _lib.vtgs_prepare_frame.argtypes = ctypes.c_int, [_I32] + [_P] * 13
+_lib.vtgs_prepare_frame_backward.restype = ctypes.c_int
+_lib.vtgs_prepare_frame_backward.argtypes = [_I32, ctypes.c_uint32] + [_P] * 22
+
+
+def _rotation_of(q: torch.Tensor) -> torch.Tensor:
+    """R(q/|q|) for a single (w,x,y,z) quaternion, differentiable (utils/slam_external.py:25-42)."""
+    q = q / q.norm()
+    r, x, y, z = q.unbind()
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]).reshape(3, 3)
+
+
+class _RenderFrame(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, rgb, unnorm_rot, logit_op, log_scales, cam_q, cam_t, depth_w2c, cam: _Camera, flags: int):
+        dev = means3D.device
+        n = means3D.shape[0]
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        means3D, rgb, unnorm_rot, logit_op, log_scales = map(f32, (means3D, rgb, unnorm_rot, logit_op, log_scales))
+        cam_q, cam_t, depth_w2c = f32(cam_q).reshape(-1), f32(cam_t).reshape(-1), f32(depth_w2c).reshape(-1)
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        means_cam, opac, scales, rot, dcol = new(n, 3), new(n, 1), new(n, 3), new(n, 4), new(n, 3)
+        stream = _stream_ptr(dev)
+        _check(_lib.vtgs_prepare_frame(n, means3D.data_ptr(), logit_op.data_ptr(), log_scales.data_ptr(),
+                                       unnorm_rot.data_ptr(), cam_q.data_ptr(), cam_t.data_ptr(), depth_w2c.data_ptr(),
+                                       means_cam.data_ptr(), opac.data_ptr(), scales.data_ptr(), rot.data_ptr(),
+                                       dcol.data_ptr(), stream), "vtgs_prepare_frame")
+        im, radii, _, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot, want_async=flags != 0)
+        _resolve_pending(fs) if flags == 0 else None
+        H, W = cam.H, cam.W
+        depth_sil, depth2, state = new(3, H, W), new(1, H, W), new(H * W)
+        _check(_lib.vtgs_forward_shared(ctypes.byref(cam.c), n, dcol.data_ptr(), depth_sil.data_ptr(), depth2.data_ptr(),
+                                        fs.workspace.data_ptr(), fs.workspace.numel(), fs.capacity, fs.tile_cap,
+                                        state.data_ptr(), stream), "vtgs_forward_shared")
+        ctx.fs, ctx.state, ctx.flags, ctx.n = fs, state, flags, n
+        ctx.save_for_backward(means3D, rgb, unnorm_rot, logit_op, log_scales, cam_q, cam_t, depth_w2c,
+                              means_cam, opac, scales, rot, dcol, im, depth_sil)
+        ctx.mark_non_differentiable(radii)
+        return im, depth_sil, radii
+
+    @staticmethod
+    def backward(ctx, g_im, g_ds, _g_radii):
+        (means3D, rgb, unnorm_rot, logit_op, log_scales, cam_q, cam_t, depth_w2c,
+         means_cam, opac, scales, rot, dcol, im, depth_sil) = ctx.saved_tensors
+        dev, n, flags, fs = means3D.device, ctx.n, ctx.flags, ctx.fs
+        g_im = torch.zeros_like(im) if g_im is None else g_im.to(torch.float32).contiguous()
+        g_ds = torch.zeros_like(depth_sil) if g_ds is None else g_ds.to(torch.float32).contiguous()
+        ga = _run_backward(fs, means_cam, rgb, opac, scales, rot, im, g_im)            # resolves the async forward
+        fsb = _ForwardState()
+        (fsb.cam, fsb.n, fsb.workspace, fsb.capacity, fsb.tile_cap, fsb.instances, fsb.image_state, fsb.pending,
+         fsb.key) = fs.cam, fs.n, fs.workspace, fs.capacity, fs.tile_cap, fs.instances, ctx.state, None, fs.key
+        gb = _run_backward(fsb, means_cam, dcol, opac, scales, rot, depth_sil, g_ds)
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        want_g, want_p, want_a = bool(flags & 1), bool(flags & 2), bool(flags & 4)
+        g_means3D = new(n, 3) if want_g else None
+        g_ur = new(n, 4) if want_g else None
+        g_logit = new(n, 1) if want_a else None
+        g_ls = new(n, 1) if want_a else None
+        rows = int(_lib.vtgs_pose_partial_rows(n))
+        partials = new(rows, 12) if want_p else None
+        ptr = lambda t: None if t is None else t.data_ptr()
+        _check(_lib.vtgs_prepare_frame_backward(
+            n, flags, means3D.data_ptr(), logit_op.data_ptr(), log_scales.data_ptr(), unnorm_rot.data_ptr(),
+            cam_q.data_ptr(), cam_t.data_ptr(), depth_w2c.data_ptr(), ga[0].data_ptr(), gb[0].data_ptr(), gb[2].data_ptr(),
+            ga[3].data_ptr(), gb[3].data_ptr(), ga[4].data_ptr(), gb[4].data_ptr(), ga[5].data_ptr(), gb[5].data_ptr(),
+            ptr(g_means3D), ptr(g_logit), ptr(g_ls), ptr(g_ur), ptr(partials), _stream_ptr(dev)),
+            "vtgs_prepare_frame_backward")
+        g_q = g_t = None
+        if want_p:
+            s = partials.sum(0)                                   # 12 floats: dL/dt | dL/dR
+            g_t = s[:3].clone()
+            with torch.enable_grad():
+                qq = cam_q.detach().clone().requires_grad_(True)
+                (_rotation_of(qq) * s[3:].reshape(3, 3)).sum().backward()
+            g_q = qq.grad
+        return (g_means3D, ga[2] if want_a else None, g_ur, g_logit, g_ls, g_q, g_t, None, None, None)
+
+
+def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings, first_frame_w2c: torch.Tensor,
+                 gaussians_grad: bool, camera_grad: bool, radius_rule: Optional[str] = None):
+    """RGB render + [z,1,z^2] render of frame `time_idx` (see module docstring).  Returns (im [3,H,W],
+    depth_sil [3,H,W], radii [N] int32)."""
+    if params["log_scales"].shape[1] != 1:
+        raise NotImplementedError("render_frame covers isotropic maps (log_scales [N,1]) -- what every reference config "
+                                  "uses; anisotropic maps go through transform_to_frame + GaussianRasterizer")
+    dev = params["means3D"].device
+    if dev.type != "cuda":
+        raise RuntimeError("render_frame needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
+    import os
+    rule = _RADIUS_RULES[radius_rule or os.environ.get("VTGS_RADIUS_RULE", "3sigma")]
+    cam = _Camera(raster_settings, dev, rule, None)
+    q = params["cam_unnorm_rots"][0, :, time_idx]
+    t = params["cam_trans"][0, :, time_idx]
+    if not camera_grad:
+        q, t = q.detach(), t.detach()
+    # like the reference, gaussians_grad=False detaches only the geometry (means3D, unnorm_rotations); colours,
+    # opacities and scales keep their gradient whenever they require one (utils/slam_helpers.py:362-367, 152-159)
+    g = lambda x: x if gaussians_grad else x.detach()
+    grad_on = torch.is_grad_enabled()
+    appearance = any(params[k].requires_grad for k in ("rgb_colors", "logit_opacities", "log_scales"))
+    flags = ((1 if gaussians_grad and grad_on else 0) | (2 if camera_grad and grad_on else 0)
+             | (4 if appearance and grad_on else 0))
+    return _RenderFrame.apply(g(params["means3D"]), params["rgb_colors"], g(params["unnorm_rotations"]),
+                              params["logit_opacities"], params["log_scales"], q, t,
+                              first_frame_w2c.to(dev), cam, flags)
