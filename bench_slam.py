@@ -12,6 +12,7 @@ and must recover the motion -- the reported pose error is an end-to-end check of
 
     python bench_slam.py --frames 3                        # one JSON line
     python bench_slam.py --frames 3 --shared-geometry      # depth/silhouette pass reuses the RGB pass's binning (8f-2)
+    python bench_slam.py --frames 3 --fused                # + fused caller chain (8f-1) and loss kernels (8f-3)
 """
 import argparse
 import json
@@ -44,7 +45,8 @@ def main():
     ap.add_argument("--tracking-iters", type=int, default=60)
     ap.add_argument("--mapping-iters", type=int, default=100)
     ap.add_argument("--shared-geometry", action="store_true", help="depth/silhouette pass reuses the RGB pass's binning (8f-2)")
-    ap.add_argument("--fused", action="store_true", help="fused pose transform + render variables + both renders (8f-1)")
+    ap.add_argument("--fused", action="store_true", help="fused pose transform + render variables + both renders (8f-1), "
+                                                         "HIP SSIM kernel and sync-free masked sums (8f-3)")
     args = ap.parse_args()
     assert torch.cuda.is_available(), "bench_slam.py needs an MI355X"
     dev = torch.device("cuda", 0)
@@ -72,6 +74,8 @@ def main():
         gt_rots[0, :, t], gt_trans[0, :, t] = q.to(dev), tr.to(dev)
 
     from diff_gaussian_rasterization.fused import render_frame
+    from diff_gaussian_rasterization.losses import fused_ssim
+    ssim_fn, gather = (fused_ssim, False) if args.fused else (None, True)
 
     def render_pair(params, t_idx, gaussians_grad, camera_grad):
         if args.fused:
@@ -121,6 +125,16 @@ def main():
             dq = (q1 * gt_rots[0, :, t]).sum().abs().clamp(max=1.0)
             return dt, math.degrees(2 * math.acos(dq.item()))
 
+    # untimed warm-up (kernel selection / compilation inside MIOpen, allocator pools, capacity hints): a few iterations
+    # of each phase on a throw-away copy of the parameters
+    warm = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    for _ in range(3):
+        im, depth_sil, _ = render_pair(warm, 1, gaussians_grad=False, camera_grad=True)
+        sc.tracking_loss(im, depth_sil, gts[1][0], gts[1][1], 0.99, gather=gather).backward()
+        im, depth_sil, _ = render_pair(warm, 1, gaussians_grad=True, camera_grad=False)
+        sc.mapping_loss(im, depth_sil, gts[1][0], gts[1][1], ssim_fn=ssim_fn, gather=gather).backward()
+    del warm
+
     track_ms, map_ms, errs_before, errs_after = [], [], [], []
     torch.cuda.synchronize()
     t_all = time.perf_counter()
@@ -138,7 +152,7 @@ def main():
             im, depth_sil, _ = render_pair(params, t, gaussians_grad=False, camera_grad=True)
             if it == 0:
                 sil_thres = sc.best_silhouette_threshold(im, depth_sil[1], gt_im, gt_depth)
-            loss = sc.tracking_loss(im, depth_sil, gt_im, gt_depth, sil_thres)
+            loss = sc.tracking_loss(im, depth_sil, gt_im, gt_depth, sil_thres, gather=gather)
             loss.backward()
             with torch.no_grad():
                 lv = loss.detach()
@@ -153,7 +167,7 @@ def main():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for it in range(args.mapping_iters):
             im, depth_sil, _ = render_pair(params, t, gaussians_grad=True, camera_grad=False)
-            loss = sc.mapping_loss(im, depth_sil, gt_im, gt_depth)
+            loss = sc.mapping_loss(im, depth_sil, gt_im, gt_depth, ssim_fn=ssim_fn, gather=gather)
             loss.backward()
             opt.step(); opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize(); map_ms.append((time.perf_counter() - t0) * 1e3 / args.mapping_iters)
@@ -171,6 +185,10 @@ def main():
         "pose_error_before_tracking_cm_deg": [[round(a, 3), round(b, 4)] for a, b in errs_before],
         "pose_error_after_tracking_cm_deg": [[round(a, 3), round(b, 4)] for a, b in errs_after],
     }
+    ms = torch.cuda.memory_stats()
+    out["allocator"] = {"device_allocs": ms.get("num_device_alloc", 0), "device_frees": ms.get("num_device_free", 0),
+                        "alloc_retries": ms.get("num_alloc_retries", 0),
+                        "reserved_gb": round(torch.cuda.memory_reserved() / 1e9, 2)}
     print(json.dumps(out))
 
 

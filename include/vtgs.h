@@ -173,6 +173,18 @@ int vtgs_prepare_frame_backward(int32_t n, uint32_t flags, const float* means3D,
                                 float* g_means3D, float* g_logit_opacities, float* g_log_scales, float* g_unnorm_rotations,
                                 float* pose_partials, void* stream);
 
+/* ---- SSIM of the mapping loss ------------------------------------------------------------------
+ * Replaces utils/slam_external.py:66-97 (calc_ssim): mean SSIM of two [C,H,W] images with the 11x11 Gaussian window
+ * (sigma 1.5, zero padding, per-channel).  vtgs_ssim_forward writes one partial sum of the SSIM map per workgroup into
+ * partial_sums[vtgs_ssim_partial_rows(C,H,W)] (mean = sum / (C*H*W)) and, if grad_maps is not NULL, three [C,H,W]
+ * derivative maps for the backward.  vtgs_ssim_backward gives dL/dimg1 for dL/d(mean SSIM) = *upstream (device scalar).
+ * img2 is treated as a constant (it is the ground-truth image in the reference).                                      */
+uint32_t vtgs_ssim_partial_rows(int32_t channels, int32_t height, int32_t width);
+int vtgs_ssim_forward(const float* img1, const float* img2, int32_t channels, int32_t height, int32_t width,
+                      float* partial_sums, float* grad_maps, void* stream);
+int vtgs_ssim_backward(const float* img1, const float* img2, const float* grad_maps, const float* upstream,
+                       int32_t channels, int32_t height, int32_t width, float* grad_img1, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on (used by bench.py for
  * the roofline of the dominant kernel).  While enabled, every kernel launch of the library is bracketed by two
  * events; vtgs_profile_collect synchronises the device, sums elapsed time per kernel name since enabling and

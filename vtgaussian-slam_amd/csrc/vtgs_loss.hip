@@ -1,0 +1,175 @@
+// vtgs_loss.hip -- SSIM of the mapping loss as two kernels.
+//
+// Replaces utils/slam_external.py:66-97 (calc_ssim / _ssim): five grouped 11x11 Gaussian convolutions (sigma 1.5,
+// zero padding) + element-wise algebra + mean, and their autograd backward (five more convolutions).  The window is an
+// outer product (utils/slam_external.py:60-63), so every blur is separable: a workgroup stages a (32+10)^2 patch of one
+// channel in LDS, blurs rows then columns for the five moments, evaluates the SSIM map and reduces it to one partial sum
+// (fixed order, no atomics).  When a gradient is wanted it also writes three per-pixel derivative maps
+//     A = d/dmu1 - 2 mu1 d/ds11 - mu2 d/ds12,  B = d/ds11,  C = d/ds12     (derivatives of the SSIM map)
+// and the backward is   dL/dx = g/(C H W) * ( blur(A) + 2 x blur(B) + y blur(C) )   -- three blurs, same tiling.
+#include "../../include/vtgs.h"
+#include "vtgs_internal.h"
+
+namespace vtgs {
+
+constexpr int kST = 32;                 // output tile edge
+constexpr int kSR = 5;                  // window radius
+constexpr int kSP = kST + 2 * kSR;      // staged patch edge (42)
+
+__device__ __forceinline__ void gauss11(float (&w)[11]) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 11; ++i) { w[i] = __expf(-(float)((i - 5) * (i - 5)) / (2.f * 1.5f * 1.5f)); s += w[i]; }
+#pragma unroll
+  for (int i = 0; i < 11; ++i) w[i] /= s;
+}
+
+__global__ __launch_bounds__(256) void ssim_forward_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
+                                                           int C, int H, int W, int tiles_x, int tiles_y,
+                                                           float* __restrict__ partial, float* __restrict__ gmaps) {
+  __shared__ float px[kSP * kSP], py[kSP * kSP];
+  __shared__ float hz[5][kSP * kST];
+  __shared__ float red[4];
+  float w[11];
+  gauss11(w);
+  const int t = (int)threadIdx.x;
+  const int b = (int)blockIdx.x;
+  const int c = b / (tiles_x * tiles_y), tb = b - c * tiles_x * tiles_y;
+  const int ty = tb / tiles_x, tx = tb - ty * tiles_x;
+  const int x0 = tx * kST - kSR, y0 = ty * kST - kSR;
+  const size_t plane = (size_t)c * H * W;
+  for (int i = t; i < kSP * kSP; i += 256) {
+    const int r = i / kSP, q = i - r * kSP;
+    const int gy = y0 + r, gx = x0 + q;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;          // zero padding
+    const size_t o = plane + (size_t)gy * W + gx;
+    px[i] = in ? img1[o] : 0.f;
+    py[i] = in ? img2[o] : 0.f;
+  }
+  __syncthreads();
+  for (int i = t; i < kSP * kST; i += 256) {                          // rows: 42 x 32 outputs
+    const int r = i / kST, q = i - r * kST;
+    float m1 = 0.f, m2 = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float a = px[r * kSP + q + k], d = py[r * kSP + q + k];
+      m1 = fmaf(w[k], a, m1); m2 = fmaf(w[k], d, m2);
+      xx = fmaf(w[k], a * a, xx); yy = fmaf(w[k], d * d, yy); xy = fmaf(w[k], a * d, xy);
+    }
+    hz[0][i] = m1; hz[1][i] = m2; hz[2][i] = xx; hz[3][i] = yy; hz[4][i] = xy;
+  }
+  __syncthreads();
+  float acc = 0.f;
+  const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+  for (int i = t; i < kST * kST; i += 256) {                          // columns: 32 x 32 outputs
+    const int r = i / kST, q = i - r * kST;
+    const int gy = ty * kST + r, gx = tx * kST + q;
+    float m1 = 0.f, m2 = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const int j = (r + k) * kST + q;
+      m1 = fmaf(w[k], hz[0][j], m1); m2 = fmaf(w[k], hz[1][j], m2);
+      xx = fmaf(w[k], hz[2][j], xx); yy = fmaf(w[k], hz[3][j], yy); xy = fmaf(w[k], hz[4][j], xy);
+    }
+    if (gy < H && gx < W) {
+      const float s11 = xx - m1 * m1, s22 = yy - m2 * m2, s12 = xy - m1 * m2;
+      const float a1 = 2.f * m1 * m2 + c1, a2 = 2.f * s12 + c2, b1 = m1 * m1 + m2 * m2 + c1, b2 = s11 + s22 + c2;
+      const float ib = 1.f / (b1 * b2);
+      const float ssim = a1 * a2 * ib;
+      acc += ssim;
+      if (gmaps) {
+        const float d_mu1 = 2.f * m2 * a2 * ib - ssim * 2.f * m1 / b1;
+        const float d_s11 = -ssim / b2, d_s12 = 2.f * a1 * ib;
+        const size_t o = plane + (size_t)gy * W + gx, P3 = (size_t)C * H * W;
+        gmaps[o] = d_mu1 - 2.f * m1 * d_s11 - m2 * d_s12;
+        gmaps[P3 + o] = d_s11;
+        gmaps[2 * P3 + o] = d_s12;
+      }
+    }
+  }
+  acc = wave_sum(acc);
+  if ((t & 63) == 0) red[t >> 6] = acc;
+  __syncthreads();
+  if (t == 0) partial[b] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void ssim_backward_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
+                                                            const float* __restrict__ gmaps, const float* __restrict__ upstream,
+                                                            int C, int H, int W, int tiles_x, int tiles_y,
+                                                            float* __restrict__ g_img1) {
+  __shared__ float pm[3][kSP * kSP];
+  __shared__ float hz[3][kSP * kST];
+  float w[11];
+  gauss11(w);
+  const int t = (int)threadIdx.x;
+  const int b = (int)blockIdx.x;
+  const int c = b / (tiles_x * tiles_y), tb = b - c * tiles_x * tiles_y;
+  const int ty = tb / tiles_x, tx = tb - ty * tiles_x;
+  const int x0 = tx * kST - kSR, y0 = ty * kST - kSR;
+  const size_t plane = (size_t)c * H * W, P3 = (size_t)C * H * W;
+  for (int i = t; i < kSP * kSP; i += 256) {
+    const int r = i / kSP, q = i - r * kSP;
+    const int gy = y0 + r, gx = x0 + q;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;          // the adjoint of a zero-padded blur is the same blur
+    const size_t o = plane + (size_t)gy * W + gx;
+    pm[0][i] = in ? gmaps[o] : 0.f; pm[1][i] = in ? gmaps[P3 + o] : 0.f; pm[2][i] = in ? gmaps[2 * P3 + o] : 0.f;
+  }
+  __syncthreads();
+  for (int i = t; i < kSP * kST; i += 256) {
+    const int r = i / kST, q = i - r * kST;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const int j = r * kSP + q + k;
+      s0 = fmaf(w[k], pm[0][j], s0); s1 = fmaf(w[k], pm[1][j], s1); s2 = fmaf(w[k], pm[2][j], s2);
+    }
+    hz[0][i] = s0; hz[1][i] = s1; hz[2][i] = s2;
+  }
+  __syncthreads();
+  const float scale = upstream[0] / (float)((size_t)C * H * W);
+  for (int i = t; i < kST * kST; i += 256) {
+    const int r = i / kST, q = i - r * kST;
+    const int gy = ty * kST + r, gx = tx * kST + q;
+    if (gy >= H || gx >= W) continue;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const int j = (r + k) * kST + q;
+      s0 = fmaf(w[k], hz[0][j], s0); s1 = fmaf(w[k], hz[1][j], s1); s2 = fmaf(w[k], hz[2][j], s2);
+    }
+    const size_t o = plane + (size_t)gy * W + gx;
+    g_img1[o] = scale * (s0 + 2.f * img1[o] * s1 + img2[o] * s2);
+  }
+}
+
+}  // namespace vtgs
+
+using namespace vtgs;
+
+extern "C" {
+
+uint32_t vtgs_ssim_partial_rows(int32_t channels, int32_t height, int32_t width) {
+  if (channels <= 0 || height <= 0 || width <= 0) return 0;
+  return (uint32_t)(channels * ((height + kST - 1) / kST) * ((width + kST - 1) / kST));
+}
+
+int vtgs_ssim_forward(const float* img1, const float* img2, int32_t channels, int32_t height, int32_t width,
+                      float* partial_sums, float* grad_maps, void* stream) {
+  if (!img1 || !img2 || !partial_sums || channels <= 0 || height <= 0 || width <= 0) return VTGS_ERR_INVALID_ARGUMENT;
+  const int tx = (width + kST - 1) / kST, ty = (height + kST - 1) / kST;
+  hipLaunchKernelGGL(ssim_forward_kernel, dim3(channels * tx * ty), dim3(256), 0, (hipStream_t)stream, img1, img2, channels,
+                     height, width, tx, ty, partial_sums, grad_maps);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+int vtgs_ssim_backward(const float* img1, const float* img2, const float* grad_maps, const float* upstream,
+                       int32_t channels, int32_t height, int32_t width, float* grad_img1, void* stream) {
+  if (!img1 || !img2 || !grad_maps || !upstream || !grad_img1 || channels <= 0 || height <= 0 || width <= 0)
+    return VTGS_ERR_INVALID_ARGUMENT;
+  const int tx = (width + kST - 1) / kST, ty = (height + kST - 1) / kST;
+  hipLaunchKernelGGL(ssim_backward_kernel, dim3(channels * tx * ty), dim3(256), 0, (hipStream_t)stream, img1, img2, grad_maps,
+                     upstream, channels, height, width, tx, ty, grad_img1);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+}  // extern "C"
