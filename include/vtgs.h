@@ -161,6 +161,9 @@ int vtgs_mark_visible(const VtgsCamera* cam, int32_t n, const float* means3D,
  * [dL/dt (3) | dL/dR (9, row-major)] into pose_partials[vtgs_pose_partial_rows(n)][12]; the caller sums the rows and
  * takes the 12 -> 7 step through the quaternion.  No atomics: results are bitwise reproducible.                     */
 uint32_t vtgs_pose_partial_rows(int32_t n);
+/* Sums the partial rows and takes the 12 -> 7 step through the normalised quaternion: g_cam_q[4], g_cam_t[3] (device). */
+int vtgs_pose_gradient(const float* pose_partials, uint32_t rows, const float* cam_q, float* g_cam_q, float* g_cam_t,
+                       void* stream);
 int vtgs_prepare_frame(int32_t n, const float* means3D, const float* logit_opacities, const float* log_scales,
                        const float* unnorm_rotations, const float* cam_q, const float* cam_t, const float* depth_w2c,
                        float* out_means_cam, float* out_opacities, float* out_scales, float* out_rotations,

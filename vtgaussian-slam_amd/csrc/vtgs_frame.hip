@@ -112,11 +112,55 @@ __global__ __launch_bounds__(256) void prepare_frame_backward_kernel(
   }
 }
 
+// One workgroup: sums the per-workgroup partial rows (fixed order) and takes the 12 -> 7 step:
+// dL/dt = sum[0..2];  dL/dq = J_norm^T ( dR/dq_hat : dL/dR )  with q_hat = q/|q|  (utils/slam_external.py:25-42).
+__global__ __launch_bounds__(256) void pose_gradient_kernel(const float* __restrict__ partials, uint32_t rows,
+                                                            const float* __restrict__ cam_q, float* __restrict__ g_q,
+                                                            float* __restrict__ g_t) {
+  __shared__ float red[4][12];
+  float acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+  for (uint32_t r = threadIdx.x; r < rows; r += 256u)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] += partials[(size_t)r * 12 + k];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = wave_sum(acc[k]);
+  if (lane_id() == 0)
+    for (int k = 0; k < 12; ++k) red[threadIdx.x >> 6][k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s[12];
+    for (int k = 0; k < 12; ++k) s[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    g_t[0] = s[0]; g_t[1] = s[1]; g_t[2] = s[2];
+    const float* dR = s + 3;                                     // row-major dL/dR
+    const float n2 = cam_q[0] * cam_q[0] + cam_q[1] * cam_q[1] + cam_q[2] * cam_q[2] + cam_q[3] * cam_q[3];
+    const float inv = rsqrtf(n2);
+    const float qr = cam_q[0] * inv, qx = cam_q[1] * inv, qy = cam_q[2] * inv, qz = cam_q[3] * inv;
+    float gh[4];                                                 // dL/dq_hat (same expressions as splat_backward's rot)
+    gh[0] = 2.f * (-qz * dR[1] + qy * dR[2] + qz * dR[3] - qx * dR[5] - qy * dR[6] + qx * dR[7]);
+    gh[1] = 2.f * (qy * dR[1] + qz * dR[2] + qy * dR[3] - 2.f * qx * dR[4] - qr * dR[5] + qz * dR[6] + qr * dR[7] - 2.f * qx * dR[8]);
+    gh[2] = 2.f * (-2.f * qy * dR[0] + qx * dR[1] + qr * dR[2] + qx * dR[3] + qz * dR[5] - qr * dR[6] + qz * dR[7] - 2.f * qy * dR[8]);
+    gh[3] = 2.f * (-2.f * qz * dR[0] - qr * dR[1] + qx * dR[2] + qr * dR[3] - 2.f * qz * dR[4] + qy * dR[5] + qx * dR[6] + qy * dR[7]);
+    const float qh[4] = {qr, qx, qy, qz};
+    const float dot = qh[0] * gh[0] + qh[1] * gh[1] + qh[2] * gh[2] + qh[3] * gh[3];
+    for (int k = 0; k < 4; ++k) g_q[k] = (gh[k] - qh[k] * dot) * inv;   // through q_hat = q / |q|
+  }
+}
+
 }  // namespace vtgs
 
 using namespace vtgs;
 
 extern "C" {
+
+int vtgs_pose_gradient(const float* pose_partials, uint32_t rows, const float* cam_q, float* g_cam_q, float* g_cam_t,
+                       void* stream) {
+  if (!pose_partials || !cam_q || !g_cam_q || !g_cam_t) return VTGS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(pose_gradient_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pose_partials, rows, cam_q, g_cam_q,
+                     g_cam_t);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
 
 uint32_t vtgs_pose_partial_rows(int32_t n) { return n > 0 ? (uint32_t)((n + 255) / 256) : 0u; }
 

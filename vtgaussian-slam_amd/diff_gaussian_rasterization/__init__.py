@@ -254,6 +254,19 @@ def _resolve_pending(fs: "_ForwardState") -> None:
     fs.instances = int(info.instances)
 
 
+_MAX_WORKSPACE_BYTES = int(os.environ.get("VTGS_MAX_WORKSPACE_GB", "96")) << 30
+
+
+def _workspace(n, W, H, capacity, tile_cap, device):
+    nbytes = _lib.vtgs_workspace_bytes(n, W, H, capacity, tile_cap)
+    if nbytes > _MAX_WORKSPACE_BYTES:
+        raise RuntimeError(
+            f"the forward workspace would need {nbytes / 2**30:.1f} GiB (every one of the {((W + 7) // 8) * ((H + 7) // 8)} "
+            f"8x8 tiles gets a bin of {tile_cap} entries, sized by the longest tile list): some tile is hit by an "
+            f"extreme number of splats. Raise VTGS_MAX_WORKSPACE_GB if that is intended.")
+    return nbytes, torch.empty((nbytes,), dtype=torch.uint8, device=device)
+
+
 def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, want_async: bool):
     global _ring
     device = means3D.device
@@ -272,8 +285,7 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
     if use_async:
         if _ring is None:
             _ring = _PinnedInfoRing()
-        nbytes = _lib.vtgs_workspace_bytes(n, W, H, capacity, tile_cap)
-        workspace = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
         slot = _ring.take()
         st = _lib.vtgs_forward(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
                                scales.data_ptr(), rotations.data_ptr(), color.data_ptr(), depth.data_ptr(),
@@ -287,8 +299,7 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
         return color, radii, depth, fs
     info = _VtgsForwardInfo()
     for _attempt in range(4):
-        nbytes = _lib.vtgs_workspace_bytes(n, W, H, capacity, tile_cap)
-        workspace = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
         st = _lib.vtgs_forward(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
                                scales.data_ptr(), rotations.data_ptr(), color.data_ptr(), depth.data_ptr(),
                                radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, tile_cap,

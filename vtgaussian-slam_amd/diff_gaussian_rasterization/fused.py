@@ -12,7 +12,8 @@ is equivalent to the reference's
 
 for isotropic maps (log_scales [N,1], every reference config), but runs the element-wise chain as one HIP kernel
 each way (vtgs_prepare_frame / vtgs_prepare_frame_backward), projects / bins / sorts once for both renders
-(vtgs_forward + vtgs_forward_shared) and reduces dL/dmeans to the 7 pose scalars on the device.
+(vtgs_forward + vtgs_forward_shared) and reduces dL/dmeans to the 7 pose scalars on the device
+(vtgs_prepare_frame_backward + vtgs_pose_gradient).
 Opt-in: the unmodified driver keeps working through the plain GaussianRasterizer.
 """
 from __future__ import annotations
@@ -29,15 +30,7 @@ _lib.vtgs_pose_partial_rows.restype, _lib.vtgs_pose_partial_rows.argtypes = ctyp
 _lib.vtgs_prepare_frame.restype, _lib.vtgs_prepare_frame.argtypes = ctypes.c_int, [_I32] + [_P] * 13
 _lib.vtgs_prepare_frame_backward.restype = ctypes.c_int
 _lib.vtgs_prepare_frame_backward.argtypes = [_I32, ctypes.c_uint32] + [_P] * 22
-
-
-def _rotation_of(q: torch.Tensor) -> torch.Tensor:
-    """R(q/|q|) for a single (w,x,y,z) quaternion, differentiable (utils/slam_external.py:25-42)."""
-    q = q / q.norm()
-    r, x, y, z = q.unbind()
-    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
-                        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
-                        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]).reshape(3, 3)
+_lib.vtgs_pose_gradient.restype, _lib.vtgs_pose_gradient.argtypes = ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P]
 
 
 class _RenderFrame(torch.autograd.Function):
@@ -96,13 +89,10 @@ class _RenderFrame(torch.autograd.Function):
             ptr(g_means3D), ptr(g_logit), ptr(g_ls), ptr(g_ur), ptr(partials), _stream_ptr(dev)),
             "vtgs_prepare_frame_backward")
         g_q = g_t = None
-        if want_p:
-            s = partials.sum(0)                                   # 12 floats: dL/dt | dL/dR
-            g_t = s[:3].clone()
-            with torch.enable_grad():
-                qq = cam_q.detach().clone().requires_grad_(True)
-                (_rotation_of(qq) * s[3:].reshape(3, 3)).sum().backward()
-            g_q = qq.grad
+        if want_p:                                                # 12 partial sums per workgroup -> dL/dq, dL/dt
+            g_q, g_t = new(4), new(3)
+            _check(_lib.vtgs_pose_gradient(partials.data_ptr(), rows, cam_q.data_ptr(), g_q.data_ptr(), g_t.data_ptr(),
+                                           _stream_ptr(dev)), "vtgs_pose_gradient")
         return (g_means3D, ga[2] if want_a else None, g_ur, g_logit, g_ls, g_q, g_t, None, None, None)
 
 
