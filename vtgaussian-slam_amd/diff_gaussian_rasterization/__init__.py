@@ -235,7 +235,8 @@ def _record_info(key, n, W, H, capacity, info):
 
 
 def _resolve_pending(fs: "_ForwardState") -> None:
-    """Wait for the asynchronous result record of a forward and act on it (called before its backward)."""
+    """Wait for the asynchronous result record of a forward and act on it (called once its backward is enqueued).
+    Idempotent: a shared-geometry state carries the same pending record as the forward it shares."""
     if fs.pending is None:
         return
     slot, event = fs.pending
@@ -332,7 +333,7 @@ def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotatio
         return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
     # Asynchronous forward: enqueue the backward first (scratch sized by capacity; the kernels check the device-side
     # overflow flag themselves) and verify the result record afterwards, so the GPU never waits for the host.
-    sbytes = _lib.vtgs_backward_scratch_bytes(n, fs.instances if fs.pending is None else fs.capacity)
+    sbytes = _lib.vtgs_backward_scratch_bytes(n, fs.capacity if fs.instances is None else fs.instances)
     scratch = torch.empty((sbytes,), dtype=torch.uint8, device=device)
     state_ptr = fs.image_state.data_ptr() if fs.image_state is not None else None
     st = _lib.vtgs_backward(ctypes.byref(fs.cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
@@ -382,8 +383,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if shared_from is None:
             color, radii, depth, fs = _run_forward(cam, means3D, colors, opac, scales_c, rot, want_async=want_async)
         else:
-            base = shared_from
-            _resolve_pending(base)
+            base = shared_from                  # its result record may still be in flight: share it, do not wait
             H, W = cam.H, cam.W
             color = torch.empty((3, H, W), dtype=torch.float32, device=device)
             depth = torch.empty((1, H, W), dtype=torch.float32, device=device)
@@ -394,7 +394,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _check(st, "vtgs_forward_shared")
             fs = _ForwardState()
             fs.cam, fs.n, fs.workspace, fs.capacity, fs.tile_cap, fs.instances, fs.image_state, fs.pending, fs.key = (
-                base.cam, base.n, base.workspace, base.capacity, base.tile_cap, base.instances, state, None, base.key)
+                base.cam, base.n, base.workspace, base.capacity, base.tile_cap, base.instances, state, base.pending, base.key)
             radii = None
         ctx.fs = fs
         ctx.save_for_backward(means3D, colors, opac, scales_c, rot, color)

@@ -49,7 +49,6 @@ class _RenderFrame(torch.autograd.Function):
                                        means_cam.data_ptr(), opac.data_ptr(), scales.data_ptr(), rot.data_ptr(),
                                        dcol.data_ptr(), stream), "vtgs_prepare_frame")
         im, radii, _, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot, want_async=flags != 0)
-        _resolve_pending(fs) if flags == 0 else None
         H, W = cam.H, cam.W
         depth_sil, depth2, state = new(3, H, W), new(1, H, W), new(H * W)
         _check(_lib.vtgs_forward_shared(ctypes.byref(cam.c), n, dcol.data_ptr(), depth_sil.data_ptr(), depth2.data_ptr(),
@@ -71,7 +70,7 @@ class _RenderFrame(torch.autograd.Function):
         ga = _run_backward(fs, means_cam, rgb, opac, scales, rot, im, g_im)            # resolves the async forward
         fsb = _ForwardState()
         (fsb.cam, fsb.n, fsb.workspace, fsb.capacity, fsb.tile_cap, fsb.instances, fsb.image_state, fsb.pending,
-         fsb.key) = fs.cam, fs.n, fs.workspace, fs.capacity, fs.tile_cap, fs.instances, ctx.state, None, fs.key
+         fsb.key) = fs.cam, fs.n, fs.workspace, fs.capacity, fs.tile_cap, fs.instances, ctx.state, fs.pending, fs.key
         gb = _run_backward(fsb, means_cam, dcol, opac, scales, rot, depth_sil, g_ds)
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         want_g, want_p, want_a = bool(flags & 1), bool(flags & 2), bool(flags & 4)
