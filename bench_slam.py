@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--mapping-iters", type=int, default=100)
     ap.add_argument("--shared-geometry", action="store_true", help="depth/silhouette pass reuses the RGB pass's binning (8f-2)")
     ap.add_argument("--fused", action="store_true", help="fused pose transform + render variables + both renders (8f-1), "
-                                                         "HIP SSIM kernel and sync-free masked sums (8f-3)")
+                                                         "loss kernels (8f-3), torch fused Adam")
     args = ap.parse_args()
     assert torch.cuda.is_available(), "bench_slam.py needs an MI355X"
     dev = torch.device("cuda", 0)
@@ -74,8 +74,15 @@ def main():
         gt_rots[0, :, t], gt_trans[0, :, t] = q.to(dev), tr.to(dev)
 
     from diff_gaussian_rasterization.fused import render_frame
-    from diff_gaussian_rasterization.losses import fused_ssim
-    ssim_fn, gather = (fused_ssim, False) if args.fused else (None, True)
+    from diff_gaussian_rasterization import losses as fl
+    if args.fused:                                    # loss kernels (8f-3) and PyTorch's single-kernel Adam
+        track_loss = lambda im, ds, gi, gd, thr: fl.tracking_loss(im, ds, gi, gd, thr)
+        map_loss = lambda im, ds, gi, gd: fl.mapping_loss(im, ds, gi, gd)
+        adam_kw = {"fused": True}
+    else:                                             # exactly the reference's PyTorch formulation
+        track_loss = lambda im, ds, gi, gd, thr: sc.tracking_loss(im, ds, gi, gd, thr)
+        map_loss = lambda im, ds, gi, gd: sc.mapping_loss(im, ds, gi, gd)
+        adam_kw = {}
 
     def render_pair(params, t_idx, gaussians_grad, camera_grad):
         if args.fused:
@@ -130,9 +137,9 @@ def main():
     warm = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
     for _ in range(3):
         im, depth_sil, _ = render_pair(warm, 1, gaussians_grad=False, camera_grad=True)
-        sc.tracking_loss(im, depth_sil, gts[1][0], gts[1][1], 0.99, gather=gather).backward()
+        track_loss(im, depth_sil, gts[1][0], gts[1][1], 0.99).backward()
         im, depth_sil, _ = render_pair(warm, 1, gaussians_grad=True, camera_grad=False)
-        sc.mapping_loss(im, depth_sil, gts[1][0], gts[1][1], ssim_fn=ssim_fn, gather=gather).backward()
+        map_loss(im, depth_sil, gts[1][0], gts[1][1]).backward()
     del warm
 
     track_ms, map_ms, errs_before, errs_after = [], [], [], []
@@ -145,14 +152,14 @@ def main():
             params["cam_trans"][..., t] = params["cam_trans"][..., t - 1]
         errs_before.append(pose_error(t))
         # ---- tracking
-        opt = torch.optim.Adam([{"params": [v], "name": k, "lr": track_lrs[k]} for k, v in params.items()])
+        opt = torch.optim.Adam([{"params": [v], "name": k, "lr": track_lrs[k]} for k, v in params.items()], **adam_kw)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         sil_thres, best = 0.99, (float("inf"), None, None)
         for it in range(args.tracking_iters):
             im, depth_sil, _ = render_pair(params, t, gaussians_grad=False, camera_grad=True)
             if it == 0:
                 sil_thres = sc.best_silhouette_threshold(im, depth_sil[1], gt_im, gt_depth)
-            loss = sc.tracking_loss(im, depth_sil, gt_im, gt_depth, sil_thres, gather=gather)
+            loss = track_loss(im, depth_sil, gt_im, gt_depth, sil_thres)
             loss.backward()
             with torch.no_grad():
                 lv = loss.detach()
@@ -163,11 +170,12 @@ def main():
         torch.cuda.synchronize(); track_ms.append((time.perf_counter() - t0) * 1e3 / args.tracking_iters)
         errs_after.append(pose_error(t))
         # ---- mapping
-        opt = torch.optim.Adam([{"params": [v], "name": k, "lr": map_lrs[k]} for k, v in params.items()], lr=0.0, eps=1e-15)
+        opt = torch.optim.Adam([{"params": [v], "name": k, "lr": map_lrs[k]} for k, v in params.items()], lr=0.0, eps=1e-15,
+                               **adam_kw)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for it in range(args.mapping_iters):
             im, depth_sil, _ = render_pair(params, t, gaussians_grad=True, camera_grad=False)
-            loss = sc.mapping_loss(im, depth_sil, gt_im, gt_depth, ssim_fn=ssim_fn, gather=gather)
+            loss = map_loss(im, depth_sil, gt_im, gt_depth)
             loss.backward()
             opt.step(); opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize(); map_ms.append((time.perf_counter() - t0) * 1e3 / args.mapping_iters)

@@ -188,6 +188,16 @@ int vtgs_ssim_forward(const float* img1, const float* img2, int32_t channels, in
 int vtgs_ssim_backward(const float* img1, const float* img2, const float* grad_maps, const float* upstream,
                        int32_t channels, int32_t height, int32_t width, float* grad_img1, void* stream);
 
+/* Masked L1 terms of get_loss (src/vtgaussian_slam.py:519-608) with their gradient images, one pass over the pixels.
+ * im, gt_im [3,P]; depth_sil [3,P] = the [z,1,z^2] render; gt_depth [P].  mode 0 = tracking (mask: gt_depth > 0, finite
+ * depth and uncertainty, silhouette > sil_thres; colour and depth sums over the mask), mode 1 = mapping (depth over the
+ * mask without the silhouette test, colour over all pixels).  partial_sums[vtgs_masked_l1_partial_rows(P)][3] =
+ * {sum |gt_im - im|, sum |gt_depth - depth|, mask count} per workgroup; g_im [3,P] and g_depth_sil [3,P] receive the
+ * derivatives of the two sums (channels 1 and 2 of depth_sil only feed detached masks: zero).                          */
+uint32_t vtgs_masked_l1_partial_rows(int32_t pixels);
+int vtgs_masked_l1(const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth, int32_t pixels,
+                   float sil_thres, int32_t mode, float* partial_sums, float* g_im, float* g_depth_sil, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on (used by bench.py for
  * the roofline of the dominant kernel).  While enabled, every kernel launch of the library is bracketed by two
  * events; vtgs_profile_collect synchronises the device, sums elapsed time per kernel name since enabling and

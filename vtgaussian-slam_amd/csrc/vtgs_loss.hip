@@ -142,11 +142,61 @@ __global__ __launch_bounds__(256) void ssim_backward_kernel(const float* __restr
   }
 }
 
+// ---- masked L1 terms of get_loss (src/vtgaussian_slam.py:519-608), value and gradient images in one pass -------------
+// mode 0 (tracking): mask = gt_depth > 0 & finite depth & finite uncertainty & silhouette > sil_thres;
+//                    partial[b] = {sum_mask |gt_im - im| (3 channels), sum_mask |gt_depth - depth|, count}
+// mode 1 (mapping):  mask = gt_depth > 0 & finite depth & finite uncertainty;   colour L1 over ALL pixels (it is a mean)
+// Gradient images hold d(sum)/d(im) and d(sum)/d(depth_sil[0]) (channels 1, 2 of depth_sil only enter detached masks).
+__global__ __launch_bounds__(256) void masked_l1_kernel(const float* __restrict__ im, const float* __restrict__ ds,
+                                                        const float* __restrict__ gt_im, const float* __restrict__ gt_depth,
+                                                        int P, float sil_thres, int mode, float* __restrict__ partial,
+                                                        float* __restrict__ g_im, float* __restrict__ g_ds) {
+  __shared__ float red[4][3];
+  float s_im = 0.f, s_d = 0.f, cnt = 0.f;
+  for (int i = (int)(blockIdx.x * 256u + threadIdx.x); i < P; i += (int)(gridDim.x * 256u)) {
+    const float depth = ds[i], sil = ds[P + i], unc = ds[2 * (size_t)P + i] - depth * depth;
+    const float gd = gt_depth[i];
+    bool m = gd > 0.f && depth == depth && unc == unc;
+    if (mode == 0) m = m && sil > sil_thres;
+    const bool mc = (mode == 0) ? m : true;
+    float d = gd - depth;
+    s_d += m ? fabsf(d) : 0.f;
+    cnt += m ? 1.f : 0.f;
+    g_ds[i] = m ? (d > 0.f ? -1.f : (d < 0.f ? 1.f : 0.f)) : 0.f;
+    g_ds[P + i] = 0.f; g_ds[2 * (size_t)P + i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float e = gt_im[(size_t)c * P + i] - im[(size_t)c * P + i];
+      s_im += mc ? fabsf(e) : 0.f;
+      g_im[(size_t)c * P + i] = mc ? (e > 0.f ? -1.f : (e < 0.f ? 1.f : 0.f)) : 0.f;
+    }
+  }
+  s_im = wave_sum(s_im); s_d = wave_sum(s_d); cnt = wave_sum(cnt);
+  if (lane_id() == 0) { red[threadIdx.x >> 6][0] = s_im; red[threadIdx.x >> 6][1] = s_d; red[threadIdx.x >> 6][2] = cnt; }
+  __syncthreads();
+  if (threadIdx.x < 3) partial[blockIdx.x * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 }  // namespace vtgs
 
 using namespace vtgs;
 
 extern "C" {
+
+uint32_t vtgs_masked_l1_partial_rows(int32_t pixels) {
+  if (pixels <= 0) return 0;
+  const uint32_t b = (uint32_t)((pixels + 255) / 256);
+  return b < 1024u ? b : 1024u;
+}
+
+int vtgs_masked_l1(const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth, int32_t pixels,
+                   float sil_thres, int32_t mode, float* partial_sums, float* g_im, float* g_depth_sil, void* stream) {
+  if (!im || !depth_sil || !gt_im || !gt_depth || !partial_sums || !g_im || !g_depth_sil || pixels <= 0 || (mode != 0 && mode != 1))
+    return VTGS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(masked_l1_kernel, dim3(vtgs_masked_l1_partial_rows(pixels)), dim3(256), 0, (hipStream_t)stream, im,
+                     depth_sil, gt_im, gt_depth, pixels, sil_thres, mode, partial_sums, g_im, g_depth_sil);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
 
 uint32_t vtgs_ssim_partial_rows(int32_t channels, int32_t height, int32_t width) {
   if (channels <= 0 || height <= 0 || width <= 0) return 0;

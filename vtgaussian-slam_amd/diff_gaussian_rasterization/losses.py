@@ -1,4 +1,6 @@
-"""Loss kernels: `fused_ssim(img1, img2)` == utils/slam_external.py:66-97 `calc_ssim(img1, img2)` (mean
+"""Loss kernels: `tracking_loss` / `mapping_loss` == the Replica branches of get_loss
+(src/vtgaussian_slam.py:519-608, 678-679) with the masked L1 sums and their gradients in one pass (vtgs_masked_l1);
+`fused_ssim(img1, img2)` == utils/slam_external.py:66-97 `calc_ssim(img1, img2)` (mean
 SSIM, 11x11 Gaussian window, sigma 1.5, zero padding, per channel) as one HIP kernel each way instead of ten grouped
 convolutions.  img2 is treated as a constant (the ground-truth image at the reference's call site,
 src/vtgaussian_slam.py:608)."""
@@ -49,3 +51,49 @@ class _FusedSSIM(torch.autograd.Function):
 def fused_ssim(img1: torch.Tensor, img2: torch.Tensor) -> torch.Tensor:
     """Mean SSIM of two [C,H,W] images; differentiable with respect to img1."""
     return _FusedSSIM.apply(img1, img2)
+
+
+_lib.vtgs_masked_l1_partial_rows.restype, _lib.vtgs_masked_l1_partial_rows.argtypes = ctypes.c_uint32, [_I32]
+_lib.vtgs_masked_l1.restype = ctypes.c_int
+_lib.vtgs_masked_l1.argtypes = [_P, _P, _P, _P, _I32, ctypes.c_float, _I32, _P, _P, _P, _P]
+
+
+class _MaskedL1(torch.autograd.Function):
+    """(sum |gt_im - im|, sum |gt_depth - depth|, mask count) with the masks of get_loss; differentiable in im, depth_sil."""
+
+    @staticmethod
+    def forward(ctx, im, depth_sil, gt_im, gt_depth, sil_thres: float, mode: int):
+        if not im.is_cuda:
+            raise RuntimeError("the fused losses need tensors on a HIP device (torch 'cuda'); no CPU path exists")
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        a, d, ga, gd = f32(im), f32(depth_sil), f32(gt_im), f32(gt_depth)
+        P = a.shape[-1] * a.shape[-2]
+        rows = int(_lib.vtgs_masked_l1_partial_rows(P))
+        partial = torch.empty((rows, 3), dtype=torch.float32, device=a.device)
+        g_im, g_ds = torch.empty_like(a), torch.empty_like(d)
+        _check(_lib.vtgs_masked_l1(a.data_ptr(), d.data_ptr(), ga.data_ptr(), gd.data_ptr(), P, float(sil_thres), int(mode),
+                                   partial.data_ptr(), g_im.data_ptr(), g_ds.data_ptr(), _stream_ptr(a.device)),
+               "vtgs_masked_l1")
+        ctx.save_for_backward(g_im, g_ds)
+        s = partial.sum(0)
+        ctx.mark_non_differentiable(s[2:3])
+        return s[0], s[1], s[2]
+
+    @staticmethod
+    def backward(ctx, g_sum_im, g_sum_depth, _g_count):
+        g_im, g_ds = ctx.saved_tensors
+        return (None if g_sum_im is None else g_im * g_sum_im, None if g_sum_depth is None else g_ds * g_sum_depth,
+                None, None, None, None)
+
+
+def tracking_loss(im, depth_sil, gt_im, gt_depth, sil_thres: float, w_im: float = 0.5, w_depth: float = 0.025):
+    """Replica tracking loss: w_im * masked L1 SUM of colour + w_depth * masked L1 SUM of depth."""
+    s_im, s_d, _ = _MaskedL1.apply(im, depth_sil, gt_im, gt_depth, sil_thres, 0)
+    return w_im * s_im + w_depth * s_d
+
+
+def mapping_loss(im, depth_sil, gt_im, gt_depth, w_im: float = 1.0, w_depth: float = 1.0):
+    """Mapping loss: w_depth * masked L1 MEAN of depth + w_im * (0.8 * L1 mean + 0.2 * (1 - SSIM)) of colour."""
+    s_im, s_d, cnt = _MaskedL1.apply(im, depth_sil, gt_im, gt_depth, 0.0, 1)
+    l_im = 0.8 * s_im / float(im.numel()) + 0.2 * (1.0 - fused_ssim(im, gt_im))
+    return w_im * l_im + w_depth * s_d / cnt

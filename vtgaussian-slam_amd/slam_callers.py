@@ -136,33 +136,23 @@ def split_depth_silhouette(depth_sil: torch.Tensor):
     return depth, depth_sil[1], (depth_sil[2:3] - depth ** 2).detach()
 
 
-def _masked_sum(x, mask, gather: bool):
-    """sum of x over mask.  gather=True indexes like the reference (`x[mask].sum()`: a nonzero + gather and a host
-    sync); gather=False selects with where() -- same value up to summation order, no sync, NaNs outside the mask ignored."""
-    return x[mask].sum() if gather else torch.where(mask, x, torch.zeros_like(x)).sum()
-
-
-def tracking_loss(im, depth_sil, gt_im, gt_depth, sil_thres: float, w_im: float = 0.5, w_depth: float = 0.025,
-                  gather: bool = True):
+def tracking_loss(im, depth_sil, gt_im, gt_depth, sil_thres: float, w_im: float = 0.5, w_depth: float = 0.025):
     """Replica tracking branch of get_loss: masked L1 SUMS over pixels with valid depth, finite renders and
     silhouette > sil_thres (src/vtgaussian_slam.py:513-605, 678-679)."""
     depth, sil, unc = split_depth_silhouette(depth_sil)
     mask = (gt_depth > 0) & ~torch.isnan(depth) & ~torch.isnan(unc) & (sil > sil_thres)[None]
     mask = mask.detach()
-    l_depth = _masked_sum((gt_depth - depth).abs(), mask, gather)
-    l_im = _masked_sum((gt_im - im).abs(), mask.expand(3, -1, -1), gather)
+    l_depth = (gt_depth - depth).abs()[mask].sum()              # boolean indexing, like the reference (nonzero + gather)
+    l_im = (gt_im - im).abs()[mask.expand(3, -1, -1)].sum()
     return w_im * l_im + w_depth * l_depth
 
 
-def mapping_loss(im, depth_sil, gt_im, gt_depth, w_im: float = 1.0, w_depth: float = 1.0, ssim_fn=None,
-                 gather: bool = True):
-    """Mapping branch: masked L1 MEAN on depth, 0.8 L1 + 0.2 (1 - SSIM) on colour (src/vtgaussian_slam.py:592-608).
-    `ssim_fn` defaults to the convolution form `calc_ssim`; pass diff_gaussian_rasterization.losses.fused_ssim for the
-    HIP kernel."""
+def mapping_loss(im, depth_sil, gt_im, gt_depth, w_im: float = 1.0, w_depth: float = 1.0):
+    """Mapping branch: masked L1 MEAN on depth, 0.8 L1 + 0.2 (1 - SSIM) on colour (src/vtgaussian_slam.py:592-608)."""
     depth, _, unc = split_depth_silhouette(depth_sil)
     mask = ((gt_depth > 0) & ~torch.isnan(depth) & ~torch.isnan(unc)).detach()
-    l_depth = _masked_sum((gt_depth - depth).abs(), mask, gather) / (mask.sum() if not gather else mask.sum())
-    l_im = 0.8 * l1_loss_v1(im, gt_im) + 0.2 * (1.0 - (ssim_fn or calc_ssim)(im, gt_im))
+    l_depth = (gt_depth - depth).abs()[mask].mean()
+    l_im = 0.8 * l1_loss_v1(im, gt_im) + 0.2 * (1.0 - calc_ssim(im, gt_im))
     return w_im * l_im + w_depth * l_depth
 
 
