@@ -148,32 +148,57 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
 
   // pass 2: reserve a slot in every reached tile, lanes in lock-step so runs can share atomics.  The returning
   // atomic of step i is consumed in step i+1, so its round trip overlaps the next step's work.
-  const int max_area = wave_max_i(area);
   const unsigned long long key = ((unsigned long long)__float_as_uint(sp.depth) << 32) | (unsigned long long)(uint32_t)gid;
   uint32_t ord = 0;
   Reservation pend;
   pend.base = 0; pend.head_lane = 0; pend.rank = 0; pend.act = false; pend.tile = -1;
-  for (int i = 0, tx = 0, ty = 0; i <= max_area; ++i) {
-    Reservation cur;
-    cur.base = 0; cur.head_lane = 0; cur.rank = 0; cur.act = false; cur.tile = -1;
-    if (i < max_area) {                                      // wave-uniform
-      const bool in = i < area;
-      const int ttx = w.cx0 + tx, tty = w.cy0 + ty;
-      const bool act = in && ((i < 64) ? ((reach_mask >> i) & 1ull) != 0ull : tile_reached(cam, sp, tau, ttx, tty));
-      cur = reserve_issue(tile_cnt, act ? (tty * cam.gx8 + ttx) : -1, act);
-      if (in && ++tx == w.cw) { tx = 0; ++ty; }
-    }
-    const uint32_t slot = reserve_resolve(pend);
-    if (pend.act) {
+  auto consume = [&](const Reservation& r) {                  // all 64 lanes call it
+    const uint32_t slot = reserve_resolve(r);
+    if (r.act) {
       const unsigned long long id = (unsigned long long)inst_base + ord;
       if (id < capacity && slot < tile_cap) {                  // an overflowing bin / id is dropped and flagged later
-        const size_t pos = (size_t)pend.tile * tile_cap + slot;
+        const size_t pos = (size_t)r.tile * tile_cap + slot;
         keys[pos] = key;
         vals[pos] = (uint32_t)id;
       }
       ++ord;
     }
-    pend = cur;
+  };
+  const int max_area = wave_max_i(area);
+  if (max_area <= 64) {
+    // common case: step k handles every lane's k-th REACHED tile (k-th set bit of its mask).  Raster-ordered
+    // neighbours have near-identical masks, so runs still form, and there are ~3 steps instead of ~16.
+    const int steps = wave_max_i((int)cnt);
+    unsigned long long m = reach_mask;
+    for (int k = 0; k <= steps; ++k) {
+      Reservation cur;
+      cur.base = 0; cur.head_lane = 0; cur.rank = 0; cur.act = false; cur.tile = -1;
+      if (k < steps) {                                       // wave-uniform
+        const bool act = m != 0ull;
+        const int i = act ? __builtin_ctzll(m) : 0;
+        m &= m - 1ull;
+        const int cwd = max(w.cw, 1);
+        const int tty = w.cy0 + i / cwd, ttx = w.cx0 + (i - (i / cwd) * cwd);
+        cur = reserve_issue(tile_cnt, act ? (tty * cam.gx8 + ttx) : -1, act);
+      }
+      consume(pend);
+      pend = cur;
+    }
+  } else {
+    // a splat of this wavefront covers more than 64 candidate tiles: walk all candidates in lock-step
+    for (int i = 0, tx = 0, ty = 0; i <= max_area; ++i) {
+      Reservation cur;
+      cur.base = 0; cur.head_lane = 0; cur.rank = 0; cur.act = false; cur.tile = -1;
+      if (i < max_area) {                                    // wave-uniform
+        const bool in = i < area;
+        const int ttx = w.cx0 + tx, tty = w.cy0 + ty;
+        const bool act = in && ((i < 64) ? ((reach_mask >> i) & 1ull) != 0ull : tile_reached(cam, sp, tau, ttx, tty));
+        cur = reserve_issue(tile_cnt, act ? (tty * cam.gx8 + ttx) : -1, act);
+        if (in && ++tx == w.cw) { tx = 0; ++ty; }
+      }
+      consume(pend);
+      pend = cur;
+    }
   }
 }
 
