@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--mapping-iters", type=int, default=100)
     ap.add_argument("--shared-geometry", action="store_true", help="depth/silhouette pass reuses the RGB pass's binning (8f-2)")
     ap.add_argument("--fused", action="store_true", help="fused pose transform + render variables + both renders (8f-1), "
-                                                         "loss kernels (8f-3), torch fused Adam")
+                                                         "loss kernels, threshold sweep and one-launch Adam (8f-3)")
     args = ap.parse_args()
     assert torch.cuda.is_available(), "bench_slam.py needs an MI355X"
     dev = torch.device("cuda", 0)
@@ -75,14 +75,15 @@ def main():
 
     from diff_gaussian_rasterization.fused import render_frame
     from diff_gaussian_rasterization import losses as fl
-    if args.fused:                                    # loss kernels (8f-3) and PyTorch's single-kernel Adam
+    if args.fused:                                    # loss kernels, threshold sweep and one-launch Adam (8f-3)
+        from diff_gaussian_rasterization.optim import FusedAdam
         track_loss = lambda im, ds, gi, gd, thr: fl.tracking_loss(im, ds, gi, gd, thr)
         map_loss = lambda im, ds, gi, gd: fl.mapping_loss(im, ds, gi, gd)
-        adam_kw = {"fused": True}
+        pick_threshold, make_adam = fl.best_silhouette_threshold, FusedAdam
     else:                                             # exactly the reference's PyTorch formulation
         track_loss = lambda im, ds, gi, gd, thr: sc.tracking_loss(im, ds, gi, gd, thr)
         map_loss = lambda im, ds, gi, gd: sc.mapping_loss(im, ds, gi, gd)
-        adam_kw = {}
+        pick_threshold, make_adam = sc.best_silhouette_threshold, torch.optim.Adam
 
     def render_pair(params, t_idx, gaussians_grad, camera_grad):
         if args.fused:
@@ -152,13 +153,13 @@ def main():
             params["cam_trans"][..., t] = params["cam_trans"][..., t - 1]
         errs_before.append(pose_error(t))
         # ---- tracking
-        opt = torch.optim.Adam([{"params": [v], "name": k, "lr": track_lrs[k]} for k, v in params.items()], **adam_kw)
+        opt = make_adam([{"params": [v], "name": k, "lr": track_lrs[k]} for k, v in params.items()])
         torch.cuda.synchronize(); t0 = time.perf_counter()
         sil_thres, best = 0.99, (float("inf"), None, None)
         for it in range(args.tracking_iters):
             im, depth_sil, _ = render_pair(params, t, gaussians_grad=False, camera_grad=True)
             if it == 0:
-                sil_thres = sc.best_silhouette_threshold(im, depth_sil[1], gt_im, gt_depth)
+                sil_thres = pick_threshold(im, depth_sil[1], gt_im, gt_depth)
             loss = track_loss(im, depth_sil, gt_im, gt_depth, sil_thres)
             loss.backward()
             with torch.no_grad():
@@ -170,8 +171,7 @@ def main():
         torch.cuda.synchronize(); track_ms.append((time.perf_counter() - t0) * 1e3 / args.tracking_iters)
         errs_after.append(pose_error(t))
         # ---- mapping
-        opt = torch.optim.Adam([{"params": [v], "name": k, "lr": map_lrs[k]} for k, v in params.items()], lr=0.0, eps=1e-15,
-                               **adam_kw)
+        opt = make_adam([{"params": [v], "name": k, "lr": map_lrs[k]} for k, v in params.items()], lr=0.0, eps=1e-15)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for it in range(args.mapping_iters):
             im, depth_sil, _ = render_pair(params, t, gaussians_grad=True, camera_grad=False)

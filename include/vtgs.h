@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VTGS_ABI_VERSION 3
+#define VTGS_ABI_VERSION 4
 
 typedef enum VtgsStatus {
   VTGS_OK = 0,
@@ -197,6 +197,31 @@ int vtgs_ssim_backward(const float* img1, const float* img2, const float* grad_m
 uint32_t vtgs_masked_l1_partial_rows(int32_t pixels);
 int vtgs_masked_l1(const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth, int32_t pixels,
                    float sil_thres, int32_t mode, float* partial_sums, float* g_im, float* g_depth_sil, void* stream);
+
+/* Silhouette-threshold sweep of tracking iteration 0 (src/vtgaussian_slam.py:472-510): for each of n_thresholds <= 8
+ * candidates c_k, over the pixels with silhouette > c_k and gt_depth > 0:  partial_sums[row][2k] = sum over the three
+ * channels of (gt_im - im)^2, partial_sums[row][2k+1] = pixel count; rows = vtgs_masked_l1_partial_rows(P), row stride
+ * 2*n_thresholds.  The masked MSE of candidate k is sum_k / (3 * count_k); the caller takes the arg-min like the
+ * reference.  thresholds is a HOST array (copied into the launch).                                                    */
+int vtgs_silhouette_sweep(const float* im, const float* silhouette, const float* gt_im, const float* gt_depth,
+                          int32_t pixels, const float* thresholds, int32_t n_thresholds, float* partial_sums, void* stream);
+
+/* ---- Adam over the parameter groups ------------------------------------------------------------------
+ * Replaces torch.optim.Adam as the reference configures it (src/vtgaussian_slam.py:180-187: one group per tensor with its
+ * own lr, betas (0.9, 0.999), eps 1e-8 tracking / 1e-15 mapping, no weight decay, no amsgrad) by ONE launch over up to
+ * VTGS_ADAM_MAX_GROUPS tensors:  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+ * p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps).   groups is a HOST array of device pointers.    */
+#define VTGS_ADAM_MAX_GROUPS 8
+typedef struct VtgsAdamGroup {
+  float* param;         /* [count] updated in place */
+  const float* grad;    /* [count] */
+  float* exp_avg;       /* [count] first moment, updated in place */
+  float* exp_avg_sq;    /* [count] second moment, updated in place */
+  uint64_t count;
+  float lr;
+  float eps;
+} VtgsAdamGroup;
+int vtgs_adam_step(const VtgsAdamGroup* groups, int32_t n_groups, int32_t step, float beta1, float beta2, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on (used by bench.py for
  * the roofline of the dominant kernel).  While enabled, every kernel launch of the library is bracketed by two

@@ -67,3 +67,58 @@ def test_fused_slam_losses_match_the_restatement(gpu_device, mode):
     assert abs(out.item() - ref.item()) <= 2e-5 * abs(ref.item())
     assert (im.grad - r_im).abs().max().item() <= 1e-3 * r_im.abs().max().item() + 1e-9
     assert (torch.nan_to_num(ds.grad) - r_ds).abs().max().item() <= 1e-5 * r_ds.abs().max().item() + 1e-9
+
+
+def test_silhouette_sweep_matches_the_restatement(gpu_device):
+    """vtgs_silhouette_sweep vs the five masked gathers of src/vtgaussian_slam.py:476-496 (restated in slam_callers)."""
+    from diff_gaussian_rasterization import losses
+    dev = gpu_device
+    cands = (0.990, 0.993, 0.995, 0.997, 0.999)
+    for seed, (H, W) in enumerate([(97, 131), (680, 1200)]):
+        g = torch.Generator().manual_seed(seed)
+        im, gt = torch.rand(3, H, W, generator=g).to(dev), torch.rand(3, H, W, generator=g).to(dev)
+        sil = (0.985 + 0.015 * torch.rand(H, W, generator=g)).to(dev)
+        # make the error grow with the silhouette deficit so the arg-min is decided by the data, not by noise
+        im = gt + (im - gt) * ((1.0 - sil) * 60.0)[None]
+        gd = (torch.rand(1, H, W, generator=g) > 0.1).float().to(dev) * 2.0
+        sums = losses.silhouette_sweep(im, sil, gt, gd, cands).cpu()
+        for k, c in enumerate(cands):
+            m = (sil > c) & (gd[0] > 0)
+            ref_sum = ((gt - im).double() ** 2)[m[None].expand(3, -1, -1)].sum().item()
+            assert int(sums[k, 1]) == int(m.sum().item())
+            assert abs(sums[k, 0].item() - ref_sum) <= 1e-5 * ref_sum
+        assert losses.best_silhouette_threshold(im, sil, gt, gd, cands) == sc.best_silhouette_threshold(im, sil, gt, gd, cands)
+    # empty mask everywhere: first candidate, like the restatement
+    assert losses.best_silhouette_threshold(im, sil * 0, gt, gd, cands) == cands[0]
+
+
+@pytest.mark.parametrize("eps", [1e-8, 1e-15])
+def test_fused_adam_matches_torch_adam(gpu_device, eps):
+    """vtgs_adam_step vs torch.optim.Adam as initialize_optimizer configures it (per-tensor groups and lrs, one with
+    lr 0, one parameter that only starts receiving gradients later)."""
+    from diff_gaussian_rasterization.optim import FusedAdam
+    dev = gpu_device
+    g = torch.Generator().manual_seed(3)
+    shapes = {"means3D": (1000, 3), "rgb_colors": (1000, 3), "unnorm_rotations": (1000, 4), "logit_opacities": (1000, 1),
+              "log_scales": (1000, 1), "cam_unnorm_rots": (1, 4, 7), "cam_trans": (1, 3, 7)}
+    lrs = {"means3D": 1e-4, "rgb_colors": 2.5e-3, "unnorm_rotations": 1e-3, "logit_opacities": 5e-2, "log_scales": 1e-3,
+           "cam_unnorm_rots": 0.0, "cam_trans": 2e-3}
+    init = {k: torch.randn(*s, generator=g) for k, s in shapes.items()}
+    pa = {k: v.clone().to(dev).requires_grad_(True) for k, v in init.items()}
+    pb = {k: v.clone().to(dev).requires_grad_(True) for k, v in init.items()}
+    groups = lambda p: [{"params": [v], "name": k, "lr": lrs[k]} for k, v in p.items()]
+    ref = torch.optim.Adam(groups(pa), lr=0.0, eps=eps)
+    ours = FusedAdam(groups(pb), lr=0.0, eps=eps)
+    for it in range(40):
+        for k in shapes:
+            if k == "rgb_colors" and it < 5:
+                continue                                             # no gradient yet: both optimizers skip it
+            gr = (torch.randn(*shapes[k], generator=g) * (10.0 ** ((it % 7) - 4))).to(dev)
+            pa[k].grad, pb[k].grad = gr.clone(), gr.clone()
+        ref.step(); ours.step()
+        ref.zero_grad(set_to_none=True); ours.zero_grad(set_to_none=True)
+    for k in shapes:
+        a, b = pa[k].detach(), pb[k].detach()
+        moved = (a - init[k].to(dev)).abs().max().item()
+        assert (a - b).abs().max().item() <= 1e-5 * max(moved, 1e-12) + 1e-7, k
+    assert torch.equal(pb["cam_unnorm_rots"].detach().cpu(), init["cam_unnorm_rots"])      # lr 0 leaves it untouched

@@ -177,6 +177,61 @@ __global__ __launch_bounds__(256) void masked_l1_kernel(const float* __restrict_
   if (threadIdx.x < 3) partial[blockIdx.x * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+
+// ---- silhouette-threshold sweep (src/vtgaussian_slam.py:472-510): masked squared colour error per candidate ----------
+struct SweepThresholds { float c[8]; int n; };
+
+__global__ __launch_bounds__(256) void silhouette_sweep_kernel(const float* __restrict__ im, const float* __restrict__ sil,
+                                                               const float* __restrict__ gt_im, const float* __restrict__ gt_depth,
+                                                               int P, SweepThresholds th, float* __restrict__ partial) {
+  __shared__ float red[4][16];
+  float sum[8], cnt[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sum[k] = 0.f; cnt[k] = 0.f; }
+  for (int i = (int)(blockIdx.x * 256u + threadIdx.x); i < P; i += (int)(gridDim.x * 256u)) {
+    const float e0 = gt_im[i] - im[i], e1 = gt_im[(size_t)P + i] - im[(size_t)P + i],
+                e2 = gt_im[2 * (size_t)P + i] - im[2 * (size_t)P + i];
+    const float sq = e0 * e0 + e1 * e1 + e2 * e2;
+    const float s = sil[i];
+    const bool valid = gt_depth[i] > 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool m = valid && k < th.n && s > th.c[k];
+      sum[k] += m ? sq : 0.f;
+      cnt[k] += m ? 1.f : 0.f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float a = wave_sum(sum[k]), b = wave_sum(cnt[k]);
+    if (lane_id() == 0) { red[threadIdx.x >> 6][2 * k] = a; red[threadIdx.x >> 6][2 * k + 1] = b; }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * th.n)
+    partial[(size_t)blockIdx.x * 2 * th.n + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// ---- Adam over up to 8 tensors in one launch (src/vtgaussian_slam.py:180-187) ----------------------------------------------
+struct AdamLaunch {
+  VtgsAdamGroup g[VTGS_ADAM_MAX_GROUPS];
+  float step_size_scale;   // 1 / (1 - b1^step)
+  float sqrt_bias2;        // sqrt(1 - b2^step)
+  float beta1, beta2;
+};
+
+__global__ __launch_bounds__(256) void adam_step_kernel(AdamLaunch a) {
+  const VtgsAdamGroup& g = a.g[blockIdx.y];
+  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= g.count) return;
+  const float gr = g.grad[i];
+  const float m = g.exp_avg[i] + (1.f - a.beta1) * (gr - g.exp_avg[i]);            // lerp, like torch
+  const float v = a.beta2 * g.exp_avg_sq[i] + (1.f - a.beta2) * gr * gr;
+  g.exp_avg[i] = m;
+  g.exp_avg_sq[i] = v;
+  const float denom = sqrtf(v) / a.sqrt_bias2 + g.eps;
+  g.param[i] -= (g.lr * a.step_size_scale) * (m / denom);
+}
+
 }  // namespace vtgs
 
 using namespace vtgs;
@@ -195,6 +250,45 @@ int vtgs_masked_l1(const float* im, const float* depth_sil, const float* gt_im, 
     return VTGS_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(masked_l1_kernel, dim3(vtgs_masked_l1_partial_rows(pixels)), dim3(256), 0, (hipStream_t)stream, im,
                      depth_sil, gt_im, gt_depth, pixels, sil_thres, mode, partial_sums, g_im, g_depth_sil);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+int vtgs_silhouette_sweep(const float* im, const float* silhouette, const float* gt_im, const float* gt_depth,
+                          int32_t pixels, const float* thresholds, int32_t n_thresholds, float* partial_sums, void* stream) {
+  if (!im || !silhouette || !gt_im || !gt_depth || !thresholds || !partial_sums || pixels <= 0 || n_thresholds <= 0 ||
+      n_thresholds > 8)
+    return VTGS_ERR_INVALID_ARGUMENT;
+  SweepThresholds th;
+  th.n = n_thresholds;
+  for (int k = 0; k < 8; ++k) th.c[k] = k < n_thresholds ? thresholds[k] : 0.f;
+  hipLaunchKernelGGL(silhouette_sweep_kernel, dim3(vtgs_masked_l1_partial_rows(pixels)), dim3(256), 0, (hipStream_t)stream,
+                     im, silhouette, gt_im, gt_depth, pixels, th, partial_sums);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+int vtgs_adam_step(const VtgsAdamGroup* groups, int32_t n_groups, int32_t step, float beta1, float beta2, void* stream) {
+  if (!groups || n_groups <= 0 || n_groups > VTGS_ADAM_MAX_GROUPS || step <= 0 || !(beta1 >= 0.f && beta1 < 1.f) ||
+      !(beta2 >= 0.f && beta2 < 1.f))
+    return VTGS_ERR_INVALID_ARGUMENT;
+  AdamLaunch a;
+  uint64_t longest = 0;
+  for (int k = 0; k < VTGS_ADAM_MAX_GROUPS; ++k) {
+    if (k < n_groups) {
+      a.g[k] = groups[k];
+      if (a.g[k].count && (!a.g[k].param || !a.g[k].grad || !a.g[k].exp_avg || !a.g[k].exp_avg_sq)) return VTGS_ERR_INVALID_ARGUMENT;
+      longest = a.g[k].count > longest ? a.g[k].count : longest;
+    } else {
+      a.g[k] = VtgsAdamGroup{nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0.f};
+    }
+  }
+  if (longest == 0) return VTGS_OK;
+  if (longest > (uint64_t)0x7fffffff * 256u) return VTGS_ERR_INVALID_ARGUMENT;
+  a.step_size_scale = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));   // lr / bias_correction1
+  a.sqrt_bias2 = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  a.beta1 = beta1;
+  a.beta2 = beta2;
+  hipLaunchKernelGGL(adam_step_kernel, dim3((uint32_t)((longest + 255) / 256), (uint32_t)n_groups), dim3(256), 0,
+                     (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
 }
 

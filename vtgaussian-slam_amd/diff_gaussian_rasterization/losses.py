@@ -97,3 +97,39 @@ def mapping_loss(im, depth_sil, gt_im, gt_depth, w_im: float = 1.0, w_depth: flo
     s_im, s_d, cnt = _MaskedL1.apply(im, depth_sil, gt_im, gt_depth, 0.0, 1)
     l_im = 0.8 * s_im / float(im.numel()) + 0.2 * (1.0 - fused_ssim(im, gt_im))
     return w_im * l_im + w_depth * s_d / cnt
+
+
+_lib.vtgs_silhouette_sweep.restype = ctypes.c_int
+_lib.vtgs_silhouette_sweep.argtypes = [_P, _P, _P, _P, _I32, ctypes.POINTER(ctypes.c_float), _I32, _P, _P]
+
+
+def silhouette_sweep(im, silhouette, gt_im, gt_depth, candidates):
+    """Per candidate c: (sum over channels of (gt_im - im)^2, pixel count) over silhouette > c & gt_depth > 0, as a
+    [K,2] float64 tensor on the device (one kernel; src/vtgaussian_slam.py:476-496)."""
+    if not im.is_cuda:
+        raise RuntimeError("the fused losses need tensors on a HIP device (torch 'cuda'); no CPU path exists")
+    f32 = lambda t: t.detach().to(torch.float32).contiguous()
+    a, s, ga, gd = f32(im), f32(silhouette), f32(gt_im), f32(gt_depth)
+    K = len(candidates)
+    if not 1 <= K <= 8:
+        raise ValueError("1..8 candidate thresholds")
+    P = a.shape[-1] * a.shape[-2]
+    rows = int(_lib.vtgs_masked_l1_partial_rows(P))
+    partial = torch.empty((rows, K, 2), dtype=torch.float32, device=a.device)
+    th = (ctypes.c_float * K)(*[float(c) for c in candidates])
+    _check(_lib.vtgs_silhouette_sweep(a.data_ptr(), s.data_ptr(), ga.data_ptr(), gd.data_ptr(), P, th, K, partial.data_ptr(),
+                                      _stream_ptr(a.device)), "vtgs_silhouette_sweep")
+    return partial.sum(0, dtype=torch.float64)
+
+
+def best_silhouette_threshold(im, silhouette, gt_im, gt_depth, candidates=(0.990, 0.993, 0.995, 0.997, 0.999)) -> float:
+    """Tracking iteration 0 of the Replica branch: the candidate with the smallest masked colour MSE, first one on ties
+    (src/vtgaussian_slam.py:472-510) -- one kernel and one host read instead of five masked gathers and five .item()."""
+    sums = silhouette_sweep(im, silhouette, gt_im, gt_depth, candidates).cpu()
+    best, best_mse = candidates[0], float("inf")
+    for k, c in enumerate(candidates):
+        cnt = float(sums[k, 1])
+        mse = float(sums[k, 0]) / (3.0 * cnt) if cnt > 0 else float("inf")      # an empty mask gives NaN in the reference
+        if mse < best_mse:
+            best, best_mse = c, mse
+    return best
