@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VTGS_ABI_VERSION 4
+#define VTGS_ABI_VERSION 5
 
 typedef enum VtgsStatus {
   VTGS_OK = 0,
@@ -142,6 +142,26 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n,
                   float* g_means3D, float* g_means2D, float* g_colors, float* g_opacities,
                   float* g_scales, float* g_rotations, void* stream);
 
+/* ---- Dual render ("6 channels") -------------------------------------------------------------------
+ * The two back-to-back renders of get_loss (src/vtgaussian_slam.py:461 RGB, :466 [z,1,z^2]) as ONE composite pass:
+ * same cam / means3D / opacities / scales / rotations, two colour sets.  Every exponent, alpha and transmittance is
+ * computed once; out_color_a / out_color_b are bit-identical to vtgs_forward + vtgs_forward_shared.  No depth image
+ * (the reference discards it at both call sites).  vtgs_backward_dual differentiates both images at once:
+ * grad_color_a/b in, ONE set of geometry gradients (= the sum over the two renders, as autograd would accumulate
+ * it) plus g_colors_a / g_colors_b out.  Scratch: vtgs_backward_dual_scratch_bytes (64-byte records).            */
+size_t vtgs_backward_dual_scratch_bytes(int32_t n, uint64_t instances);
+int vtgs_forward_dual(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors_a, const float* colors_b,
+                      const float* opacities, const float* scales, const float* rotations, float* out_color_a,
+                      float* out_color_b, int32_t* out_radii, void* workspace, size_t workspace_bytes,
+                      uint64_t instance_capacity, uint32_t tile_capacity, VtgsForwardInfo* info, uint32_t flags,
+                      void* stream);
+int vtgs_backward_dual(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors_a, const float* colors_b,
+                       const float* opacities, const float* scales, const float* rotations, const float* out_color_a,
+                       const float* out_color_b, const float* grad_color_a, const float* grad_color_b,
+                       const void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
+                       void* scratch, size_t scratch_bytes, float* g_means3D, float* g_means2D, float* g_colors_a,
+                       float* g_colors_b, float* g_opacities, float* g_scales, float* g_rotations, void* stream);
+
 /* Replaces `_C.mark_visible` (GaussianRasterizer.markVisible; unused by the reference driver).
  * out_visible[N] bytes: 1 when the point passes the near-plane test of the forward.                 */
 int vtgs_mark_visible(const VtgsCamera* cam, int32_t n, const float* means3D,
@@ -159,7 +179,8 @@ int vtgs_mark_visible(const VtgsCamera* cam, int32_t n, const float* means3D,
  * means3D / unnorm_rotations, (flags bit 2) those of logit_opacities / log_scales -- the reference's gaussians_grad=False
  * detaches only the former pair -- and (flags bit 1) per-workgroup partial sums of
  * [dL/dt (3) | dL/dR (9, row-major)] into pose_partials[vtgs_pose_partial_rows(n)][12]; the caller sums the rows and
- * takes the 12 -> 7 step through the quaternion.  No atomics: results are bitwise reproducible.                     */
+ * takes the 12 -> 7 step through the quaternion.  No atomics: results are bitwise reproducible.  The four *_b inputs
+ * may all be NULL (after vtgs_backward_dual the *_a set already holds the sum over both renders).                       */
 uint32_t vtgs_pose_partial_rows(int32_t n);
 /* Sums the partial rows and takes the 12 -> 7 step through the normalised quaternion: g_cam_q[4], g_cam_t[3] (device). */
 int vtgs_pose_gradient(const float* pose_partials, uint32_t rows, const float* cam_q, float* g_cam_q, float* g_cam_t,

@@ -85,3 +85,40 @@ def test_fused_render_frame_equals_unfused_chain(gpu_device, gaussians_grad, cam
             assert err <= 1e-4 * ref["log_scales"].abs().max().item() if ref["log_scales"] is not None else True
             continue
         assert err <= 2e-3 * scale + 1e-7, (k, err, scale)
+
+
+@pytest.mark.parametrize("shape,n,opacity_boost", [((160, 120), 12000, 0.0), ((333, 201), 60000, 0.0), ((96, 64), 40000, 6.0)])
+def test_dual_composite_equals_two_renders(gpu_device, monkeypatch, shape, n, opacity_boost):
+    """vtgs_forward_dual / vtgs_backward_dual (one six-channel pass) against vtgs_forward + vtgs_forward_shared + two
+    vtgs_backward (VTGS_DUAL=0): images bit-identical, gradients equal up to float32 summation order.  The third case
+    saturates most pixels (stop rule, wave-uniform slow path); a non-zero background exercises the bg terms."""
+    from diff_gaussian_rasterization.fused import render_frame
+    dev = gpu_device
+    W, H = shape
+    params, cam = _params(dev, n, W, H, seed=9)
+    if opacity_boost:
+        with torch.no_grad():
+            params["logit_opacities"] += opacity_boost
+    st = to_settings(cam, dev, bg=torch.tensor([0.3, 0.1, 0.7]))
+    w2c = torch.eye(4, device=dev)
+    w2c[:3, 3] = torch.tensor([0.02, -0.01, 0.03], device=dev)
+    g = torch.Generator().manual_seed(4)
+    g1 = (torch.rand(3, H, W, generator=g) * 2 - 1).to(dev)
+    g2 = (torch.rand(3, H, W, generator=g) * 2 - 1).to(dev)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VTGS_DUAL", mode)
+        for v in params.values():
+            v.grad = None
+        im, ds, radii = render_frame(params, 1, st, w2c, True, True)
+        ((im * g1).sum() + (ds * g2).sum()).backward()
+        res[mode] = (im.detach().clone(), ds.detach().clone(), radii.clone(), {k: v.grad.clone() for k, v in params.items()})
+    assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1]) and torch.equal(res["0"][2], res["1"][2])
+    if opacity_boost:                                     # the saturating case must really stop pixels early (T < 1e-4)
+        assert float((res["1"][1][1] > 0.9999).float().mean()) > 0.1
+    for k in params:
+        a, b = res["0"][3][k], res["1"][3][k]
+        scale = a.abs().max().item()
+        if k == "unnorm_rotations":                       # isotropic: float noise around zero in both routes
+            continue
+        assert (a - b).abs().max().item() <= 2e-4 * scale + 1e-7, (k, (a - b).abs().max().item(), scale)

@@ -17,19 +17,21 @@ __global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint
                            const Counters*);
 __global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                   const GeomRec*, const float*, float*, float*, float*, const Counters*);
-template <int WAVES>
+template <int WAVES, bool DUAL>
 __global__ void composite_forward_mx(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
-                                     const GeomRec*, const float*, float*, float*, float*, const Counters*);
+                                     const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*,
+                                     float*);
 __global__ void composite_backward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                    const uint32_t*, const GeomRec*, const float*, const float*, const float*,
                                    const float*, float*, const Counters*);
-template <int WAVES>
+template <int WAVES, bool DUAL>
 __global__ void composite_backward_mx(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                       const uint32_t*, const GeomRec*, const float*, const float*, const float*,
-                                      const float*, float*, const Counters*);
+                                      const float*, float*, const Counters*, const float*, const float*, const float*);
+template <bool DUAL>
 __global__ void gather_splat_grads(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
                                    const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*,
-                                   float*, const Counters*);
+                                   float*, const Counters*, float*);
 __global__ void mark_visible_kernel(const float*, int, const float*, uint8_t*);
 }  // namespace vtgs
 
@@ -124,25 +126,37 @@ size_t vtgs_backward_scratch_bytes(int32_t n, uint64_t instances) {
   return align256((size_t)(instances ? instances : 1) * kGradRec * sizeof(float));
 }
 
+size_t vtgs_backward_dual_scratch_bytes(int32_t n, uint64_t instances) {
+  (void)n;
+  return align256((size_t)(instances ? instances : 1) * kGradRecDual * sizeof(float));
+}
+
 #include <stdlib.h>
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }
 
+// colors_b / out_color_b != NULL: dual render (two colour sets over the same geometry, no depth image)
 static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs, int rows16, const WsLayout& L,
                                     char* ws, const float* colors, float* out_color, float* out_depth,
-                                    float* image_state, hipStream_t st) {
+                                    float* image_state, hipStream_t st, const float* colors_b = nullptr,
+                                    float* out_color_b = nullptr) {
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   const uint32_t nblk = (uint32_t)(gx16 * rows16);
   const int impl = env_int("VTGS_FWD_IMPL", 1);            // 1 = matrix-core kernel, 0 = scalar kernel (read per call)
   {
-    ProfScope ps__("composite_forward", st);
-    if (impl == 1)
-      hipLaunchKernelGGL((composite_forward_mx<4>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
+    ProfScope ps__(colors_b ? "composite_forward_dual" : "composite_forward", st);
+    if (colors_b)
+      hipLaunchKernelGGL((composite_forward_mx<4, true>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
+                         (const GeomRec*)(ws + L.geom), colors, out_color, (float*)nullptr, image_state,
+                         (const Counters*)(ws + L.counters), colors_b, out_color_b);
+    else if (impl == 1)
+      hipLaunchKernelGGL((composite_forward_mx<4, false>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
-                         (const Counters*)(ws + L.counters));
+                         (const Counters*)(ws + L.counters), (const float*)nullptr, (float*)nullptr);
     else
       hipLaunchKernelGGL(composite_forward, dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
@@ -153,14 +167,16 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
   return VTGS_OK;
 }
 
-int vtgs_forward(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* opacities,
-                 const float* scales, const float* rotations, float* out_color, float* out_depth, int32_t* out_radii,
-                 void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
-                 VtgsForwardInfo* info, uint32_t flags, void* stream) {
-  if (!cam_ok(cam) || n < 0 || !out_color || !out_depth || !workspace || instance_capacity == 0 ||
+static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* colors_b,
+                        const float* opacities, const float* scales, const float* rotations, float* out_color,
+                        float* out_depth, float* out_color_b, int32_t* out_radii, void* workspace, size_t workspace_bytes,
+                        uint64_t instance_capacity, uint32_t tile_capacity, VtgsForwardInfo* info, uint32_t flags,
+                        void* stream, bool dual) {
+  if (!cam_ok(cam) || n < 0 || !out_color || (dual ? !out_color_b : !out_depth) || !workspace || instance_capacity == 0 ||
       instance_capacity > 0xFFFFFFFFull || tile_capacity == 0)
     return VTGS_ERR_INVALID_ARGUMENT;
-  if (n > 0 && (!means3D || !colors || !opacities || !scales || !rotations || !out_radii)) return VTGS_ERR_INVALID_ARGUMENT;
+  if (n > 0 && (!means3D || !colors || (dual && !colors_b) || !opacities || !scales || !rotations || !out_radii))
+    return VTGS_ERR_INVALID_ARGUMENT;
   int r8b, r8e, rows16, row16_0;
   if (!band_of(cam, &r8b, &r8e, &rows16, &row16_0)) return VTGS_ERR_INVALID_ARGUMENT;
   const WsLayout L = make_layout(n, cam->image_width, cam->image_height, instance_capacity, tile_capacity);
@@ -177,7 +193,8 @@ int vtgs_forward(const VtgsCamera* cam, int32_t n, const float* means3D, const f
     // its own rows when it assembles the bands
     const size_t P = (size_t)cam->image_width * cam->image_height;
     VTGS_HIP(hipMemsetAsync(out_color, 0, 3 * P * sizeof(float), st));
-    VTGS_HIP(hipMemsetAsync(out_depth, 0, P * sizeof(float), st));
+    if (dual) VTGS_HIP(hipMemsetAsync(out_color_b, 0, 3 * P * sizeof(float), st));
+    else VTGS_HIP(hipMemsetAsync(out_depth, 0, P * sizeof(float), st));
   }
   if (n > 0) {
     { ProfScope ps__("project_and_bin", st); hipLaunchKernelGGL(project_and_bin, dim3((n + 1023) / 1024), dim3(1024), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
@@ -197,7 +214,8 @@ int vtgs_forward(const VtgsCamera* cam, int32_t n, const float* means3D, const f
                      (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
                      (uint32_t*)(ws + L.sorted_inst), L.tiles8, L.tile_cap, (const Counters*)ctr); }
   VTGS_HIP(hipGetLastError());
-  int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st);
+  int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st,
+                                    dual ? colors_b : nullptr, dual ? out_color_b : nullptr);
   if (rc != VTGS_OK) return rc;
   // result record: assembled on the device by finalize_forward at byte 64 of the counters block
   static_assert(sizeof(VtgsForwardInfo) == 40, "VtgsForwardInfo layout is mirrored in Counters");
@@ -212,6 +230,23 @@ int vtgs_forward(const VtgsCamera* cam, int32_t n, const float* means3D, const f
   VTGS_HIP(hipStreamSynchronize(st));
   if (info) *info = host;
   return host.overflow ? VTGS_ERR_INSTANCE_OVERFLOW : VTGS_OK;
+}
+
+int vtgs_forward(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* opacities,
+                 const float* scales, const float* rotations, float* out_color, float* out_depth, int32_t* out_radii,
+                 void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
+                 VtgsForwardInfo* info, uint32_t flags, void* stream) {
+  return forward_impl(cam, n, means3D, colors, nullptr, opacities, scales, rotations, out_color, out_depth, nullptr,
+                      out_radii, workspace, workspace_bytes, instance_capacity, tile_capacity, info, flags, stream, false);
+}
+
+int vtgs_forward_dual(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors_a, const float* colors_b,
+                      const float* opacities, const float* scales, const float* rotations, float* out_color_a,
+                      float* out_color_b, int32_t* out_radii, void* workspace, size_t workspace_bytes,
+                      uint64_t instance_capacity, uint32_t tile_capacity, VtgsForwardInfo* info, uint32_t flags,
+                      void* stream) {
+  return forward_impl(cam, n, means3D, colors_a, colors_b, opacities, scales, rotations, out_color_a, nullptr, out_color_b,
+                      out_radii, workspace, workspace_bytes, instance_capacity, tile_capacity, info, flags, stream, true);
 }
 
 int vtgs_forward_shared(const VtgsCamera* cam, int32_t n, const float* colors, float* out_color, float* out_depth,
@@ -234,37 +269,46 @@ int vtgs_forward_shared(const VtgsCamera* cam, int32_t n, const float* colors, f
   return launch_composite_forward(cam, cs, rows16, L, (char*)workspace, colors, out_color, out_depth, image_state, st);
 }
 
-int vtgs_backward(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* opacities,
-                  const float* scales, const float* rotations, const float* out_color, const float* grad_color,
-                  const void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
-                  const float* image_state, void* scratch, size_t scratch_bytes, float* g_means3D, float* g_means2D,
-                  float* g_colors, float* g_opacities, float* g_scales, float* g_rotations, void* stream) {
+static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* colors_b,
+                         const float* opacities, const float* scales, const float* rotations, const float* out_color,
+                         const float* out_color_b, const float* grad_color, const float* grad_color_b,
+                         const void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
+                         const float* image_state, void* scratch, size_t scratch_bytes, float* g_means3D, float* g_means2D,
+                         float* g_colors, float* g_colors_b, float* g_opacities, float* g_scales, float* g_rotations,
+                         void* stream, bool dual) {
   if (!cam_ok(cam) || n < 0 || !out_color || !grad_color || !workspace || !scratch || instance_capacity == 0 ||
-      instance_capacity > 0xFFFFFFFFull || tile_capacity == 0)
+      instance_capacity > 0xFFFFFFFFull || tile_capacity == 0 || (dual && (!out_color_b || !grad_color_b)))
     return VTGS_ERR_INVALID_ARGUMENT;
   if (n > 0 && (!means3D || !colors || !opacities || !scales || !rotations || !g_means3D || !g_means2D || !g_colors ||
-                !g_opacities || !g_scales || !g_rotations))
+                !g_opacities || !g_scales || !g_rotations || (dual && (!colors_b || !g_colors_b))))
     return VTGS_ERR_INVALID_ARGUMENT;
   int r8b, r8e, rows16, row16_0;
   if (!band_of(cam, &r8b, &r8e, &rows16, &row16_0)) return VTGS_ERR_INVALID_ARGUMENT;
   if (n == 0) return VTGS_OK;
   const WsLayout L = make_layout(n, cam->image_width, cam->image_height, instance_capacity, tile_capacity);
   if (workspace_bytes < L.total) return VTGS_ERR_WORKSPACE_TOO_SMALL;
-  if (scratch_bytes < kGradRec * sizeof(float)) return VTGS_ERR_INVALID_ARGUMENT;
+  if (scratch_bytes < (dual ? kGradRecDual : kGradRec) * sizeof(float)) return VTGS_ERR_INVALID_ARGUMENT;
   hipStream_t st = (hipStream_t)stream;
   const char* ws = (const char*)workspace;
   const CamScalars cs = scalars_of(cam, r8b, r8e);
   const float* state = image_state ? image_state : (const float*)(ws + L.final_T);
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   const uint32_t nblk16 = (uint32_t)(gx16 * rows16);
-  const int bwd_impl = env_int("VTGS_BWD_IMPL", 1);          // 1 = matrix-core kernel, 0 = scalar kernel (read per call)
+  const int bwd_impl = dual ? 1 : env_int("VTGS_BWD_IMPL", 1);   // 1 = matrix-core kernel, 0 = scalar kernel (read per call)
   {
-    ProfScope ps__("composite_backward", st);
-    if (bwd_impl == 1)
-      hipLaunchKernelGGL((composite_backward_mx<4>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
+    ProfScope ps__(dual ? "composite_backward_dual" : "composite_backward", st);
+    if (dual)
+      hipLaunchKernelGGL((composite_backward_mx<4, true>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
-                         grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters));
+                         grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), colors_b, out_color_b,
+                         grad_color_b);
+    else if (bwd_impl == 1)
+      hipLaunchKernelGGL((composite_backward_mx<4, false>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
+                         (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
+                         grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), (const float*)nullptr,
+                         (const float*)nullptr, (const float*)nullptr);
     else
       hipLaunchKernelGGL(composite_backward, dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
@@ -272,12 +316,43 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n, const float* means3D, const 
                          grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters));
   }
   VTGS_HIP(hipGetLastError());
-  { ProfScope ps__("gather_splat_grads", st); hipLaunchKernelGGL(gather_splat_grads, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
-                     means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, bwd_impl == 1 ? 1 : 0,
-                     g_means3D, g_means2D, g_colors, g_opacities, g_scales, g_rotations,
-                     (const Counters*)(ws + L.counters)); }
+  {
+    ProfScope ps__(dual ? "gather_splat_grads_dual" : "gather_splat_grads", st);
+    if (dual)
+      hipLaunchKernelGGL(gather_splat_grads<true>, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+                         means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, 1,
+                         g_means3D, g_means2D, g_colors, g_opacities, g_scales, g_rotations,
+                         (const Counters*)(ws + L.counters), g_colors_b);
+    else
+      hipLaunchKernelGGL(gather_splat_grads<false>, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+                         means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, bwd_impl == 1 ? 1 : 0,
+                         g_means3D, g_means2D, g_colors, g_opacities, g_scales, g_rotations,
+                         (const Counters*)(ws + L.counters), (float*)nullptr);
+  }
   VTGS_HIP(hipGetLastError());
   return VTGS_OK;
+}
+
+int vtgs_backward(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* opacities,
+                  const float* scales, const float* rotations, const float* out_color, const float* grad_color,
+                  const void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
+                  const float* image_state, void* scratch, size_t scratch_bytes, float* g_means3D, float* g_means2D,
+                  float* g_colors, float* g_opacities, float* g_scales, float* g_rotations, void* stream) {
+  return backward_impl(cam, n, means3D, colors, nullptr, opacities, scales, rotations, out_color, nullptr, grad_color, nullptr,
+                       workspace, workspace_bytes, instance_capacity, tile_capacity, image_state, scratch, scratch_bytes,
+                       g_means3D, g_means2D, g_colors, nullptr, g_opacities, g_scales, g_rotations, stream, false);
+}
+
+int vtgs_backward_dual(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors_a, const float* colors_b,
+                       const float* opacities, const float* scales, const float* rotations, const float* out_color_a,
+                       const float* out_color_b, const float* grad_color_a, const float* grad_color_b,
+                       const void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
+                       void* scratch, size_t scratch_bytes, float* g_means3D, float* g_means2D, float* g_colors_a,
+                       float* g_colors_b, float* g_opacities, float* g_scales, float* g_rotations, void* stream) {
+  return backward_impl(cam, n, means3D, colors_a, colors_b, opacities, scales, rotations, out_color_a, out_color_b,
+                       grad_color_a, grad_color_b, workspace, workspace_bytes, instance_capacity, tile_capacity, nullptr,
+                       scratch, scratch_bytes, g_means3D, g_means2D, g_colors_a, g_colors_b, g_opacities, g_scales,
+                       g_rotations, stream, true);
 }
 
 int vtgs_profile_enable(int on) {

@@ -152,14 +152,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct MxSplat {           // what lane L holds for splat L of the current 64-chunk
   float K[6];
-  float4 pay;              // c0 c1 c2 depth
+  float4 pay;              // c0 c1 c2 depth          (dual render: c0 c1 c2 c3)
+  float2 pay2;             //                          (dual render: c4 c5)
 };
 
+// DUAL: two renders over the same geometry in one pass -- the second render's colours ride along
+// as channels 3..5; the depth image (which the fused caller discards) is not produced.
+template <bool DUAL = false>
 __device__ __forceinline__ MxSplat mx_gather(const uint32_t* __restrict__ sorted_gid, const GeomRec* __restrict__ geom,
-                                             const float* __restrict__ colors, uint32_t pos, bool in, float cx, float cy) {
+                                             const float* __restrict__ colors, uint32_t pos, bool in, float cx, float cy,
+                                             const float* __restrict__ colors_b = nullptr) {
   MxSplat m;
   m.K[0] = -1e30f; m.K[1] = m.K[2] = m.K[3] = m.K[4] = m.K[5] = 0.f;
   m.pay = make_float4(0.f, 0.f, 0.f, 0.f);
+  m.pay2 = make_float2(0.f, 0.f);
   if (in) {
     const uint32_t gid = sorted_gid[pos];
     const float4* gp = reinterpret_cast<const float4*>(geom + gid);
@@ -170,7 +176,8 @@ __device__ __forceinline__ MxSplat mx_gather(const uint32_t* __restrict__ sorted
     m.K[1] = -2.f * qa * sx - qb * sy;
     m.K[2] = -2.f * qc * sy - qb * sx;
     m.K[3] = qa; m.K[4] = qb; m.K[5] = qc;
-    m.pay = make_float4(colors[3 * gid], colors[3 * gid + 1], colors[3 * gid + 2], g1.z);
+    m.pay = make_float4(colors[3 * gid], colors[3 * gid + 1], colors[3 * gid + 2], DUAL ? colors_b[3 * gid] : g1.z);
+    if (DUAL) m.pay2 = make_float2(colors_b[3 * gid + 1], colors_b[3 * gid + 2]);
   }
   return m;
 }
@@ -183,21 +190,26 @@ __device__ __forceinline__ f32x16 mx_exponents(const float (&K)[6], const float 
   return d;
 }
 
+template <bool DUAL>
 struct MxFwdState {
   float Tb[4];             // transmittance of pixel (blk, j) at the start of the batch; 0 = finished (replicated over q)
   float Tfin[4];           // set by the lane that stopped the pixel: T before the stopping splat
-  float C[4][4];           // this lane's share of colour (3) + depth sums of pixel (blk, j)
+  float C[4][DUAL ? 6 : 4];   // this lane's share of colour (3) + depth sums of pixel (blk, j); dual: 6 colour sums
 };
 
-template <int B>
-__device__ __forceinline__ void mx_forward_batch(MxFwdState& st, const float (&K)[6], const float (&Phi)[6],
+template <int B, bool DUAL>
+__device__ __forceinline__ void mx_forward_batch(MxFwdState<DUAL>& st, const float (&K)[6], const float (&Phi)[6],
                                                  const float4* __restrict__ lds_pay, float4* __restrict__ lds_xch,
-                                                 int l) {
+                                                 int l, const float2* __restrict__ lds_pay2 = nullptr) {
   const int j = l & 15, q = l >> 4;
   const f32x16 d = mx_exponents<B>(K, Phi);
   float4 pay[4];
+  float2 pay2[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) pay[r] = lds_pay[16 * B + 4 * q + r];
+  for (int r = 0; r < 4; ++r) {
+    pay[r] = lds_pay[16 * B + 4 * q + r];
+    if (DUAL) pay2[r] = lds_pay2[16 * B + 4 * q + r];
+  }
   const unsigned long long lower_q = 0x0001000100010001ull & ((q == 0) ? 0ull : ((1ull << (16 * q)) - 1ull));
   float2* xch2 = reinterpret_cast<float2*>(lds_xch);
   // two half-passes over the pixel groups {0,1} and {2,3} (keeps the live register set small)
@@ -265,22 +277,28 @@ __device__ __forceinline__ void mx_forward_batch(MxFwdState& st, const float (&K
         st.C[blk][1] = fmaf(w[r], pay[r].y, st.C[blk][1]);
         st.C[blk][2] = fmaf(w[r], pay[r].z, st.C[blk][2]);
         st.C[blk][3] = fmaf(w[r], pay[r].w, st.C[blk][3]);
+        if constexpr (DUAL) {
+          st.C[blk][4] = fmaf(w[r], pay2[r].x, st.C[blk][4]);
+          st.C[blk][5] = fmaf(w[r], pay2[r].y, st.C[blk][5]);
+        }
       }
       st.Tb[blk] = (was_alive && !pixel_stopped) ? Tend[i] : 0.f;
     }
   }
 }
 
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 4) void composite_forward_mx(
+template <int WAVES, bool DUAL>
+__global__ __launch_bounds__(64 * WAVES, DUAL ? 3 : 4) void composite_forward_mx(
     CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
     const uint32_t* __restrict__ tile_cnt, uint32_t tile_cap, const uint32_t* __restrict__ sorted_gid,
     const GeomRec* __restrict__ geom, const float* __restrict__ colors,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
-    const Counters* __restrict__ ctr) {
+    const Counters* __restrict__ ctr, const float* __restrict__ colors_b, float* __restrict__ out_color_b) {
+  constexpr int NC = DUAL ? 6 : 4;                          // accumulated channels; + 1 row for T_final in the reduction
   __shared__ float4 lds_pay_all[WAVES][64];
+  __shared__ float2 lds_pay2_all[DUAL ? WAVES : 1][DUAL ? 64 : 1];
   __shared__ float4 lds_xch_all[WAVES][64];
-  __shared__ float lds_red_all[WAVES][5 * 64 * 4];          // [value 0..4][q][pixel 0..63]
+  __shared__ float lds_red_all[WAVES][(NC + 1) * 64 * 4];   // [value 0..NC][q][pixel 0..63]
   if (ctr->overflow) return;                                // bins hold unwritten slots after an overflow
   const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
   const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
@@ -289,6 +307,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void composite_forward_mx(
   const int l = lane_id();
   const int wv = (WAVES == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float4* lds_pay = lds_pay_all[wv];
+  float2* lds_pay2 = lds_pay2_all[DUAL ? wv : 0];
   float4* lds_xch = lds_xch_all[wv];
   float* lds_red = lds_red_all[wv];
   const int j = l & 15, q = l >> 4;
@@ -298,50 +317,59 @@ __global__ __launch_bounds__(64 * WAVES, 4) void composite_forward_mx(
   const float Phi[6] = {1.f, X, Y, X * X, X * Y, Y * Y};
   const uint32_t s = (uint32_t)tc.tile * tile_cap, e = s + min(tile_cnt[tc.tile], tile_cap);
 
-  MxFwdState st;
+  MxFwdState<DUAL> st;
 #pragma unroll
   for (int blk = 0; blk < 4; ++blk) {
     const int p = 16 * blk + j;                               // pixel (blk, j) of the tile
     const bool in_img = (tx0 + (p & 7)) < cs.W && (ty0 + (p >> 3)) < cs.H;
     st.Tb[blk] = in_img ? 1.f : 0.f;
     st.Tfin[blk] = 0.f;
-    st.C[blk][0] = st.C[blk][1] = st.C[blk][2] = st.C[blk][3] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) st.C[blk][c] = 0.f;
   }
   for (uint32_t base = s; base < e; base += 64u) {
     const bool alive = st.Tb[0] > 0.f || st.Tb[1] > 0.f || st.Tb[2] > 0.f || st.Tb[3] > 0.f;
     if (__ballot(alive) == 0ull) break;
     const int n = (int)min(64u, e - base);
-    const MxSplat m = mx_gather(sorted_gid, geom, colors, base + (uint32_t)l, l < n, cx, cy);
+    const MxSplat m = mx_gather<DUAL>(sorted_gid, geom, colors, base + (uint32_t)l, l < n, cx, cy, colors_b);
     lds_pay[l] = m.pay;
-    mx_forward_batch<0>(st, m.K, Phi, lds_pay, lds_xch, l);
-    if (n > 16) mx_forward_batch<1>(st, m.K, Phi, lds_pay, lds_xch, l);
-    if (n > 32) mx_forward_batch<2>(st, m.K, Phi, lds_pay, lds_xch, l);
-    if (n > 48) mx_forward_batch<3>(st, m.K, Phi, lds_pay, lds_xch, l);
+    if (DUAL) lds_pay2[l] = m.pay2;
+    mx_forward_batch<0, DUAL>(st, m.K, Phi, lds_pay, lds_xch, l, lds_pay2);
+    if (n > 16) mx_forward_batch<1, DUAL>(st, m.K, Phi, lds_pay, lds_xch, l, lds_pay2);
+    if (n > 32) mx_forward_batch<2, DUAL>(st, m.K, Phi, lds_pay, lds_xch, l, lds_pay2);
+    if (n > 48) mx_forward_batch<3, DUAL>(st, m.K, Phi, lds_pay, lds_xch, l, lds_pay2);
   }
   // reduce the four quad-lanes of every pixel: lane L outputs pixel L = (blk = L>>4, j = L&15)
 #pragma unroll
   for (int blk = 0; blk < 4; ++blk) {
     const int p = 16 * blk + j;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) lds_red[(c * 4 + q) * 64 + p] = st.C[blk][c];
-    lds_red[(4 * 4 + q) * 64 + p] = st.Tfin[blk];
+    for (int c = 0; c < NC; ++c) lds_red[(c * 4 + q) * 64 + p] = st.C[blk][c];
+    lds_red[(NC * 4 + q) * 64 + p] = st.Tfin[blk];
   }
-  float out[5];
+  float out[NC + 1];
 #pragma unroll
-  for (int c = 0; c < 5; ++c)
+  for (int c = 0; c < NC + 1; ++c)
     out[c] = lds_red[(c * 4 + 0) * 64 + l] + lds_red[(c * 4 + 1) * 64 + l] + lds_red[(c * 4 + 2) * 64 + l] + lds_red[(c * 4 + 3) * 64 + l];
   const float Tb_mine = (q == 0) ? st.Tb[0] : (q == 1) ? st.Tb[1] : (q == 2) ? st.Tb[2] : st.Tb[3];   // pixel L has blk == q
-  const float T = (Tb_mine > 0.f) ? Tb_mine : out[4];
+  const float T = (Tb_mine > 0.f) ? Tb_mine : out[NC];
   if (tc.inside) {
     const size_t P = (size_t)cs.W * cs.H, pix = (size_t)tc.py * cs.W + tc.px;
     out_color[pix] = out[0] + T * bg[0];
     out_color[P + pix] = out[1] + T * bg[1];
     out_color[2 * P + pix] = out[2] + T * bg[2];
-    out_depth[pix] = out[3];
+    if constexpr (DUAL) {
+      out_color_b[pix] = out[3] + T * bg[0];
+      out_color_b[P + pix] = out[4] + T * bg[1];
+      out_color_b[2 * P + pix] = out[5] + T * bg[2];
+    } else {
+      out_depth[pix] = out[3];
+    }
     final_T[pix] = T;
   }
 }
-template __global__ void composite_forward_mx<4>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*);
+template __global__ void composite_forward_mx<4, false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*);
+template __global__ void composite_forward_mx<4, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*);
 
 // ---------------------------------------------------------------------------------------------------
 // Backward composite.  Pixel-major replay produces, per (splat k, pixel p), two scalars:
@@ -486,21 +514,27 @@ __global__ __launch_bounds__(256) void composite_backward(
 // scalar form; the gather kernel divides the six geometric sums by o) and w = alpha*T, writes them transposed into the
 // per-wavefront LDS images and the existing f32-MFMA contraction over the 64 pixels forms the nine per-splat sums.
 // ---------------------------------------------------------------------------------------------------
+template <bool DUAL>
 struct MxBwdState {
   float Tb[4], Pb[4];      // transmittance / gradient prefix of pixel (blk, j) at the start of the batch (replicated over q)
-  float g[4][3];           // dL/dcolor of pixel (blk, j)
+  float g[4][DUAL ? 6 : 3];   // dL/dcolor of pixel (blk, j); dual: both renders' image gradients
   float CB[4];             // g.(out - T_final bg) + T_final (g.bg)
 };
 
-template <int B>
-__device__ __forceinline__ void mx_backward_batch(MxBwdState& st, const float (&K)[6], const float (&Phi)[6],
+template <int B, bool DUAL>
+__device__ __forceinline__ void mx_backward_batch(MxBwdState<DUAL>& st, const float (&K)[6], const float (&Phi)[6],
                                                   const float4* __restrict__ lds_pay, float4* __restrict__ lds_xch,
-                                                  float* __restrict__ Us, float* __restrict__ Ws, int l) {
+                                                  float* __restrict__ Us, float* __restrict__ Ws, int l,
+                                                  const float2* __restrict__ lds_pay2 = nullptr) {
   const int j = l & 15, q = l >> 4;
   const f32x16 d = mx_exponents<B>(K, Phi);
   float4 pay[4];
+  float2 pay2[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) pay[r] = lds_pay[16 * B + 4 * q + r];
+  for (int r = 0; r < 4; ++r) {
+    pay[r] = lds_pay[16 * B + 4 * q + r];
+    if (DUAL) pay2[r] = lds_pay2[16 * B + 4 * q + r];
+  }
   const unsigned long long lower_q = 0x0001000100010001ull & ((q == 0) ? 0ull : ((1ull << (16 * q)) - 1ull));
   // two half-passes over the pixel groups {0,1} and {2,3}: halves the number of live per-pair values
 #pragma unroll
@@ -518,6 +552,7 @@ __device__ __forceinline__ void mx_backward_batch(MxBwdState& st, const float (&
         a[i][r] = valid ? al : 0.f;
         Gm[i][r] = (valid && alive) ? Gp : 0.f;              // alpha_unclamped where this pair can contribute, else 0
         gc[i][r] = st.g[blk][0] * pay[r].x + st.g[blk][1] * pay[r].y + st.g[blk][2] * pay[r].z;
+        if constexpr (DUAL) gc[i][r] += st.g[blk][3] * pay[r].w + st.g[blk][4] * pay2[r].x + st.g[blk][5] * pay2[r].y;
       }
       pl[i][0] = 1.f - a[i][0];
       pl[i][1] = pl[i][0] * (1.f - a[i][1]);
@@ -589,14 +624,18 @@ __device__ __forceinline__ void mx_backward_batch(MxBwdState& st, const float (&
   }
 }
 
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
+template <int WAVES, bool DUAL>
+__global__ __launch_bounds__(64 * WAVES, DUAL ? 2 : 3) void composite_backward_mx(
     CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
     const uint32_t* __restrict__ tile_cnt, uint32_t tile_cap, const uint32_t* __restrict__ sorted_gid,
     const uint32_t* __restrict__ sorted_inst, const GeomRec* __restrict__ geom, const float* __restrict__ colors,
     const float* __restrict__ out_color, const float* __restrict__ grad_color, const float* __restrict__ final_T,
-    float* __restrict__ grad_inst, const Counters* __restrict__ ctr) {
+    float* __restrict__ grad_inst, const Counters* __restrict__ ctr, const float* __restrict__ colors_b,
+    const float* __restrict__ out_color_b, const float* __restrict__ grad_color_b) {
+  constexpr int NG = DUAL ? 6 : 3;                            // image-gradient channels
+  constexpr int REC = DUAL ? kGradRecDual : kGradRec;         // floats per (splat, tile) record
   __shared__ float4 lds_pay_all[WAVES][64];
+  __shared__ float2 lds_pay2_all[DUAL ? WAVES : 1][DUAL ? 64 : 1];
   __shared__ float4 lds_xch_all[WAVES][128];
   if (ctr->overflow) return;
   __shared__ float lds_uw[WAVES][2][16 * kRowStride];
@@ -607,6 +646,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   const int l = lane_id();
   const int wv = (WAVES == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float4* lds_pay = lds_pay_all[wv];
+  float2* lds_pay2 = lds_pay2_all[DUAL ? wv : 0];
   float4* lds_xch = lds_xch_all[wv];
   float* __restrict__ Us = lds_uw[wv][0];
   float* __restrict__ Ws = lds_uw[wv][1];
@@ -620,7 +660,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   const float Phi[6] = {1.f, X, Y, X * X, X * Y, Y * Y};
   const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
 
-  MxBwdState st;
+  MxBwdState<DUAL> st;
 #pragma unroll
   for (int blk = 0; blk < 4; ++blk) {
     const int p = 16 * blk + j;
@@ -628,7 +668,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     const bool in_img = qx < cs.W && qy < cs.H;
     st.Tb[blk] = in_img ? 1.f : 0.f;
     st.Pb[blk] = 0.f;
-    st.g[blk][0] = st.g[blk][1] = st.g[blk][2] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NG; ++c) st.g[blk][c] = 0.f;
     st.CB[blk] = 0.f;
     if (in_img) {
       const size_t pix = (size_t)qy * cs.W + qx;
@@ -637,6 +678,12 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
       st.g[blk][0] = g0; st.g[blk][1] = g1; st.g[blk][2] = g2;
       st.CB[blk] = g0 * (out_color[pix] - Tf * b0) + g1 * (out_color[P + pix] - Tf * b1) + g2 * (out_color[2 * P + pix] - Tf * b2)
                    + Tf * (g0 * b0 + g1 * b1 + g2 * b2);
+      if constexpr (DUAL) {
+        const float g3 = grad_color_b[pix], g4 = grad_color_b[P + pix], g5 = grad_color_b[2 * P + pix];
+        st.g[blk][3] = g3; st.g[blk][4] = g4; st.g[blk][5] = g5;
+        st.CB[blk] += g3 * (out_color_b[pix] - Tf * b0) + g4 * (out_color_b[P + pix] - Tf * b1) + g5 * (out_color_b[2 * P + pix] - Tf * b2)
+                      + Tf * (g3 * b0 + g4 * b1 + g5 * b2);
+      }
     }
   }
   // B operand of the pixel contraction: lane (bj = l&15, bk = l>>4), step t <-> pixel p = 16*bk + t
@@ -649,30 +696,35 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     float v = 0.f;
     v = (bj == 0) ? 1.f : v; v = (bj == 1) ? PX : v; v = (bj == 2) ? PY : v;
     v = (bj == 3) ? PX * PX : v; v = (bj == 4) ? PX * PY : v; v = (bj == 5) ? PY * PY : v;
-    if (bj >= 6 && bj <= 8) {
+    if (bj >= 6 && bj < 6 + NG) {
       const int qx = tx0 + (p & 7), qy = ty0 + (p >> 3);
-      if (qx < cs.W && qy < cs.H) v = grad_color[(size_t)(bj - 6) * P + (size_t)qy * cs.W + qx];
+      if (qx < cs.W && qy < cs.H) {
+        const size_t pix = (size_t)qy * cs.W + qx;
+        v = (bj < 9) ? grad_color[(size_t)(bj - 6) * P + pix] : grad_color_b[(size_t)(bj - 9) * P + pix];
+      }
     }
     Bv[t] = v;
   }
   const int a_off = bj * kRowStride + 16 * bk;
   const uint32_t tile_bits = (uint32_t)tc.tile;
+  constexpr int kTileCol = 6 + NG;                            // record column that carries the tile id
 
   uint32_t base = s;
   for (; base < e; base += 64u) {
     const bool alive = st.Tb[0] > 0.f || st.Tb[1] > 0.f || st.Tb[2] > 0.f || st.Tb[3] > 0.f;
     if (__ballot(alive) == 0ull) break;
     const int n = (int)min(64u, e - base);
-    const MxSplat m = mx_gather(sorted_gid, geom, colors, base + (uint32_t)l, l < n, cx, cy);
+    const MxSplat m = mx_gather<DUAL>(sorted_gid, geom, colors, base + (uint32_t)l, l < n, cx, cy, colors_b);
     const uint32_t my_inst = (l < n) ? sorted_inst[base + (uint32_t)l] : 0u;
     lds_pay[l] = m.pay;
+    if (DUAL) lds_pay2[l] = m.pay2;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       if (16 * b >= n) break;                                 // wave-uniform
-      if (b == 0) mx_backward_batch<0>(st, m.K, Phi, lds_pay, lds_xch, Us, Ws, l);
-      if (b == 1) mx_backward_batch<1>(st, m.K, Phi, lds_pay, lds_xch, Us, Ws, l);
-      if (b == 2) mx_backward_batch<2>(st, m.K, Phi, lds_pay, lds_xch, Us, Ws, l);
-      if (b == 3) mx_backward_batch<3>(st, m.K, Phi, lds_pay, lds_xch, Us, Ws, l);
+      if (b == 0) mx_backward_batch<0, DUAL>(st, m.K, Phi, lds_pay, lds_xch, Us, Ws, l, lds_pay2);
+      if (b == 1) mx_backward_batch<1, DUAL>(st, m.K, Phi, lds_pay, lds_xch, Us, Ws, l, lds_pay2);
+      if (b == 2) mx_backward_batch<2, DUAL>(st, m.K, Phi, lds_pay, lds_xch, Us, Ws, l, lds_pay2);
+      if (b == 3) mx_backward_batch<3, DUAL>(st, m.K, Phi, lds_pay, lds_xch, Us, Ws, l, lds_pay2);
       const int nb = min(16, n - 16 * b);
       f32x4 D1 = {0.f, 0.f, 0.f, 0.f}, D2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -685,9 +737,9 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
         const int row = 4 * bk + rr;
         const uint32_t inst = (uint32_t)__shfl((int)my_inst, 16 * b + row, 64);
         float val = (bj < 6) ? D1[rr] : D2[rr];
-        val = (bj == 9) ? __uint_as_float(tile_bits) : val;
-        val = (bj > 9) ? 0.f : val;
-        if (row < nb && bj < kGradRec) grad_inst[(size_t)inst * kGradRec + bj] = val;
+        val = (bj == kTileCol) ? __uint_as_float(tile_bits) : val;
+        val = (bj > kTileCol) ? 0.f : val;
+        if (row < nb && bj < REC) grad_inst[(size_t)inst * REC + bj] = val;
       }
     }
   }
@@ -695,15 +747,22 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     const int n = (int)min(64u, e - base);
     if (l < n) {
       const uint32_t inst = sorted_inst[base + (uint32_t)l];
-      float4* p = reinterpret_cast<float4*>(grad_inst + (size_t)inst * kGradRec);
+      float4* p = reinterpret_cast<float4*>(grad_inst + (size_t)inst * REC);
       p[0] = p[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-      p[2] = make_float4(0.f, __uint_as_float(tile_bits), 0.f, 0.f);
+      if constexpr (DUAL) {
+        p[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        p[3] = make_float4(__uint_as_float(tile_bits), 0.f, 0.f, 0.f);
+      } else {
+        p[2] = make_float4(0.f, __uint_as_float(tile_bits), 0.f, 0.f);
+      }
     }
   }
 }
-template __global__ void composite_backward_mx<4>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*);
+template __global__ void composite_backward_mx<4, false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*);
+template __global__ void composite_backward_mx<4, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*);
 
 // one thread per Gaussian: re-centre and sum its instance records (fixed order), then the projection backward
+template <bool DUAL>
 __global__ __launch_bounds__(256) void gather_splat_grads(
     CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
     const float* __restrict__ means3D, const float* __restrict__ opacities,
@@ -711,7 +770,7 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     const GaussAux* __restrict__ gaux, const float* __restrict__ grad_inst, int moments_scaled_by_opacity,
     float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_colors,
     float* __restrict__ g_opacities, float* __restrict__ g_scales, float* __restrict__ g_rotations,
-    const Counters* __restrict__ ctr) {
+    const Counters* __restrict__ ctr, float* __restrict__ g_colors_b) {
   if (ctr->overflow) return;                     // the forward did not complete: nothing valid to differentiate
   const CamParams cam = load_cam(cs, Vp, PVp);
   const int gid = (int)(blockIdx.x * 256u + threadIdx.x);
@@ -719,6 +778,7 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
   SplatGrads g;
   for (int i = 0; i < 3; ++i) { g.mean3D[i] = g.mean2D[i] = g.color[i] = g.scale[i] = 0.f; }
   g.opacity = 0.f; g.rot[0] = g.rot[1] = g.rot[2] = g.rot[3] = 0.f;
+  float cb0 = 0.f, cb1 = 0.f, cb2 = 0.f;         // dual: dL/d(second render's colours)
   const GaussAux ga = gaux[gid];
   if (ga.inst_cnt) {
     const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
@@ -730,11 +790,18 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     if (project_splat(cam, mean, sc, q, op, sp, aux)) {
       SplatMoments mo;
       for (int k = 0; k < 9; ++k) mo.m[k] = 0.f;
-      const float4* rec = reinterpret_cast<const float4*>(grad_inst + (size_t)ga.inst_base * kGradRec);
+      constexpr int RV = (DUAL ? kGradRecDual : kGradRec) / 4;       // float4 per record
+      const float4* rec = reinterpret_cast<const float4*>(grad_inst) + (size_t)ga.inst_base * RV;
       for (uint32_t i = 0; i < ga.inst_cnt; ++i) {
-        const float4 a = rec[3 * i], b = rec[3 * i + 1], c = rec[3 * i + 2];
-        // record = tile-local moments (U0, UX, UY, UXX, UXY, UYY), colour sums, tile id
-        const uint32_t tile = __float_as_uint(c.y);
+        const float4 a = rec[RV * i], b = rec[RV * i + 1], c = rec[RV * i + 2];
+        // record = tile-local moments (U0, UX, UY, UXX, UXY, UYY), colour sums (3 or 6), tile id
+        uint32_t tile;
+        if constexpr (DUAL) {
+          tile = __float_as_uint(rec[RV * i + 3].x);
+          cb0 += c.y; cb1 += c.z; cb2 += c.w;
+        } else {
+          tile = __float_as_uint(c.y);
+        }
         const int ty = (int)(tile / (uint32_t)cam.gx8), tx = (int)(tile - (uint32_t)ty * (uint32_t)cam.gx8);
         const float sx = sp.u - ((float)(tx * kSubTile) + 3.5f), sy = sp.v - ((float)(ty * kSubTile) + 3.5f);
         const float U0 = a.x, UX = a.y, UY = a.z, UXX = a.w, UXY = b.x, UYY = b.y;
@@ -761,7 +828,10 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
   }
   g_opacities[gid] = g.opacity;
   reinterpret_cast<float4*>(g_rotations)[gid] = make_float4(g.rot[0], g.rot[1], g.rot[2], g.rot[3]);
+  if constexpr (DUAL) { g_colors_b[3 * gid] = cb0; g_colors_b[3 * gid + 1] = cb1; g_colors_b[3 * gid + 2] = cb2; }
 }
+template __global__ void gather_splat_grads<false>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*);
+template __global__ void gather_splat_grads<true>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*);
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(const float* __restrict__ Vp, int n,
                                                            const float* __restrict__ means3D, uint8_t* __restrict__ out) {

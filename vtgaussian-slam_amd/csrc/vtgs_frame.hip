@@ -71,15 +71,17 @@ __global__ __launch_bounds__(256) void prepare_frame_backward_kernel(
     const float cz = P.R[6] * x + P.R[7] * y + P.R[8] * z + P.t[2];
     const float zz = P.zr[0] * cx + P.zr[1] * cy + P.zr[2] * cz + P.zr[3];
     const float dz = g_dcol[3 * i] + 2.f * zz * g_dcol[3 * i + 2];
-    const float g0 = gm_a[3 * i] + gm_b[3 * i] + dz * P.zr[0];
-    const float g1 = gm_a[3 * i + 1] + gm_b[3 * i + 1] + dz * P.zr[1];
-    const float g2 = gm_a[3 * i + 2] + gm_b[3 * i + 2] + dz * P.zr[2];
+    const bool hb = gm_b != nullptr;          // second set of rasterizer gradients (absent after a dual backward)
+    const float g0 = gm_a[3 * i] + (hb ? gm_b[3 * i] : 0.f) + dz * P.zr[0];
+    const float g1 = gm_a[3 * i + 1] + (hb ? gm_b[3 * i + 1] : 0.f) + dz * P.zr[1];
+    const float g2 = gm_a[3 * i + 2] + (hb ? gm_b[3 * i + 2] : 0.f) + dz * P.zr[2];
     if (flags & 1) {
       g_means3D[3 * i] = P.R[0] * g0 + P.R[3] * g1 + P.R[6] * g2;
       g_means3D[3 * i + 1] = P.R[1] * g0 + P.R[4] * g1 + P.R[7] * g2;
       g_means3D[3 * i + 2] = P.R[2] * g0 + P.R[5] * g1 + P.R[8] * g2;
       const float4 u = reinterpret_cast<const float4*>(unnorm_rot)[i];
-      const float4 ga = reinterpret_cast<const float4*>(grot_a)[i], gb = reinterpret_cast<const float4*>(grot_b)[i];
+      const float4 ga = reinterpret_cast<const float4*>(grot_a)[i];
+      const float4 gb = hb ? reinterpret_cast<const float4*>(grot_b)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       const float gr[4] = {ga.x + gb.x, ga.y + gb.y, ga.z + gb.z, ga.w + gb.w};
       const float un = rsqrtf(fmaxf(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w, 1e-24f));
       const float r[4] = {u.x * un, u.y * un, u.z * un, u.w * un};
@@ -89,9 +91,10 @@ __global__ __launch_bounds__(256) void prepare_frame_backward_kernel(
     }
     if (flags & 4) {
       const float o = 1.f / (1.f + __expf(-logit_op[i]));
-      g_logit[i] = (gop_a[i] + gop_b[i]) * o * (1.f - o);
+      g_logit[i] = (gop_a[i] + (hb ? gop_b[i] : 0.f)) * o * (1.f - o);
       const float s = __expf(log_scales[i]);
-      g_log_scales[i] = s * (gsc_a[3 * i] + gsc_a[3 * i + 1] + gsc_a[3 * i + 2] + gsc_b[3 * i] + gsc_b[3 * i + 1] + gsc_b[3 * i + 2]);
+      g_log_scales[i] = s * (gsc_a[3 * i] + gsc_a[3 * i + 1] + gsc_a[3 * i + 2] +
+                             (hb ? gsc_b[3 * i] + gsc_b[3 * i + 1] + gsc_b[3 * i + 2] : 0.f));
     }
     if (flags & 2) {
       acc[0] = g0; acc[1] = g1; acc[2] = g2;                                   // dL/dt
@@ -188,8 +191,9 @@ int vtgs_prepare_frame_backward(int32_t n, uint32_t flags, const float* means3D,
                                 float* pose_partials, void* stream) {
   if (n < 0 || !cam_q || !cam_t || !depth_w2c || (flags & ~7u)) return VTGS_ERR_INVALID_ARGUMENT;
   if (n == 0 || flags == 0) return VTGS_OK;
-  if (!means3D || !logit_opacities || !log_scales || !unnorm_rotations || !g_means_a || !g_means_b || !g_depth_colors ||
-      !g_opac_a || !g_opac_b || !g_scales_a || !g_scales_b || !g_rot_a || !g_rot_b)
+  const bool any_b = g_means_b || g_opac_b || g_scales_b || g_rot_b;      // the *_b set is all-or-none
+  if (!means3D || !logit_opacities || !log_scales || !unnorm_rotations || !g_means_a || !g_depth_colors ||
+      !g_opac_a || !g_scales_a || !g_rot_a || (any_b && (!g_means_b || !g_opac_b || !g_scales_b || !g_rot_b)))
     return VTGS_ERR_INVALID_ARGUMENT;
   if ((flags & 1u) && (!g_means3D || !g_unnorm_rotations)) return VTGS_ERR_INVALID_ARGUMENT;
   if ((flags & 4u) && (!g_logit_opacities || !g_log_scales)) return VTGS_ERR_INVALID_ARGUMENT;

@@ -47,7 +47,8 @@ struct alignas(8) GaussAux { uint32_t inst_base, inst_cnt; };
 
 struct alignas(16) BlockStats { uint32_t visible, pad; unsigned long long r16; };
 
-constexpr int kGradRec = 12;   // floats per instance gradient record (9 used, 48-byte stride)
+constexpr int kGradRec = 12;       // floats per instance gradient record (9 sums + tile id, 48-byte stride)
+constexpr int kGradRecDual = 16;   // dual render: 6 moments + 6 colour sums + tile id, 64-byte stride
 
 struct WsLayout {
   size_t counters, geom, gaux, block_stats, tile_cnt, keys, vals, sorted_gid, sorted_inst, final_T, total;

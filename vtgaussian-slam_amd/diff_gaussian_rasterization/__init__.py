@@ -49,7 +49,7 @@ class _VtgsProfileEntry(ctypes.Structure):
 
 
 VTGS_OK, VTGS_ERR_INSTANCE_OVERFLOW = 0, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 VTGS_FORWARD_SYNC, VTGS_FORWARD_ASYNC = 0, 1
 _P, _U64, _I32, _SZ = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
 
@@ -65,6 +65,11 @@ _SIGNATURES = {
                                            ctypes.c_uint32, _P, _P]),
     "vtgs_backward": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _U64,
                                      ctypes.c_uint32, _P, _P, _SZ, _P, _P, _P, _P, _P, _P, _P]),
+    "vtgs_backward_dual_scratch_bytes": (_SZ, [_I32, _U64]),
+    "vtgs_forward_dual": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _U64,
+                                         ctypes.c_uint32, _P, ctypes.c_uint32, _P]),
+    "vtgs_backward_dual": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32] + [_P] * 11 + [_SZ, _U64, ctypes.c_uint32, _P, _SZ]
+                           + [_P] * 8),
     "vtgs_mark_visible": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P]),
     "vtgs_debug_layout": (ctypes.c_int, [_I32, _I32, _I32, _U64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]),
     "vtgs_profile_enable": (ctypes.c_int, [ctypes.c_int]),
@@ -268,14 +273,28 @@ def _workspace(n, W, H, capacity, tile_cap, device):
     return nbytes, torch.empty((nbytes,), dtype=torch.uint8, device=device)
 
 
-def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, want_async: bool):
+def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, want_async: bool, colors_b=None):
+    """colors_b given: dual render (vtgs_forward_dual) -- the third return value is then the second colour image
+    [3,H,W] instead of the depth image."""
     global _ring
     device = means3D.device
     n = means3D.shape[0]
     H, W = cam.H, cam.W
     color = torch.empty((3, H, W), dtype=torch.float32, device=device)
-    depth = torch.empty((1, H, W), dtype=torch.float32, device=device)
+    depth = torch.empty((3 if colors_b is not None else 1, H, W), dtype=torch.float32, device=device)
     radii = torch.empty((n,), dtype=torch.int32, device=device)
+
+    def launch(workspace, nbytes, capacity, tile_cap, info_ptr, flags):
+        if colors_b is None:
+            return _lib.vtgs_forward(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
+                                     scales.data_ptr(), rotations.data_ptr(), color.data_ptr(), depth.data_ptr(),
+                                     radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, tile_cap, info_ptr, flags,
+                                     _stream_ptr(device))
+        return _lib.vtgs_forward_dual(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), colors_b.data_ptr(),
+                                      opacities.data_ptr(), scales.data_ptr(), rotations.data_ptr(), color.data_ptr(),
+                                      depth.data_ptr(), radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, tile_cap,
+                                      info_ptr, flags, _stream_ptr(device))
+
     key = (device.index, n, W, H, cam.band)
     hint = _capacity_hint.get(key, 0)
     capacity, tile_cap = _choose_capacities(key, n)
@@ -288,10 +307,7 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
             _ring = _PinnedInfoRing()
         nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
         slot = _ring.take()
-        st = _lib.vtgs_forward(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
-                               scales.data_ptr(), rotations.data_ptr(), color.data_ptr(), depth.data_ptr(),
-                               radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, tile_cap,
-                               _ring.buf[slot].data_ptr(), VTGS_FORWARD_ASYNC, _stream_ptr(device))
+        st = launch(workspace, nbytes, capacity, tile_cap, _ring.buf[slot].data_ptr(), VTGS_FORWARD_ASYNC)
         _check(st, "vtgs_forward")
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))
@@ -301,10 +317,7 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
     info = _VtgsForwardInfo()
     for _attempt in range(4):
         nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
-        st = _lib.vtgs_forward(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
-                               scales.data_ptr(), rotations.data_ptr(), color.data_ptr(), depth.data_ptr(),
-                               radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, tile_cap,
-                               ctypes.addressof(info), VTGS_FORWARD_SYNC, _stream_ptr(device))
+        st = launch(workspace, nbytes, capacity, tile_cap, ctypes.addressof(info), VTGS_FORWARD_SYNC)
         if st == VTGS_ERR_INSTANCE_OVERFLOW:          # the record says what is needed: grow whichever was short
             if info.overflow & 1:
                 capacity = int(info.instances_needed * 1.25) + 4096
@@ -344,6 +357,29 @@ def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotatio
     _check(st, "vtgs_backward")
     _resolve_pending(fs)                 # raises if that forward had overflowed its capacity
     return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
+
+
+def _run_backward_dual(fs: _ForwardState, means3D, colors_a, colors_b, opacities, scales, rotations, out_a, out_b, grad_a,
+                       grad_b):
+    """Backward of a dual render: (g_means3D, g_means2D, g_colors_a, g_opac, g_scales, g_rot, g_colors_b); the geometry
+    gradients are the sums over both renders."""
+    device = means3D.device
+    n = fs.n
+    new = lambda *s: torch.empty(s, dtype=torch.float32, device=device)
+    g_means3D, g_means2D, g_ca, g_cb, g_opac, g_scales, g_rot = new(n, 3), new(n, 3), new(n, 3), new(n, 3), new(n, 1), new(n, 3), new(n, 4)
+    if n == 0:
+        return g_means3D, g_means2D, g_ca, g_opac, g_scales, g_rot, g_cb
+    sbytes = _lib.vtgs_backward_dual_scratch_bytes(n, fs.capacity if fs.instances is None else fs.instances)
+    scratch = torch.empty((sbytes,), dtype=torch.uint8, device=device)
+    st = _lib.vtgs_backward_dual(ctypes.byref(fs.cam.c), n, means3D.data_ptr(), colors_a.data_ptr(), colors_b.data_ptr(),
+                                 opacities.data_ptr(), scales.data_ptr(), rotations.data_ptr(), out_a.data_ptr(),
+                                 out_b.data_ptr(), grad_a.data_ptr(), grad_b.data_ptr(), fs.workspace.data_ptr(),
+                                 fs.workspace.numel(), fs.capacity, fs.tile_cap, scratch.data_ptr(), sbytes,
+                                 g_means3D.data_ptr(), g_means2D.data_ptr(), g_ca.data_ptr(), g_cb.data_ptr(),
+                                 g_opac.data_ptr(), g_scales.data_ptr(), g_rot.data_ptr(), _stream_ptr(device))
+    _check(st, "vtgs_backward_dual")
+    _resolve_pending(fs)                 # raises if that forward had overflowed its capacity
+    return g_means3D, g_means2D, g_ca, g_opac, g_scales, g_rot, g_cb
 
 
 def debug_tile_lists(rasterizer: "GaussianRasterizer"):

@@ -11,9 +11,10 @@ is equivalent to the reference's
     depth_sil, _, _   = Renderer(cam)(**transformed_params2depthplussilhouette(params, w2c, tg))        :255-287
 
 for isotropic maps (log_scales [N,1], every reference config), but runs the element-wise chain as one HIP kernel
-each way (vtgs_prepare_frame / vtgs_prepare_frame_backward), projects / bins / sorts once for both renders
-(vtgs_forward + vtgs_forward_shared) and reduces dL/dmeans to the 7 pose scalars on the device
-(vtgs_prepare_frame_backward + vtgs_pose_gradient).
+each way (vtgs_prepare_frame / vtgs_prepare_frame_backward), projects / bins / sorts once and composites BOTH
+renders in one six-channel pass each way (vtgs_forward_dual / vtgs_backward_dual; VTGS_DUAL=0 selects the earlier
+vtgs_forward + vtgs_forward_shared + 2 x vtgs_backward route, kept as the cross-check) and reduces dL/dmeans to the 7
+pose scalars on the device (vtgs_prepare_frame_backward + vtgs_pose_gradient).
 Opt-in: the unmodified driver keeps working through the plain GaussianRasterizer.
 """
 from __future__ import annotations
@@ -23,8 +24,10 @@ from typing import Dict, Optional
 
 import torch
 
-from . import (_Camera, _ForwardState, _RADIUS_RULES, _check, _lib, _run_backward, _run_forward, _resolve_pending,
-               _stream_ptr, _I32, _P)
+import os
+
+from . import (_Camera, _ForwardState, _RADIUS_RULES, _check, _lib, _run_backward, _run_backward_dual, _run_forward,
+               _resolve_pending, _stream_ptr, _I32, _P)
 
 _lib.vtgs_pose_partial_rows.restype, _lib.vtgs_pose_partial_rows.argtypes = ctypes.c_uint32, [_I32]
 _lib.vtgs_prepare_frame.restype, _lib.vtgs_prepare_frame.argtypes = ctypes.c_int, [_I32] + [_P] * 13
@@ -48,13 +51,19 @@ class _RenderFrame(torch.autograd.Function):
                                        unnorm_rot.data_ptr(), cam_q.data_ptr(), cam_t.data_ptr(), depth_w2c.data_ptr(),
                                        means_cam.data_ptr(), opac.data_ptr(), scales.data_ptr(), rot.data_ptr(),
                                        dcol.data_ptr(), stream), "vtgs_prepare_frame")
-        im, radii, _, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot, want_async=flags != 0)
-        H, W = cam.H, cam.W
-        depth_sil, depth2, state = new(3, H, W), new(1, H, W), new(H * W)
-        _check(_lib.vtgs_forward_shared(ctypes.byref(cam.c), n, dcol.data_ptr(), depth_sil.data_ptr(), depth2.data_ptr(),
-                                        fs.workspace.data_ptr(), fs.workspace.numel(), fs.capacity, fs.tile_cap,
-                                        state.data_ptr(), stream), "vtgs_forward_shared")
-        ctx.fs, ctx.state, ctx.flags, ctx.n = fs, state, flags, n
+        dual = os.environ.get("VTGS_DUAL", "1") != "0"             # read per call, like the other implementation switches
+        state = None
+        if dual:
+            im, radii, depth_sil, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot, want_async=flags != 0,
+                                                    colors_b=dcol)
+        else:
+            im, radii, _, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot, want_async=flags != 0)
+            H, W = cam.H, cam.W
+            depth_sil, depth2, state = new(3, H, W), new(1, H, W), new(H * W)
+            _check(_lib.vtgs_forward_shared(ctypes.byref(cam.c), n, dcol.data_ptr(), depth_sil.data_ptr(), depth2.data_ptr(),
+                                            fs.workspace.data_ptr(), fs.workspace.numel(), fs.capacity, fs.tile_cap,
+                                            state.data_ptr(), stream), "vtgs_forward_shared")
+        ctx.fs, ctx.state, ctx.flags, ctx.n, ctx.dual = fs, state, flags, n, dual
         ctx.save_for_backward(means3D, rgb, unnorm_rot, logit_op, log_scales, cam_q, cam_t, depth_w2c,
                               means_cam, opac, scales, rot, dcol, im, depth_sil)
         ctx.mark_non_differentiable(radii)
@@ -67,12 +76,18 @@ class _RenderFrame(torch.autograd.Function):
         dev, n, flags, fs = means3D.device, ctx.n, ctx.flags, ctx.fs
         g_im = torch.zeros_like(im) if g_im is None else g_im.to(torch.float32).contiguous()
         g_ds = torch.zeros_like(depth_sil) if g_ds is None else g_ds.to(torch.float32).contiguous()
-        ga = _run_backward(fs, means_cam, rgb, opac, scales, rot, im, g_im)            # resolves the async forward
-        fsb = _ForwardState()
-        (fsb.cam, fsb.n, fsb.workspace, fsb.capacity, fsb.tile_cap, fsb.instances, fsb.image_state, fsb.pending,
-         fsb.key) = fs.cam, fs.n, fs.workspace, fs.capacity, fs.tile_cap, fs.instances, ctx.state, fs.pending, fs.key
-        gb = _run_backward(fsb, means_cam, dcol, opac, scales, rot, depth_sil, g_ds)
+        if ctx.dual:                                                # one pass; the geometry gradients arrive summed
+            ga = _run_backward_dual(fs, means_cam, rgb, dcol, opac, scales, rot, im, depth_sil, g_im, g_ds)
+            g_dcol, gb = ga[6], (None,) * 6
+        else:
+            ga = _run_backward(fs, means_cam, rgb, opac, scales, rot, im, g_im)        # resolves the async forward
+            fsb = _ForwardState()
+            (fsb.cam, fsb.n, fsb.workspace, fsb.capacity, fsb.tile_cap, fsb.instances, fsb.image_state, fsb.pending,
+             fsb.key) = fs.cam, fs.n, fs.workspace, fs.capacity, fs.tile_cap, fs.instances, ctx.state, fs.pending, fs.key
+            gb = _run_backward(fsb, means_cam, dcol, opac, scales, rot, depth_sil, g_ds)
+            g_dcol = gb[2]
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        ptr = lambda t: None if t is None else t.data_ptr()
         want_g, want_p, want_a = bool(flags & 1), bool(flags & 2), bool(flags & 4)
         g_means3D = new(n, 3) if want_g else None
         g_ur = new(n, 4) if want_g else None
@@ -80,11 +95,10 @@ class _RenderFrame(torch.autograd.Function):
         g_ls = new(n, 1) if want_a else None
         rows = int(_lib.vtgs_pose_partial_rows(n))
         partials = new(rows, 12) if want_p else None
-        ptr = lambda t: None if t is None else t.data_ptr()
         _check(_lib.vtgs_prepare_frame_backward(
             n, flags, means3D.data_ptr(), logit_op.data_ptr(), log_scales.data_ptr(), unnorm_rot.data_ptr(),
-            cam_q.data_ptr(), cam_t.data_ptr(), depth_w2c.data_ptr(), ga[0].data_ptr(), gb[0].data_ptr(), gb[2].data_ptr(),
-            ga[3].data_ptr(), gb[3].data_ptr(), ga[4].data_ptr(), gb[4].data_ptr(), ga[5].data_ptr(), gb[5].data_ptr(),
+            cam_q.data_ptr(), cam_t.data_ptr(), depth_w2c.data_ptr(), ga[0].data_ptr(), ptr(gb[0]), g_dcol.data_ptr(),
+            ga[3].data_ptr(), ptr(gb[3]), ga[4].data_ptr(), ptr(gb[4]), ga[5].data_ptr(), ptr(gb[5]),
             ptr(g_means3D), ptr(g_logit), ptr(g_ls), ptr(g_ur), ptr(partials), _stream_ptr(dev)),
             "vtgs_prepare_frame_backward")
         g_q = g_t = None
