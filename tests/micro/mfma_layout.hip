@@ -2,6 +2,8 @@
 //   v_mfma_f32_16x16x1_4b_f32 with cbsz=2/abid=b:  D[4*blk + r] of lane (j = L&15, q = L>>4)
 //        = A(lane 16*b + 4*q + r) * B(lane 16*blk + j)          (4 blocks in the 4 register groups, A broadcast from block b)
 //   v_mfma_f32_16x16x4_f32:                          D[r] of lane (j, q) = sum_k A(lane (4q + r) + 16 k) * B(lane j + 16 k)
+//   v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 blocks, block = L>>2):
+//        D[v] of lane L = A(lane 4*(L>>2) + v) * B(lane L)                 (row v from the block's lanes, column = L&3)
 // Exit code 0 = layout as assumed.  Build: hipcc --offload-arch=gfx950 mfma_layout.hip -o mfma_layout.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -22,6 +24,13 @@ __global__ void k16x4(float* out) {
   f32x4 d = {0, 0, 0, 0};
   // A(lane) = 1 + lane, B(lane) = 2^-(lane&15): the sum over the 4 k-slots identifies both operands
   d = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(1 + l), (float)(l & 15) + 1.f, d, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) out[l * 4 + r] = d[r];
+}
+__global__ void k4x4(float* out) {
+  const int l = threadIdx.x;
+  f32x4 d = {0, 0, 0, 0};
+  d = __builtin_amdgcn_mfma_f32_4x4x1f32((float)(1 + l), (float)(3 + l), d, 0, 0, 0);
+  d = __builtin_amdgcn_mfma_f32_4x4x1f32(1.f, 1.f, d, 0, 0, 0);            // accumulates: + 1 everywhere
   for (int r = 0; r < 4; ++r) out[l * 4 + r] = d[r];
 }
 #define CK(x) do { if ((x) != hipSuccess) { printf("HIP error line %d\n", __LINE__); return 2; } } while (0)
@@ -56,6 +65,14 @@ int main() {
       for (int k = 0; k < 4; ++k) want += (float)(1 + row + 16 * k) * ((float)j + 1.f);
       if (h[l * 4 + r] != want) ++bad;
     }
+  k4x4<<<1, 64>>>(d);
+  CK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+  int bad4 = 0;
+  for (int l = 0; l < 64; ++l)
+    for (int v = 0; v < 4; ++v)
+      if (h[l * 4 + v] != (float)(1 + 4 * (l >> 2) + v) * (float)(3 + l) + 1.f) ++bad4;
+  if (bad4) printf("4x4x1_16b: %d mismatches (lane 5: %g %g %g %g)\n", bad4, h[20], h[21], h[22], h[23]);
+  bad += bad4;
   printf(bad ? "MFMA layout DIFFERS from what the kernels assume (%d)\n" : "mfma layouts ok\n", bad);
   return bad ? 1 : 0;
 }

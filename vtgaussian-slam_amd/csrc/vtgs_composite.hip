@@ -511,116 +511,166 @@ __global__ __launch_bounds__(256) void composite_backward(
 // quad q, exponents from six 4-block MFMAs).  Besides the transmittance, the gradient prefix
 //     P_k = sum_{i<=k} (g.c_i) alpha_i T_i      is chained across the quad-lanes:  P_in(q) = P_batch + sum_{q'<q} T_in(q') S(q')
 // with S the T-free local sum.  Per (pixel, splat) the lane produces u' = alpha_unclamped * dL/dalpha (= o * u of the
-// scalar form; the gather kernel divides the six geometric sums by o) and w = alpha*T, writes them transposed into the
-// per-wavefront LDS images and the existing f32-MFMA contraction over the 64 pixels forms the nine per-splat sums.
+// scalar form; the gather kernel divides the six geometric sums by o) and w = alpha*T and writes them into two
+// per-wavefront LDS images laid out [pixel quarter][splat][16 pixels + 4 pad].
+//
+// The contraction over the 64 pixels runs on v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 blocks = 4 splat groups x
+// 4 pixel quarters, each accumulating [4 splats] x [4 columns] over its 16 pixels -- one chain per column group
+// (Phi0..3 | Phi4,5 | g0..2 [| g3..5]).  f32 MFMAs share the fp32 FMA lanes with the VALU on CDNA (same peak, no
+// co-execution: measured by ablation), so what counts is MACs issued: the 16x16x4 form spends
+// 32 instructions x 1024 MACs on 9 useful columns of 16, this form 48 x 256 with 9 (12) of 12 (16) useful.  The four
+// pixel-quarter partials are summed across the 16-lane rows with v_permlane32_swap / v_permlane16_swap butterflies
+// (two values per swap), which leaves lane (column c, splat group sg, row rho) holding the total of splat 4 sg + rho.
 // ---------------------------------------------------------------------------------------------------
+constexpr int kImgRow = 20;                 // floats per (splat, pixel quarter) row: 16 pixels + 4 pad (bank spread)
+constexpr int kImgQuarter = 16 * kImgRow;   // 320 floats = 5 x 64 banks: the quarter does not move the bank
+constexpr int kImgFloats = 4 * kImgQuarter; // one image (u' or w) per wavefront
+constexpr int kPhiQuarter = 8 * kImgRow;    // Phi table [pixel quarter][8 columns][16 + 4 pad], shared by the workgroup
+
+__device__ __forceinline__ float swap32_add(float a, float b) {    // rows (a0+a2, a1+a3, b0+b2, b1+b3)
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap16_add(float a, float b) {    // rows (a0+a1, b0+b1, a2+a3, b2+b3)
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sum over the four 16-lane rows of the four registers of one chain: row rho of the result = total of register rho
+__device__ __forceinline__ float quarter_sum(const f32x4& p) {
+  return swap16_add(swap32_add(p[0], p[2]), swap32_add(p[1], p[3]));
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Per-pixel state; the two components of every f32x2 are the pixel blocks 2h and 2h+1 of half-pass h, so the
+// element-wise arithmetic below compiles to packed v_pk_{mul,add,fma}_f32 (two pixels per instruction).
 template <bool DUAL>
 struct MxBwdState {
-  float Tb[4], Pb[4];      // transmittance / gradient prefix of pixel (blk, j) at the start of the batch (replicated over q)
-  float g[4][DUAL ? 6 : 3];   // dL/dcolor of pixel (blk, j); dual: both renders' image gradients
-  float CB[4];             // g.(out - T_final bg) + T_final (g.bg)
+  f32x2 Tb[2], Pb[2];      // transmittance / gradient prefix of pixel (blk, j) at the start of the batch (replicated over q)
+  f32x2 CB[2];             // g.(out - T_final bg) + T_final (g.bg)
+  float gown[DUAL ? 6 : 3];   // dL/dcolor of the lane's OWN pixel (lane L <-> pixel L): B operand of the g.c products
 };
 
+// g.c for 64 pixels x 16 splats: a rank-3 (dual: rank-6) bilinear form, so it comes out of the matrix cores in the
+// same layout as the exponents (A = the lanes' own splat colours, B = the lanes' own pixel gradients).
 template <int B, bool DUAL>
-__device__ __forceinline__ void mx_backward_batch(MxBwdState<DUAL>& st, const float (&K)[6], const float (&Phi)[6],
-                                                  const float4* __restrict__ lds_pay, float4* __restrict__ lds_xch,
-                                                  float* __restrict__ Us, float* __restrict__ Ws, int l,
-                                                  const float2* __restrict__ lds_pay2 = nullptr) {
-  const int j = l & 15, q = l >> 4;
-  const f32x16 d = mx_exponents<B>(K, Phi);
-  float4 pay[4];
-  float2 pay2[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    pay[r] = lds_pay[16 * B + 4 * q + r];
-    if (DUAL) pay2[r] = lds_pay2[16 * B + 4 * q + r];
+__device__ __forceinline__ f32x16 mx_gdotc(const MxSplat& m, const float (&g)[DUAL ? 6 : 3]) {
+  f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  d = __builtin_amdgcn_mfma_f32_16x16x1f32(m.pay.x, g[0], d, 2, B, 0);
+  d = __builtin_amdgcn_mfma_f32_16x16x1f32(m.pay.y, g[1], d, 2, B, 0);
+  d = __builtin_amdgcn_mfma_f32_16x16x1f32(m.pay.z, g[2], d, 2, B, 0);
+  if constexpr (DUAL) {
+    d = __builtin_amdgcn_mfma_f32_16x16x1f32(m.pay.w, g[3], d, 2, B, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x1f32(m.pay2.x, g[4], d, 2, B, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x1f32(m.pay2.y, g[5], d, 2, B, 0);
   }
-  const unsigned long long lower_q = 0x0001000100010001ull & ((q == 0) ? 0ull : ((1ull << (16 * q)) - 1ull));
-  // two half-passes over the pixel groups {0,1} and {2,3}: halves the number of live per-pair values
+  return d;
+}
+
+template <int B, bool DUAL>
+__device__ __forceinline__ void mx_backward_batch(MxBwdState<DUAL>& st, const MxSplat& m, const float (&Phi)[6],
+                                                  float4* __restrict__ lds_xch, float* __restrict__ Us,
+                                                  float* __restrict__ Ws, int l) {
+  const int j = l & 15, q = l >> 4;
+  const f32x16 d = mx_exponents<B>(m.K, Phi);
+  const f32x16 gcv = mx_gdotc<B, DUAL>(m, st.gown);
+  const f32x2 one = {1.f, 1.f};
+  // two half-passes over the pixel groups {0,1} and {2,3}: halves the number of live per-pair values.
+  // Everything that does not depend on the incoming transmittance / prefix is folded before the quad-lane exchange:
+  //   u' = Gm (t gc - (CB - P) / (1 - a)),  t = Tin pl[r-1]   ==>   u' = Tin gt - (CB - P) gr,   w = Tin wl
+  //   with gt = Gm pl[r-1] gc,  gr = Gm / (1 - a),  wl = a pl[r-1]   (pl[-1] = 1)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    float Gm[2][4], a[2][4], pl[2][4], gc[2][4], S[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int blk = 2 * h + i;
-      const bool alive = st.Tb[blk] > 0.f;                   // pixel not finished at the start of the batch
+    f32x2 gt[4], gr[4], wl[4], pl[4], S[4];
+    const bool alive0 = st.Tb[h].x > 0.f, alive1 = st.Tb[h].y > 0.f;     // pixel not finished at the start of the batch
+    {
+      f32x2 Gm[4], a[4], gc[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float Gp = __builtin_amdgcn_exp2f(d[4 * blk + r]);
-        const float al = fminf(kAlphaMax, Gp);
-        const bool valid = al >= kAlphaMin;
-        a[i][r] = valid ? al : 0.f;
-        Gm[i][r] = (valid && alive) ? Gp : 0.f;              // alpha_unclamped where this pair can contribute, else 0
-        gc[i][r] = st.g[blk][0] * pay[r].x + st.g[blk][1] * pay[r].y + st.g[blk][2] * pay[r].z;
-        if constexpr (DUAL) gc[i][r] += st.g[blk][3] * pay[r].w + st.g[blk][4] * pay2[r].x + st.g[blk][5] * pay2[r].y;
+        const float Gp0 = __builtin_amdgcn_exp2f(d[8 * h + r]), Gp1 = __builtin_amdgcn_exp2f(d[8 * h + 4 + r]);
+        const float al0 = fminf(kAlphaMax, Gp0), al1 = fminf(kAlphaMax, Gp1);
+        const bool v0 = al0 >= kAlphaMin, v1 = al1 >= kAlphaMin;
+        a[r].x = v0 ? al0 : 0.f; a[r].y = v1 ? al1 : 0.f;
+        Gm[r].x = (v0 && alive0) ? Gp0 : 0.f;                  // alpha_unclamped where this pair can contribute, else 0
+        Gm[r].y = (v1 && alive1) ? Gp1 : 0.f;                  // (the 0.99 clamp passes the gradient through)
+        gc[r].x = gcv[8 * h + r]; gc[r].y = gcv[8 * h + 4 + r];
       }
-      pl[i][0] = 1.f - a[i][0];
-      pl[i][1] = pl[i][0] * (1.f - a[i][1]);
-      pl[i][2] = pl[i][1] * (1.f - a[i][2]);
-      pl[i][3] = pl[i][2] * (1.f - a[i][3]);
-      S[i][0] = gc[i][0] * a[i][0];
-      S[i][1] = fmaf(gc[i][1] * a[i][1], pl[i][0], S[i][0]);
-      S[i][2] = fmaf(gc[i][2] * a[i][2], pl[i][1], S[i][1]);
-      S[i][3] = fmaf(gc[i][3] * a[i][3], pl[i][2], S[i][2]);
+      const f32x2 om1 = one - a[1], om2 = one - a[2], om3 = one - a[3];
+      pl[0] = one - a[0];
+      pl[1] = pl[0] * om1;
+      pl[2] = pl[1] * om2;
+      pl[3] = pl[2] * om3;
+      // 1 / (1 - a_r) for the four splats from ONE reciprocal of their product (v_rcp_f32 is quarter rate):
+      //   1/pl3 -> 1/om3 = pl2/pl3,  1/pl2 = om3/pl3 -> 1/om2 = pl1/pl2, ...      (om >= 0.01, so pl3 >= 1e-8)
+      const f32x2 i3 = {__builtin_amdgcn_rcpf(pl[3].x), __builtin_amdgcn_rcpf(pl[3].y)};
+      const f32x2 i2 = i3 * om3, i1 = i2 * om2;
+      gr[0] = Gm[0] * (i1 * om1); gr[1] = Gm[1] * (pl[0] * i1); gr[2] = Gm[2] * (pl[1] * i2); gr[3] = Gm[3] * (pl[2] * i3);
+      const f32x2 tg1 = pl[0] * gc[1], tg2 = pl[1] * gc[2], tg3 = pl[2] * gc[3];
+      S[0] = gc[0] * a[0];
+      S[1] = __builtin_elementwise_fma(tg1, a[1], S[0]);
+      S[2] = __builtin_elementwise_fma(tg2, a[2], S[1]);
+      S[3] = __builtin_elementwise_fma(tg3, a[3], S[2]);
+      wl[0] = a[0]; wl[1] = a[1] * pl[0]; wl[2] = a[2] * pl[1]; wl[3] = a[3] * pl[2];
+      gt[0] = Gm[0] * gc[0]; gt[1] = Gm[1] * tg1; gt[2] = Gm[2] * tg2; gt[3] = Gm[3] * tg3;
     }
     // exchange (local product, local T-free prefix sum) of both pixel groups among the four quad-lanes of a pixel
     float4* xch = lds_xch + 64 * h;
-    xch[l] = make_float4(pl[0][3], pl[1][3], S[0][3], S[1][3]);
+    xch[l] = make_float4(pl[3].x, pl[3].y, S[3].x, S[3].y);
     const float4 x0 = xch[j], x1 = xch[16 + j], x2 = xch[32 + j], x3 = xch[48 + j];
-    float Tin[2], Pin[2], Tend[2], Pend[2];
-    bool cross = false;
+    const f32x2 P0 = {x0.x, x0.y}, P1 = {x1.x, x1.y}, P2 = {x2.x, x2.y}, P3 = {x3.x, x3.y};
+    const f32x2 S0 = {x0.z, x0.w}, S1 = {x1.z, x1.w}, S2 = {x2.z, x2.w}, S3 = {x3.z, x3.w};
+    const f32x2 T0 = st.Tb[h];
+    const f32x2 T1 = T0 * P0, T2 = T1 * P1, T3 = T2 * P2;
+    const f32x2 Q0 = st.Pb[h];
+    const f32x2 Q1 = __builtin_elementwise_fma(T0, S0, Q0), Q2 = __builtin_elementwise_fma(T1, S1, Q1),
+                Q3 = __builtin_elementwise_fma(T2, S2, Q2);
+    const f32x2 Tin = (q == 0) ? T0 : (q == 1) ? T1 : (q == 2) ? T2 : T3;
+    const f32x2 Pin = (q == 0) ? Q0 : (q == 1) ? Q1 : (q == 2) ? Q2 : Q3;
+    const f32x2 Tend = T3 * P3;
+    const f32x2 Pend = __builtin_elementwise_fma(T3, S3, Q3);
+    const bool cross = (alive0 && Tend.x < kTStop) || (alive1 && Tend.y < kTStop);
+    bool stopped0 = false, stopped1 = false;
+    if (__ballot(cross) != 0ull) {                              // wave-uniform; rarely true
+      // exact stop rule: the first (quad, splat) in list order with T*(1-alpha) < 1e-4 ends the pixel before adding;
+      // everything from there on (this quad and the quads behind it) contributes nothing
+      const unsigned long long lower_q = 0x0001000100010001ull & ((q == 0) ? 0ull : ((1ull << (16 * q)) - 1ull));
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int blk = 2 * h + i;
-      const float P0 = i ? x0.y : x0.x, P1 = i ? x1.y : x1.x, P2 = i ? x2.y : x2.x, P3 = i ? x3.y : x3.x;
-      const float S0 = i ? x0.w : x0.z, S1 = i ? x1.w : x1.z, S2 = i ? x2.w : x2.z, S3 = i ? x3.w : x3.z;
-      const float T0 = st.Tb[blk];
-      const float T1 = T0 * P0, T2 = T1 * P1, T3 = T2 * P2;
-      const float Q0 = st.Pb[blk];
-      const float Q1 = fmaf(T0, S0, Q0), Q2 = fmaf(T1, S1, Q1), Q3 = fmaf(T2, S2, Q2);
-      Tin[i] = (q == 0) ? T0 : (q == 1) ? T1 : (q == 2) ? T2 : T3;
-      Pin[i] = (q == 0) ? Q0 : (q == 1) ? Q1 : (q == 2) ? Q2 : Q3;
-      Tend[i] = T3 * P3;
-      Pend[i] = fmaf(T3, S3, Q3);
-      cross = cross || (T0 > 0.f && Tend[i] < kTStop);
-    }
-    const bool slow = __ballot(cross) != 0ull;                 // wave-uniform; rarely true
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int blk = 2 * h + i;
-      const float t0 = Tin[i], t1 = t0 * pl[i][0], t2 = t0 * pl[i][1], t3 = t0 * pl[i][2];
-      const float t[4] = {t0, t1, t2, t3};
-      const bool was_alive = st.Tb[blk] > 0.f;
-      bool pixel_stopped = false;
-      if (slow) {
-        // exact stop rule: the first (quad, splat) in list order with T*(1-alpha) < 1e-4 ends the pixel before adding;
-        // everything from there on (this quad and the quads behind it) contributes nothing
+      for (int i = 0; i < 2; ++i) {
+        const float tin = i ? Tin.y : Tin.x;
+        const bool was_alive = i ? alive1 : alive0;
         bool livep = true, any = false;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool stop = a[i][r] > 0.f && Tin[i] * pl[i][r] < kTStop;
+          const float wr = i ? wl[r].y : wl[r].x, plr = i ? pl[r].y : pl[r].x;     // wl > 0  <=>  alpha >= 1/255
+          const bool stop = wr > 0.f && tin * plr < kTStop;
           any = any || (livep && stop);
           livep = livep && !stop;
-          if (!livep) { Gm[i][r] = 0.f; a[i][r] = 0.f; }
+          if (!livep) { if (i) { gt[r].y = 0.f; gr[r].y = 0.f; wl[r].y = 0.f; } else { gt[r].x = 0.f; gr[r].x = 0.f; wl[r].x = 0.f; } }
         }
         const unsigned long long bal = __ballot(any && was_alive) >> j;
-        pixel_stopped = (bal & 0x0001000100010001ull) != 0ull;
+        const bool pixel_stopped = (bal & 0x0001000100010001ull) != 0ull;
+        if (i) stopped1 = pixel_stopped; else stopped0 = pixel_stopped;
         if ((bal & lower_q) != 0ull) {                          // a quad in front of mine already ended the pixel
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { Gm[i][r] = 0.f; a[i][r] = 0.f; }
+          for (int r = 0; r < 4; ++r) { if (i) { gt[r].y = 0.f; gr[r].y = 0.f; wl[r].y = 0.f; } else { gt[r].x = 0.f; gr[r].x = 0.f; wl[r].x = 0.f; } }
         }
       }
-      // fast path: no predicates -- Gm is 0 where the pair cannot contribute, a*t is 0 for invalid pairs and dead pixels
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float Pr = fmaf(Tin[i], S[i][r], Pin[i]);            // prefix including this splat
-        const float dLda = t[r] * gc[i][r] - (st.CB[blk] - Pr) * __builtin_amdgcn_rcpf(1.f - a[i][r]);
-        Us[(4 * q + r) * kRowStride + 16 * blk + j] = Gm[i][r] * dLda;   // 0.99 clamp passes the gradient through
-        Ws[(4 * q + r) * kRowStride + 16 * blk + j] = a[i][r] * t[r];
-      }
-      st.Tb[blk] = (was_alive && !pixel_stopped) ? Tend[i] : 0.f;
-      st.Pb[blk] = Pend[i];
     }
+    // no predicates from here: gt = gr = 0 where the pair cannot contribute, wl = 0 for invalid pairs, Tin = 0 for dead pixels
+    const f32x2 CB = st.CB[h];
+    float* __restrict__ us = Us + (2 * h) * kImgQuarter + (4 * q) * kImgRow + j;   // pixel block = pixel quarter
+    float* __restrict__ ws = Ws + (2 * h) * kImgQuarter + (4 * q) * kImgRow + j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x2 Pr = __builtin_elementwise_fma(Tin, S[r], Pin);      // prefix including this splat
+      const f32x2 u = __builtin_elementwise_fma(Tin, gt[r], -((CB - Pr) * gr[r]));
+      const f32x2 w = Tin * wl[r];
+      us[r * kImgRow] = u.x; us[r * kImgRow + kImgQuarter] = u.y;
+      ws[r * kImgRow] = w.x; ws[r * kImgRow + kImgQuarter] = w.y;
+    }
+    st.Tb[h].x = (alive0 && !stopped0) ? Tend.x : 0.f;
+    st.Tb[h].y = (alive1 && !stopped1) ? Tend.y : 0.f;
+    st.Pb[h] = Pend;
   }
 }
 
@@ -634,19 +684,27 @@ __global__ __launch_bounds__(64 * WAVES, DUAL ? 2 : 3) void composite_backward_m
     const float* __restrict__ out_color_b, const float* __restrict__ grad_color_b) {
   constexpr int NG = DUAL ? 6 : 3;                            // image-gradient channels
   constexpr int REC = DUAL ? kGradRecDual : kGradRec;         // floats per (splat, tile) record
-  __shared__ float4 lds_pay_all[WAVES][64];
-  __shared__ float2 lds_pay2_all[DUAL ? WAVES : 1][DUAL ? 64 : 1];
   __shared__ float4 lds_xch_all[WAVES][128];
-  if (ctr->overflow) return;
-  __shared__ float lds_uw[WAVES][2][16 * kRowStride];
+  __shared__ __attribute__((aligned(16))) float lds_uw[WAVES][2][kImgFloats];
+  __shared__ __attribute__((aligned(16))) float lds_phi[4 * kPhiQuarter];
+  if (ctr->overflow) return;                                  // uniform over the grid
+  // Phi table for the contraction's B operands: [pixel quarter][column 0..7][pixel 0..15 (+4 pad)], columns 6,7 = 0
+  for (int i = (int)threadIdx.x; i < 4 * kPhiQuarter; i += 64 * WAVES) {
+    const int pqt = i / kPhiQuarter, c = (i - pqt * kPhiQuarter) / kImgRow, kk = i - pqt * kPhiQuarter - c * kImgRow;
+    const int p = 16 * pqt + kk;
+    const float PX = (float)(p & 7) - 3.5f, PY = (float)(p >> 3) - 3.5f;
+    float v = 0.f;
+    v = (c == 0) ? 1.f : v; v = (c == 1) ? PX : v; v = (c == 2) ? PY : v;
+    v = (c == 3) ? PX * PX : v; v = (c == 4) ? PX * PY : v; v = (c == 5) ? PY * PY : v;
+    lds_phi[i] = (kk < 16) ? v : 0.f;
+  }
+  __syncthreads();                                            // before any per-wavefront exit
   const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
   const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
   const TileCoord tc = tile_coord<WAVES>(cs, nblk, gx16, gx8, gy8);
   if (!tc.tile_ok) return;
   const int l = lane_id();
   const int wv = (WAVES == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  float4* lds_pay = lds_pay_all[wv];
-  float2* lds_pay2 = lds_pay2_all[DUAL ? wv : 0];
   float4* lds_xch = lds_xch_all[wv];
   float* __restrict__ Us = lds_uw[wv][0];
   float* __restrict__ Ws = lds_uw[wv][1];
@@ -666,80 +724,94 @@ __global__ __launch_bounds__(64 * WAVES, DUAL ? 2 : 3) void composite_backward_m
     const int p = 16 * blk + j;
     const int qx = tx0 + (p & 7), qy = ty0 + (p >> 3);
     const bool in_img = qx < cs.W && qy < cs.H;
-    st.Tb[blk] = in_img ? 1.f : 0.f;
-    st.Pb[blk] = 0.f;
-#pragma unroll
-    for (int c = 0; c < NG; ++c) st.g[blk][c] = 0.f;
-    st.CB[blk] = 0.f;
+    float cb = 0.f;
     if (in_img) {
       const size_t pix = (size_t)qy * cs.W + qx;
       const float g0 = grad_color[pix], g1 = grad_color[P + pix], g2 = grad_color[2 * P + pix];
       const float Tf = final_T[pix];
-      st.g[blk][0] = g0; st.g[blk][1] = g1; st.g[blk][2] = g2;
-      st.CB[blk] = g0 * (out_color[pix] - Tf * b0) + g1 * (out_color[P + pix] - Tf * b1) + g2 * (out_color[2 * P + pix] - Tf * b2)
-                   + Tf * (g0 * b0 + g1 * b1 + g2 * b2);
+      cb = g0 * (out_color[pix] - Tf * b0) + g1 * (out_color[P + pix] - Tf * b1) + g2 * (out_color[2 * P + pix] - Tf * b2)
+           + Tf * (g0 * b0 + g1 * b1 + g2 * b2);
       if constexpr (DUAL) {
         const float g3 = grad_color_b[pix], g4 = grad_color_b[P + pix], g5 = grad_color_b[2 * P + pix];
-        st.g[blk][3] = g3; st.g[blk][4] = g4; st.g[blk][5] = g5;
-        st.CB[blk] += g3 * (out_color_b[pix] - Tf * b0) + g4 * (out_color_b[P + pix] - Tf * b1) + g5 * (out_color_b[2 * P + pix] - Tf * b2)
-                      + Tf * (g3 * b0 + g4 * b1 + g5 * b2);
+        cb += g3 * (out_color_b[pix] - Tf * b0) + g4 * (out_color_b[P + pix] - Tf * b1) + g5 * (out_color_b[2 * P + pix] - Tf * b2)
+              + Tf * (g3 * b0 + g4 * b1 + g5 * b2);
       }
     }
+    if (blk & 1) { st.Tb[blk >> 1].y = in_img ? 1.f : 0.f; st.CB[blk >> 1].y = cb; st.Pb[blk >> 1].y = 0.f; }
+    else         { st.Tb[blk >> 1].x = in_img ? 1.f : 0.f; st.CB[blk >> 1].x = cb; st.Pb[blk >> 1].x = 0.f; }
   }
-  // B operand of the pixel contraction: lane (bj = l&15, bk = l>>4), step t <-> pixel p = 16*bk + t
-  const int bj = j, bk = q;
-  float Bv[16];
+#pragma unroll
+  for (int c = 0; c < NG; ++c) st.gown[c] = 0.f;
+  if (tc.inside) {                                              // lane L <-> pixel L (tc.px, tc.py)
+    const size_t pix = (size_t)tc.py * cs.W + tc.px;
+    st.gown[0] = grad_color[pix]; st.gown[1] = grad_color[P + pix]; st.gown[2] = grad_color[2 * P + pix];
+    if constexpr (DUAL) { st.gown[3] = grad_color_b[pix]; st.gown[4] = grad_color_b[P + pix]; st.gown[5] = grad_color_b[2 * P + pix]; }
+  }
+  // Contraction roles: l = cj + 4 sg + 16 pq -- column cj of every group, splat group sg, pixel quarter pq.
+  // A operand: row (l & 3) of block (sg, pq) = splat 4 sg + (l & 3) = image row (l & 15); B operand: column cj.
+  const int cj = l & 3, pq = q;
+  float Bg[16];                                               // dL/dcolor channel cj at the quarter's 16 pixels (cj = 3: 0)
+  float Bg2[DUAL ? 16 : 1];
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
-    const int p = 16 * bk + t;
-    const float PX = (float)(p & 7) - 3.5f, PY = (float)(p >> 3) - 3.5f;
-    float v = 0.f;
-    v = (bj == 0) ? 1.f : v; v = (bj == 1) ? PX : v; v = (bj == 2) ? PY : v;
-    v = (bj == 3) ? PX * PX : v; v = (bj == 4) ? PX * PY : v; v = (bj == 5) ? PY * PY : v;
-    if (bj >= 6 && bj < 6 + NG) {
-      const int qx = tx0 + (p & 7), qy = ty0 + (p >> 3);
-      if (qx < cs.W && qy < cs.H) {
-        const size_t pix = (size_t)qy * cs.W + qx;
-        v = (bj < 9) ? grad_color[(size_t)(bj - 6) * P + pix] : grad_color_b[(size_t)(bj - 9) * P + pix];
-      }
-    }
-    Bv[t] = v;
+    const int p = 16 * pq + t;
+    const int qx = tx0 + (p & 7), qy = ty0 + (p >> 3);
+    const bool ok = cj < 3 && qx < cs.W && qy < cs.H;
+    const size_t pix = (size_t)cj * P + (size_t)qy * cs.W + qx;
+    Bg[t] = ok ? grad_color[pix] : 0.f;
+    if constexpr (DUAL) Bg2[t] = ok ? grad_color_b[pix] : 0.f;
   }
-  const int a_off = bj * kRowStride + 16 * bk;
+  const float4* Ua4 = reinterpret_cast<const float4*>(Us + pq * kImgQuarter + (l & 15) * kImgRow);   // alias Us / Ws: no restrict
+  const float4* Wa4 = reinterpret_cast<const float4*>(Ws + pq * kImgQuarter + (l & 15) * kImgRow);
+  const float4* __restrict__ PhiA4 = reinterpret_cast<const float4*>(lds_phi + pq * kPhiQuarter + cj * kImgRow);
+  const float4* __restrict__ PhiB4 = reinterpret_cast<const float4*>(lds_phi + pq * kPhiQuarter + (4 + cj) * kImgRow);
   const uint32_t tile_bits = (uint32_t)tc.tile;
-  constexpr int kTileCol = 6 + NG;                            // record column that carries the tile id
+  // record columns: chain a -> 0..3, chain b -> 4,5 and two pad columns, chain w -> 6..8 and the tile id
+  // (dual: w -> 6..8 + tile id in 12, w2 -> 9..11 + pad 15)
+  const int col_b = (cj < 2) ? 4 + cj : REC - 5 + cj;          // 12: 10, 11   16: 13, 14
+  const int col_w = (DUAL && cj == 3) ? 12 : 6 + cj;
+  const int col_w2 = (cj == 3) ? 15 : 9 + cj;
 
   uint32_t base = s;
   for (; base < e; base += 64u) {
-    const bool alive = st.Tb[0] > 0.f || st.Tb[1] > 0.f || st.Tb[2] > 0.f || st.Tb[3] > 0.f;
+    const bool alive = st.Tb[0].x > 0.f || st.Tb[0].y > 0.f || st.Tb[1].x > 0.f || st.Tb[1].y > 0.f;
     if (__ballot(alive) == 0ull) break;
     const int n = (int)min(64u, e - base);
     const MxSplat m = mx_gather<DUAL>(sorted_gid, geom, colors, base + (uint32_t)l, l < n, cx, cy, colors_b);
     const uint32_t my_inst = (l < n) ? sorted_inst[base + (uint32_t)l] : 0u;
-    lds_pay[l] = m.pay;
-    if (DUAL) lds_pay2[l] = m.pay2;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       if (16 * b >= n) break;                                 // wave-uniform
-      if (b == 0) mx_backward_batch<0, DUAL>(st, m.K, Phi, lds_pay, lds_xch, Us, Ws, l, lds_pay2);
-      if (b == 1) mx_backward_batch<1, DUAL>(st, m.K, Phi, lds_pay, lds_xch, Us, Ws, l, lds_pay2);
-      if (b == 2) mx_backward_batch<2, DUAL>(st, m.K, Phi, lds_pay, lds_xch, Us, Ws, l, lds_pay2);
-      if (b == 3) mx_backward_batch<3, DUAL>(st, m.K, Phi, lds_pay, lds_xch, Us, Ws, l, lds_pay2);
+      if (b == 0) mx_backward_batch<0, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
+      if (b == 1) mx_backward_batch<1, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
+      if (b == 2) mx_backward_batch<2, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
+      if (b == 3) mx_backward_batch<3, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
       const int nb = min(16, n - 16 * b);
-      f32x4 D1 = {0.f, 0.f, 0.f, 0.f}, D2 = {0.f, 0.f, 0.f, 0.f};
+      f32x4 Pa = {0.f, 0.f, 0.f, 0.f}, Pb = {0.f, 0.f, 0.f, 0.f}, Pw = {0.f, 0.f, 0.f, 0.f}, Pw2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Us[a_off + t], Bv[t], D1, 0, 0, 0);
-        D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws[a_off + t], Bv[t], D2, 0, 0, 0);
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const float4 ua = Ua4[t4], wa = Wa4[t4], ba = PhiA4[t4], bb = PhiB4[t4];
+        const float uav[4] = {ua.x, ua.y, ua.z, ua.w}, wav[4] = {wa.x, wa.y, wa.z, wa.w};
+        const float bav[4] = {ba.x, ba.y, ba.z, ba.w}, bbv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          Pa = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bav[e4], Pa, 0, 0, 0);
+          Pb = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bbv[e4], Pb, 0, 0, 0);
+          Pw = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], Bg[4 * t4 + e4], Pw, 0, 0, 0);
+          if constexpr (DUAL) Pw2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], Bg2[4 * t4 + e4], Pw2, 0, 0, 0);
+        }
       }
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int row = 4 * bk + rr;
-        const uint32_t inst = (uint32_t)__shfl((int)my_inst, 16 * b + row, 64);
-        float val = (bj < 6) ? D1[rr] : D2[rr];
-        val = (bj == kTileCol) ? __uint_as_float(tile_bits) : val;
-        val = (bj > kTileCol) ? 0.f : val;
-        if (row < nb && bj < REC) grad_inst[(size_t)inst * REC + bj] = val;
+      // lane (cj, sg, rho = l >> 4) ends up with the totals of splat 4 sg + rho
+      const float Fa = quarter_sum(Pa), Fb = quarter_sum(Pb), Fw = quarter_sum(Pw);
+      const float Fw2 = DUAL ? quarter_sum(Pw2) : 0.f;           // cross-lane: must run with all lanes active
+      const int srow = (l & 12) + (l >> 4);                     // 4 sg + rho
+      const uint32_t inst = (uint32_t)__shfl((int)my_inst, 16 * b + srow, 64);
+      if (srow < nb) {
+        float* __restrict__ rec = grad_inst + (size_t)inst * REC;
+        rec[cj] = Fa;
+        rec[col_b] = Fb;
+        rec[col_w] = (cj == 3) ? __uint_as_float(tile_bits) : Fw;
+        if constexpr (DUAL) rec[col_w2] = Fw2;
       }
     }
   }
