@@ -337,3 +337,24 @@ def test_saturating_scene_exercises_the_stop_rule(gpu_device, opacity_scale):
             os.environ.pop("VTGS_FWD_IMPL"); os.environ.pop("VTGS_BWD_IMPL")
         _check_images(ref_c, ref_d, got_c, got_d)
         _check_grads(ref_g, got_g)
+
+
+def test_giant_splats_and_long_lists(gpu_device):
+    """A handful of splats wider than the frame (hundreds of candidate tiles each: the lock-step candidate walk of
+    project_and_bin, not the reach-bitmask path) over a bed of small ones, fwd + bwd against the oracle."""
+    scene, cam = go.view_tied_scene(3000, 136, 104, seed=31)
+    g = torch.Generator().manual_seed(31)
+    k = 12
+    big = {"means3D": torch.cat([0.6 * (torch.rand(k, 2, generator=g) - 0.5), 1.5 + torch.rand(k, 1, generator=g)], 1),
+           "colors_precomp": torch.rand(k, 3, generator=g),
+           "opacities": 0.05 + 0.3 * torch.rand(k, 1, generator=g),
+           "scales": (0.15 + 0.5 * torch.rand(k, 1, generator=g)).repeat(1, 3) * torch.tensor([[1.0, 0.6, 1.3]]),
+           "rotations": torch.nn.functional.normalize(torch.randn(k, 4, generator=g)), "means2D": torch.zeros(k, 3)}
+    scene = {key: torch.cat([big[key], scene[key]], 0) for key in scene}
+    grad_color = torch.rand(3, cam.image_height, cam.image_width, generator=g) * 2 - 1
+    ref_c, ref_r, ref_d, ref_g, aux = run_oracle(scene, cam, grad_color)
+    got_c, got_r, got_d, got_g = run_hip(scene, cam, gpu_device, grad_color)
+    assert int(got_r[:k].max()) > 2 * max(cam.image_width, cam.image_height) // 4      # really frame-sized splats
+    assert ((ref_r > 0) != (got_r > 0)).sum().item() == 0
+    _check_images(ref_c, ref_d, got_c, got_d)
+    _check_grads(ref_g, got_g)
