@@ -663,7 +663,7 @@ __device__ __forceinline__ void mx_backward_batch(MxBwdState<DUAL>& st, const Mx
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const f32x2 Pr = __builtin_elementwise_fma(Tin, S[r], Pin);      // prefix including this splat
-      const f32x2 u = __builtin_elementwise_fma(Tin, gt[r], -((CB - Pr) * gr[r]));
+      const f32x2 u = __builtin_elementwise_fma(Pr - CB, gr[r], Tin * gt[r]);
       const f32x2 w = Tin * wl[r];
       us[r * kImgRow] = u.x; us[r * kImgRow + kImgQuarter] = u.y;
       ws[r * kImgRow] = w.x; ws[r * kImgRow + kImgQuarter] = w.y;
@@ -675,7 +675,7 @@ __device__ __forceinline__ void mx_backward_batch(MxBwdState<DUAL>& st, const Mx
 }
 
 template <int WAVES, bool DUAL>
-__global__ __launch_bounds__(64 * WAVES, DUAL ? 2 : 3) void composite_backward_mx(
+__global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
     const uint32_t* __restrict__ tile_cnt, uint32_t tile_cap, const uint32_t* __restrict__ sorted_gid,
     const uint32_t* __restrict__ sorted_inst, const GeomRec* __restrict__ geom, const float* __restrict__ colors,
