@@ -358,3 +358,20 @@ def test_giant_splats_and_long_lists(gpu_device):
     assert ((ref_r > 0) != (got_r > 0)).sum().item() == 0
     _check_images(ref_c, ref_d, got_c, got_d)
     _check_grads(ref_g, got_g)
+
+
+def test_lds_binning_and_global_atomic_binning_agree(gpu_device, monkeypatch):
+    """The two slot-reservation schemes of project_and_bin (LDS table + one global range per tile and workgroup, vs
+    run-aggregated global atomics: VTGS_BIN_IMPL=0) fill the bins with the same sets, so everything downstream of the
+    sort is bit-identical."""
+    scene, cam = go.view_tied_scene(50000, 333, 201, seed=13)
+    g = torch.Generator().manual_seed(2)
+    grad_color = torch.rand(3, cam.image_height, cam.image_width, generator=g) * 2 - 1
+    res = {}
+    for impl in ("1", "0"):
+        monkeypatch.setenv("VTGS_BIN_IMPL", impl)
+        res[impl] = run_hip(scene, cam, gpu_device, grad_color)
+    for a, b in zip(res["1"][:3], res["0"][:3]):
+        assert torch.equal(a, b)
+    for k in GRAD_KEYS:
+        assert torch.equal(res["1"][3][k], res["0"][3][k]), k

@@ -8,6 +8,7 @@
 
 namespace vtgs {
 // kernels (vtgs_binning.hip / vtgs_composite.hip)
+template <bool LDSBINS>
 __global__ void project_and_bin(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
                                 const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*,
                                 Counters*, BlockStats*, unsigned long long, uint32_t);
@@ -197,11 +198,23 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
     else VTGS_HIP(hipMemsetAsync(out_depth, 0, P * sizeof(float), st));
   }
   if (n > 0) {
-    { ProfScope ps__("project_and_bin", st); hipLaunchKernelGGL(project_and_bin, dim3((n + 1023) / 1024), dim3(1024), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
-                       means3D, opacities, scales, rotations, out_radii, (GeomRec*)(ws + L.geom),
-                       (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt), (unsigned long long*)(ws + L.keys),
-                       (uint32_t*)(ws + L.vals), ctr, (BlockStats*)(ws + L.block_stats),
-                       (unsigned long long)instance_capacity, L.tile_cap); }
+    // LDS-binned form while the per-tile table (4 B per 8x8 tile) fits the default 64 KB of dynamic LDS
+    const bool lds_bins = L.tiles8 <= 16384u && env_int("VTGS_BIN_IMPL", 1) == 1;
+    {
+      ProfScope ps__("project_and_bin", st);
+      if (lds_bins)
+        hipLaunchKernelGGL(project_and_bin<true>, dim3((n + 1023) / 1024), dim3(1024), (size_t)L.tiles8 * 4, st, cs,
+                           cam->viewmatrix, cam->projmatrix, n, means3D, opacities, scales, rotations, out_radii,
+                           (GeomRec*)(ws + L.geom), (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt),
+                           (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), ctr,
+                           (BlockStats*)(ws + L.block_stats), (unsigned long long)instance_capacity, L.tile_cap);
+      else
+        hipLaunchKernelGGL(project_and_bin<false>, dim3((n + 1023) / 1024), dim3(1024), 0, st, cs,
+                           cam->viewmatrix, cam->projmatrix, n, means3D, opacities, scales, rotations, out_radii,
+                           (GeomRec*)(ws + L.geom), (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt),
+                           (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), ctr,
+                           (BlockStats*)(ws + L.block_stats), (unsigned long long)instance_capacity, L.tile_cap);
+    }
     VTGS_HIP(hipGetLastError());
   }
   // overflow flags and statistics first: on overflow some bin slots were never written, so the consumers must bail

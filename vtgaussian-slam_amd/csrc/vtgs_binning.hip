@@ -63,16 +63,44 @@ __device__ __forceinline__ TileWalk make_walk(const CamParams& cam, const Splat&
 }
 
 // does the splat's alpha >= 1/255 region reach the pixel centres of 8x8 tile (tx,ty)?
-__device__ __forceinline__ bool tile_reached(const CamParams& cam, const Splat& sp, float tau, int tx, int ty) {
+// Same minimum as vtgs_math.h's min_quadratic_over_rect (the four edge minima of q = 1/2 (A dx^2 + C dy^2) + B dx dy, or 0
+// when the centre lies inside), with the two divisions hoisted out of the per-tile loop (they were half of this kernel's
+// vector instructions) and v_med3_f32 for the clamps.  The differences are rounding-level; tau carries 1e-4 of slack.
+struct ReachForm { float hA, B, hC, kx, ky; bool regular; };
+
+__device__ __forceinline__ ReachForm make_reach_form(const Splat& sp) {
+  ReachForm f;
+  f.hA = 0.5f * sp.A; f.B = sp.B; f.hC = 0.5f * sp.C;
+  f.regular = sp.A > 0.f && sp.C > 0.f;                        // always true for a projected (positive-definite) conic
+  f.kx = f.regular ? -sp.B / sp.C : 0.f;                       // dy* = kx dx on a vertical edge
+  f.ky = f.regular ? -sp.B / sp.A : 0.f;                       // dx* = ky dy on a horizontal edge
+  return f;
+}
+
+__device__ __forceinline__ bool tile_reached(const CamParams& cam, const Splat& sp, const ReachForm& f, float tau, int tx,
+                                             int ty) {
   const float px0 = (float)(tx * kSubTile), py0 = (float)(ty * kSubTile);
   const float px1 = fminf(px0 + (float)(kSubTile - 1), (float)(cam.W - 1));
   const float py1 = fminf(py0 + (float)(kSubTile - 1), (float)(cam.H - 1));
-  const float q = min_quadratic_over_rect(sp.A, sp.B, sp.C, sp.u, sp.v, px0, py0, px1, py1);
-  return q <= tau;
+  if (!f.regular) return min_quadratic_over_rect(sp.A, sp.B, sp.C, sp.u, sp.v, px0, py0, px1, py1) <= tau;
+  // d = centre - pixel, pixel in the rectangle => dx in [u - px1, u - px0]
+  const float dx0 = sp.u - px1, dx1 = sp.u - px0, dy0 = sp.v - py1, dy1 = sp.v - py0;
+  const bool inside = dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f;
+  auto q = [&](float dx, float dy) { return fmaf(f.hC * dy, dy, dx * fmaf(f.hA, dx, f.B * dy)); };
+  const float q0 = q(dx0, __builtin_amdgcn_fmed3f(f.kx * dx0, dy0, dy1));
+  const float q1 = q(dx1, __builtin_amdgcn_fmed3f(f.kx * dx1, dy0, dy1));
+  const float q2 = q(__builtin_amdgcn_fmed3f(f.ky * dy0, dx0, dx1), dy0);
+  const float q3 = q(__builtin_amdgcn_fmed3f(f.ky * dy1, dx0, dx1), dy1);
+  return (inside ? 0.f : fminf(fminf(q0, q1), fminf(q2, q3))) <= tau;
 }
 
 constexpr int kProjBlock = 1024;     // threads per workgroup: one allocation atomic per 1024 Gaussians
 
+// LDSBINS (tile count fits the LDS table): the workgroup first histograms its instances per tile in LDS, then takes ONE
+// global slot range per touched tile -- all those device-scope atomics are in flight together, so their round trip
+// (microseconds: they execute at the memory side) is paid once per workgroup instead of once per step of the lock-step
+// walk -- and hands out the slots with LDS atomics.  Otherwise: run-aggregated, software-pipelined global atomics.
+template <bool LDSBINS>
 __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
     const float* __restrict__ means3D, const float* __restrict__ opacities,
@@ -81,7 +109,13 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     uint32_t* __restrict__ tile_cnt, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
     Counters* __restrict__ ctr, BlockStats* __restrict__ block_stats, unsigned long long capacity, uint32_t tile_cap) {
   constexpr int kWaves = kProjBlock / 64;
+  extern __shared__ uint32_t lds_tile[];                         // LDSBINS: [gx8 * gy8]
   const CamParams cam = load_cam(cs, Vp, PVp);
+  const int tiles8 = cam.gx8 * cam.gy8;
+  if constexpr (LDSBINS) {
+    for (int i = (int)threadIdx.x; i < tiles8; i += kProjBlock) lds_tile[i] = 0u;
+    __syncthreads();
+  }
   const int gid = (int)(blockIdx.x * (uint32_t)kProjBlock + threadIdx.x);
   const int l = lane_id();
   const bool valid = gid < n;
@@ -102,6 +136,7 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
   float tau = -1.f;
   if (vis && op * 255.f >= 1.f) { tau = logf(255.f * op); tau += 1e-4f * tau + 1e-4f; }
   const bool reach = vis && tau >= 0.f;
+  const ReachForm rf = make_reach_form(sp);
   const TileWalk w = make_walk(cam, sp, reach);
   const int area = w.cw * w.ch;
 
@@ -109,9 +144,10 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
   uint32_t cnt = 0;
   unsigned long long reach_mask = 0ull;
   for (int i = 0, tx = 0, ty = 0; i < area; ++i) {
-    const bool hit = tile_reached(cam, sp, tau, w.cx0 + tx, w.cy0 + ty);
+    const bool hit = tile_reached(cam, sp, rf, tau, w.cx0 + tx, w.cy0 + ty);
     cnt += hit ? 1u : 0u;
     if (i < 64 && hit) reach_mask |= 1ull << i;
+    if constexpr (LDSBINS) { if (hit) atomicAdd(&lds_tile[(w.cy0 + ty) * cam.gx8 + w.cx0 + tx], 1u); }
     if (++tx == w.cw) { tx = 0; ++ty; }
   }
   // Instances of one splat are contiguous: reserve [base, base+cnt).  ONE atomic per workgroup on the
@@ -133,6 +169,13 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     bs.visible = v; bs.pad = 0; bs.r16 = r;
     block_stats[blockIdx.x] = bs;
   }
+  if constexpr (LDSBINS) {
+    // one global reservation per tile this workgroup touches; the table entry becomes the running slot index
+    for (int i = (int)threadIdx.x; i < tiles8; i += kProjBlock) {
+      const uint32_t c = lds_tile[i];
+      if (c) lds_tile[i] = atomicAdd(&tile_cnt[i], c);
+    }
+  }
   __syncthreads();
   uint32_t wave_base = s_block_base;
   for (int k = 0; k < wv; ++k) wave_base += s_wave_cnt[k];
@@ -150,6 +193,26 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
   // atomic of step i is consumed in step i+1, so its round trip overlaps the next step's work.
   const unsigned long long key = ((unsigned long long)__float_as_uint(sp.depth) << 32) | (unsigned long long)(uint32_t)gid;
   uint32_t ord = 0;
+  if constexpr (LDSBINS) {
+    // pass 2, LDS form: every lane walks its own reached tiles; the slot comes from the LDS table
+    for (int i = 0, tx = 0, ty = 0; i < area; ++i) {
+      const int ttx = w.cx0 + tx, tty = w.cy0 + ty;
+      const bool hit = (i < 64) ? ((reach_mask >> i) & 1ull) != 0ull : tile_reached(cam, sp, rf, tau, ttx, tty);
+      if (hit) {
+        const int tile = tty * cam.gx8 + ttx;
+        const uint32_t slot = atomicAdd(&lds_tile[tile], 1u);
+        const unsigned long long id = (unsigned long long)inst_base + ord;
+        if (id < capacity && slot < tile_cap) {                  // an overflowing bin / id is dropped and flagged later
+          const size_t pos = (size_t)tile * tile_cap + slot;
+          keys[pos] = key;
+          vals[pos] = (uint32_t)id;
+        }
+        ++ord;
+      }
+      if (++tx == w.cw) { tx = 0; ++ty; }
+    }
+    return;
+  }
   Reservation pend;
   pend.base = 0; pend.head_lane = 0; pend.rank = 0; pend.act = false; pend.tile = -1;
   auto consume = [&](const Reservation& r) {                  // all 64 lanes call it
@@ -192,7 +255,7 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
       if (i < max_area) {                                    // wave-uniform
         const bool in = i < area;
         const int ttx = w.cx0 + tx, tty = w.cy0 + ty;
-        const bool act = in && ((i < 64) ? ((reach_mask >> i) & 1ull) != 0ull : tile_reached(cam, sp, tau, ttx, tty));
+        const bool act = in && ((i < 64) ? ((reach_mask >> i) & 1ull) != 0ull : tile_reached(cam, sp, rf, tau, ttx, tty));
         cur = reserve_issue(tile_cnt, act ? (tty * cam.gx8 + ttx) : -1, act);
         if (in && ++tx == w.cw) { tx = 0; ++ty; }
       }
@@ -201,6 +264,9 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     }
   }
 }
+
+template __global__ void project_and_bin<false>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin<true>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
 
 // One workgroup right after the binning: longest tile list, statistics, overflow flags and the image of the
 // host-visible VtgsForwardInfo.
