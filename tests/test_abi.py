@@ -57,7 +57,7 @@ def test_invalid_arguments_are_rejected_before_any_device_work(lib):
     out = (ctypes.c_uint64 * 8)()
     lib.vtgs_debug_layout.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
     assert lib.vtgs_debug_layout(5, 33, 17, 64, 32, out) == 0
-    assert out[7] == 5 * 3 and out[1] == 256            # ceil(33/8) x ceil(17/8) tiles; geom right after counters
+    assert out[7] == 5 * 3 and out[3] == 256            # ceil(33/8) x ceil(17/8) tiles; tile_cnt right after counters
 
 
 def test_python_surface_matches_reference_call_sites():

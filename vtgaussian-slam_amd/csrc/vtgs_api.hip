@@ -13,7 +13,7 @@ __global__ void project_and_bin(CamScalars, const float*, const float*, int, con
                                 const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*,
                                 Counters*, BlockStats*, unsigned long long, uint32_t);
 __global__ void finalize_forward(const uint32_t*, uint32_t, Counters*, unsigned long long, uint32_t, const BlockStats*,
-                                 uint32_t);
+                                 uint32_t, VtgsForwardInfo*);
 __global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t,
                            const Counters*);
 __global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
@@ -187,8 +187,8 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   const CamScalars cs = scalars_of(cam, r8b, r8e);
   Counters* ctr = (Counters*)(ws + L.counters);
 
-  VTGS_HIP(hipMemsetAsync(ws + L.counters, 0, 256, st));
-  VTGS_HIP(hipMemsetAsync(ws + L.tile_cnt, 0, ((size_t)L.tiles8 + 1) * 4, st));
+  // counters + per-tile list lengths in one fill (adjacent in the layout, padded to 256 B)
+  VTGS_HIP(hipMemsetAsync(ws + L.counters, 0, 256 + align256(((size_t)L.tiles8 + 1) * 4), st));
   if (rows16 * kBinTile < cam->image_height || cam->tile_row_begin != 0) {
     // band mode: pixels outside the band are written as zero (include/vtgs.h); the caller keeps only
     // its own rows when it assembles the bands
@@ -218,9 +218,17 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
     VTGS_HIP(hipGetLastError());
   }
   // overflow flags and statistics first: on overflow some bin slots were never written, so the consumers must bail
+  // asynchronous mode: the record goes straight into the caller's pinned buffer when the device can address it
+  // (one store from the kernel instead of a copy command behind the composite)
+  VtgsForwardInfo* host_record = nullptr;
+  if ((flags & VTGS_FORWARD_ASYNC) && info) {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, info, 0) == hipSuccess) host_record = (VtgsForwardInfo*)dp;
+    else (void)hipGetLastError();                               // not mapped: fall back to the copy below
+  }
   { ProfScope ps__("finalize_forward", st); hipLaunchKernelGGL(finalize_forward, dim3(1), dim3(1024), 0, st, (const uint32_t*)(ws + L.tile_cnt), L.tiles8, ctr,
                      (unsigned long long)instance_capacity, L.tile_cap, (const BlockStats*)(ws + L.block_stats),
-                     (uint32_t)((n + 1023) / 1024)); }
+                     (uint32_t)((n + 1023) / 1024), host_record); }
   VTGS_HIP(hipGetLastError());
 
   { ProfScope ps__("sort_tiles", st); hipLaunchKernelGGL(sort_tiles, dim3((L.tiles8 + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
@@ -235,8 +243,8 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   const char* image = (const char*)ctr + offsetof(Counters, info_instances);
   if (flags & VTGS_FORWARD_ASYNC) {
     if (!info) return VTGS_ERR_INVALID_ARGUMENT;
-    VTGS_HIP(hipMemcpyAsync(info, image, sizeof(VtgsForwardInfo), hipMemcpyDeviceToHost, st));
-    return VTGS_OK;
+    if (!host_record) VTGS_HIP(hipMemcpyAsync(info, image, sizeof(VtgsForwardInfo), hipMemcpyDeviceToHost, st));
+    return VTGS_OK;                                             // (else finalize_forward already stored it there)
   }
   VtgsForwardInfo host;
   VTGS_HIP(hipMemcpyAsync(&host, image, sizeof(VtgsForwardInfo), hipMemcpyDeviceToHost, st));

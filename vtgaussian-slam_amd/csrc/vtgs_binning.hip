@@ -14,6 +14,7 @@
 // The replaced implementation [UPSTREAM-PUBLIC] sorts all (tile|depth) keys with a global radix sort (several passes
 // over 12 B x R) and reads the total back to the host to size it.  Here the tile is resolved by binning (one pass,
 // no prefix scan) and only the short per-tile lists are sorted, on chip.
+#include "../../include/vtgs.h"
 #include "vtgs_internal.h"
 
 namespace vtgs {
@@ -273,7 +274,7 @@ template __global__ void project_and_bin<true>(CamScalars, const float*, const f
 __global__ __launch_bounds__(1024) void finalize_forward(const uint32_t* __restrict__ tile_cnt, uint32_t tiles,
                                                          Counters* __restrict__ ctr, unsigned long long capacity,
                                                          uint32_t tile_cap, const BlockStats* __restrict__ block_stats,
-                                                         uint32_t nblocks) {
+                                                         uint32_t nblocks, VtgsForwardInfo* host_record) {
   __shared__ uint32_t wmax[16], svis[16];
   __shared__ unsigned long long sr16[16];
   const uint32_t t = threadIdx.x;
@@ -297,6 +298,13 @@ __global__ __launch_bounds__(1024) void finalize_forward(const uint32_t* __restr
     ctr->info_instances = ovf ? 0ull : (unsigned long long)total;
     ctr->info_needed = total; ctr->info_r16 = r;
     ctr->info_visible = v; ctr->info_max_list = m; ctr->info_overflow = ovf; ctr->info_complete = 1u;
+    if (host_record) {                         // asynchronous mode: the caller's pinned record, device-addressable
+      host_record->instances = ovf ? 0ull : (unsigned long long)total;
+      host_record->instances_needed = total; host_record->tiles16_touched = r;
+      host_record->visible = v; host_record->max_tile_list = m; host_record->overflow = ovf;
+      __threadfence_system();
+      host_record->complete = 1u;              // last: the host treats the record as landed once this is set
+    }
   }
 }
 

@@ -65,11 +65,11 @@ inline WsLayout make_layout(int32_t n, int32_t w, int32_t h, uint64_t cap, uint3
   L.tile_cap = tile_cap;
   const size_t slots = (size_t)L.tiles8 * tile_cap;
   size_t o = 0;
-  L.counters = o;    o += 256;
+  L.counters = o;    o += 256;                                   // counters and tile_cnt are adjacent: ONE memset clears both
+  L.tile_cnt = o;    o += align256(((size_t)L.tiles8 + 1) * 4);
   L.geom = o;        o += align256((size_t)n * sizeof(GeomRec));
   L.gaux = o;        o += align256((size_t)n * sizeof(GaussAux));
   L.block_stats = o; o += align256(((size_t)(n + 1023) / 1024 + 1) * sizeof(BlockStats));
-  L.tile_cnt = o;    o += align256(((size_t)L.tiles8 + 1) * 4);
   L.keys = o;        o += align256(slots * 8);
   L.vals = o;        o += align256(slots * 4);
   L.sorted_gid = o;  o += align256(slots * 4);

@@ -149,13 +149,32 @@ def _dev_f32(t, device) -> torch.Tensor:
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+_cam_tensor_cache: dict = {}
+
+
+def _cam_tensor(t, device) -> torch.Tensor:
+    """Contiguous float32 device copy of a small camera tensor.  The reference hands over transposed views
+    (utils/recon_helpers.py:8,12) built once per run, so the copy is cached per (storage, version, layout) -- an in-place
+    edit bumps `_version` and misses the cache."""
+    if not isinstance(t, torch.Tensor):
+        return _dev_f32(t, device).reshape(-1)
+    key = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype, t.device, device)
+    hit = _cam_tensor_cache.get(key)
+    if hit is None:
+        if len(_cam_tensor_cache) > 256:
+            _cam_tensor_cache.clear()
+        hit = (_dev_f32(t, device).reshape(-1).clone(), t)       # keeping `t` alive keeps data_ptr unique
+        _cam_tensor_cache[key] = hit
+    return hit[0]
+
+
 class _Camera:
     """Device-side copies of the three small camera tensors + the ctypes record pointing at them."""
 
     def __init__(self, settings: GaussianRasterizationSettings, device, radius_rule: int, tile_rows):
-        self.bg = _dev_f32(settings.bg, device).reshape(-1)
-        self.view = _dev_f32(settings.viewmatrix, device).reshape(-1)
-        self.proj = _dev_f32(settings.projmatrix, device).reshape(-1)
+        self.bg = _cam_tensor(settings.bg, device)
+        self.view = _cam_tensor(settings.viewmatrix, device)
+        self.proj = _cam_tensor(settings.projmatrix, device)
         if self.bg.numel() != 3 or self.view.numel() != 16 or self.proj.numel() != 16:
             raise ValueError("bg must have 3 elements, viewmatrix/projmatrix 16 (a leading batch dim of 1 is fine)")
         b, e = (0, 0) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
@@ -434,6 +453,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             radii = None
         ctx.fs = fs
         ctx.save_for_backward(means3D, colors, opac, scales_c, rot, color)
+        ctx.set_materialize_grads(False)            # no zero-filled gradients for the radii / depth outputs
         ctx.mark_non_differentiable(depth)
         if radii is not None:
             ctx.mark_non_differentiable(radii)

@@ -66,6 +66,7 @@ class _RenderFrame(torch.autograd.Function):
         ctx.fs, ctx.state, ctx.flags, ctx.n, ctx.dual = fs, state, flags, n, dual
         ctx.save_for_backward(means3D, rgb, unnorm_rot, logit_op, log_scales, cam_q, cam_t, depth_w2c,
                               means_cam, opac, scales, rot, dcol, im, depth_sil)
+        ctx.set_materialize_grads(False)            # no zero-filled gradient for the radii output
         ctx.mark_non_differentiable(radii)
         return im, depth_sil, radii
 
