@@ -311,11 +311,12 @@ def test_mfma_register_layout_assumptions(gpu_device, tmp_path):
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", "mfma_layout.hip")
-    exe = str(tmp_path / "mfma_layout.bin")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-Wno-unused-result", src, "-o", exe], check=True)
-    out = subprocess.run([exe], capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout + out.stderr
+    for name in ("mfma_layout", "permlane_swap"):       # incl. the 4x4x1 16-block MFMA and the row swaps of the backward
+        src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", name + ".hip")
+        exe = str(tmp_path / (name + ".bin"))
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-Wno-unused-result", src, "-o", exe], check=True)
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
 
 
 @pytest.mark.parametrize("opacity_scale", [1.0, 0.35])
