@@ -1,6 +1,7 @@
 // Self-checking micro-test of the two MFMA facts composite_*_mx relies on (gfx950):
 //   v_mfma_f32_16x16x1_4b_f32 with cbsz=2/abid=b:  D[4*blk + r] of lane (j = L&15, q = L>>4)
 //        = A(lane 16*b + 4*q + r) * B(lane 16*blk + j)          (4 blocks in the 4 register groups, A broadcast from block b)
+//   the same with cbsz=0:  D[4*blk + r] of lane (j, q) = A(lane 16*blk + 4*q + r) * B(lane 16*blk + j)   (no sharing)
 //   v_mfma_f32_16x16x4_f32:                          D[r] of lane (j, q) = sum_k A(lane (4q + r) + 16 k) * B(lane j + 16 k)
 //   v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 blocks, block = L>>2):
 //        D[v] of lane L = A(lane 4*(L>>2) + v) * B(lane L)                 (row v from the block's lanes, column = L&3)
@@ -17,6 +18,15 @@ __global__ void k16x1(float* out) {
   d = __builtin_amdgcn_mfma_f32_16x16x1f32(100.f + l, 1.f, d, 2, ABID, 0);
   f32x16 e = {0};
   e = __builtin_amdgcn_mfma_f32_16x16x1f32(1.f, 1000.f + l, e, 2, ABID, 0);
+  for (int r = 0; r < 16; ++r) { out[l * 32 + r] = d[r]; out[l * 32 + 16 + r] = e[r]; }
+}
+// no broadcast (cbsz = 0): every block multiplies ITS OWN 16 A lanes with its own 16 B lanes
+__global__ void k16x1_own(float* out) {
+  const int l = threadIdx.x;
+  f32x16 d = {0};
+  d = __builtin_amdgcn_mfma_f32_16x16x1f32(100.f + l, 1.f, d, 0, 0, 0);
+  f32x16 e = {0};
+  e = __builtin_amdgcn_mfma_f32_16x16x1f32(1.f, 1000.f + l, e, 0, 0, 0);
   for (int r = 0; r < 16; ++r) { out[l * 32 + r] = d[r]; out[l * 32 + 16 + r] = e[r]; }
 }
 __global__ void k16x4(float* out) {
@@ -55,6 +65,21 @@ int main() {
   float* d;
   CK(hipMalloc(&d, 64 * 32 * sizeof(float)));
   int bad = check16x1<0>(d) + check16x1<1>(d) + check16x1<2>(d) + check16x1<3>(d);
+  {
+    float g[64 * 32];
+    k16x1_own<<<1, 64>>>(d);
+    CK(hipMemcpy(g, d, sizeof(g), hipMemcpyDeviceToHost));
+    int bad0 = 0;
+    for (int l = 0; l < 64; ++l)
+      for (int blk = 0; blk < 4; ++blk)
+        for (int r = 0; r < 4; ++r) {
+          const int j = l & 15, q = l >> 4;
+          if (g[l * 32 + 4 * blk + r] != 100.f + 16 * blk + 4 * q + r) ++bad0;      // A row 4q+r of block blk
+          if (g[l * 32 + 16 + 4 * blk + r] != 1000.f + 16 * blk + j) ++bad0;         // B column j of block blk
+        }
+    if (bad0) printf("16x16x1_4b cbsz=0: %d mismatches\n", bad0);
+    bad += bad0;
+  }
   float h[64 * 4];
   k16x4<<<1, 64>>>(d);
   CK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
