@@ -1,7 +1,7 @@
 """Per-kernel timing of the fwd+bwd step at the headline shape (HIP events inside the library).
 
     python tools/kernel_timing.py            # env: ABL_N (Gaussians), ABL_BWD=0 forward only, ABL_TAG label,
-                                             #      VTGS_FWD_IMPL / VTGS_BWD_IMPL = 0 scalar kernels, 1 matrix-core kernels
+                                             #      VTGS_FWD_IMPL / VTGS_BWD_IMPL = 0 scalar kernels, 1 matrix-core kernels; ABL_W / ABL_H image size
 """
 import sys, os, time, torch
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,10 +11,11 @@ from parity_util import to_settings
 import diff_gaussian_rasterization as dgr
 dev=torch.device('cuda:0')
 N=int(os.environ.get('ABL_N','1000000'))
-scene,cam=go.view_tied_scene(N,1200,680,seed=0)
+W=int(os.environ.get('ABL_W','1200')); H=int(os.environ.get('ABL_H','680'))
+scene,cam=go.view_tied_scene(N,W,H,seed=0)
 leaves={k:v.to(dev).requires_grad_(True) for k,v in scene.items()}
 rast=dgr.GaussianRasterizer(raster_settings=to_settings(cam,dev))
-g=torch.rand(3,680,1200,device=dev)
+g=torch.rand(3,H,W,device=dev)
 bwd=os.environ.get('ABL_BWD','1')=='1'
 def step():
     c,r,d=rast(**leaves)

@@ -198,12 +198,24 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
     else VTGS_HIP(hipMemsetAsync(out_depth, 0, P * sizeof(float), st));
   }
   if (n > 0) {
-    // LDS-binned form while the per-tile table (4 B per 8x8 tile) fits the default 64 KB of dynamic LDS
-    const bool lds_bins = L.tiles8 <= 16384u && env_int("VTGS_BIN_IMPL", 1) == 1;
+    // LDS-binned form while the per-tile table (4 B per 8x8 tile of this call's band) leaves room for two workgroups
+    // per CU: 79 KB = 20 K tiles (1200x680: 12.7 K; 1296x968: 19.6 K; a band of 1752x1168 on >= 2 GPUs).  Beyond that
+    // the run-aggregated global-atomic walk is faster again (5 M splats at 1752x1168: 488 us vs 525 us with a 128 KB
+    // table and one workgroup per CU).
+    const size_t table_bytes = (size_t)(r8e - r8b) * (size_t)((cam->image_width + kSubTile - 1) / kSubTile) * 4;
+    bool lds_bins = table_bytes <= (79u << 10) && env_int("VTGS_BIN_IMPL", 1) == 1;
+    if (lds_bins && table_bytes > (64u << 10)) {
+      static bool raised = false;                             // per process; the attribute sticks to the function
+      if (!raised) {
+        if (hipFuncSetAttribute((const void*)project_and_bin<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess)
+          raised = true;
+        else { (void)hipGetLastError(); lds_bins = false; }
+      }
+    }
     {
       ProfScope ps__("project_and_bin", st);
       if (lds_bins)
-        hipLaunchKernelGGL(project_and_bin<true>, dim3((n + 1023) / 1024), dim3(1024), (size_t)L.tiles8 * 4, st, cs,
+        hipLaunchKernelGGL(project_and_bin<true>, dim3((n + 1023) / 1024), dim3(1024), table_bytes, st, cs,
                            cam->viewmatrix, cam->projmatrix, n, means3D, opacities, scales, rotations, out_radii,
                            (GeomRec*)(ws + L.geom), (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt),
                            (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), ctr,

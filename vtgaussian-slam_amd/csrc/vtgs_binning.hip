@@ -110,9 +110,10 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     uint32_t* __restrict__ tile_cnt, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
     Counters* __restrict__ ctr, BlockStats* __restrict__ block_stats, unsigned long long capacity, uint32_t tile_cap) {
   constexpr int kWaves = kProjBlock / 64;
-  extern __shared__ uint32_t lds_tile[];                         // LDSBINS: [gx8 * gy8]
+  extern __shared__ uint32_t lds_tile[];                         // LDSBINS: one entry per 8x8 tile of this call's band
   const CamParams cam = load_cam(cs, Vp, PVp);
-  const int tiles8 = cam.gx8 * cam.gy8;
+  const int tile0 = cam.row8_begin * cam.gx8;                    // first tile of the band (tile-row multi-GPU partition)
+  const int tiles8 = (cam.row8_end - cam.row8_begin) * cam.gx8;
   if constexpr (LDSBINS) {
     for (int i = (int)threadIdx.x; i < tiles8; i += kProjBlock) lds_tile[i] = 0u;
     __syncthreads();
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     const bool hit = tile_reached(cam, sp, rf, tau, w.cx0 + tx, w.cy0 + ty);
     cnt += hit ? 1u : 0u;
     if (i < 64 && hit) reach_mask |= 1ull << i;
-    if constexpr (LDSBINS) { if (hit) atomicAdd(&lds_tile[(w.cy0 + ty) * cam.gx8 + w.cx0 + tx], 1u); }
+    if constexpr (LDSBINS) { if (hit) atomicAdd(&lds_tile[(w.cy0 + ty) * cam.gx8 + w.cx0 + tx - tile0], 1u); }
     if (++tx == w.cw) { tx = 0; ++ty; }
   }
   // Instances of one splat are contiguous: reserve [base, base+cnt).  ONE atomic per workgroup on the
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     // one global reservation per tile this workgroup touches; the table entry becomes the running slot index
     for (int i = (int)threadIdx.x; i < tiles8; i += kProjBlock) {
       const uint32_t c = lds_tile[i];
-      if (c) lds_tile[i] = atomicAdd(&tile_cnt[i], c);
+      if (c) lds_tile[i] = atomicAdd(&tile_cnt[tile0 + i], c);
     }
   }
   __syncthreads();
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
       const bool hit = (i < 64) ? ((reach_mask >> i) & 1ull) != 0ull : tile_reached(cam, sp, rf, tau, ttx, tty);
       if (hit) {
         const int tile = tty * cam.gx8 + ttx;
-        const uint32_t slot = atomicAdd(&lds_tile[tile], 1u);
+        const uint32_t slot = atomicAdd(&lds_tile[tile - tile0], 1u);
         const unsigned long long id = (unsigned long long)inst_base + ord;
         if (id < capacity && slot < tile_cap) {                  // an overflowing bin / id is dropped and flagged later
           const size_t pos = (size_t)tile * tile_cap + slot;
