@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VTGS_ABI_VERSION 5
+#define VTGS_ABI_VERSION 6
 
 typedef enum VtgsStatus {
   VTGS_OK = 0,
@@ -226,6 +226,23 @@ int vtgs_masked_l1(const float* im, const float* depth_sil, const float* gt_im, 
  * reference.  thresholds is a HOST array (copied into the launch).                                                    */
 int vtgs_silhouette_sweep(const float* im, const float* silhouette, const float* gt_im, const float* gt_depth,
                           int32_t pixels, const float* thresholds, int32_t n_thresholds, float* partial_sums, void* stream);
+
+/* The Replica branch of get_loss as a whole (src/vtgaussian_slam.py:519-608, 678-679).  mode 0 = tracking:
+ * w_im * masked sum |gt_im - im| + w_depth * masked sum |gt_depth - depth| (mask: gt_depth > 0, finite depth and
+ * uncertainty, silhouette > sil_thres).  mode 1 = mapping: w_im * (0.8 * mean |gt_im - im| + 0.2 * (1 - SSIM)) +
+ * w_depth * masked mean |gt_depth - depth| (same mask without the silhouette test).  Images are [3,H,W] / [1,H,W].
+ * forward: 2-3 launches; out5 (device) = {loss, mask count, sum |d im|, sum |d depth|, mean SSIM}; scratch =
+ * vtgs_loss_scratch_floats(H, W) floats; ssim_grad_maps = 9*H*W floats (mode 1 with a backward to follow, else NULL).
+ * backward: 1-2 launches writing g_im [3,H,W] and g_depth_sil [3,H,W] = upstream[0] * dloss/d(.) with `upstream` a
+ * DEVICE scalar (the gradient arriving at the loss): no host wait, no element-wise multiplies afterwards.            */
+size_t vtgs_loss_scratch_floats(int32_t height, int32_t width);
+int vtgs_slam_loss_forward(int32_t mode, const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth,
+                           int32_t height, int32_t width, float sil_thres, float w_im, float w_depth, float* scratch,
+                           float* ssim_grad_maps, float* out5, void* stream);
+int vtgs_slam_loss_backward(int32_t mode, const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth,
+                            int32_t height, int32_t width, float sil_thres, float w_im, float w_depth,
+                            const float* ssim_grad_maps, const float* fwd_out5, const float* upstream, float* g_im,
+                            float* g_depth_sil, void* stream);
 
 /* ---- Adam over the parameter groups ------------------------------------------------------------------
  * Replaces torch.optim.Adam as the reference configures it (src/vtgaussian_slam.py:180-187: one group per tensor with its

@@ -59,11 +59,11 @@ def test_fused_slam_losses_match_the_restatement(gpu_device, mode):
     else:
         ref = sc.mapping_loss(im, ds, gt_im, gt_depth)
         fn = lambda: losses.mapping_loss(im, ds, gt_im, gt_depth)
-    ref.backward()
+    (ref * 2.5).backward()                                # an upstream gradient other than 1 (read on the device)
     r_im, r_ds = im.grad.clone(), torch.nan_to_num(ds.grad.clone())
     im.grad = None; ds.grad = None
     out = fn()
-    out.backward()
+    (out * 2.5).backward()
     assert abs(out.item() - ref.item()) <= 2e-5 * abs(ref.item())
     assert (im.grad - r_im).abs().max().item() <= 1e-3 * r_im.abs().max().item() + 1e-9
     assert (torch.nan_to_num(ds.grad) - r_ds).abs().max().item() <= 1e-5 * r_ds.abs().max().item() + 1e-9

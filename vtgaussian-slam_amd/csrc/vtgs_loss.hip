@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void ssim_forward_kernel(const float* __restri
 __global__ __launch_bounds__(256) void ssim_backward_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
                                                             const float* __restrict__ gmaps, const float* __restrict__ upstream,
                                                             int C, int H, int W, int tiles_x, int tiles_y,
-                                                            float* __restrict__ g_img1) {
+                                                            float* __restrict__ g_img1, float ssim_coef, float l1_coef) {
   __shared__ float pm[3][kSP * kSP];
   __shared__ float hz[3][kSP * kST];
   float w[11];
@@ -126,7 +126,9 @@ __global__ __launch_bounds__(256) void ssim_backward_kernel(const float* __restr
     hz[0][i] = s0; hz[1][i] = s1; hz[2][i] = s2;
   }
   __syncthreads();
-  const float scale = upstream[0] / (float)((size_t)C * H * W);
+  // dL/dimg1 = upstream * ( ssim_coef * d(mean SSIM)/dimg1 + l1_coef * sign(img1 - img2) )   (plain SSIM: 1, 0)
+  const float scale = upstream[0] * ssim_coef / (float)((size_t)C * H * W);
+  const float l1s = upstream[0] * l1_coef;
   for (int i = t; i < kST * kST; i += 256) {
     const int r = i / kST, q = i - r * kST;
     const int gy = ty * kST + r, gx = tx * kST + q;
@@ -138,7 +140,8 @@ __global__ __launch_bounds__(256) void ssim_backward_kernel(const float* __restr
       s0 = fmaf(w[k], hz[0][j], s0); s1 = fmaf(w[k], hz[1][j], s1); s2 = fmaf(w[k], hz[2][j], s2);
     }
     const size_t o = plane + (size_t)gy * W + gx;
-    g_img1[o] = scale * (s0 + 2.f * img1[o] * s1 + img2[o] * s2);
+    const float x = img1[o], y = img2[o];
+    g_img1[o] = scale * (s0 + 2.f * x * s1 + y * s2) + ((x > y) ? l1s : (x < y) ? -l1s : 0.f);
   }
 }
 
@@ -162,13 +165,15 @@ __global__ __launch_bounds__(256) void masked_l1_kernel(const float* __restrict_
     float d = gd - depth;
     s_d += m ? fabsf(d) : 0.f;
     cnt += m ? 1.f : 0.f;
-    g_ds[i] = m ? (d > 0.f ? -1.f : (d < 0.f ? 1.f : 0.f)) : 0.f;
-    g_ds[P + i] = 0.f; g_ds[2 * (size_t)P + i] = 0.f;
+    if (g_ds) {
+      g_ds[i] = m ? (d > 0.f ? -1.f : (d < 0.f ? 1.f : 0.f)) : 0.f;
+      g_ds[P + i] = 0.f; g_ds[2 * (size_t)P + i] = 0.f;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float e = gt_im[(size_t)c * P + i] - im[(size_t)c * P + i];
       s_im += mc ? fabsf(e) : 0.f;
-      g_im[(size_t)c * P + i] = mc ? (e > 0.f ? -1.f : (e < 0.f ? 1.f : 0.f)) : 0.f;
+      if (g_im) g_im[(size_t)c * P + i] = mc ? (e > 0.f ? -1.f : (e < 0.f ? 1.f : 0.f)) : 0.f;
     }
   }
   s_im = wave_sum(s_im); s_d = wave_sum(s_d); cnt = wave_sum(cnt);
@@ -230,6 +235,62 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamLaunch a) {
   g.exp_avg_sq[i] = v;
   const float denom = sqrtf(v) / a.sqrt_bias2 + g.eps;
   g.param[i] -= (g.lr * a.step_size_scale) * (m / denom);
+}
+
+// ---- whole loss of get_loss in a handful of launches (src/vtgaussian_slam.py:519-608, 678-679) ----------------------------
+// value:    masked_l1_kernel (no gradient images) [+ ssim_forward_kernel] + loss_finalize_kernel
+//           out = {loss, mask count, sum |gt_im - im|, sum |gt_depth - depth|, mean SSIM}
+// gradient: loss_backward_kernel (depth plane, and the colour planes of the tracking loss)
+//           [+ ssim_backward_kernel with the L1 term folded in for the mapping loss]; the upstream gradient is read from
+//           device memory, so nothing waits for the host and no element-wise multiply follows.
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ l1_partial, uint32_t l1_rows,
+                                                            const float* __restrict__ ssim_partial, uint32_t ssim_rows,
+                                                            int mode, float w_im, float w_depth, float numel_im,
+                                                            float* __restrict__ out) {
+  __shared__ float red[4][4];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (uint32_t r = threadIdx.x; r < l1_rows; r += 256u) { a0 += l1_partial[3 * r]; a1 += l1_partial[3 * r + 1]; a2 += l1_partial[3 * r + 2]; }
+  for (uint32_t r = threadIdx.x; r < ssim_rows; r += 256u) a3 += ssim_partial[r];
+  a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+  if (lane_id() == 0) { red[threadIdx.x >> 6][0] = a0; red[threadIdx.x >> 6][1] = a1; red[threadIdx.x >> 6][2] = a2; red[threadIdx.x >> 6][3] = a3; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float s_im = red[0][0] + red[1][0] + red[2][0] + red[3][0], s_d = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    const float cnt = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+    const float ssim = (red[0][3] + red[1][3] + red[2][3] + red[3][3]) / numel_im;
+    float loss;
+    if (mode == 0) loss = w_im * s_im + w_depth * s_d;                                   // tracking: masked SUMS
+    else loss = w_im * (0.8f * s_im / numel_im + 0.2f * (1.f - ssim)) + w_depth * s_d / cnt;   // mapping: means + SSIM
+    out[0] = loss; out[1] = cnt; out[2] = s_im; out[3] = s_d; out[4] = ssim;
+  }
+}
+
+// mode 0 (tracking): g_im = up w_im sign(im - gt) on the mask, g_ds[0] = up w_depth sign(depth - gt) on the mask.
+// mode 1 (mapping):  g_ds[0] = up w_depth / count * sign(depth - gt) on the mask; g_im comes from ssim_backward_kernel.
+__global__ __launch_bounds__(256) void loss_backward_kernel(const float* __restrict__ im, const float* __restrict__ ds,
+                                                            const float* __restrict__ gt_im, const float* __restrict__ gt_depth,
+                                                            int P, float sil_thres, int mode, float w_im, float w_depth,
+                                                            const float* __restrict__ upstream, const float* __restrict__ fwd_out,
+                                                            float* __restrict__ g_im, float* __restrict__ g_ds) {
+  const float up = upstream[0];
+  const float cd = (mode == 0) ? up * w_depth : up * w_depth / fwd_out[1];
+  const float ci = up * w_im;
+  for (int i = (int)(blockIdx.x * 256u + threadIdx.x); i < P; i += (int)(gridDim.x * 256u)) {
+    const float depth = ds[i], sil = ds[P + i], unc = ds[2 * (size_t)P + i] - depth * depth;
+    const float gd = gt_depth[i];
+    bool m = gd > 0.f && depth == depth && unc == unc;
+    if (mode == 0) m = m && sil > sil_thres;
+    const float d = gd - depth;
+    g_ds[i] = m ? (d > 0.f ? -cd : (d < 0.f ? cd : 0.f)) : 0.f;
+    g_ds[P + i] = 0.f; g_ds[2 * (size_t)P + i] = 0.f;
+    if (mode == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float e = gt_im[(size_t)c * P + i] - im[(size_t)c * P + i];
+        g_im[(size_t)c * P + i] = m ? (e > 0.f ? -ci : (e < 0.f ? ci : 0.f)) : 0.f;
+      }
+    }
+  }
 }
 
 }  // namespace vtgs
@@ -312,7 +373,54 @@ int vtgs_ssim_backward(const float* img1, const float* img2, const float* grad_m
     return VTGS_ERR_INVALID_ARGUMENT;
   const int tx = (width + kST - 1) / kST, ty = (height + kST - 1) / kST;
   hipLaunchKernelGGL(ssim_backward_kernel, dim3(channels * tx * ty), dim3(256), 0, (hipStream_t)stream, img1, img2, grad_maps,
-                     upstream, channels, height, width, tx, ty, grad_img1);
+                     upstream, channels, height, width, tx, ty, grad_img1, 1.f, 0.f);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+size_t vtgs_loss_scratch_floats(int32_t height, int32_t width) {
+  if (height <= 0 || width <= 0) return 0;
+  return (size_t)vtgs_masked_l1_partial_rows(height * width) * 3 + vtgs_ssim_partial_rows(3, height, width);
+}
+
+int vtgs_slam_loss_forward(int32_t mode, const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth,
+                           int32_t height, int32_t width, float sil_thres, float w_im, float w_depth, float* scratch,
+                           float* ssim_grad_maps, float* out5, void* stream) {
+  if ((mode != 0 && mode != 1) || !im || !depth_sil || !gt_im || !gt_depth || !scratch || !out5 || height <= 0 || width <= 0)
+    return VTGS_ERR_INVALID_ARGUMENT;
+  const int32_t P = height * width;
+  const uint32_t l1_rows = vtgs_masked_l1_partial_rows(P);
+  float* ssim_partial = scratch + (size_t)l1_rows * 3;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(masked_l1_kernel, dim3(l1_rows), dim3(256), 0, st, im, depth_sil, gt_im, gt_depth, P, sil_thres, mode,
+                     scratch, (float*)nullptr, (float*)nullptr);
+  uint32_t ssim_rows = 0;
+  if (mode == 1) {
+    const int tx = (width + kST - 1) / kST, ty = (height + kST - 1) / kST;
+    ssim_rows = (uint32_t)(3 * tx * ty);
+    hipLaunchKernelGGL(ssim_forward_kernel, dim3(ssim_rows), dim3(256), 0, st, im, gt_im, 3, height, width, tx, ty,
+                       ssim_partial, ssim_grad_maps);
+  }
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, l1_rows, ssim_partial, ssim_rows, mode, w_im,
+                     w_depth, (float)((size_t)3 * P), out5);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+int vtgs_slam_loss_backward(int32_t mode, const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth,
+                            int32_t height, int32_t width, float sil_thres, float w_im, float w_depth,
+                            const float* ssim_grad_maps, const float* fwd_out5, const float* upstream, float* g_im,
+                            float* g_depth_sil, void* stream) {
+  if ((mode != 0 && mode != 1) || !im || !depth_sil || !gt_im || !gt_depth || !fwd_out5 || !upstream || !g_im || !g_depth_sil ||
+      height <= 0 || width <= 0 || (mode == 1 && !ssim_grad_maps))
+    return VTGS_ERR_INVALID_ARGUMENT;
+  const int32_t P = height * width;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(loss_backward_kernel, dim3(vtgs_masked_l1_partial_rows(P)), dim3(256), 0, st, im, depth_sil, gt_im,
+                     gt_depth, P, sil_thres, mode, w_im, w_depth, upstream, fwd_out5, g_im, g_depth_sil);
+  if (mode == 1) {
+    const int tx = (width + kST - 1) / kST, ty = (height + kST - 1) / kST;
+    hipLaunchKernelGGL(ssim_backward_kernel, dim3(3 * tx * ty), dim3(256), 0, st, im, gt_im, ssim_grad_maps, upstream, 3,
+                       height, width, tx, ty, g_im, -0.2f * w_im, 0.8f * w_im / (float)((size_t)3 * P));
+  }
   return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
 }
 

@@ -86,17 +86,64 @@ class _MaskedL1(torch.autograd.Function):
                 None, None, None, None)
 
 
+_lib.vtgs_loss_scratch_floats.restype, _lib.vtgs_loss_scratch_floats.argtypes = ctypes.c_size_t, [_I32, _I32]
+_lib.vtgs_slam_loss_forward.restype = ctypes.c_int
+_lib.vtgs_slam_loss_forward.argtypes = [_I32, _P, _P, _P, _P, _I32, _I32, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P]
+_lib.vtgs_slam_loss_backward.restype = ctypes.c_int
+_lib.vtgs_slam_loss_backward.argtypes = [_I32, _P, _P, _P, _P, _I32, _I32, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P,
+                                         _P, _P, _P]
+
+
+class _SlamLoss(torch.autograd.Function):
+    """The whole Replica branch of get_loss as one node: 2-3 launches for the value, 1-2 for both gradient images (the
+    upstream gradient is read on the device).  mode 0 = tracking, 1 = mapping."""
+
+    @staticmethod
+    def forward(ctx, im, depth_sil, gt_im, gt_depth, mode: int, sil_thres: float, w_im: float, w_depth: float):
+        if not im.is_cuda:
+            raise RuntimeError("the fused losses need tensors on a HIP device (torch 'cuda'); no CPU path exists")
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        a, d, ga, gd = f32(im), f32(depth_sil), f32(gt_im), f32(gt_depth)
+        if a.shape[-3] != 3 or d.shape[-3] != 3:
+            raise ValueError("im and depth_sil must be [3,H,W]")
+        H, W = a.shape[-2], a.shape[-1]
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        scratch = torch.empty(int(_lib.vtgs_loss_scratch_floats(H, W)), dtype=torch.float32, device=a.device)
+        gmaps = torch.empty((3, 3, H, W), dtype=torch.float32, device=a.device) if (mode == 1 and need) else None
+        out = torch.empty(5, dtype=torch.float32, device=a.device)
+        _check(_lib.vtgs_slam_loss_forward(mode, a.data_ptr(), d.data_ptr(), ga.data_ptr(), gd.data_ptr(), H, W,
+                                           float(sil_thres), float(w_im), float(w_depth), scratch.data_ptr(),
+                                           None if gmaps is None else gmaps.data_ptr(), out.data_ptr(),
+                                           _stream_ptr(a.device)), "vtgs_slam_loss_forward")
+        ctx.save_for_backward(a, d, ga, gd, out, gmaps if gmaps is not None else out)
+        ctx.cfg = (mode, float(sil_thres), float(w_im), float(w_depth), need, gmaps is not None)
+        ctx.set_materialize_grads(False)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        mode, sil_thres, w_im, w_depth, need, has_maps = ctx.cfg
+        if g is None or not need:
+            return (None,) * 8
+        a, d, ga, gd, out, gmaps = ctx.saved_tensors
+        H, W = a.shape[-2], a.shape[-1]
+        up = g.detach().to(torch.float32).reshape(1).contiguous()
+        g_im, g_ds = torch.empty_like(a), torch.empty_like(d)
+        _check(_lib.vtgs_slam_loss_backward(mode, a.data_ptr(), d.data_ptr(), ga.data_ptr(), gd.data_ptr(), H, W, sil_thres,
+                                            w_im, w_depth, gmaps.data_ptr() if has_maps else None, out.data_ptr(),
+                                            up.data_ptr(), g_im.data_ptr(), g_ds.data_ptr(), _stream_ptr(a.device)),
+               "vtgs_slam_loss_backward")
+        return g_im, g_ds, None, None, None, None, None, None
+
+
 def tracking_loss(im, depth_sil, gt_im, gt_depth, sil_thres: float, w_im: float = 0.5, w_depth: float = 0.025):
     """Replica tracking loss: w_im * masked L1 SUM of colour + w_depth * masked L1 SUM of depth."""
-    s_im, s_d, _ = _MaskedL1.apply(im, depth_sil, gt_im, gt_depth, sil_thres, 0)
-    return w_im * s_im + w_depth * s_d
+    return _SlamLoss.apply(im, depth_sil, gt_im, gt_depth, 0, sil_thres, w_im, w_depth)
 
 
 def mapping_loss(im, depth_sil, gt_im, gt_depth, w_im: float = 1.0, w_depth: float = 1.0):
     """Mapping loss: w_depth * masked L1 MEAN of depth + w_im * (0.8 * L1 mean + 0.2 * (1 - SSIM)) of colour."""
-    s_im, s_d, cnt = _MaskedL1.apply(im, depth_sil, gt_im, gt_depth, 0.0, 1)
-    l_im = 0.8 * s_im / float(im.numel()) + 0.2 * (1.0 - fused_ssim(im, gt_im))
-    return w_im * l_im + w_depth * s_d / cnt
+    return _SlamLoss.apply(im, depth_sil, gt_im, gt_depth, 1, 0.0, w_im, w_depth)
 
 
 _lib.vtgs_silhouette_sweep.restype = ctypes.c_int
