@@ -5,6 +5,7 @@
 //   v_mfma_f32_16x16x4_f32:                          D[r] of lane (j, q) = sum_k A(lane (4q + r) + 16 k) * B(lane j + 16 k)
 //   v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 blocks, block = L>>2):
 //        D[v] of lane L = A(lane 4*(L>>2) + v) * B(lane L)                 (row v from the block's lanes, column = L&3)
+//   the same with cbsz=4/abid=g:  D[v] of lane L = A(lane 4*g + v) * B(lane L)      (all blocks share block g's A rows)
 // Exit code 0 = layout as assumed.  Build: hipcc --offload-arch=gfx950 mfma_layout.hip -o mfma_layout.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -42,6 +43,26 @@ __global__ void k4x4(float* out) {
   d = __builtin_amdgcn_mfma_f32_4x4x1f32((float)(1 + l), (float)(3 + l), d, 0, 0, 0);
   d = __builtin_amdgcn_mfma_f32_4x4x1f32(1.f, 1.f, d, 0, 0, 0);            // accumulates: + 1 everywhere
   for (int r = 0; r < 4; ++r) out[l * 4 + r] = d[r];
+}
+// A broadcast for the 16-block form: cbsz = 4 makes all 16 blocks read block ABID's four A lanes
+template <int ABID>
+__global__ void k4x4_bcast(float* out) {
+  const int l = threadIdx.x;
+  f32x4 d = {0, 0, 0, 0};
+  d = __builtin_amdgcn_mfma_f32_4x4x1f32((float)(1 + l), (float)(3 + l), d, 4, ABID, 0);
+  for (int r = 0; r < 4; ++r) out[l * 4 + r] = d[r];
+}
+template <int ABID>
+static int check4x4_bcast(float* d) {
+  float h[64 * 4];
+  k4x4_bcast<ABID><<<1, 64>>>(d);
+  if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return 1000;
+  int bad = 0;
+  for (int l = 0; l < 64; ++l)
+    for (int v = 0; v < 4; ++v)
+      if (h[l * 4 + v] != (float)(1 + 4 * ABID + v) * (float)(3 + l)) ++bad;
+  if (bad) printf("4x4x1_16b cbsz=4 abid=%d: %d mismatches (lane 9: %g %g %g %g)\n", ABID, bad, h[36], h[37], h[38], h[39]);
+  return bad;
 }
 #define CK(x) do { if ((x) != hipSuccess) { printf("HIP error line %d\n", __LINE__); return 2; } } while (0)
 
@@ -98,6 +119,7 @@ int main() {
       if (h[l * 4 + v] != (float)(1 + 4 * (l >> 2) + v) * (float)(3 + l) + 1.f) ++bad4;
   if (bad4) printf("4x4x1_16b: %d mismatches (lane 5: %g %g %g %g)\n", bad4, h[20], h[21], h[22], h[23]);
   bad += bad4;
+  bad += check4x4_bcast<0>(d) + check4x4_bcast<5>(d) + check4x4_bcast<15>(d);
   printf(bad ? "MFMA layout DIFFERS from what the kernels assume (%d)\n" : "mfma layouts ok\n", bad);
   return bad ? 1 : 0;
 }

@@ -376,3 +376,28 @@ def test_lds_binning_and_global_atomic_binning_agree(gpu_device, monkeypatch):
         assert torch.equal(a, b)
     for k in GRAD_KEYS:
         assert torch.equal(res["1"][3][k], res["0"][3][k]), k
+
+
+@pytest.mark.parametrize("scene_name", ["view_tied_dense", "random_aniso"])
+def test_forward_kernel_variants_agree(gpu_device, monkeypatch, scene_name):
+    """The three forward composites -- scalar (0), lane = pixel x splat-quad with chained transmittance (1), lane = pixel
+    with the broadcast 16-block MFMA (2) -- see the same lists in the same order; only float32 grouping differs.  The
+    backward (which replays the list itself) is run on top of each forward's image state."""
+    scene, cam = SCENES[scene_name]()
+    g = torch.Generator().manual_seed(17)
+    grad_color = torch.rand(3, cam.image_height, cam.image_width, generator=g) * 2 - 1
+    res = {}
+    for impl in ("0", "1", "2"):
+        monkeypatch.setenv("VTGS_FWD_IMPL", impl)
+        res[impl] = run_hip(scene, cam, gpu_device, grad_color)
+    ref = res["0"]
+    for impl in ("1", "2"):
+        got = res[impl]
+        assert torch.equal(ref[1], got[1])
+        for a, b in ((ref[0], got[0]), (ref[2], got[2])):
+            assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item(), impl
+        for k in GRAD_KEYS:
+            if k == "rotations" and scene_name.startswith("view_tied"):
+                continue                                       # isotropic: float noise around zero
+            mx, p999 = grad_error(ref[3][k], got[3][k])
+            assert mx <= 1e-3 and p999 <= 1e-3, (impl, k, mx, p999)

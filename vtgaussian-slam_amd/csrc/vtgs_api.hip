@@ -22,6 +22,10 @@ template <int WAVES, bool DUAL>
 __global__ void composite_forward_mx(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                      const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*,
                                      float*);
+template <int WAVES, bool DUAL>
+__global__ void composite_forward_px(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
+                                     const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*,
+                                     float*);
 __global__ void composite_backward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                    const uint32_t*, const GeomRec*, const float*, const float*, const float*,
                                    const float*, float*, const Counters*);
@@ -145,14 +149,25 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
                                     float* out_color_b = nullptr) {
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   const uint32_t nblk = (uint32_t)(gx16 * rows16);
-  const int impl = env_int("VTGS_FWD_IMPL", 1);            // 1 = matrix-core kernel, 0 = scalar kernel (read per call)
+  const int impl = env_int("VTGS_FWD_IMPL", 2);            // 2 = lane-per-pixel matrix-core kernel (default), 1 = pixel x splat-quad
+                                                           // matrix-core kernel, 0 = scalar kernel (read per call)
   {
     ProfScope ps__(colors_b ? "composite_forward_dual" : "composite_forward", st);
-    if (colors_b)
+    if (colors_b && impl != 1)
+      hipLaunchKernelGGL((composite_forward_px<4, true>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
+                         (const GeomRec*)(ws + L.geom), colors, out_color, (float*)nullptr, image_state,
+                         (const Counters*)(ws + L.counters), colors_b, out_color_b);
+    else if (colors_b)
       hipLaunchKernelGGL((composite_forward_mx<4, true>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const GeomRec*)(ws + L.geom), colors, out_color, (float*)nullptr, image_state,
                          (const Counters*)(ws + L.counters), colors_b, out_color_b);
+    else if (impl == 2)                                     // lane = pixel, exponents from the broadcast 16-block MFMA
+      hipLaunchKernelGGL((composite_forward_px<4, false>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
+                         (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
+                         (const Counters*)(ws + L.counters), (const float*)nullptr, (float*)nullptr);
     else if (impl == 1)
       hipLaunchKernelGGL((composite_forward_mx<4, false>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void composite_forward(
 // (the exponent carries ~1e-5 absolute rounding from the expansion; alpha is still clamped to 0.99).
 // ---------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct MxSplat {           // what lane L holds for splat L of the current 64-chunk
   float K[6];
@@ -372,6 +373,135 @@ template __global__ void composite_forward_mx<4, false>(CamScalars, const float*
 template __global__ void composite_forward_mx<4, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*);
 
 // ---------------------------------------------------------------------------------------------------
+// Forward composite, lane = pixel ("px").  Same bilinear exponent, but from v_mfma_f32_4x4x1_16b_f32 with the A operand
+// broadcast (cbsz = 4, abid = g): all 16 blocks multiply the four splats held by lanes 4g..4g+3 with their own four
+// pixels, so lane L receives the exponents of splats 4g..4g+3 at ITS pixel L -- four MFMAs per rank-1 term give a lane
+// one pixel x 16 splats (same MAC count as the 4-block form above, layout checked by tests/micro/mfma_layout.hip).
+// The transmittance chain then runs inside the lane: no quad exchange, no per-lane selects, no reduction at the end;
+// the per-splat payload is an LDS broadcast read.  A batch of 16 is first composited without the stop test; only if
+// some pixel of the wavefront ends inside it (T(1 - alpha) < 1e-4) is the batch redone with the exact per-splat rule
+// (wave-uniform branch, rare).  Per pixel this is the scalar kernel's recurrence: w = alpha T, C += w c, T' = T - w.
+// ---------------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ f32x4 px_exponents(const float (&K)[6], const float (&Phi)[6]) {
+  f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < 6; ++m) d = __builtin_amdgcn_mfma_f32_4x4x1f32(K[m], Phi[m], d, 4, G, 0);
+  return d;
+}
+
+template <int B, bool DUAL>
+__device__ __forceinline__ void px_forward_batch(float& T, float& Tfin, float (&C)[DUAL ? 6 : 4], const float (&K)[6],
+                                                 const float (&Phi)[6], const float4* __restrict__ lds_pay,
+                                                 const float2* __restrict__ lds_pay2) {
+  constexpr int NC = DUAL ? 6 : 4;
+  const f32x4 d[4] = {px_exponents<4 * B>(K, Phi), px_exponents<4 * B + 1>(K, Phi), px_exponents<4 * B + 2>(K, Phi),
+                      px_exponents<4 * B + 3>(K, Phi)};
+  auto alpha = [&](int k) {
+    const float al = fminf(kAlphaMax, __builtin_amdgcn_exp2f(d[k >> 2][k & 3]));
+    return (al >= kAlphaMin) ? al : 0.f;
+  };
+  // optimistic pass: no stop test
+  float Tn = T, Cn[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) Cn[c] = C[c];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float ak = alpha(k);
+    const float4 py = lds_pay[16 * B + k];                       // same address in every lane: LDS broadcast
+    const float w = ak * Tn;
+    Cn[0] = fmaf(w, py.x, Cn[0]); Cn[1] = fmaf(w, py.y, Cn[1]); Cn[2] = fmaf(w, py.z, Cn[2]); Cn[3] = fmaf(w, py.w, Cn[3]);
+    if constexpr (DUAL) {
+      const float2 p2 = lds_pay2[16 * B + k];
+      Cn[4] = fmaf(w, p2.x, Cn[4]); Cn[5] = fmaf(w, p2.y, Cn[5]);
+    }
+    Tn = Tn - w;                                                 // T (1 - alpha), with the product already at hand
+  }
+  if (__ballot(T > 0.f && Tn < kTStop) == 0ull) {                // nobody ends inside this batch
+    T = Tn;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) C[c] = Cn[c];
+    return;
+  }
+  // exact rule: the first splat with T (1 - alpha) < 1e-4 ends the pixel BEFORE it is added
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float ak = alpha(k);
+    const float wk = ak * T;
+    const float tn = T - wk;                                     // the same expression as in the optimistic pass
+    const bool hit = T > 0.f && ak > 0.f;
+    const bool stop = hit && tn < kTStop;
+    const float4 py = lds_pay[16 * B + k];
+    const float w = (hit && !stop) ? wk : 0.f;
+    C[0] = fmaf(w, py.x, C[0]); C[1] = fmaf(w, py.y, C[1]); C[2] = fmaf(w, py.z, C[2]); C[3] = fmaf(w, py.w, C[3]);
+    if constexpr (DUAL) {
+      const float2 p2 = lds_pay2[16 * B + k];
+      C[4] = fmaf(w, p2.x, C[4]); C[5] = fmaf(w, p2.y, C[5]);
+    }
+    Tfin = stop ? T : Tfin;
+    T = stop ? 0.f : (hit ? tn : T);
+  }
+}
+
+template <int WAVES, bool DUAL>
+__global__ __launch_bounds__(64 * WAVES, 4) void composite_forward_px(
+    CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
+    const uint32_t* __restrict__ tile_cnt, uint32_t tile_cap, const uint32_t* __restrict__ sorted_gid,
+    const GeomRec* __restrict__ geom, const float* __restrict__ colors,
+    float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
+    const Counters* __restrict__ ctr, const float* __restrict__ colors_b, float* __restrict__ out_color_b) {
+  constexpr int NC = DUAL ? 6 : 4;
+  __shared__ float4 lds_pay_all[WAVES][64];
+  __shared__ float2 lds_pay2_all[DUAL ? WAVES : 1][DUAL ? 64 : 1];
+  if (ctr->overflow) return;                                // bins hold unwritten slots after an overflow
+  const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
+  const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
+  const TileCoord tc = tile_coord<WAVES>(cs, nblk, gx16, gx8, gy8);   // lane L <-> pixel L of the tile (x = L&7, y = L>>3)
+  if (!tc.tile_ok) return;
+  const int l = lane_id();
+  const int wv = (WAVES == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float4* lds_pay = lds_pay_all[wv];
+  float2* lds_pay2 = lds_pay2_all[DUAL ? wv : 0];
+  const int tx0 = tc.px - (l & 7), ty0 = tc.py - (l >> 3);
+  const float cx = (float)tx0 + 3.5f, cy = (float)ty0 + 3.5f;
+  const float X = (float)(l & 7) - 3.5f, Y = (float)(l >> 3) - 3.5f;
+  const float Phi[6] = {1.f, X, Y, X * X, X * Y, Y * Y};
+  const uint32_t s = (uint32_t)tc.tile * tile_cap, e = s + min(tile_cnt[tc.tile], tile_cap);
+
+  float T = tc.inside ? 1.f : 0.f, Tfin = 0.f, C[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) C[c] = 0.f;
+  for (uint32_t base = s; base < e; base += 64u) {
+    if (__ballot(T > 0.f) == 0ull) break;
+    const int n = (int)min(64u, e - base);
+    const MxSplat m = mx_gather<DUAL>(sorted_gid, geom, colors, base + (uint32_t)l, l < n, cx, cy, colors_b);
+    lds_pay[l] = m.pay;
+    if (DUAL) lds_pay2[l] = m.pay2;
+    px_forward_batch<0, DUAL>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
+    if (n > 16) px_forward_batch<1, DUAL>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
+    if (n > 32) px_forward_batch<2, DUAL>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
+    if (n > 48) px_forward_batch<3, DUAL>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
+  }
+  const float Tout = (T > 0.f) ? T : Tfin;
+  if (tc.inside) {
+    const size_t P = (size_t)cs.W * cs.H, pix = (size_t)tc.py * cs.W + tc.px;
+    out_color[pix] = C[0] + Tout * bg[0];
+    out_color[P + pix] = C[1] + Tout * bg[1];
+    out_color[2 * P + pix] = C[2] + Tout * bg[2];
+    if constexpr (DUAL) {
+      out_color_b[pix] = C[3] + Tout * bg[0];
+      out_color_b[P + pix] = C[4] + Tout * bg[1];
+      out_color_b[2 * P + pix] = C[5] + Tout * bg[2];
+    } else {
+      out_depth[pix] = C[3];
+    }
+    final_T[pix] = Tout;
+  }
+}
+template __global__ void composite_forward_px<4, false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*);
+template __global__ void composite_forward_px<4, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*);
+
+// ---------------------------------------------------------------------------------------------------
 // Backward composite.  Pixel-major replay produces, per (splat k, pixel p), two scalars:
 //     u_kp = G_kp * dL/dalpha_kp      and      w_kp = alpha_kp * T_kp
 // and the nine per-splat sums are a contraction over the 64 pixels of the tile:
@@ -385,7 +515,6 @@ template __global__ void composite_forward_mx<4, true>(CamScalars, const float*,
 // whole tile.  The tile-local moments are re-centred on the splat in gather_splat_grads (the record carries the
 // tile id), so nothing here depends on the splat position and there is no cross-lane reduction at all.
 // ---------------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kRowStride = 65;
 
 __global__ __launch_bounds__(256) void composite_backward(
