@@ -379,16 +379,16 @@ def test_lds_binning_and_global_atomic_binning_agree(gpu_device, monkeypatch):
 
 
 @pytest.mark.parametrize("scene_name", ["view_tied_dense", "random_aniso"])
-def test_forward_kernel_variants_agree(gpu_device, monkeypatch, scene_name):
-    """The three forward composites -- scalar (0), lane = pixel x splat-quad with chained transmittance (1), lane = pixel
-    with the broadcast 16-block MFMA (2) -- see the same lists in the same order; only float32 grouping differs.  The
-    backward (which replays the list itself) is run on top of each forward's image state."""
+def test_composite_kernel_variants_agree(gpu_device, monkeypatch, scene_name):
+    """The three composite pairs -- scalar (0), lane = pixel x splat-quad with chained transmittance (1), lane = pixel
+    with the broadcast 16-block MFMA (2) -- see the same lists in the same order; only float32 grouping differs."""
     scene, cam = SCENES[scene_name]()
     g = torch.Generator().manual_seed(17)
     grad_color = torch.rand(3, cam.image_height, cam.image_width, generator=g) * 2 - 1
     res = {}
     for impl in ("0", "1", "2"):
         monkeypatch.setenv("VTGS_FWD_IMPL", impl)
+        monkeypatch.setenv("VTGS_BWD_IMPL", impl)
         res[impl] = run_hip(scene, cam, gpu_device, grad_color)
     ref = res["0"]
     for impl in ("1", "2"):

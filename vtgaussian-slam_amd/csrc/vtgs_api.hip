@@ -29,7 +29,7 @@ __global__ void composite_forward_px(CamScalars, const float*, uint32_t, const u
 __global__ void composite_backward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                    const uint32_t*, const GeomRec*, const float*, const float*, const float*,
                                    const float*, float*, const Counters*);
-template <int WAVES, bool DUAL>
+template <int WAVES, bool DUAL, bool PX>
 __global__ void composite_backward_mx(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                       const uint32_t*, const GeomRec*, const float*, const float*, const float*,
                                       const float*, float*, const Counters*, const float*, const float*, const float*);
@@ -342,17 +342,30 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
   const float* state = image_state ? image_state : (const float*)(ws + L.final_T);
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   const uint32_t nblk16 = (uint32_t)(gx16 * rows16);
-  const int bwd_impl = dual ? 1 : env_int("VTGS_BWD_IMPL", 1);   // 1 = matrix-core kernel, 0 = scalar kernel (read per call)
+  int bwd_impl = env_int("VTGS_BWD_IMPL", 2);                // 2 = lane-per-pixel matrix-core replay (default), 1 = pixel x splat-quad replay,
+  if (dual && bwd_impl == 0) bwd_impl = 1;                   // 0 = scalar kernel (single render only); read per call
   {
     ProfScope ps__(dual ? "composite_backward_dual" : "composite_backward", st);
-    if (dual)
-      hipLaunchKernelGGL((composite_backward_mx<4, true>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
+    if (dual && bwd_impl == 2)
+      hipLaunchKernelGGL((composite_backward_mx<4, true, true>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
                          grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), colors_b, out_color_b,
                          grad_color_b);
+    else if (dual)
+      hipLaunchKernelGGL((composite_backward_mx<4, true, false>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
+                         (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
+                         grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), colors_b, out_color_b,
+                         grad_color_b);
+    else if (bwd_impl == 2)                                 // lane = pixel replay
+      hipLaunchKernelGGL((composite_backward_mx<4, false, true>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
+                         (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
+                         grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), (const float*)nullptr,
+                         (const float*)nullptr, (const float*)nullptr);
     else if (bwd_impl == 1)
-      hipLaunchKernelGGL((composite_backward_mx<4, false>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
+      hipLaunchKernelGGL((composite_backward_mx<4, false, false>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
                          grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), (const float*)nullptr,
@@ -373,7 +386,7 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
                          (const Counters*)(ws + L.counters), g_colors_b);
     else
       hipLaunchKernelGGL(gather_splat_grads<false>, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
-                         means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, bwd_impl == 1 ? 1 : 0,
+                         means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, bwd_impl != 0 ? 1 : 0,
                          g_means3D, g_means2D, g_colors, g_opacities, g_scales, g_rotations,
                          (const Counters*)(ws + L.counters), (float*)nullptr);
   }

@@ -803,7 +803,101 @@ __device__ __forceinline__ void mx_backward_batch(MxBwdState<DUAL>& st, const Mx
   }
 }
 
-template <int WAVES, bool DUAL>
+// ---- lane = pixel replay (PX): the backward twin of composite_forward_px -------------------------------------------------
+// Exponents and g.c for the lane's own pixel x 16 splats from the A-broadcast 16-block MFMA; T and the gradient prefix P
+// run inside the lane with the forward's recurrence (w = alpha T, T' = T - w: the stop decisions are the forward's by
+// construction); u' and w go to the same LDS images, so the contraction below is shared with the quad form.  A pixel that
+// has ended carries T = 0 and CB = P, which makes every later u' and w exactly zero without a mask.
+template <int G, bool DUAL>
+__device__ __forceinline__ f32x4 px_gdotc(const MxSplat& m, const float (&g)[DUAL ? 6 : 3]) {
+  f32x4 d = {0.f, 0.f, 0.f, 0.f};
+  d = __builtin_amdgcn_mfma_f32_4x4x1f32(m.pay.x, g[0], d, 4, G, 0);
+  d = __builtin_amdgcn_mfma_f32_4x4x1f32(m.pay.y, g[1], d, 4, G, 0);
+  d = __builtin_amdgcn_mfma_f32_4x4x1f32(m.pay.z, g[2], d, 4, G, 0);
+  if constexpr (DUAL) {
+    d = __builtin_amdgcn_mfma_f32_4x4x1f32(m.pay.w, g[3], d, 4, G, 0);
+    d = __builtin_amdgcn_mfma_f32_4x4x1f32(m.pay2.x, g[4], d, 4, G, 0);
+    d = __builtin_amdgcn_mfma_f32_4x4x1f32(m.pay2.y, g[5], d, 4, G, 0);
+  }
+  return d;
+}
+
+struct PxBwdState { float T, P, CB; };
+
+// One batch of 16 splats for the lane's pixel, in two sweeps so that no per-splat division is needed:
+//   front to back:  alpha_k, w_k = alpha_k T_k (-> LDS), T_{k+1} = T_k - w_k, P_k = P_{k-1} + (g.c_k) w_k
+//   back to front:  A = colour still behind splat k, seen from behind it = (CB - P_k) / T_{k+1}; anchored ONCE per batch at
+//                   its end, then A_{k-1} = A_k + alpha_k (g.c_k - A_k), and
+//                   u'_k = alpha_unclamped_k dL/dalpha_k = G_k T_k (g.c_k - A_k)          (the reference's recurrence)
+// dL/dalpha_k = T_k g.c_k - (CB - P_k)/(1 - alpha_k) is the same thing since (CB - P_k)/(1 - alpha_k) = T_k A_k.
+template <int B, bool DUAL>
+__device__ __forceinline__ void px_backward_batch(PxBwdState& st, const MxSplat& m, const float (&Phi)[6],
+                                                  const float (&gown)[DUAL ? 6 : 3], float* __restrict__ Us,
+                                                  float* __restrict__ Ws, int l) {
+  const f32x4 d[4] = {px_exponents<4 * B>(m.K, Phi), px_exponents<4 * B + 1>(m.K, Phi), px_exponents<4 * B + 2>(m.K, Phi),
+                      px_exponents<4 * B + 3>(m.K, Phi)};
+  const f32x4 gcv[4] = {px_gdotc<4 * B, DUAL>(m, gown), px_gdotc<4 * B + 1, DUAL>(m, gown), px_gdotc<4 * B + 2, DUAL>(m, gown),
+                        px_gdotc<4 * B + 3, DUAL>(m, gown)};
+  float* __restrict__ us = Us + (l >> 4) * kImgQuarter + (l & 15);   // image [pixel quarter][splat][16 px]
+  float* __restrict__ ws = Ws + (l >> 4) * kImgQuarter + (l & 15);
+  float a[16], gT[16];                                         // alpha_k and G_k T_k (0 where the pair contributes nothing)
+  // front to back, optimistic: no stop test
+  float Tn = st.T, Pn = st.P;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float Gp = __builtin_amdgcn_exp2f(d[k >> 2][k & 3]);
+    const float al = fminf(kAlphaMax, Gp);
+    const bool valid = al >= kAlphaMin;
+    a[k] = valid ? al : 0.f;
+    gT[k] = valid ? Gp * Tn : 0.f;                             // the 0.99 clamp passes the gradient through
+    const float w = a[k] * Tn;
+    ws[k * kImgRow] = w;
+    Pn = fmaf(gcv[k >> 2][k & 3], w, Pn);
+    Tn = Tn - w;
+  }
+  float Tanchor = Tn;
+  if (__ballot(st.T > 0.f && Tn < kTStop) != 0ull) {
+    // some pixel of the wavefront ends inside this batch: redo the sweep with the exact rule; from the ending splat on
+    // alpha and G T are zero, so the back sweep passes A through unchanged and writes zeros
+    float T = st.T;
+    Pn = st.P;
+    Tanchor = 0.f;
+    bool ended = false;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float Gp = __builtin_amdgcn_exp2f(d[k >> 2][k & 3]);
+      const float al = fminf(kAlphaMax, Gp);
+      const bool valid = al >= kAlphaMin;
+      const float wk = (valid ? al : 0.f) * T;
+      const float tn = T - wk;
+      const bool hit = T > 0.f && valid;
+      const bool stop = hit && tn < kTStop;
+      const bool live = hit && !stop;
+      a[k] = live ? al : 0.f;
+      gT[k] = live ? Gp * T : 0.f;
+      const float w = live ? wk : 0.f;
+      ws[k * kImgRow] = w;
+      Pn = fmaf(gcv[k >> 2][k & 3], w, Pn);
+      Tanchor = (stop && !ended) ? T : Tanchor;                // transmittance in front of the ending splat
+      ended = ended || stop;
+      T = stop ? 0.f : (T - w);
+    }
+    Tanchor = ended ? Tanchor : T;
+    Tn = T;
+  }
+  // anchor: colour behind the batch (or behind the ending splat) per unit of transmittance there
+  float A = (Tanchor > 0.f) ? (st.CB - Pn) * __builtin_amdgcn_rcpf(Tanchor) : 0.f;
+  st.T = Tn; st.P = Pn;
+  // back to front
+#pragma unroll
+  for (int k = 15; k >= 0; --k) {
+    const float t = gcv[k >> 2][k & 3] - A;
+    us[k * kImgRow] = gT[k] * t;
+    A = fmaf(a[k], t, A);
+  }
+}
+
+template <int WAVES, bool DUAL, bool PXL>
 __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
     const uint32_t* __restrict__ tile_cnt, uint32_t tile_cap, const uint32_t* __restrict__ sorted_gid,
@@ -813,9 +907,11 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     const float* __restrict__ out_color_b, const float* __restrict__ grad_color_b) {
   constexpr int NG = DUAL ? 6 : 3;                            // image-gradient channels
   constexpr int REC = DUAL ? kGradRecDual : kGradRec;         // floats per (splat, tile) record
-  __shared__ float4 lds_xch_all[WAVES][128];
+  __shared__ float4 lds_xch_all[WAVES][PXL ? 1 : 128];
   __shared__ __attribute__((aligned(16))) float lds_uw[WAVES][2][kImgFloats];
   __shared__ __attribute__((aligned(16))) float lds_phi[4 * kPhiQuarter];
+  // dual render: the contraction's dL/dcolor operands live in LDS ([wave][second set?][quarter][column][16 + 4]), not in 32 VGPRs
+  __shared__ __attribute__((aligned(16))) float lds_g_all[DUAL ? WAVES : 1][DUAL ? 2 * 16 * kImgRow : 4];
   if (ctr->overflow) return;                                  // uniform over the grid
   // Phi table for the contraction's B operands: [pixel quarter][column 0..7][pixel 0..15 (+4 pad)], columns 6,7 = 0
   for (int i = (int)threadIdx.x; i < 4 * kPhiQuarter; i += 64 * WAVES) {
@@ -848,8 +944,22 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
 
   MxBwdState<DUAL> st;
+  PxBwdState ps{tc.inside ? 1.f : 0.f, 0.f, 0.f};
+  if (PXL && tc.inside) {                                        // lane L <-> pixel L
+    const size_t pix = (size_t)tc.py * cs.W + tc.px;
+    const float g0 = grad_color[pix], g1 = grad_color[P + pix], g2 = grad_color[2 * P + pix];
+    const float Tf = final_T[pix];
+    ps.CB = g0 * (out_color[pix] - Tf * b0) + g1 * (out_color[P + pix] - Tf * b1) + g2 * (out_color[2 * P + pix] - Tf * b2)
+            + Tf * (g0 * b0 + g1 * b1 + g2 * b2);
+    if constexpr (DUAL) {
+      const float g3 = grad_color_b[pix], g4 = grad_color_b[P + pix], g5 = grad_color_b[2 * P + pix];
+      ps.CB += g3 * (out_color_b[pix] - Tf * b0) + g4 * (out_color_b[P + pix] - Tf * b1) + g5 * (out_color_b[2 * P + pix] - Tf * b2)
+               + Tf * (g3 * b0 + g4 * b1 + g5 * b2);
+    }
+  }
 #pragma unroll
   for (int blk = 0; blk < 4; ++blk) {
+    if (PXL) break;
     const int p = 16 * blk + j;
     const int qx = tx0 + (p & 7), qy = ty0 + (p >> 3);
     const bool in_img = qx < cs.W && qy < cs.H;
@@ -879,17 +989,23 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   // Contraction roles: l = cj + 4 sg + 16 pq -- column cj of every group, splat group sg, pixel quarter pq.
   // A operand: row (l & 3) of block (sg, pq) = splat 4 sg + (l & 3) = image row (l & 15); B operand: column cj.
   const int cj = l & 3, pq = q;
-  float Bg[16];                                               // dL/dcolor channel cj at the quarter's 16 pixels (cj = 3: 0)
-  float Bg2[DUAL ? 16 : 1];
+  float Bg[DUAL ? 1 : 16];                                    // dL/dcolor channel cj at the quarter's 16 pixels (cj = 3: 0)
+  float* lds_g = lds_g_all[DUAL ? wv : 0];                    // dual: row (pq, cj) of set a at [(4 pq + cj) * kImgRow], set b 320 floats on
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     const int p = 16 * pq + t;
     const int qx = tx0 + (p & 7), qy = ty0 + (p >> 3);
     const bool ok = cj < 3 && qx < cs.W && qy < cs.H;
     const size_t pix = (size_t)cj * P + (size_t)qy * cs.W + qx;
-    Bg[t] = ok ? grad_color[pix] : 0.f;
-    if constexpr (DUAL) Bg2[t] = ok ? grad_color_b[pix] : 0.f;
+    if constexpr (DUAL) {                                     // (the four splat groups write the same values)
+      lds_g[(4 * pq + cj) * kImgRow + t] = ok ? grad_color[pix] : 0.f;
+      lds_g[16 * kImgRow + (4 * pq + cj) * kImgRow + t] = ok ? grad_color_b[pix] : 0.f;
+    } else {
+      Bg[t] = ok ? grad_color[pix] : 0.f;
+    }
   }
+  const float4* __restrict__ Ga4 = reinterpret_cast<const float4*>(lds_g + (4 * pq + cj) * kImgRow);
+  const float4* __restrict__ Gb4 = reinterpret_cast<const float4*>(lds_g + 16 * kImgRow + (4 * pq + cj) * kImgRow);
   const float4* Ua4 = reinterpret_cast<const float4*>(Us + pq * kImgQuarter + (l & 15) * kImgRow);   // alias Us / Ws: no restrict
   const float4* Wa4 = reinterpret_cast<const float4*>(Ws + pq * kImgQuarter + (l & 15) * kImgRow);
   const float4* __restrict__ PhiA4 = reinterpret_cast<const float4*>(lds_phi + pq * kPhiQuarter + cj * kImgRow);
@@ -903,7 +1019,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
 
   uint32_t base = s;
   for (; base < e; base += 64u) {
-    const bool alive = st.Tb[0].x > 0.f || st.Tb[0].y > 0.f || st.Tb[1].x > 0.f || st.Tb[1].y > 0.f;
+    const bool alive = PXL ? ps.T > 0.f : (st.Tb[0].x > 0.f || st.Tb[0].y > 0.f || st.Tb[1].x > 0.f || st.Tb[1].y > 0.f);
     if (__ballot(alive) == 0ull) break;
     const int n = (int)min(64u, e - base);
     const MxSplat m = mx_gather<DUAL>(sorted_gid, geom, colors, base + (uint32_t)l, l < n, cx, cy, colors_b);
@@ -911,10 +1027,17 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       if (16 * b >= n) break;                                 // wave-uniform
-      if (b == 0) mx_backward_batch<0, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
-      if (b == 1) mx_backward_batch<1, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
-      if (b == 2) mx_backward_batch<2, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
-      if (b == 3) mx_backward_batch<3, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
+      if constexpr (PXL) {
+        if (b == 0) px_backward_batch<0, DUAL>(ps, m, Phi, st.gown, Us, Ws, l);
+        if (b == 1) px_backward_batch<1, DUAL>(ps, m, Phi, st.gown, Us, Ws, l);
+        if (b == 2) px_backward_batch<2, DUAL>(ps, m, Phi, st.gown, Us, Ws, l);
+        if (b == 3) px_backward_batch<3, DUAL>(ps, m, Phi, st.gown, Us, Ws, l);
+      } else {
+        if (b == 0) mx_backward_batch<0, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
+        if (b == 1) mx_backward_batch<1, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
+        if (b == 2) mx_backward_batch<2, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
+        if (b == 3) mx_backward_batch<3, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
+      }
       const int nb = min(16, n - 16 * b);
       f32x4 Pa = {0.f, 0.f, 0.f, 0.f}, Pb = {0.f, 0.f, 0.f, 0.f}, Pw = {0.f, 0.f, 0.f, 0.f}, Pw2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -922,12 +1045,21 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
         const float4 ua = Ua4[t4], wa = Wa4[t4], ba = PhiA4[t4], bb = PhiB4[t4];
         const float uav[4] = {ua.x, ua.y, ua.z, ua.w}, wav[4] = {wa.x, wa.y, wa.z, wa.w};
         const float bav[4] = {ba.x, ba.y, ba.z, ba.w}, bbv[4] = {bb.x, bb.y, bb.z, bb.w};
+        float gav[4], gbv[4];
+        if constexpr (DUAL) {
+          const float4 ga = Ga4[t4], gb = Gb4[t4];
+          gav[0] = ga.x; gav[1] = ga.y; gav[2] = ga.z; gav[3] = ga.w;
+          gbv[0] = gb.x; gbv[1] = gb.y; gbv[2] = gb.z; gbv[3] = gb.w;
+        } else {
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) { gav[e4] = Bg[4 * t4 + e4]; gbv[e4] = 0.f; }
+        }
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
           Pa = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bav[e4], Pa, 0, 0, 0);
           Pb = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bbv[e4], Pb, 0, 0, 0);
-          Pw = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], Bg[4 * t4 + e4], Pw, 0, 0, 0);
-          if constexpr (DUAL) Pw2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], Bg2[4 * t4 + e4], Pw2, 0, 0, 0);
+          Pw = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], gav[e4], Pw, 0, 0, 0);
+          if constexpr (DUAL) Pw2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], gbv[e4], Pw2, 0, 0, 0);
         }
       }
       // lane (cj, sg, rho = l >> 4) ends up with the totals of splat 4 sg + rho
@@ -959,8 +1091,10 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     }
   }
 }
-template __global__ void composite_backward_mx<4, false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*);
-template __global__ void composite_backward_mx<4, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*);
+template __global__ void composite_backward_mx<4, false, false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*);
+template __global__ void composite_backward_mx<4, true, false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*);
+template __global__ void composite_backward_mx<4, false, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*);
+template __global__ void composite_backward_mx<4, true, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*);
 
 // one thread per Gaussian: re-centre and sum its instance records (fixed order), then the projection backward
 template <bool DUAL>
