@@ -12,7 +12,7 @@ tag = sys.argv[1]
 
 
 def kname(full):
-    return full.replace("void ", "").split("(")[0].replace("vtgs::", "").split("<")[0].replace("_mx", "")
+    return full.replace("void ", "").split("(")[0].replace("vtgs::", "").split("<")[0].replace("_mx", "").replace("_px", "")
 
 
 def find(dirname, suffix):
