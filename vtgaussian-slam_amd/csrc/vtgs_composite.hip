@@ -155,7 +155,12 @@ struct MxSplat {           // what lane L holds for splat L of the current 64-ch
   float K[6];
   float4 pay;              // c0 c1 c2 depth          (dual render: c0 c1 c2 c3)
   float2 pay2;             //                          (dual render: c4 c5)
+  bool hot;                // opacity above kClampGuard: alpha of this splat can reach the 0.99 clamp
 };
+// log2(alpha) = log2(o) - (a non-negative quadratic form, up to ~1e-5 of rounding): with o <= 0.98 the min(0.99, .) never
+// binds.  A chunk without hot splats takes the clamp-free sweeps below (one instruction less per pair in the forward, four
+// in the backward, where alpha_unclamped T == alpha T == w).
+constexpr float kClampGuard = 0.98f;
 
 // DUAL: two renders over the same geometry in one pass -- the second render's colours ride along
 // as channels 3..5; the depth image (which the fused caller discards) is not produced.
@@ -167,6 +172,7 @@ __device__ __forceinline__ MxSplat mx_gather(const uint32_t* __restrict__ sorted
   m.K[0] = -1e30f; m.K[1] = m.K[2] = m.K[3] = m.K[4] = m.K[5] = 0.f;
   m.pay = make_float4(0.f, 0.f, 0.f, 0.f);
   m.pay2 = make_float2(0.f, 0.f);
+  m.hot = false;
   if (in) {
     const uint32_t gid = sorted_gid[pos];
     const float4* gp = reinterpret_cast<const float4*>(geom + gid);
@@ -177,6 +183,7 @@ __device__ __forceinline__ MxSplat mx_gather(const uint32_t* __restrict__ sorted
     m.K[1] = -2.f * qa * sx - qb * sy;
     m.K[2] = -2.f * qc * sy - qb * sx;
     m.K[3] = qa; m.K[4] = qb; m.K[5] = qc;
+    m.hot = g1.y > kClampGuard;
     m.pay = make_float4(colors[3 * gid], colors[3 * gid + 1], colors[3 * gid + 2], DUAL ? colors_b[3 * gid] : g1.z);
     if (DUAL) m.pay2 = make_float2(colors_b[3 * gid + 1], colors_b[3 * gid + 2]);
   }
@@ -390,7 +397,7 @@ __device__ __forceinline__ f32x4 px_exponents(const float (&K)[6], const float (
   return d;
 }
 
-template <int B, bool DUAL>
+template <int B, bool DUAL, bool CLAMP>
 __device__ __forceinline__ void px_forward_batch(float& T, float& Tfin, float (&C)[DUAL ? 6 : 4], const float (&K)[6],
                                                  const float (&Phi)[6], const float4* __restrict__ lds_pay,
                                                  const float2* __restrict__ lds_pay2) {
@@ -401,13 +408,17 @@ __device__ __forceinline__ void px_forward_batch(float& T, float& Tfin, float (&
     const float al = fminf(kAlphaMax, __builtin_amdgcn_exp2f(d[k >> 2][k & 3]));
     return (al >= kAlphaMin) ? al : 0.f;
   };
+  auto alpha_noclamp = [&](int k) {                            // CLAMP == false: no splat of the chunk can reach 0.99
+    const float al = __builtin_amdgcn_exp2f(d[k >> 2][k & 3]);
+    return (al >= kAlphaMin) ? al : 0.f;
+  };
   // optimistic pass: no stop test
   float Tn = T, Cn[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) Cn[c] = C[c];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const float ak = alpha(k);
+    const float ak = CLAMP ? alpha(k) : alpha_noclamp(k);
     const float4 py = lds_pay[16 * B + k];                       // same address in every lane: LDS broadcast
     const float w = ak * Tn;
     Cn[0] = fmaf(w, py.x, Cn[0]); Cn[1] = fmaf(w, py.y, Cn[1]); Cn[2] = fmaf(w, py.z, Cn[2]); Cn[3] = fmaf(w, py.w, Cn[3]);
@@ -444,7 +455,7 @@ __device__ __forceinline__ void px_forward_batch(float& T, float& Tfin, float (&
 }
 
 template <int WAVES, bool DUAL>
-__global__ __launch_bounds__(64 * WAVES, 4) void composite_forward_px(
+__global__ __launch_bounds__(64 * WAVES, 3) void composite_forward_px(
     CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
     const uint32_t* __restrict__ tile_cnt, uint32_t tile_cap, const uint32_t* __restrict__ sorted_gid,
     const GeomRec* __restrict__ geom, const float* __restrict__ colors,
@@ -477,10 +488,17 @@ __global__ __launch_bounds__(64 * WAVES, 4) void composite_forward_px(
     const MxSplat m = mx_gather<DUAL>(sorted_gid, geom, colors, base + (uint32_t)l, l < n, cx, cy, colors_b);
     lds_pay[l] = m.pay;
     if (DUAL) lds_pay2[l] = m.pay2;
-    px_forward_batch<0, DUAL>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
-    if (n > 16) px_forward_batch<1, DUAL>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
-    if (n > 32) px_forward_batch<2, DUAL>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
-    if (n > 48) px_forward_batch<3, DUAL>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
+    if (__ballot(m.hot) != 0ull) {                            // wave-uniform: some splat of the chunk may hit the clamp
+      px_forward_batch<0, DUAL, true>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
+      if (n > 16) px_forward_batch<1, DUAL, true>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
+      if (n > 32) px_forward_batch<2, DUAL, true>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
+      if (n > 48) px_forward_batch<3, DUAL, true>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
+    } else {
+      px_forward_batch<0, DUAL, false>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
+      if (n > 16) px_forward_batch<1, DUAL, false>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
+      if (n > 32) px_forward_batch<2, DUAL, false>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
+      if (n > 48) px_forward_batch<3, DUAL, false>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
+    }
   }
   const float Tout = (T > 0.f) ? T : Tfin;
   if (tc.inside) {
@@ -830,7 +848,7 @@ struct PxBwdState { float T, P, CB; };
 //                   its end, then A_{k-1} = A_k + alpha_k (g.c_k - A_k), and
 //                   u'_k = alpha_unclamped_k dL/dalpha_k = G_k T_k (g.c_k - A_k)          (the reference's recurrence)
 // dL/dalpha_k = T_k g.c_k - (CB - P_k)/(1 - alpha_k) is the same thing since (CB - P_k)/(1 - alpha_k) = T_k A_k.
-template <int B, bool DUAL>
+template <int B, bool DUAL, bool CLAMP>
 __device__ __forceinline__ void px_backward_batch(PxBwdState& st, const MxSplat& m, const float (&Phi)[6],
                                                   const float (&gown)[DUAL ? 6 : 3], float* __restrict__ Us,
                                                   float* __restrict__ Ws, int l) {
@@ -846,11 +864,18 @@ __device__ __forceinline__ void px_backward_batch(PxBwdState& st, const MxSplat&
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const float Gp = __builtin_amdgcn_exp2f(d[k >> 2][k & 3]);
-    const float al = fminf(kAlphaMax, Gp);
-    const bool valid = al >= kAlphaMin;
-    a[k] = valid ? al : 0.f;
-    gT[k] = valid ? Gp * Tn : 0.f;                             // the 0.99 clamp passes the gradient through
-    const float w = a[k] * Tn;
+    float w;
+    if constexpr (CLAMP) {
+      const float al = fminf(kAlphaMax, Gp);
+      const bool valid = al >= kAlphaMin;
+      a[k] = valid ? al : 0.f;
+      gT[k] = valid ? Gp * Tn : 0.f;                           // the 0.99 clamp passes the gradient through
+      w = a[k] * Tn;
+    } else {                                                   // no clamp possible in this chunk: alpha == alpha_unclamped
+      a[k] = (Gp >= kAlphaMin) ? Gp : 0.f;
+      w = a[k] * Tn;
+      gT[k] = w;
+    }
     ws[k * kImgRow] = w;
     Pn = fmaf(gcv[k >> 2][k & 3], w, Pn);
     Tn = Tn - w;
@@ -1024,14 +1049,22 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     const int n = (int)min(64u, e - base);
     const MxSplat m = mx_gather<DUAL>(sorted_gid, geom, colors, base + (uint32_t)l, l < n, cx, cy, colors_b);
     const uint32_t my_inst = (l < n) ? sorted_inst[base + (uint32_t)l] : 0u;
+    const bool hot = __ballot(m.hot) != 0ull;                 // wave-uniform: some splat of the chunk may hit the 0.99 clamp
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       if (16 * b >= n) break;                                 // wave-uniform
       if constexpr (PXL) {
-        if (b == 0) px_backward_batch<0, DUAL>(ps, m, Phi, st.gown, Us, Ws, l);
-        if (b == 1) px_backward_batch<1, DUAL>(ps, m, Phi, st.gown, Us, Ws, l);
-        if (b == 2) px_backward_batch<2, DUAL>(ps, m, Phi, st.gown, Us, Ws, l);
-        if (b == 3) px_backward_batch<3, DUAL>(ps, m, Phi, st.gown, Us, Ws, l);
+        if (hot) {
+          if (b == 0) px_backward_batch<0, DUAL, true>(ps, m, Phi, st.gown, Us, Ws, l);
+          if (b == 1) px_backward_batch<1, DUAL, true>(ps, m, Phi, st.gown, Us, Ws, l);
+          if (b == 2) px_backward_batch<2, DUAL, true>(ps, m, Phi, st.gown, Us, Ws, l);
+          if (b == 3) px_backward_batch<3, DUAL, true>(ps, m, Phi, st.gown, Us, Ws, l);
+        } else {
+          if (b == 0) px_backward_batch<0, DUAL, false>(ps, m, Phi, st.gown, Us, Ws, l);
+          if (b == 1) px_backward_batch<1, DUAL, false>(ps, m, Phi, st.gown, Us, Ws, l);
+          if (b == 2) px_backward_batch<2, DUAL, false>(ps, m, Phi, st.gown, Us, Ws, l);
+          if (b == 3) px_backward_batch<3, DUAL, false>(ps, m, Phi, st.gown, Us, Ws, l);
+        }
       } else {
         if (b == 0) mx_backward_batch<0, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
         if (b == 1) mx_backward_batch<1, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
