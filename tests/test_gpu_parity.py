@@ -401,3 +401,20 @@ def test_composite_kernel_variants_agree(gpu_device, monkeypatch, scene_name):
                 continue                                       # isotropic: float noise around zero
             mx, p999 = grad_error(ref[3][k], got[3][k])
             assert mx <= 1e-3 and p999 <= 1e-3, (impl, k, mx, p999)
+
+
+def test_packed_key_sort_matches_the_key_value_sort(gpu_device, monkeypatch):
+    """sort_tiles with the payload packed into the key's low bits (N <= 2^21) vs the key + value network
+    (VTGS_SORT_PACKED=0): identical lists, hence bit-identical outputs; equal depths are present (quantised z)."""
+    scene, cam = go.view_tied_scene(40000, 200, 136, seed=23)
+    scene["means3D"][:, 2] = (scene["means3D"][:, 2] * 8).round() / 8       # many exact depth ties -> the id breaks them
+    g = torch.Generator().manual_seed(3)
+    grad_color = torch.rand(3, cam.image_height, cam.image_width, generator=g) * 2 - 1
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VTGS_SORT_PACKED", mode)
+        res[mode] = run_hip(scene, cam, gpu_device, grad_color)
+    for a, b in zip(res["1"][:3], res["0"][:3]):
+        assert torch.equal(a, b)
+    for k in GRAD_KEYS:
+        assert torch.equal(res["1"][3][k], res["0"][3][k]), k

@@ -15,7 +15,7 @@ __global__ void project_and_bin(CamScalars, const float*, const float*, int, con
 __global__ void finalize_forward(const uint32_t*, uint32_t, Counters*, unsigned long long, uint32_t, const BlockStats*,
                                  uint32_t, VtgsForwardInfo*);
 __global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t,
-                           const Counters*);
+                           const Counters*, int);
 __global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                   const GeomRec*, const float*, float*, float*, float*, const Counters*);
 template <int WAVES, bool DUAL>
@@ -260,7 +260,8 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
 
   { ProfScope ps__("sort_tiles", st); hipLaunchKernelGGL(sort_tiles, dim3((L.tiles8 + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
                      (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
-                     (uint32_t*)(ws + L.sorted_inst), L.tiles8, L.tile_cap, (const Counters*)ctr); }
+                     (uint32_t*)(ws + L.sorted_inst), L.tiles8, L.tile_cap, (const Counters*)ctr,
+                     (n <= (1 << 21) && env_int("VTGS_SORT_PACKED", 1) == 1) ? 1 : 0); }
   VTGS_HIP(hipGetLastError());
   int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st,
                                     dual ? colors_b : nullptr, dual ? out_color_b : nullptr);

@@ -321,7 +321,8 @@ __global__ __launch_bounds__(1024) void finalize_forward(const uint32_t* __restr
 constexpr int kSortLds = 2048;
 constexpr int kWaveSortMax = 1024;
 
-template <int E>
+// HASV = false sorts the keys alone (the payload travels in their low bits, see wave_sort_tile): a third less to move.
+template <int E, bool HASV>
 __device__ __forceinline__ void wave_sort_regs(unsigned long long (&k)[E], uint32_t (&v)[E], int lane) {
 #pragma unroll
   for (int k2 = 2; k2 <= 64 * E; k2 <<= 1) {
@@ -334,7 +335,8 @@ __device__ __forceinline__ void wave_sort_regs(unsigned long long (&k)[E], uint3
           const bool sw = k[r] > k[p];
           const unsigned long long a = k[r], b = k[p];
           const uint32_t va = v[r], vb = v[p];
-          k[r] = sw ? b : a; k[p] = sw ? a : b; v[r] = sw ? vb : va; v[p] = sw ? va : vb;
+          k[r] = sw ? b : a; k[p] = sw ? a : b;
+          if (HASV) { v[r] = sw ? vb : va; v[p] = sw ? va : vb; }
         }
       }
     } else {
@@ -344,12 +346,13 @@ __device__ __forceinline__ void wave_sort_regs(unsigned long long (&k)[E], uint3
 #pragma unroll
       for (int r = 0; r < E; ++r) {
         pk[r] = (unsigned long long)__shfl_xor((long long)k[E - 1 - r], M, 64);
-        pv[r] = (uint32_t)__shfl_xor((int)v[E - 1 - r], M, 64);
+        pv[r] = HASV ? (uint32_t)__shfl_xor((int)v[E - 1 - r], M, 64) : 0u;
       }
 #pragma unroll
       for (int r = 0; r < E; ++r) {
         const bool take = lower ? (pk[r] < k[r]) : (pk[r] > k[r]);
-        k[r] = take ? pk[r] : k[r]; v[r] = take ? pv[r] : v[r];
+        k[r] = take ? pk[r] : k[r];
+        if (HASV) v[r] = take ? pv[r] : v[r];
       }
     }
     // ---- half-cleaners: partner = e ^ j
@@ -363,7 +366,8 @@ __device__ __forceinline__ void wave_sort_regs(unsigned long long (&k)[E], uint3
             const bool sw = k[r] > k[p];
             const unsigned long long a = k[r], b = k[p];
             const uint32_t va = v[r], vb = v[p];
-            k[r] = sw ? b : a; k[p] = sw ? a : b; v[r] = sw ? vb : va; v[p] = sw ? va : vb;
+            k[r] = sw ? b : a; k[p] = sw ? a : b;
+          if (HASV) { v[r] = sw ? vb : va; v[p] = sw ? va : vb; }
           }
         }
       } else {
@@ -372,16 +376,21 @@ __device__ __forceinline__ void wave_sort_regs(unsigned long long (&k)[E], uint3
 #pragma unroll
         for (int r = 0; r < E; ++r) {
           const unsigned long long pk = (unsigned long long)__shfl_xor((long long)k[r], m, 64);
-          const uint32_t pv = (uint32_t)__shfl_xor((int)v[r], m, 64);
+          const uint32_t pv = HASV ? (uint32_t)__shfl_xor((int)v[r], m, 64) : 0u;
           const bool take = lower ? (pk < k[r]) : (pk > k[r]);
-          k[r] = take ? pk : k[r]; v[r] = take ? pv : v[r];
+          k[r] = take ? pk : k[r];
+          if (HASV) v[r] = take ? pv : v[r];
         }
       }
     }
   }
 }
 
-template <int E>
+// PACKED (Gaussian ids below 2^21, list positions below 2^11 -- the host decides): the low key word becomes
+// (gid << 11 | bin slot); the order (depth, gid) is unchanged, the instance id is fetched from its slot afterwards.
+constexpr uint32_t kSlotBits = 11u, kPackedGidLimit = 1u << 21;
+
+template <int E, bool PACKED>
 __device__ __forceinline__ void wave_sort_tile(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                uint32_t* __restrict__ sorted_gid, uint32_t* __restrict__ sorted_inst,
                                                uint32_t s, uint32_t L, int lane) {
@@ -390,13 +399,26 @@ __device__ __forceinline__ void wave_sort_tile(const unsigned long long* __restr
   for (int r = 0; r < E; ++r) {
     const uint32_t e = (uint32_t)lane * E + r;
     k[r] = (e < L) ? keys[s + e] : ~0ull;
-    v[r] = (e < L) ? vals[s + e] : 0u;
+    if (PACKED) {
+      if (e < L) k[r] = (k[r] & 0xFFFFFFFF00000000ull) | (unsigned long long)((((uint32_t)k[r]) << kSlotBits) | e);
+      v[r] = 0u;
+    } else {
+      v[r] = (e < L) ? vals[s + e] : 0u;
+    }
   }
-  wave_sort_regs<E>(k, v, lane);
+  wave_sort_regs<E, !PACKED>(k, v, lane);
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     const uint32_t e = (uint32_t)lane * E + r;
-    if (e < L) { sorted_gid[s + e] = (uint32_t)k[r]; sorted_inst[s + e] = v[r]; }
+    if (e < L) {
+      if (PACKED) {
+        const uint32_t lo = (uint32_t)k[r];
+        sorted_gid[s + e] = lo >> kSlotBits;
+        sorted_inst[s + e] = vals[s + (lo & ((1u << kSlotBits) - 1u))];
+      } else {
+        sorted_gid[s + e] = (uint32_t)k[r]; sorted_inst[s + e] = v[r];
+      }
+    }
   }
 }
 
@@ -432,7 +454,7 @@ __device__ __forceinline__ void sort_network(unsigned long long* k, uint32_t* v,
 __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ tile_cnt, unsigned long long* __restrict__ keys,
                                                   uint32_t* __restrict__ vals, uint32_t* __restrict__ sorted_gid,
                                                   uint32_t* __restrict__ sorted_inst, uint32_t tiles, uint32_t tile_cap,
-                                                  const Counters* __restrict__ ctr) {
+                                                  const Counters* __restrict__ ctr, int packed) {
   __shared__ unsigned long long sk[kSortLds];
   __shared__ uint32_t sv[kSortLds];
   if (ctr->overflow) return;                    // some bin slots were never written: nothing valid to sort
@@ -446,12 +468,19 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
       const uint32_t s = tile * tile_cap, L = min(tile_cnt[tile], tile_cap);
       if (L == 1u) {
         if (lane == 0) { sorted_gid[s] = (uint32_t)keys[s]; sorted_inst[s] = vals[s]; }
-      } else if (L <= 64u) {
-        if (L) wave_sort_tile<1>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
-      } else if (L <= 128u) wave_sort_tile<2>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
-      else if (L <= 256u) wave_sort_tile<4>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
-      else if (L <= 512u) wave_sort_tile<8>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
-      else if (L <= (uint32_t)kWaveSortMax) wave_sort_tile<16>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
+      } else if (packed) {
+        if (L <= 64u) { if (L) wave_sort_tile<1, true>(keys, vals, sorted_gid, sorted_inst, s, L, lane); }
+        else if (L <= 128u) wave_sort_tile<2, true>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
+        else if (L <= 256u) wave_sort_tile<4, true>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
+        else if (L <= 512u) wave_sort_tile<8, true>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
+        else if (L <= (uint32_t)kWaveSortMax) wave_sort_tile<16, true>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
+      } else {
+        if (L <= 64u) { if (L) wave_sort_tile<1, false>(keys, vals, sorted_gid, sorted_inst, s, L, lane); }
+        else if (L <= 128u) wave_sort_tile<2, false>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
+        else if (L <= 256u) wave_sort_tile<4, false>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
+        else if (L <= 512u) wave_sort_tile<8, false>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
+        else if (L <= (uint32_t)kWaveSortMax) wave_sort_tile<16, false>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
+      }
     }
   }
   // long lists: the whole workgroup takes them one at a time (workgroup-uniform control flow)
