@@ -139,7 +139,21 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
   if (vis && op * 255.f >= 1.f) { tau = logf(255.f * op); tau += 1e-4f * tau + 1e-4f; }
   const bool reach = vis && tau >= 0.f;
   const ReachForm rf = make_reach_form(sp);
-  const TileWalk w = make_walk(cam, sp, reach);
+  TileWalk w = make_walk(cam, sp, reach);
+  if (reach && rf.regular) {
+    // shrink the walk to the tiles under the bounding box of the alpha >= 1/255 ellipse (half-widths sqrt(2 tau C / det),
+    // sqrt(2 tau A / det); tau carries the slack): a few-pixel splat then tests ~4 candidates instead of the 16 under its
+    // 16x16-tile rectangle.  The exact test below still decides; the box only removes tiles it cannot pass.
+    const float idet = 1.f / fmaxf(sp.A * sp.C - sp.B * sp.B, 1e-30f);
+    const float hx = sqrtf(2.f * tau * sp.C * idet), hy = sqrtf(2.f * tau * sp.A * idet);
+    const float inv8 = 1.f / (float)kSubTile;
+    const int bx0 = (int)ceilf((sp.u - hx - (float)(kSubTile - 1)) * inv8), bx1 = (int)floorf((sp.u + hx) * inv8);
+    const int by0 = (int)ceilf((sp.v - hy - (float)(kSubTile - 1)) * inv8), by1 = (int)floorf((sp.v + hy) * inv8);
+    const int x0 = max(w.cx0, bx0), x1 = min(w.cx0 + w.cw, bx1 + 1);
+    const int y0 = max(w.cy0, by0), y1 = min(w.cy0 + w.ch, by1 + 1);
+    if (x1 > x0 && y1 > y0) { w.cx0 = x0; w.cy0 = y0; w.cw = x1 - x0; w.ch = y1 - y0; }
+    else { w.cw = 0; w.ch = 0; }
+  }
   const int area = w.cw * w.ch;
 
   // pass 1: which candidate tiles does this splat really reach (remembered as a bitmask for the first 64)
