@@ -389,6 +389,8 @@ template __global__ void composite_forward_mx<4, true>(CamScalars, const float*,
 // some pixel of the wavefront ends inside it (T(1 - alpha) < 1e-4) is the batch redone with the exact per-splat rule
 // (wave-uniform branch, rare).  Per pixel this is the scalar kernel's recurrence: w = alpha T, C += w c, T' = T - w.
 // ---------------------------------------------------------------------------------------------------
+constexpr int kExactFirstEndings = 3;   // pixels (of 64) ending in a batch that make the next batch skip the optimistic sweep
+
 template <int G>
 __device__ __forceinline__ f32x4 px_exponents(const float (&K)[6], const float (&Phi)[6]) {
   f32x4 d = {0.f, 0.f, 0.f, 0.f};
@@ -397,61 +399,70 @@ __device__ __forceinline__ f32x4 px_exponents(const float (&K)[6], const float (
   return d;
 }
 
-template <int B, bool DUAL, bool CLAMP>
-__device__ __forceinline__ void px_forward_batch(float& T, float& Tfin, float (&C)[DUAL ? 6 : 4], const float (&K)[6],
-                                                 const float (&Phi)[6], const float4* __restrict__ lds_pay,
-                                                 const float2* __restrict__ lds_pay2) {
+// State of a pixel: T = transmittance in front of the next splat, FROZEN once the pixel has ended (then it is the value
+// the reference reports as final T: the transmittance in front of the ending splat); `done` marks ended / off-image pixels.
+// `exact` (wave-uniform): after a batch in which several pixels ended, the next batch goes straight to the exact sweep, and
+// keeps doing so while pixels keep ending -- in saturating scenes they end batch after batch, and optimistic-then-redo
+// would cost more; where endings are sparse the optimistic sweep stays the first choice.
+template <int B, bool DUAL, bool CLAMP, bool EXACT_FIRST>
+__device__ __forceinline__ void px_forward_batch(float& T, bool& done, bool& exact, float (&C)[DUAL ? 6 : 4],
+                                                 const float (&K)[6], const float (&Phi)[6],
+                                                 const float4* __restrict__ lds_pay, const float2* __restrict__ lds_pay2) {
   constexpr int NC = DUAL ? 6 : 4;
   const f32x4 d[4] = {px_exponents<4 * B>(K, Phi), px_exponents<4 * B + 1>(K, Phi), px_exponents<4 * B + 2>(K, Phi),
                       px_exponents<4 * B + 3>(K, Phi)};
   auto alpha = [&](int k) {
-    const float al = fminf(kAlphaMax, __builtin_amdgcn_exp2f(d[k >> 2][k & 3]));
+    const float g = __builtin_amdgcn_exp2f(d[k >> 2][k & 3]);
+    const float al = CLAMP ? fminf(kAlphaMax, g) : g;           // CLAMP == false: no splat of the chunk can reach 0.99
     return (al >= kAlphaMin) ? al : 0.f;
   };
-  auto alpha_noclamp = [&](int k) {                            // CLAMP == false: no splat of the chunk can reach 0.99
-    const float al = __builtin_amdgcn_exp2f(d[k >> 2][k & 3]);
-    return (al >= kAlphaMin) ? al : 0.f;
-  };
-  // optimistic pass: no stop test
-  float Tn = T, Cn[NC];
+  if constexpr (!EXACT_FIRST) {
+    // optimistic sweep: no stop test
+    float Tn = done ? 0.f : T, Cn[NC];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) Cn[c] = C[c];
+    for (int c = 0; c < NC; ++c) Cn[c] = C[c];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const float ak = CLAMP ? alpha(k) : alpha_noclamp(k);
-    const float4 py = lds_pay[16 * B + k];                       // same address in every lane: LDS broadcast
-    const float w = ak * Tn;
-    Cn[0] = fmaf(w, py.x, Cn[0]); Cn[1] = fmaf(w, py.y, Cn[1]); Cn[2] = fmaf(w, py.z, Cn[2]); Cn[3] = fmaf(w, py.w, Cn[3]);
-    if constexpr (DUAL) {
-      const float2 p2 = lds_pay2[16 * B + k];
-      Cn[4] = fmaf(w, p2.x, Cn[4]); Cn[5] = fmaf(w, p2.y, Cn[5]);
+    for (int k = 0; k < 16; ++k) {
+      const float ak = alpha(k);
+      const float4 py = lds_pay[16 * B + k];                     // same address in every lane: LDS broadcast
+      const float w = ak * Tn;
+      Cn[0] = fmaf(w, py.x, Cn[0]); Cn[1] = fmaf(w, py.y, Cn[1]); Cn[2] = fmaf(w, py.z, Cn[2]); Cn[3] = fmaf(w, py.w, Cn[3]);
+      if constexpr (DUAL) {
+        const float2 p2 = lds_pay2[16 * B + k];
+        Cn[4] = fmaf(w, p2.x, Cn[4]); Cn[5] = fmaf(w, p2.y, Cn[5]);
+      }
+      Tn = Tn - w;                                               // T (1 - alpha), with the product already at hand
     }
-    Tn = Tn - w;                                                 // T (1 - alpha), with the product already at hand
-  }
-  if (__ballot(T > 0.f && Tn < kTStop) == 0ull) {                // nobody ends inside this batch
-    T = Tn;
+    if (__ballot(!done && Tn < kTStop) == 0ull) {                // nobody ends inside this batch
+      T = done ? T : Tn;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) C[c] = Cn[c];
-    return;
+      for (int c = 0; c < NC; ++c) C[c] = Cn[c];
+      return;
+    }
   }
-  // exact rule: the first splat with T (1 - alpha) < 1e-4 ends the pixel BEFORE it is added
+  // exact sweep: the first splat with T (1 - alpha) < 1e-4 ends the pixel BEFORE it is added.  A live pixel has
+  // T >= 1e-4, so an invalid pair (alpha = 0) can never trigger the test.
+  const bool was_done = done;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const float ak = alpha(k);
     const float wk = ak * T;
-    const float tn = T - wk;                                     // the same expression as in the optimistic pass
-    const bool hit = T > 0.f && ak > 0.f;
-    const bool stop = hit && tn < kTStop;
+    const float tn = T - wk;                                     // the same expression as in the optimistic sweep
+    const bool stop = tn < kTStop;
+    const bool live = !done && !stop;
     const float4 py = lds_pay[16 * B + k];
-    const float w = (hit && !stop) ? wk : 0.f;
+    const float w = live ? wk : 0.f;
     C[0] = fmaf(w, py.x, C[0]); C[1] = fmaf(w, py.y, C[1]); C[2] = fmaf(w, py.z, C[2]); C[3] = fmaf(w, py.w, C[3]);
     if constexpr (DUAL) {
       const float2 p2 = lds_pay2[16 * B + k];
       C[4] = fmaf(w, p2.x, C[4]); C[5] = fmaf(w, p2.y, C[5]);
     }
-    Tfin = stop ? T : Tfin;
-    T = stop ? 0.f : (hit ? tn : T);
+    T = live ? tn : T;
+    done = done || stop;
   }
+  // several pixels ended in this batch: a saturation front is passing, the next batch will very likely end more
+  // (exact-first costs 14 instead of 10 instructions per pair, optimistic + redo 24: worth it above ~30 % odds)
+  exact = __builtin_popcountll(__ballot(done && !was_done)) >= kExactFirstEndings;
 }
 
 template <int WAVES, bool DUAL>
@@ -479,28 +490,31 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_forward_px(
   const float Phi[6] = {1.f, X, Y, X * X, X * Y, Y * Y};
   const uint32_t s = (uint32_t)tc.tile * tile_cap, e = s + min(tile_cnt[tc.tile], tile_cap);
 
-  float T = tc.inside ? 1.f : 0.f, Tfin = 0.f, C[NC];
+  float T = 1.f, C[NC];
+  bool done = !tc.inside, exact = false;
 #pragma unroll
   for (int c = 0; c < NC; ++c) C[c] = 0.f;
   for (uint32_t base = s; base < e; base += 64u) {
-    if (__ballot(T > 0.f) == 0ull) break;
+    if (__ballot(!done) == 0ull) break;
     const int n = (int)min(64u, e - base);
     const MxSplat m = mx_gather<DUAL>(sorted_gid, geom, colors, base + (uint32_t)l, l < n, cx, cy, colors_b);
     lds_pay[l] = m.pay;
     if (DUAL) lds_pay2[l] = m.pay2;
-    if (__ballot(m.hot) != 0ull) {                            // wave-uniform: some splat of the chunk may hit the clamp
-      px_forward_batch<0, DUAL, true>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
-      if (n > 16) px_forward_batch<1, DUAL, true>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
-      if (n > 32) px_forward_batch<2, DUAL, true>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
-      if (n > 48) px_forward_batch<3, DUAL, true>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
-    } else {
-      px_forward_batch<0, DUAL, false>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
-      if (n > 16) px_forward_batch<1, DUAL, false>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
-      if (n > 32) px_forward_batch<2, DUAL, false>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
-      if (n > 48) px_forward_batch<3, DUAL, false>(T, Tfin, C, m.K, Phi, lds_pay, lds_pay2);
+    // wave-uniform choices per chunk: clamp-free sweeps unless some splat may reach the 0.99 clamp; exact sweep first
+    // while pixels keep ending (set by the batches themselves)
+    const bool hot = __ballot(m.hot) != 0ull;
+#define VTGS_PX_FWD(CL, EX)                                                                           \
+    {                                                                                                 \
+      px_forward_batch<0, DUAL, CL, EX>(T, done, exact, C, m.K, Phi, lds_pay, lds_pay2);              \
+      if (n > 16) px_forward_batch<1, DUAL, CL, EX>(T, done, exact, C, m.K, Phi, lds_pay, lds_pay2);  \
+      if (n > 32) px_forward_batch<2, DUAL, CL, EX>(T, done, exact, C, m.K, Phi, lds_pay, lds_pay2);  \
+      if (n > 48) px_forward_batch<3, DUAL, CL, EX>(T, done, exact, C, m.K, Phi, lds_pay, lds_pay2);  \
     }
+    if (exact) VTGS_PX_FWD(true, true)                        // (one exact-first body: the clamped form is always valid)
+    else       { if (hot) VTGS_PX_FWD(true, false) else VTGS_PX_FWD(false, false) }
+#undef VTGS_PX_FWD
   }
-  const float Tout = (T > 0.f) ? T : Tfin;
+  const float Tout = T;                                     // running value, or frozen in front of the ending splat
   if (tc.inside) {
     const size_t P = (size_t)cs.W * cs.H, pix = (size_t)tc.py * cs.W + tc.px;
     out_color[pix] = C[0] + Tout * bg[0];
@@ -840,16 +854,18 @@ __device__ __forceinline__ f32x4 px_gdotc(const MxSplat& m, const float (&g)[DUA
   return d;
 }
 
-struct PxBwdState { float T, P, CB; };
+struct PxBwdState { float T, P, CB; bool done; };   // T frozen once the pixel has ended (as in the forward); done: ended / off-image
 
 // One batch of 16 splats for the lane's pixel, in two sweeps so that no per-splat division is needed:
 //   front to back:  alpha_k, w_k = alpha_k T_k (-> LDS), T_{k+1} = T_k - w_k, P_k = P_{k-1} + (g.c_k) w_k
 //   back to front:  A = colour still behind splat k, seen from behind it = (CB - P_k) / T_{k+1}; anchored ONCE per batch at
-//                   its end, then A_{k-1} = A_k + alpha_k (g.c_k - A_k), and
+//                   its end (for a pixel that has ended: in front of its ending splat, where T is frozen), then
+//                   A_{k-1} = A_k + alpha_k (g.c_k - A_k), and
 //                   u'_k = alpha_unclamped_k dL/dalpha_k = G_k T_k (g.c_k - A_k)          (the reference's recurrence)
 // dL/dalpha_k = T_k g.c_k - (CB - P_k)/(1 - alpha_k) is the same thing since (CB - P_k)/(1 - alpha_k) = T_k A_k.
-template <int B, bool DUAL, bool CLAMP>
-__device__ __forceinline__ void px_backward_batch(PxBwdState& st, const MxSplat& m, const float (&Phi)[6],
+// `exact` is the forward's switch: straight to the exact sweep while pixels keep ending.
+template <int B, bool DUAL, bool CLAMP, bool EXACT_FIRST>
+__device__ __forceinline__ void px_backward_batch(PxBwdState& st, bool& exact, const MxSplat& m, const float (&Phi)[6],
                                                   const float (&gown)[DUAL ? 6 : 3], float* __restrict__ Us,
                                                   float* __restrict__ Ws, int l) {
   const f32x4 d[4] = {px_exponents<4 * B>(m.K, Phi), px_exponents<4 * B + 1>(m.K, Phi), px_exponents<4 * B + 2>(m.K, Phi),
@@ -859,60 +875,58 @@ __device__ __forceinline__ void px_backward_batch(PxBwdState& st, const MxSplat&
   float* __restrict__ us = Us + (l >> 4) * kImgQuarter + (l & 15);   // image [pixel quarter][splat][16 px]
   float* __restrict__ ws = Ws + (l >> 4) * kImgQuarter + (l & 15);
   float a[16], gT[16];                                         // alpha_k and G_k T_k (0 where the pair contributes nothing)
-  // front to back, optimistic: no stop test
-  float Tn = st.T, Pn = st.P;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const float Gp = __builtin_amdgcn_exp2f(d[k >> 2][k & 3]);
-    float w;
-    if constexpr (CLAMP) {
-      const float al = fminf(kAlphaMax, Gp);
-      const bool valid = al >= kAlphaMin;
-      a[k] = valid ? al : 0.f;
-      gT[k] = valid ? Gp * Tn : 0.f;                           // the 0.99 clamp passes the gradient through
-      w = a[k] * Tn;
-    } else {                                                   // no clamp possible in this chunk: alpha == alpha_unclamped
-      a[k] = (Gp >= kAlphaMin) ? Gp : 0.f;
-      w = a[k] * Tn;
-      gT[k] = w;
-    }
-    ws[k * kImgRow] = w;
-    Pn = fmaf(gcv[k >> 2][k & 3], w, Pn);
-    Tn = Tn - w;
-  }
-  float Tanchor = Tn;
-  if (__ballot(st.T > 0.f && Tn < kTStop) != 0ull) {
-    // some pixel of the wavefront ends inside this batch: redo the sweep with the exact rule; from the ending splat on
-    // alpha and G T are zero, so the back sweep passes A through unchanged and writes zeros
-    float T = st.T;
-    Pn = st.P;
-    Tanchor = 0.f;
-    bool ended = false;
+  float Pn = st.P;
+  bool swept = false;
+  const bool was_done = st.done;
+  if constexpr (!EXACT_FIRST) {
+    // front to back, optimistic: no stop test
+    float Tn = st.done ? 0.f : st.T;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const float Gp = __builtin_amdgcn_exp2f(d[k >> 2][k & 3]);
-      const float al = fminf(kAlphaMax, Gp);
-      const bool valid = al >= kAlphaMin;
-      const float wk = (valid ? al : 0.f) * T;
-      const float tn = T - wk;
-      const bool hit = T > 0.f && valid;
-      const bool stop = hit && tn < kTStop;
-      const bool live = hit && !stop;
-      a[k] = live ? al : 0.f;
-      gT[k] = live ? Gp * T : 0.f;
+      float w;
+      if constexpr (CLAMP) {
+        const float al = fminf(kAlphaMax, Gp);
+        const bool valid = al >= kAlphaMin;
+        a[k] = valid ? al : 0.f;
+        gT[k] = valid ? Gp * Tn : 0.f;                         // the 0.99 clamp passes the gradient through
+        w = a[k] * Tn;
+      } else {                                                 // no clamp possible in this chunk: alpha == alpha_unclamped
+        a[k] = (Gp >= kAlphaMin) ? Gp : 0.f;
+        w = a[k] * Tn;
+        gT[k] = w;
+      }
+      ws[k * kImgRow] = w;
+      Pn = fmaf(gcv[k >> 2][k & 3], w, Pn);
+      Tn = Tn - w;
+    }
+    if (__ballot(!st.done && Tn < kTStop) == 0ull) { st.T = st.done ? st.T : Tn; swept = true; }
+    else Pn = st.P;
+  }
+  if (!swept) {
+    // exact sweep: from the ending splat on alpha and G T are zero, so the back sweep passes A through and writes zeros
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float Gp = __builtin_amdgcn_exp2f(d[k >> 2][k & 3]);
+      const float al = CLAMP ? fminf(kAlphaMax, Gp) : Gp;
+      const float av = (al >= kAlphaMin) ? al : 0.f;
+      const float wk = av * st.T;
+      const float tn = st.T - wk;
+      const bool stop = tn < kTStop;                           // a live pixel has T >= 1e-4: alpha = 0 cannot trigger it
+      const bool live = !st.done && !stop;
+      a[k] = live ? av : 0.f;
+      gT[k] = live ? ((al >= kAlphaMin) ? Gp * st.T : 0.f) : 0.f;
       const float w = live ? wk : 0.f;
       ws[k * kImgRow] = w;
       Pn = fmaf(gcv[k >> 2][k & 3], w, Pn);
-      Tanchor = (stop && !ended) ? T : Tanchor;                // transmittance in front of the ending splat
-      ended = ended || stop;
-      T = stop ? 0.f : (T - w);
+      st.T = live ? tn : st.T;
+      st.done = st.done || stop;
     }
-    Tanchor = ended ? Tanchor : T;
-    Tn = T;
+    exact = __builtin_popcountll(__ballot(st.done && !was_done)) >= kExactFirstEndings;   // as in the forward
   }
-  // anchor: colour behind the batch (or behind the ending splat) per unit of transmittance there
-  float A = (Tanchor > 0.f) ? (st.CB - Pn) * __builtin_amdgcn_rcpf(Tanchor) : 0.f;
-  st.T = Tn; st.P = Pn;
+  // anchor: colour behind the batch (behind the ending splat for an ended pixel) per unit of transmittance there; T > 0
+  float A = (st.CB - Pn) * __builtin_amdgcn_rcpf(st.T);
+  st.P = Pn;
   // back to front
 #pragma unroll
   for (int k = 15; k >= 0; --k) {
@@ -969,7 +983,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
 
   MxBwdState<DUAL> st;
-  PxBwdState ps{tc.inside ? 1.f : 0.f, 0.f, 0.f};
+  PxBwdState ps{1.f, 0.f, 0.f, !tc.inside};
+  bool px_exact = false;
   if (PXL && tc.inside) {                                        // lane L <-> pixel L
     const size_t pix = (size_t)tc.py * cs.W + tc.px;
     const float g0 = grad_color[pix], g1 = grad_color[P + pix], g2 = grad_color[2 * P + pix];
@@ -1044,27 +1059,27 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
 
   uint32_t base = s;
   for (; base < e; base += 64u) {
-    const bool alive = PXL ? ps.T > 0.f : (st.Tb[0].x > 0.f || st.Tb[0].y > 0.f || st.Tb[1].x > 0.f || st.Tb[1].y > 0.f);
+    const bool alive = PXL ? !ps.done : (st.Tb[0].x > 0.f || st.Tb[0].y > 0.f || st.Tb[1].x > 0.f || st.Tb[1].y > 0.f);
     if (__ballot(alive) == 0ull) break;
     const int n = (int)min(64u, e - base);
     const MxSplat m = mx_gather<DUAL>(sorted_gid, geom, colors, base + (uint32_t)l, l < n, cx, cy, colors_b);
     const uint32_t my_inst = (l < n) ? sorted_inst[base + (uint32_t)l] : 0u;
     const bool hot = __ballot(m.hot) != 0ull;                 // wave-uniform: some splat of the chunk may hit the 0.99 clamp
+    const bool chunk_exact = px_exact;                        // exact sweep first for this chunk (pixels kept ending before it)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       if (16 * b >= n) break;                                 // wave-uniform
       if constexpr (PXL) {
-        if (hot) {
-          if (b == 0) px_backward_batch<0, DUAL, true>(ps, m, Phi, st.gown, Us, Ws, l);
-          if (b == 1) px_backward_batch<1, DUAL, true>(ps, m, Phi, st.gown, Us, Ws, l);
-          if (b == 2) px_backward_batch<2, DUAL, true>(ps, m, Phi, st.gown, Us, Ws, l);
-          if (b == 3) px_backward_batch<3, DUAL, true>(ps, m, Phi, st.gown, Us, Ws, l);
-        } else {
-          if (b == 0) px_backward_batch<0, DUAL, false>(ps, m, Phi, st.gown, Us, Ws, l);
-          if (b == 1) px_backward_batch<1, DUAL, false>(ps, m, Phi, st.gown, Us, Ws, l);
-          if (b == 2) px_backward_batch<2, DUAL, false>(ps, m, Phi, st.gown, Us, Ws, l);
-          if (b == 3) px_backward_batch<3, DUAL, false>(ps, m, Phi, st.gown, Us, Ws, l);
+#define VTGS_PX_BWD(CL, EX)                                                                               \
+        {                                                                                                 \
+          if (b == 0) px_backward_batch<0, DUAL, CL, EX>(ps, px_exact, m, Phi, st.gown, Us, Ws, l);       \
+          if (b == 1) px_backward_batch<1, DUAL, CL, EX>(ps, px_exact, m, Phi, st.gown, Us, Ws, l);       \
+          if (b == 2) px_backward_batch<2, DUAL, CL, EX>(ps, px_exact, m, Phi, st.gown, Us, Ws, l);       \
+          if (b == 3) px_backward_batch<3, DUAL, CL, EX>(ps, px_exact, m, Phi, st.gown, Us, Ws, l);       \
         }
+        if (chunk_exact) VTGS_PX_BWD(true, true)                // (one exact-first body: the clamped form is always valid)
+        else             { if (hot) VTGS_PX_BWD(true, false) else VTGS_PX_BWD(false, false) }
+#undef VTGS_PX_BWD
       } else {
         if (b == 0) mx_backward_batch<0, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
         if (b == 1) mx_backward_batch<1, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
