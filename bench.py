@@ -168,7 +168,7 @@ def main():
                         "call_algorithmic_bytes": call_bytes,
                         "call_frac": round(call_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                         "scope": "whole frame" if world == 1 else f"rank 0 band (tile rows {tile_rows[0]}..{tile_rows[1]})",
-                        "note": "composite kernels are VALU-bound, not HBM-bound (profiles/r1g_sq_counters.md, DESIGN.md 3.2 / 4)"}
+                        "note": "composite kernels are VALU-bound, not HBM-bound (profiles/r1h_sq_counters.md, DESIGN.md 3.2 / 4)"}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
