@@ -91,7 +91,7 @@ def main():
     g = torch.Generator().manual_seed(1)
     grad_color = (torch.rand(3, H, W, generator=g) * 2 - 1).to(dev)
 
-    from diff_gaussian_rasterization.partition import band_for_rank
+    from diff_gaussian_rasterization.partition import band_for_rank, pose7_reduce
     gy16 = (H + 15) // 16
     tile_rows = band_for_rank(H, world, rank) if world > 1 else None
     rast = dgr.GaussianRasterizer(raster_settings=settings, tile_rows=tile_rows)
@@ -103,8 +103,7 @@ def main():
         color.backward(grad_color)
         if dist is not None:
             # tracking: dL/dpose is a 7-float reduction of dL/dmeans3D; all-reduce it
-            gm, m = leaves["means3D"].grad, leaves["means3D"].detach()
-            pose = torch.cat([gm.sum(0), torch.cross(m, gm, dim=1).sum(0), gm[:, 2:3].sum(0)])
+            pose = pose7_reduce(leaves["means3D"], leaves["means3D"].grad)       # 7 floats, two launches
             dist.all_reduce(pose)
         return color
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VTGS_ABI_VERSION 6
+#define VTGS_ABI_VERSION 7
 
 typedef enum VtgsStatus {
   VTGS_OK = 0,
@@ -185,6 +185,10 @@ uint32_t vtgs_pose_partial_rows(int32_t n);
 /* Sums the partial rows and takes the 12 -> 7 step through the normalised quaternion: g_cam_q[4], g_cam_t[3] (device). */
 int vtgs_pose_gradient(const float* pose_partials, uint32_t rows, const float* cam_q, float* g_cam_q, float* g_cam_t,
                        void* stream);
+/* The 7-float pose reduction each rank of the tile-row partition all-reduces (bench.py --gpus N): for
+ * points already in the camera frame (pose = identity), out7 = {sum g (3), sum p x g (3), sum g_z}; partials =
+ * vtgs_pose_partial_rows(n) x 7 floats of scratch.  Two launches, fixed summation order.                            */
+int vtgs_pose7_reduce(int32_t n, const float* points, const float* g_points, float* partials, float* out7, void* stream);
 int vtgs_prepare_frame(int32_t n, const float* means3D, const float* logit_opacities, const float* log_scales,
                        const float* unnorm_rotations, const float* cam_q, const float* cam_t, const float* depth_w2c,
                        float* out_means_cam, float* out_opacities, float* out_scales, float* out_rotations,

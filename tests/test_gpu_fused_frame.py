@@ -122,3 +122,15 @@ def test_dual_composite_equals_two_renders(gpu_device, monkeypatch, shape, n, op
         if k == "unnorm_rotations":                       # isotropic: float noise around zero in both routes
             continue
         assert (a - b).abs().max().item() <= 2e-4 * scale + 1e-7, (k, (a - b).abs().max().item(), scale)
+
+
+def test_pose7_reduce_matches_torch(gpu_device):
+    """vtgs_pose7_reduce (what each rank of the tile-row partition all-reduces) against the plain tensor expressions."""
+    from diff_gaussian_rasterization.partition import pose7_reduce
+    g = torch.Generator().manual_seed(5)
+    for n in (1, 255, 100003):
+        p = torch.randn(n, 3, generator=g).to(gpu_device)
+        gr = torch.randn(n, 3, generator=g).to(gpu_device)
+        ref = torch.cat([gr.double().sum(0), torch.cross(p.double(), gr.double(), dim=1).sum(0), gr[:, 2:3].double().sum(0)])
+        got = pose7_reduce(p, gr).double()
+        assert (got - ref).abs().max().item() <= 1e-4 * (ref.abs().max().item() + n ** 0.5)

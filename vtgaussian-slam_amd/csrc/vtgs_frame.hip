@@ -151,6 +151,44 @@ __global__ __launch_bounds__(256) void pose_gradient_kernel(const float* __restr
   }
 }
 
+// Pose-gradient reduction of the tile-row partition: with the camera at the identity, dL/dt = sum g and the
+// rotation part is sum p x g (plus sum g_z kept for the depth scale) -- the 7 floats every rank all-reduces.  Two
+// launches, fixed summation order.
+__global__ __launch_bounds__(256) void pose7_partial_kernel(int n, const float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ partials) {
+  __shared__ float red[4][7];
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+  float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < n) {
+    const float px = p[3 * i], py = p[3 * i + 1], pz = p[3 * i + 2];
+    const float gx = g[3 * i], gy = g[3 * i + 1], gz = g[3 * i + 2];
+    acc[0] = gx; acc[1] = gy; acc[2] = gz;
+    acc[3] = py * gz - pz * gy; acc[4] = pz * gx - px * gz; acc[5] = px * gy - py * gx;
+    acc[6] = gz;
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) acc[k] = wave_sum(acc[k]);
+  if (lane_id() == 0)
+    for (int k = 0; k < 7; ++k) red[threadIdx.x >> 6][k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 7) partials[(size_t)blockIdx.x * 7 + threadIdx.x] =
+      red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void pose7_final_kernel(const float* __restrict__ partials, uint32_t rows, float* __restrict__ out) {
+  __shared__ float red[4][7];
+  float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (uint32_t r = threadIdx.x; r < rows; r += 256u)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc[k] += partials[(size_t)r * 7 + k];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) acc[k] = wave_sum(acc[k]);
+  if (lane_id() == 0)
+    for (int k = 0; k < 7; ++k) red[threadIdx.x >> 6][k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 7) out[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 }  // namespace vtgs
 
 using namespace vtgs;
@@ -202,6 +240,15 @@ int vtgs_prepare_frame_backward(int32_t n, uint32_t flags, const float* means3D,
                      means3D, logit_opacities, log_scales, unnorm_rotations, cam_q, cam_t, depth_w2c, g_means_a, g_means_b,
                      g_depth_colors, g_opac_a, g_opac_b, g_scales_a, g_scales_b, g_rot_a, g_rot_b, g_means3D,
                      g_logit_opacities, g_log_scales, g_unnorm_rotations, pose_partials);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+int vtgs_pose7_reduce(int32_t n, const float* points, const float* g_points, float* partials, float* out7, void* stream) {
+  if (n < 0 || !out7 || (n > 0 && (!points || !g_points || !partials))) return VTGS_ERR_INVALID_ARGUMENT;
+  const uint32_t rows = vtgs_pose_partial_rows(n);
+  hipStream_t st = (hipStream_t)stream;
+  if (rows) hipLaunchKernelGGL(pose7_partial_kernel, dim3(rows), dim3(256), 0, st, n, points, g_points, partials);
+  hipLaunchKernelGGL(pose7_final_kernel, dim3(1), dim3(256), 0, st, partials, rows, out7);
   return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
 }
 

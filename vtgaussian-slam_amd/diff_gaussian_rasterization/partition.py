@@ -26,3 +26,27 @@ def all_bands(image_height: int, world_size: int) -> List[Tuple[int, int]]:
 
 def pixel_rows(band: Tuple[int, int], image_height: int) -> Tuple[int, int]:
     return band[0] * 16, min(band[1] * 16, int(image_height))
+
+
+
+def pose7_reduce(points, g_points):
+    """{sum g, sum p x g, sum g_z} of camera-frame points and their gradients as ONE 7-float device tensor (two launches):
+    what every rank of the tile-row partition contributes to the pose-gradient all-reduce."""
+    import ctypes
+
+    import torch
+
+    from . import _I32, _P, _check, _lib, _stream_ptr
+    _lib.vtgs_pose_partial_rows.restype, _lib.vtgs_pose_partial_rows.argtypes = ctypes.c_uint32, [_I32]
+    _lib.vtgs_pose7_reduce.restype, _lib.vtgs_pose7_reduce.argtypes = ctypes.c_int, [_I32, _P, _P, _P, _P, _P]
+    if not points.is_cuda:
+        raise RuntimeError("pose7_reduce needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
+    p = points.detach().to(torch.float32).contiguous()
+    g = g_points.detach().to(torch.float32).contiguous()
+    n = p.shape[0]
+    rows = int(_lib.vtgs_pose_partial_rows(n))
+    partials = torch.empty((max(rows, 1), 7), dtype=torch.float32, device=p.device)
+    out = torch.empty(7, dtype=torch.float32, device=p.device)
+    _check(_lib.vtgs_pose7_reduce(n, p.data_ptr(), g.data_ptr(), partials.data_ptr(), out.data_ptr(), _stream_ptr(p.device)),
+           "vtgs_pose7_reduce")
+    return out
