@@ -83,3 +83,22 @@ def test_python_surface_matches_reference_call_sites():
         r(z, z, z[:, :1], colors_precomp=z, scales=z, rotations=torch.zeros(2, 4))
     with pytest.raises(ValueError):
         dgr.GaussianRasterizer(raster_settings=st, radius_rule="bogus")
+
+
+def test_fused_operators_refuse_cpu_tensors():
+    """render_frame, the loss node, FusedAdam and the pose reduction are HIP-only: CPU tensors raise, nothing falls back."""
+    import torch
+    from diff_gaussian_rasterization import losses
+    from diff_gaussian_rasterization.optim import FusedAdam
+    from diff_gaussian_rasterization.partition import pose7_reduce
+    img = torch.rand(3, 8, 8, requires_grad=True)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        losses.tracking_loss(img, torch.rand(3, 8, 8), torch.rand(3, 8, 8), torch.rand(1, 8, 8), 0.99)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        losses.fused_ssim(img, torch.rand(3, 8, 8))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        pose7_reduce(torch.rand(4, 3), torch.rand(4, 3))
+    p = torch.nn.Parameter(torch.rand(4, 3))
+    p.grad = torch.rand(4, 3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        FusedAdam([{"params": [p], "lr": 1e-3}]).step()
