@@ -210,14 +210,18 @@ class _PinnedInfoRing:
 
     def __init__(self):
         self.buf = torch.zeros((self.SLOTS, 64), dtype=torch.uint8).pin_memory()
-        self.events = [None] * self.SLOTS
-        self.next = 0
+        self.events = [None] * self.SLOTS          # one reusable event per slot
+        self.gen = [0] * self.SLOTS                # bumped each time a slot is handed out: a pending record whose
+        self.next = 0                              # generation no longer matches was overwritten (64 forwards later)
 
     def take(self):
         i = self.next
         self.next = (i + 1) % self.SLOTS
         if self.events[i] is not None:           # a slot is only reused once its previous record has landed
             self.events[i].synchronize()
+        else:
+            self.events[i] = torch.cuda.Event()
+        self.gen[i] += 1
         self.buf[i].zero_()
         return i
 
@@ -263,10 +267,12 @@ def _resolve_pending(fs: "_ForwardState") -> None:
     Idempotent: a shared-geometry state carries the same pending record as the forward it shares."""
     if fs.pending is None:
         return
-    slot, event = fs.pending
+    slot, event, gen = fs.pending
+    fs.pending = None
+    if _ring.gen[slot] != gen:                   # more than 64 forwards ago: the slot has been handed out again and the
+        return                                   # record is gone (instance count stays unknown: scratch sized by capacity)
     event.synchronize()
     info = _ring.info(slot)
-    fs.pending = None
     if not info.complete:
         raise RuntimeError("vtgs_forward: result record never arrived (stream error?)")
     _record_info(fs.key, fs.n, fs.cam.W, fs.cam.H, fs.capacity, info)
@@ -328,10 +334,10 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
         slot = _ring.take()
         st = launch(workspace, nbytes, capacity, tile_cap, _ring.buf[slot].data_ptr(), VTGS_FORWARD_ASYNC)
         _check(st, "vtgs_forward")
-        ev = torch.cuda.Event()
+        ev = _ring.events[slot]
         ev.record(torch.cuda.current_stream(device))
-        _ring.events[slot] = ev
-        fs.workspace, fs.capacity, fs.tile_cap, fs.instances, fs.pending = workspace, capacity, tile_cap, None, (slot, ev)
+        fs.workspace, fs.capacity, fs.tile_cap, fs.instances, fs.pending = (workspace, capacity, tile_cap, None,
+                                                                            (slot, ev, _ring.gen[slot]))
         return color, radii, depth, fs
     info = _VtgsForwardInfo()
     for _attempt in range(4):
