@@ -418,3 +418,41 @@ def test_packed_key_sort_matches_the_key_value_sort(gpu_device, monkeypatch):
         assert torch.equal(a, b)
     for k in GRAD_KEYS:
         assert torch.equal(res["1"][3][k], res["0"][3][k]), k
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_odd_shapes_default_kernels_vs_scalar_kernels(gpu_device, monkeypatch, seed):
+    """Small random configurations at awkward sizes (1-pixel-wide images, one Gaussian, everything opaque, huge and tiny
+    scales, image sizes that are not multiples of 8 or 16): the default kernels against the scalar kernels."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    W = int(torch.randint(1, 70, (1,), generator=g)); H = int(torch.randint(1, 50, (1,), generator=g))
+    n = [1, 2, 63, 65, 257, 1500, 4000, 9000][seed]
+    scene, cam = go.random_scene(n, W, H, seed=seed, anisotropic=bool(seed & 1), w2c=_w2c(seed))
+    if seed % 3 == 0:
+        scene["opacities"] = torch.full_like(scene["opacities"], 0.995)          # clamp + early termination everywhere
+    if seed % 4 == 1:
+        scene["scales"] = scene["scales"] * 6.0                                  # frame-sized splats, long lists
+    if seed % 4 == 2:
+        scene["scales"] = scene["scales"] * 0.05                                 # sub-pixel splats (dilation dominates)
+    grad_color = torch.rand(3, H, W, generator=g) * 2 - 1
+    monkeypatch.setenv("VTGS_FWD_IMPL", "0"); monkeypatch.setenv("VTGS_BWD_IMPL", "0")
+    ref = run_hip(scene, cam, gpu_device, grad_color)
+    monkeypatch.setenv("VTGS_FWD_IMPL", "2"); monkeypatch.setenv("VTGS_BWD_IMPL", "2")
+    got = run_hip(scene, cam, gpu_device, grad_color)
+    assert torch.equal(ref[1], got[1])
+    for a, b in ((ref[0], got[0]), (ref[2], got[2])):
+        # a pair whose alpha sits on 1/255 (or a pixel on the 1e-4 stop) may fall on the other side: bounded outliers
+        mx, frac = image_error(a, b)
+        assert mx <= IMG_OUTLIER_MAX and frac <= max(2e-3, 2.0 / (W * H)), (seed, mx, frac)
+    for k in GRAD_KEYS:
+        if k == "rotations" and not (seed & 1):
+            continue                                       # isotropic: float noise around zero in both
+        scale = ref[3][k].abs().max().item()
+        if scale == 0:
+            assert got[3][k].abs().max().item() <= 1e-12
+            continue
+        # the same boundary pairs reach a handful of Gaussians' gradients: bound the worst case and the 99th percentile
+        r, o = ref[3][k].double(), got[3][k].double()
+        d = (r - o).abs()
+        p99 = torch.quantile((d / (r.abs() + 1e-3 * scale)).reshape(-1), 0.99).item()
+        assert (d.max() / scale).item() <= 5e-3 and p99 <= 2e-3, (seed, k, (d.max() / scale).item(), p99)
