@@ -2,6 +2,7 @@
 """Headline benchmark: rasterize forward+backward throughput (Mgaussians*pixels/s), BASELINE.json metric.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus N ...          # starts its own N ranks (torch.distributed.run) when WORLD_SIZE is unset
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -29,6 +30,36 @@ for p in (ROOT, os.path.join(ROOT, "vtgaussian-slam_amd"), os.path.join(ROOT, "t
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (= f32 MFMA) rate
+# SURVEY.md 8(d) secondary bound: per (pixel, Gaussian) evaluation the forward costs ~14 flop + 1 exp, the backward ~3x
+# that; v_exp_f32 occupies the issue slot of three v_fma_f32 (tests/micro/issue_rate.hip, profiles/r2_issue_rate.md) = 6 flop.
+FLOP_PER_EVAL_FWD_BWD = 4 * (14 + 6)
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: start N ranks as CHILD processes (one per GPU, RCCL
+    rendezvous on 127.0.0.1) and pass rank 0's JSON line through.  Nothing in this process has touched the GPU yet
+    (importing torch does not), and nothing is exec'ed: the children are fresh interpreters."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    return proc.returncode if line is not None or proc.returncode else 1
 
 
 def kernel_algorithmic_bytes(n, p, r16):
@@ -61,10 +92,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
     # one process per GPU; the gloo rehearsal mode puts every rank on device 0
     dev = torch.device("cuda", local_rank if args.backend == "nccl" else 0)
@@ -167,9 +197,21 @@ def main():
                         "call_algorithmic_bytes": call_bytes,
                         "call_frac": round(call_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                         "scope": "whole frame" if world == 1 else f"rank 0 band (tile rows {tile_rows[0]}..{tile_rows[1]})",
-                        "note": "composite kernels are VALU-bound, not HBM-bound (profiles/r1h_sq_counters.md, DESIGN.md 3.2 / 4)"}
+                        "note": "the composites are bound by fp32 issue (VALU + f32 MFMA share the lanes), see roofline.valu"}
+
+    # secondary (VALU) bound, SURVEY.md 8(d): E = 256 x (16x16 tile instances) pixel x Gaussian evaluations of the published
+    # algorithm, E_effective = 64 x (8x8 tile instances) evaluated here after the exact ellipse-vs-tile culling
+    if roofline is not None:
+        comp_us = sum(kern[k]["avg_us"] for k in kern if k.startswith("composite_"))
+        scale_r = (r_rank / r16) if r16 else 1.0
+        e_all, e_eff = 256 * r_rank, int(64 * info["instances"] * (scale_r if world > 1 else 1.0))
+        floor_us = e_eff * FLOP_PER_EVAL_FWD_BWD / (FP32_PEAK_TFLOPS * 1e12) * 1e6
+        roofline["valu"] = {"E": e_all, "E_effective": e_eff, "flop_per_eval_fwd_bwd": FLOP_PER_EVAL_FWD_BWD,
+                            "peak_tflops": FP32_PEAK_TFLOPS, "valu_floor_us": round(floor_us, 2),
+                            "composite_us": round(comp_us, 2), "frac": round(floor_us / comp_us, 4) if comp_us else None}
 
     cpu_baseline = None
+    parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         rows = (0, min(args.cpu_rows, gy16))
         cpu_scene = {k: v.clone().requires_grad_(True) for k, v in scene.items()}
@@ -185,6 +227,29 @@ def main():
                         "cores": torch.get_num_threads(), "kind": "port",
                         "sample": f"float32 PyTorch oracle fwd+bwd, same scene, tile rows {rows[0]}..{rows[1]} "
                                   f"({p_band} of {P} pixels; projection+binning of all N included), {tcpu:.1f} s"}
+        # the checker's frame against the frame the timed path produces (float32 both: discrete alpha / stop decisions can
+        # fall either way on both sides; tests/ hold the audited float64 comparison)
+        y1 = min(rows[1] * 16, H)
+        for t in leaves.values():
+            t.grad = None
+        gband = grad_color.clone()
+        gband[:, y1:] = 0
+        color = rast(**leaves)[0]
+        color.backward(gband)
+        got = color.detach()[:, :y1].cpu().double()
+        ref = c_cpu.detach()[:, :y1].double()
+        scale_img = ref.abs().max().item() + 1e-12
+        d_img = (got - ref).abs() / scale_img
+        parity = {"img_max_rel": float(d_img.max()), "img_frac_gt_1e-4": float((d_img.amax(0) > 1e-4).double().mean())}
+        worst = 0.0
+        for k in ("means3D", "opacities", "colors_precomp", "scales"):
+            r, h = cpu_scene[k].grad.double(), leaves[k].grad.cpu().double()
+            sc = r.abs().max().item()
+            if sc > 0:
+                rel = ((r - h).abs() / (r.abs() + 1e-3 * sc)).reshape(-1)[:4_000_000]
+                worst = max(worst, float(torch.quantile(rel, 0.999)))
+        parity["grad_p999"] = worst
+        parity["note"] = "GPU frame of the timed path vs the float32 CPU oracle on the cpu_baseline sample"
 
     if rank == 0:
         out = {
@@ -196,7 +261,7 @@ def main():
                        "gaussians": N, "width": W, "height": H, "instances_8x8": info["instances"],
                        "tiles16_touched_R": r16, "max_tile_list": info["max_tile_list"],
                        "partition": "none" if world == 1 else f"tile-row bands x{world} + all-reduce(7 floats)"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["avg_us"])},
         }
         print(json.dumps(out))

@@ -18,8 +18,9 @@
  *     backward scratch.  The library never allocates device memory, never frees, keeps no pointer
  *     after a call returns, and enqueues everything on `stream`.
  *   - outputs are fully overwritten (gradient arrays are written for every row, zeros included).
- *   - the only host synchronisation is in vtgs_forward with VTGS_FORWARD_SYNC (it waits for the result
- *     record to report overflow and statistics); VTGS_FORWARD_ASYNC and vtgs_backward never synchronise.
+ *   - host waits: vtgs_forward with VTGS_FORWARD_SYNC waits for the whole forward; with VTGS_FORWARD_CHECKED it waits
+ *     only for the result record, which the device writes right after the binning (the sort and the composite are
+ *     still running when the call returns); VTGS_FORWARD_ASYNC and vtgs_backward never wait.
  *   - all functions return a VtgsStatus; vtgs_strerror() gives a static message.
  */
 #ifndef VTGS_H
@@ -32,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VTGS_ABI_VERSION 7
+#define VTGS_ABI_VERSION 8
 
 typedef enum VtgsStatus {
   VTGS_OK = 0,
@@ -83,8 +84,22 @@ typedef struct VtgsForwardInfo {
 #define VTGS_FORWARD_ASYNC 1u   /* do not synchronise: `info` must be PINNED host memory that stays valid until the  */
                                 /* stream reaches the copy; the caller synchronises (event / stream) before reading */
                                 /* it and must treat info->overflow == 1 as VTGS_ERR_INSTANCE_OVERFLOW               */
+#define VTGS_FORWARD_CHECKED 2u /* enqueue everything, then wait on the HOST for the result record only: `info` must */
+                                /* be pinned, device-mapped host memory (hipHostMalloc / a pinned torch tensor).  The */
+                                /* record is written by the one-workgroup kernel that follows the binning, i.e. about */
+                                /* a quarter into the forward; on overflow the remaining kernels bail and the call    */
+                                /* returns VTGS_ERR_INSTANCE_OVERFLOW like the synchronous mode -- the caller always  */
+                                /* holds a valid image when the call returns VTGS_OK.  Falls back to a full wait when */
+                                /* `info` is not device-mapped.                                                       */
 
 uint32_t    vtgs_abi_version(void);
+/* Implementation switches (tests and ablations): "VTGS_FWD_IMPL" / "VTGS_BWD_IMPL" (2 = lane-per-pixel matrix-core
+ * composites, default; 1 = pixel x splat-quad form; 0 = scalar kernels), "VTGS_BIN_IMPL" (1 = LDS-binned slot
+ * reservation where the tile table fits, 0 = global atomics), "VTGS_SORT_PACKED" (1 = payload in the key's low bits for
+ * N <= 2^21).  Defaults come from the environment variables of the same names, read ONCE at first use.
+ * vtgs_set_option returns VTGS_ERR_INVALID_ARGUMENT for an unknown name; value < 0 restores the default.           */
+int         vtgs_set_option(const char* name, int value);
+int         vtgs_get_option(const char* name);   /* current value, or -1 for an unknown name */
 const char* vtgs_strerror(int status);
 const char* vtgs_last_hip_error(void);   /* message of the last failed HIP call on this host thread */
 

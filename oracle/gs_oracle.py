@@ -250,12 +250,13 @@ def composite_tile(px, py, xy, conic, op, col, dep, bg):
 
 def rasterize(means3D, means2D, opacities, colors_precomp, scales, rotations, cam,
               cov3D_precomp=None, radius_rule: str = "3sigma", dtype=None,
-              tile_rows: Optional[Tuple[int, int]] = None, return_aux: bool = False):
+              tile_rows: Optional[Tuple[int, int]] = None, return_aux: bool = False, tile_row_list=None):
     """Differentiable restatement of `GaussianRasterizer(raster_settings)(...)`.
 
     Returns (color [C,H,W], radii [N] int32, depth [1,H,W]).  `tile_rows=(r0,r1)` composites only
     that band of 16-pixel tile rows (rest of the image stays at bg / 0): used for the bounded CPU
-    baseline and the tile-row partition tests.
+    baseline and the tile-row partition tests; `tile_row_list=[r, ...]` does the same for scattered rows
+    (the full-size configuration tests check a few rows of a frame that is too large to composite on the CPU).
     """
     dt = dtype or means3D.dtype
     cast = lambda x: None if x is None else x.to(dt)
@@ -276,7 +277,7 @@ def rasterize(means3D, means2D, opacities, colors_precomp, scales, rotations, ca
     T_img = torch.ones(H, W, dtype=dt)
     ar = torch.arange(TILE)
     n_eval = 0
-    for ty in range(r0, r1):
+    for ty in (range(r0, r1) if tile_row_list is None else tile_row_list):
         y0, y1 = ty * TILE, min((ty + 1) * TILE, H)
         for tx in range(gx):
             x0, x1 = tx * TILE, min((tx + 1) * TILE, W)

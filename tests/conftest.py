@@ -36,3 +36,13 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _restore_library_options():
+    """Implementation switches set through vtgs_set_option live in the library, not in the environment: put the
+    defaults back after every test (only when the package is already loaded -- CPU-only tests never load it here)."""
+    yield
+    mod = sys.modules.get("diff_gaussian_rasterization")
+    if mod is not None and hasattr(mod, "reset_options"):
+        mod.reset_options()

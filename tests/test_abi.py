@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_version_strings_and_sizes(lib):
     lib.vtgs_abi_version.restype = ctypes.c_uint32
-    assert lib.vtgs_abi_version() == 7
+    assert lib.vtgs_abi_version() == 8
     lib.vtgs_strerror.restype = ctypes.c_char_p
     assert lib.vtgs_strerror(0) == b"ok" and b"instance" in lib.vtgs_strerror(3)
     lib.vtgs_workspace_bytes.restype = ctypes.c_size_t
@@ -102,3 +102,16 @@ def test_fused_operators_refuse_cpu_tensors():
     p.grad = torch.rand(4, 3)
     with pytest.raises(RuntimeError, match="no CPU path"):
         FusedAdam([{"params": [p], "lr": 1e-3}]).step()
+
+
+def test_option_api_without_a_gpu(lib):
+    """vtgs_set_option / vtgs_get_option: known names round-trip, value < 0 restores the default, unknown names are
+    rejected (no HIP call involved)."""
+    lib.vtgs_set_option.restype, lib.vtgs_set_option.argtypes = ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]
+    lib.vtgs_get_option.restype, lib.vtgs_get_option.argtypes = ctypes.c_int, [ctypes.c_char_p]
+    for name in (b"VTGS_FWD_IMPL", b"VTGS_BWD_IMPL", b"VTGS_BIN_IMPL", b"VTGS_SORT_PACKED"):
+        dflt = lib.vtgs_get_option(name)
+        assert dflt >= 0
+        assert lib.vtgs_set_option(name, 0) == 0 and lib.vtgs_get_option(name) == 0
+        assert lib.vtgs_set_option(name, -1) == 0 and lib.vtgs_get_option(name) == dflt
+    assert lib.vtgs_set_option(b"VTGS_NO_SUCH_SWITCH", 1) == 1 and lib.vtgs_get_option(b"VTGS_NO_SUCH_SWITCH") == -1

@@ -137,9 +137,35 @@ size_t vtgs_backward_dual_scratch_bytes(int32_t n, uint64_t instances) {
 }
 
 #include <stdlib.h>
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
+#include <time.h>
+// Implementation switches: defaults from the environment, read once; vtgs_set_option overrides them at run time.
+struct Option { const char* name; int dflt; int value; };
+static Option g_options[] = {{"VTGS_FWD_IMPL", 2, -1}, {"VTGS_BWD_IMPL", 2, -1}, {"VTGS_BIN_IMPL", 1, -1}, {"VTGS_SORT_PACKED", 1, -1}};
+enum { OPT_FWD_IMPL = 0, OPT_BWD_IMPL, OPT_BIN_IMPL, OPT_SORT_PACKED, OPT_COUNT };
+static bool g_options_ready = false;
+static void options_init() {
+  if (g_options_ready) return;
+  for (int i = 0; i < OPT_COUNT; ++i) {
+    const char* v = getenv(g_options[i].name);
+    if (v) g_options[i].dflt = atoi(v);
+    if (g_options[i].value < 0) g_options[i].value = g_options[i].dflt;
+  }
+  g_options_ready = true;
+}
+static inline int option(int which) { options_init(); return g_options[which].value; }
+int vtgs_set_option(const char* name, int value) {
+  options_init();
+  if (!name) return VTGS_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (strcmp(name, g_options[i].name) == 0) { g_options[i].value = value < 0 ? g_options[i].dflt : value; return VTGS_OK; }
+  return VTGS_ERR_INVALID_ARGUMENT;
+}
+int vtgs_get_option(const char* name) {
+  options_init();
+  if (!name) return -1;
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (strcmp(name, g_options[i].name) == 0) return g_options[i].value;
+  return -1;
 }
 
 // colors_b / out_color_b != NULL: dual render (two colour sets over the same geometry, no depth image)
@@ -149,7 +175,7 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
                                     float* out_color_b = nullptr) {
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   const uint32_t nblk = (uint32_t)(gx16 * rows16);
-  const int impl = env_int("VTGS_FWD_IMPL", 2);            // 2 = lane-per-pixel matrix-core kernel (default), 1 = pixel x splat-quad
+  const int impl = option(OPT_FWD_IMPL);                     // 2 = lane-per-pixel matrix-core kernel (default), 1 = pixel x splat-quad
                                                            // matrix-core kernel, 0 = scalar kernel (read per call)
   {
     ProfScope ps__(colors_b ? "composite_forward_dual" : "composite_forward", st);
@@ -218,13 +244,15 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
     // the run-aggregated global-atomic walk is faster again (5 M splats at 1752x1168: 488 us vs 525 us with a 128 KB
     // table and one workgroup per CU).
     const size_t table_bytes = (size_t)(r8e - r8b) * (size_t)((cam->image_width + kSubTile - 1) / kSubTile) * 4;
-    bool lds_bins = table_bytes <= (79u << 10) && env_int("VTGS_BIN_IMPL", 1) == 1;
+    bool lds_bins = table_bytes <= (79u << 10) && option(OPT_BIN_IMPL) == 1;
     if (lds_bins && table_bytes > (64u << 10)) {
-      static bool raised = false;                             // per process; the attribute sticks to the function
-      if (!raised) {
-        if (hipFuncSetAttribute((const void*)project_and_bin<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess)
-          raised = true;
-        else { (void)hipGetLastError(); lds_bins = false; }
+      static bool raised[64] = {false};                       // the attribute sticks to the function, per DEVICE
+      int dev_id = 0;
+      if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) { (void)hipGetLastError(); dev_id = -1; }
+      if (dev_id < 0 || !raised[dev_id]) {
+        if (hipFuncSetAttribute((const void*)project_and_bin<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess) {
+          if (dev_id >= 0) raised[dev_id] = true;
+        } else { (void)hipGetLastError(); lds_bins = false; }
       }
     }
     {
@@ -248,7 +276,8 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   // asynchronous mode: the record goes straight into the caller's pinned buffer when the device can address it
   // (one store from the kernel instead of a copy command behind the composite)
   VtgsForwardInfo* host_record = nullptr;
-  if ((flags & VTGS_FORWARD_ASYNC) && info) {
+  if ((flags & (VTGS_FORWARD_ASYNC | VTGS_FORWARD_CHECKED)) && info) {
+    if (flags & VTGS_FORWARD_CHECKED) ((volatile VtgsForwardInfo*)info)->complete = 0u;
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, info, 0) == hipSuccess) host_record = (VtgsForwardInfo*)dp;
     else (void)hipGetLastError();                               // not mapped: fall back to the copy below
@@ -261,7 +290,7 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   { ProfScope ps__("sort_tiles", st); hipLaunchKernelGGL(sort_tiles, dim3((L.tiles8 + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
                      (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
                      (uint32_t*)(ws + L.sorted_inst), L.tiles8, L.tile_cap, (const Counters*)ctr,
-                     (n <= (1 << 21) && env_int("VTGS_SORT_PACKED", 1) == 1) ? 1 : 0); }
+                     (n <= (1 << 21) && option(OPT_SORT_PACKED) == 1) ? 1 : 0); }
   VTGS_HIP(hipGetLastError());
   int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st,
                                     dual ? colors_b : nullptr, dual ? out_color_b : nullptr);
@@ -273,6 +302,30 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
     if (!info) return VTGS_ERR_INVALID_ARGUMENT;
     if (!host_record) VTGS_HIP(hipMemcpyAsync(info, image, sizeof(VtgsForwardInfo), hipMemcpyDeviceToHost, st));
     return VTGS_OK;                                             // (else finalize_forward already stored it there)
+  }
+  if ((flags & VTGS_FORWARD_CHECKED) && host_record) {
+    // The record lands in the caller's pinned memory when finalize_forward retires -- right after the binning, while
+    // the sort and the composite are still queued behind it.  Wait for it on the host (bounded: a stream error would
+    // never set the flag), so that a capacity overflow is answered before the caller sees an image.
+    volatile VtgsForwardInfo* rec = (volatile VtgsForwardInfo*)info;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    bool landed = false;
+    for (uint64_t spin = 0;; ++spin) {
+      if (rec->complete) { landed = true; break; }
+      if ((spin & 0x3FFu) == 0x3FFu) {
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) > 20) break;
+        if (hipStreamQuery(st) == hipSuccess) { landed = rec->complete != 0u; break; }   // stream drained: now or never
+      }
+      __builtin_ia32_pause();
+    }
+    if (!landed) {
+      VTGS_HIP(hipStreamSynchronize(st));
+      if (!rec->complete) { snprintf(g_hip_err, sizeof(g_hip_err), "vtgs_forward: result record never arrived"); return VTGS_ERR_HIP; }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return info->overflow ? VTGS_ERR_INSTANCE_OVERFLOW : VTGS_OK;
   }
   VtgsForwardInfo host;
   VTGS_HIP(hipMemcpyAsync(&host, image, sizeof(VtgsForwardInfo), hipMemcpyDeviceToHost, st));
@@ -343,7 +396,7 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
   const float* state = image_state ? image_state : (const float*)(ws + L.final_T);
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   const uint32_t nblk16 = (uint32_t)(gx16 * rows16);
-  int bwd_impl = env_int("VTGS_BWD_IMPL", 2);                // 2 = lane-per-pixel matrix-core replay (default), 1 = pixel x splat-quad replay,
+  int bwd_impl = option(OPT_BWD_IMPL);                       // 2 = lane-per-pixel matrix-core replay (default), 1 = pixel x splat-quad replay,
   if (dual && bwd_impl == 0) bwd_impl = 1;                   // 0 = scalar kernel (single render only); read per call
   {
     ProfScope ps__(dual ? "composite_backward_dual" : "composite_backward", st);

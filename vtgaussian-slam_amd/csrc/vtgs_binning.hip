@@ -407,7 +407,7 @@ constexpr uint32_t kSlotBits = 11u, kPackedGidLimit = 1u << 21;
 template <int E, bool PACKED>
 __device__ __forceinline__ void wave_sort_tile(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                uint32_t* __restrict__ sorted_gid, uint32_t* __restrict__ sorted_inst,
-                                               uint32_t s, uint32_t L, int lane) {
+                                               size_t s, uint32_t L, int lane) {
   unsigned long long k[E]; uint32_t v[E];
 #pragma unroll
   for (int r = 0; r < E; ++r) {
@@ -479,7 +479,8 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
   {
     const uint32_t tile = 4u * b + (uint32_t)wv;
     if (tile < tiles) {
-      const uint32_t s = tile * tile_cap, L = min(tile_cnt[tile], tile_cap);
+      const size_t s = (size_t)tile * tile_cap;
+      const uint32_t L = min(tile_cnt[tile], tile_cap);
       if (L == 1u) {
         if (lane == 0) { sorted_gid[s] = (uint32_t)keys[s]; sorted_inst[s] = vals[s]; }
       } else if (packed) {
@@ -502,7 +503,8 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
   for (uint32_t q = 0; q < 4u; ++q) {
     const uint32_t tile = 4u * b + q;
     if (tile >= tiles) break;
-    const uint32_t s = tile * tile_cap, L = min(tile_cnt[tile], tile_cap);
+    const size_t s = (size_t)tile * tile_cap;
+    const uint32_t L = min(tile_cnt[tile], tile_cap);
     if (L <= (uint32_t)kWaveSortMax) continue;
     uint32_t n2 = 1;
     while (n2 < L) n2 <<= 1;

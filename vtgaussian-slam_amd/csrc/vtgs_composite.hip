@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   const uint32_t tile_bits = (uint32_t)tc.tile;
   // record columns: chain a -> 0..3, chain b -> 4,5 and two pad columns, chain w -> 6..8 and the tile id
   // (dual: w -> 6..8 + tile id in 12, w2 -> 9..11 + pad 15)
-  const int col_b = (cj < 2) ? 4 + cj : REC - 5 + cj;          // 12: 10, 11   16: 13, 14
+  const int col_b = (cj < 2) ? 4 + cj : (REC == 12 ? 8 : 11) + cj;   // pads: 10, 11 (REC 12) / 13, 14 (REC 16): no lane shares a word
   const int col_w = (DUAL && cj == 3) ? 12 : 6 + cj;
   const int col_w2 = (cj == 3) ? 15 : 9 + cj;
 

@@ -49,12 +49,14 @@ class _VtgsProfileEntry(ctypes.Structure):
 
 
 VTGS_OK, VTGS_ERR_INSTANCE_OVERFLOW = 0, 3
-ABI_VERSION = 7
-VTGS_FORWARD_SYNC, VTGS_FORWARD_ASYNC = 0, 1
+ABI_VERSION = 8
+VTGS_FORWARD_SYNC, VTGS_FORWARD_ASYNC, VTGS_FORWARD_CHECKED = 0, 1, 2
 _P, _U64, _I32, _SZ = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
 
 _SIGNATURES = {
     "vtgs_abi_version": (ctypes.c_uint32, []),
+    "vtgs_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "vtgs_get_option": (ctypes.c_int, [ctypes.c_char_p]),
     "vtgs_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "vtgs_last_hip_error": (ctypes.c_char_p, []),
     "vtgs_workspace_bytes": (_SZ, [_I32, _I32, _I32, _U64, ctypes.c_uint32]),
@@ -144,6 +146,24 @@ def profile_collect() -> dict:
     return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches) for i in range(n.value)}
 
 
+_OPTION_NAMES = ("VTGS_FWD_IMPL", "VTGS_BWD_IMPL", "VTGS_BIN_IMPL", "VTGS_SORT_PACKED")
+
+
+def set_option(name: str, value: int) -> None:
+    """Implementation switch of the library (include/vtgs.h: vtgs_set_option); value < 0 restores the default, which is
+    the environment variable of the same name as read once at first use."""
+    _check(_lib.vtgs_set_option(name.encode(), int(value)), f"vtgs_set_option({name})")
+
+
+def get_option(name: str) -> int:
+    return int(_lib.vtgs_get_option(name.encode()))
+
+
+def reset_options() -> None:
+    for name in _OPTION_NAMES:
+        set_option(name, -1)
+
+
 def _dev_f32(t, device) -> torch.Tensor:
     t = torch.as_tensor(t)
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -200,37 +220,18 @@ def _require(t: torch.Tensor, name: str, shape_tail: int, n: int, device) -> tor
 
 
 class _ForwardState:
-    __slots__ = ("cam", "n", "workspace", "capacity", "tile_cap", "instances", "image_state", "pending", "key")
+    __slots__ = ("cam", "n", "workspace", "capacity", "tile_cap", "instances", "image_state", "key")
 
 
-class _PinnedInfoRing:
-    """Pinned host slots for the asynchronous result record of vtgs_forward (one 64-byte slot per in-flight
-    forward) + the HIP event that says the record has landed."""
-    SLOTS = 64
-
-    def __init__(self):
-        self.buf = torch.zeros((self.SLOTS, 64), dtype=torch.uint8).pin_memory()
-        self.events = [None] * self.SLOTS          # one reusable event per slot
-        self.gen = [0] * self.SLOTS                # bumped each time a slot is handed out: a pending record whose
-        self.next = 0                              # generation no longer matches was overwritten (64 forwards later)
-
-    def take(self):
-        i = self.next
-        self.next = (i + 1) % self.SLOTS
-        if self.events[i] is not None:           # a slot is only reused once its previous record has landed
-            self.events[i].synchronize()
-        else:
-            self.events[i] = torch.cuda.Event()
-        self.gen[i] += 1
-        self.buf[i].zero_()
-        return i
-
-    def info(self, i) -> _VtgsForwardInfo:
-        return _VtgsForwardInfo.from_buffer_copy(bytes(self.buf[i][:ctypes.sizeof(_VtgsForwardInfo)].numpy()))
+_info_slots: dict = {}       # device index -> pinned, device-mapped 64-byte slot the forward writes its result record to
 
 
-_ring = None
-_ASYNC_DEFAULT = os.environ.get("VTGS_SYNC_FORWARD", "0") != "1"
+def _info_slot(device) -> torch.Tensor:
+    slot = _info_slots.get(device.index)
+    if slot is None:
+        slot = torch.zeros((64,), dtype=torch.uint8).pin_memory()
+        _info_slots[device.index] = slot
+    return slot
 
 
 def _tile_capacity_for(max_list: int) -> int:
@@ -262,29 +263,6 @@ def _record_info(key, n, W, H, capacity, info):
                       capacity=int(capacity))
 
 
-def _resolve_pending(fs: "_ForwardState") -> None:
-    """Wait for the asynchronous result record of a forward and act on it (called once its backward is enqueued).
-    Idempotent: a shared-geometry state carries the same pending record as the forward it shares."""
-    if fs.pending is None:
-        return
-    slot, event, gen = fs.pending
-    fs.pending = None
-    if _ring.gen[slot] != gen:                   # more than 64 forwards ago: the slot has been handed out again and the
-        return                                   # record is gone (instance count stays unknown: scratch sized by capacity)
-    event.synchronize()
-    info = _ring.info(slot)
-    if not info.complete:
-        raise RuntimeError("vtgs_forward: result record never arrived (stream error?)")
-    _record_info(fs.key, fs.n, fs.cam.W, fs.cam.H, fs.capacity, info)
-    if info.overflow:
-        raise RuntimeError(
-            f"vtgs_forward (asynchronous mode): {info.instances_needed} (Gaussian,tile) instances / longest tile list "
-            f"{info.max_tile_list} did not fit the workspace capacities ({fs.capacity} instances, {fs.tile_cap} per "
-            f"tile); the outputs of that forward are invalid. The capacity hints have been raised -- re-run the step "
-            f"(or set VTGS_SYNC_FORWARD=1 to check inside every forward).")
-    fs.instances = int(info.instances)
-
-
 _MAX_WORKSPACE_BYTES = int(os.environ.get("VTGS_MAX_WORKSPACE_GB", "96")) << 30
 
 
@@ -298,64 +276,77 @@ def _workspace(n, W, H, capacity, tile_cap, device):
     return nbytes, torch.empty((nbytes,), dtype=torch.uint8, device=device)
 
 
-def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, want_async: bool, colors_b=None):
-    """colors_b given: dual render (vtgs_forward_dual) -- the third return value is then the second colour image
+def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, want_async: bool = False, colors_b=None):
+    """One forward through the C ABI.  Every call is CHECKED (include/vtgs.h, VTGS_FORWARD_CHECKED): all kernels are
+    enqueued, then the host waits only for the result record, which the device writes right after the binning -- about a
+    quarter into the forward, while the sort and the composite are still running.  A capacity overflow is therefore
+    answered HERE, by growing the workspace and running again, before the caller ever sees an image: the image this
+    function returns is always valid, in grad mode and in no-grad mode alike, and nothing can fail later in backward.
+    (`want_async` is accepted for the callers of earlier versions and ignored.)
+    colors_b given: dual render (vtgs_forward_dual) -- the third return value is then the second colour image
     [3,H,W] instead of the depth image."""
-    global _ring
     device = means3D.device
     n = means3D.shape[0]
     H, W = cam.H, cam.W
     color = torch.empty((3, H, W), dtype=torch.float32, device=device)
     depth = torch.empty((3 if colors_b is not None else 1, H, W), dtype=torch.float32, device=device)
     radii = torch.empty((n,), dtype=torch.int32, device=device)
+    slot = _info_slot(device)
+    stream = _stream_ptr(device)
 
-    def launch(workspace, nbytes, capacity, tile_cap, info_ptr, flags):
+    def launch(workspace, nbytes, capacity, tile_cap):
         if colors_b is None:
             return _lib.vtgs_forward(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
                                      scales.data_ptr(), rotations.data_ptr(), color.data_ptr(), depth.data_ptr(),
-                                     radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, tile_cap, info_ptr, flags,
-                                     _stream_ptr(device))
+                                     radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, tile_cap, slot.data_ptr(),
+                                     VTGS_FORWARD_CHECKED, stream)
         return _lib.vtgs_forward_dual(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), colors_b.data_ptr(),
                                       opacities.data_ptr(), scales.data_ptr(), rotations.data_ptr(), color.data_ptr(),
                                       depth.data_ptr(), radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, tile_cap,
-                                      info_ptr, flags, _stream_ptr(device))
+                                      slot.data_ptr(), VTGS_FORWARD_CHECKED, stream)
 
     key = (device.index, n, W, H, cam.band)
-    hint = _capacity_hint.get(key, 0)
     capacity, tile_cap = _choose_capacities(key, n)
-    # the first forward of a shape has no instance-count history: check it synchronously
-    use_async = want_async and _ASYNC_DEFAULT and hint > 0
     fs = _ForwardState()
-    fs.cam, fs.n, fs.image_state, fs.pending, fs.key = cam, n, None, None, key
-    if use_async:
-        if _ring is None:
-            _ring = _PinnedInfoRing()
-        nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
-        slot = _ring.take()
-        st = launch(workspace, nbytes, capacity, tile_cap, _ring.buf[slot].data_ptr(), VTGS_FORWARD_ASYNC)
-        _check(st, "vtgs_forward")
-        ev = _ring.events[slot]
-        ev.record(torch.cuda.current_stream(device))
-        fs.workspace, fs.capacity, fs.tile_cap, fs.instances, fs.pending = (workspace, capacity, tile_cap, None,
-                                                                            (slot, ev, _ring.gen[slot]))
-        return color, radii, depth, fs
-    info = _VtgsForwardInfo()
-    for _attempt in range(4):
-        nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
-        st = launch(workspace, nbytes, capacity, tile_cap, ctypes.addressof(info), VTGS_FORWARD_SYNC)
-        if st == VTGS_ERR_INSTANCE_OVERFLOW:          # the record says what is needed: grow whichever was short
-            if info.overflow & 1:
-                capacity = int(info.instances_needed * 1.25) + 4096
-            if info.overflow & 2:
-                tile_cap = _tile_capacity_for(info.max_tile_list)
-            continue
-        _check(st, "vtgs_forward")
-        break
-    else:
-        raise RuntimeError("vtgs_forward: instance capacity kept overflowing")
+    fs.cam, fs.n, fs.image_state, fs.key = cam, n, None, key
+    with _device_guard(device):
+        for _attempt in range(6):
+            nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
+            st = launch(workspace, nbytes, capacity, tile_cap)
+            info = _VtgsForwardInfo.from_buffer_copy(bytes(slot[:ctypes.sizeof(_VtgsForwardInfo)].numpy()))
+            if st == VTGS_ERR_INSTANCE_OVERFLOW:          # the record says what is needed: grow whichever was short
+                if info.overflow & 1:
+                    capacity = int(info.instances_needed * 1.5) + 4096
+                if info.overflow & 2:
+                    tile_cap = _tile_capacity_for(info.max_tile_list)
+                _caps_in_use[key] = (capacity, tile_cap)
+                continue
+            _check(st, "vtgs_forward")
+            break
+        else:
+            raise RuntimeError("vtgs_forward: instance capacity kept overflowing")
     _record_info(key, n, W, H, capacity, info)
     fs.workspace, fs.capacity, fs.tile_cap, fs.instances = workspace, capacity, tile_cap, int(info.instances)
     return color, radii, depth, fs
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _device_guard(device):
+    """Kernels and function attributes go to the CURRENT device while streams and pointers belong to the tensors' device:
+    switch when they differ (one process driving several GPUs)."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
 
 
 def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotations, out_color, grad_color):
@@ -369,18 +360,16 @@ def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotatio
     g_rot = torch.empty((n, 4), dtype=torch.float32, device=device)
     if n == 0:
         return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
-    # Asynchronous forward: enqueue the backward first (scratch sized by capacity; the kernels check the device-side
-    # overflow flag themselves) and verify the result record afterwards, so the GPU never waits for the host.
-    sbytes = _lib.vtgs_backward_scratch_bytes(n, fs.capacity if fs.instances is None else fs.instances)
+    sbytes = _lib.vtgs_backward_scratch_bytes(n, fs.instances)
     scratch = torch.empty((sbytes,), dtype=torch.uint8, device=device)
     state_ptr = fs.image_state.data_ptr() if fs.image_state is not None else None
-    st = _lib.vtgs_backward(ctypes.byref(fs.cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
-                            scales.data_ptr(), rotations.data_ptr(), out_color.data_ptr(), grad_color.data_ptr(),
-                            fs.workspace.data_ptr(), fs.workspace.numel(), fs.capacity, fs.tile_cap, state_ptr,
-                            scratch.data_ptr(), sbytes, g_means3D.data_ptr(), g_means2D.data_ptr(), g_colors.data_ptr(),
-                            g_opac.data_ptr(), g_scales.data_ptr(), g_rot.data_ptr(), _stream_ptr(device))
+    with _device_guard(device):
+        st = _lib.vtgs_backward(ctypes.byref(fs.cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
+                                scales.data_ptr(), rotations.data_ptr(), out_color.data_ptr(), grad_color.data_ptr(),
+                                fs.workspace.data_ptr(), fs.workspace.numel(), fs.capacity, fs.tile_cap, state_ptr,
+                                scratch.data_ptr(), sbytes, g_means3D.data_ptr(), g_means2D.data_ptr(), g_colors.data_ptr(),
+                                g_opac.data_ptr(), g_scales.data_ptr(), g_rot.data_ptr(), _stream_ptr(device))
     _check(st, "vtgs_backward")
-    _resolve_pending(fs)                 # raises if that forward had overflowed its capacity
     return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
 
 
@@ -394,7 +383,7 @@ def _run_backward_dual(fs: _ForwardState, means3D, colors_a, colors_b, opacities
     g_means3D, g_means2D, g_ca, g_cb, g_opac, g_scales, g_rot = new(n, 3), new(n, 3), new(n, 3), new(n, 3), new(n, 1), new(n, 3), new(n, 4)
     if n == 0:
         return g_means3D, g_means2D, g_ca, g_opac, g_scales, g_rot, g_cb
-    sbytes = _lib.vtgs_backward_dual_scratch_bytes(n, fs.capacity if fs.instances is None else fs.instances)
+    sbytes = _lib.vtgs_backward_dual_scratch_bytes(n, fs.instances)
     scratch = torch.empty((sbytes,), dtype=torch.uint8, device=device)
     st = _lib.vtgs_backward_dual(ctypes.byref(fs.cam.c), n, means3D.data_ptr(), colors_a.data_ptr(), colors_b.data_ptr(),
                                  opacities.data_ptr(), scales.data_ptr(), rotations.data_ptr(), out_a.data_ptr(),
@@ -403,7 +392,6 @@ def _run_backward_dual(fs: _ForwardState, means3D, colors_a, colors_b, opacities
                                  g_means3D.data_ptr(), g_means2D.data_ptr(), g_ca.data_ptr(), g_cb.data_ptr(),
                                  g_opac.data_ptr(), g_scales.data_ptr(), g_rot.data_ptr(), _stream_ptr(device))
     _check(st, "vtgs_backward_dual")
-    _resolve_pending(fs)                 # raises if that forward had overflowed its capacity
     return g_means3D, g_means2D, g_ca, g_opac, g_scales, g_rot, g_cb
 
 
@@ -411,7 +399,6 @@ def debug_tile_lists(rasterizer: "GaussianRasterizer"):
     """Test hook: (tile_offsets [tiles8+1] int64, sorted_gid [R] int64, geom [N,8] float32) of the last forward
     of `rasterizer`, copied to the CPU and compacted (tile t = sorted_gid[offsets[t]:offsets[t+1]]).  8x8 tiles, row-major."""
     fs = rasterizer._last_state
-    _resolve_pending(fs)
     out = (ctypes.c_uint64 * 8)()
     _check(_lib.vtgs_debug_layout(fs.n, fs.cam.W, fs.cam.H, fs.capacity, fs.tile_cap, out), "vtgs_debug_layout")
     ws = fs.workspace
@@ -433,7 +420,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, cam: _Camera,
-                shared_from: Optional[_ForwardState], want_async: bool = False):
+                shared_from: Optional[_ForwardState]):
         device = means3D.device
         n = means3D.shape[0]
         means3D = _require(means3D, "means3D", 3, n, device)
@@ -442,9 +429,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         scales_c = _require(scales, "scales", 3, n, device)
         rot = _require(rotations, "rotations", 4, n, device)
         if shared_from is None:
-            color, radii, depth, fs = _run_forward(cam, means3D, colors, opac, scales_c, rot, want_async=want_async)
+            color, radii, depth, fs = _run_forward(cam, means3D, colors, opac, scales_c, rot)
         else:
-            base = shared_from                  # its result record may still be in flight: share it, do not wait
+            base = shared_from
             H, W = cam.H, cam.W
             color = torch.empty((3, H, W), dtype=torch.float32, device=device)
             depth = torch.empty((1, H, W), dtype=torch.float32, device=device)
@@ -454,8 +441,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                           base.capacity, base.tile_cap, state.data_ptr(), _stream_ptr(device))
             _check(st, "vtgs_forward_shared")
             fs = _ForwardState()
-            fs.cam, fs.n, fs.workspace, fs.capacity, fs.tile_cap, fs.instances, fs.image_state, fs.pending, fs.key = (
-                base.cam, base.n, base.workspace, base.capacity, base.tile_cap, base.instances, state, base.pending, base.key)
+            fs.cam, fs.n, fs.workspace, fs.capacity, fs.tile_cap, fs.instances, fs.image_state, fs.key = (
+                base.cam, base.n, base.workspace, base.capacity, base.tile_cap, base.instances, state, base.key)
             radii = None
         ctx.fs = fs
         ctx.save_for_backward(means3D, colors, opac, scales_c, rot, color)
@@ -474,7 +461,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         grad_color = grad_color.to(torch.float32).contiguous()
         g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot = _run_backward(
             ctx.fs, means3D, colors, opac, scales_c, rot, color, grad_color)
-        return g_means3D, g_means2D, None, g_colors, g_opac, g_scales, g_rot, None, None, None, None
+        return g_means3D, g_means2D, None, g_colors, g_opac, g_scales, g_rot, None, None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -527,12 +514,8 @@ class GaussianRasterizer(nn.Module):
         if not means3D.is_cuda:
             raise RuntimeError("GaussianRasterizer needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
         cam = _Camera(self.raster_settings, means3D.device, self._rule, self._tile_rows)
-        # Asynchronous forward only when a backward will follow (that is where its result record is checked);
-        # grad mode is off inside autograd.Function.forward, so this is decided here.
-        want_async = torch.is_grad_enabled() and any(
-            t is not None and t.requires_grad for t in (means3D, means2D, colors_precomp, opacities, scales, rotations))
         color, radii, depth, fs = _RasterizeGaussians.apply(means3D, means2D, None, colors_precomp, opacities, scales,
-                                                            rotations, None, cam, None, want_async)
+                                                            rotations, None, cam, None)
         self._last_state = fs
         return color, radii, depth
 

@@ -27,7 +27,7 @@ import torch
 import os
 
 from . import (_Camera, _ForwardState, _RADIUS_RULES, _check, _lib, _run_backward, _run_backward_dual, _run_forward,
-               _resolve_pending, _stream_ptr, _I32, _P)
+               _stream_ptr, _I32, _P)
 
 _lib.vtgs_pose_partial_rows.restype, _lib.vtgs_pose_partial_rows.argtypes = ctypes.c_uint32, [_I32]
 _lib.vtgs_prepare_frame.restype, _lib.vtgs_prepare_frame.argtypes = ctypes.c_int, [_I32] + [_P] * 13
@@ -54,10 +54,9 @@ class _RenderFrame(torch.autograd.Function):
         dual = os.environ.get("VTGS_DUAL", "1") != "0"             # read per call, like the other implementation switches
         state = None
         if dual:
-            im, radii, depth_sil, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot, want_async=flags != 0,
-                                                    colors_b=dcol)
+            im, radii, depth_sil, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot, colors_b=dcol)
         else:
-            im, radii, _, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot, want_async=flags != 0)
+            im, radii, _, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot)
             H, W = cam.H, cam.W
             depth_sil, depth2, state = new(3, H, W), new(1, H, W), new(H * W)
             _check(_lib.vtgs_forward_shared(ctypes.byref(cam.c), n, dcol.data_ptr(), depth_sil.data_ptr(), depth2.data_ptr(),
@@ -81,10 +80,10 @@ class _RenderFrame(torch.autograd.Function):
             ga = _run_backward_dual(fs, means_cam, rgb, dcol, opac, scales, rot, im, depth_sil, g_im, g_ds)
             g_dcol, gb = ga[6], (None,) * 6
         else:
-            ga = _run_backward(fs, means_cam, rgb, opac, scales, rot, im, g_im)        # resolves the async forward
+            ga = _run_backward(fs, means_cam, rgb, opac, scales, rot, im, g_im)
             fsb = _ForwardState()
-            (fsb.cam, fsb.n, fsb.workspace, fsb.capacity, fsb.tile_cap, fsb.instances, fsb.image_state, fsb.pending,
-             fsb.key) = fs.cam, fs.n, fs.workspace, fs.capacity, fs.tile_cap, fs.instances, ctx.state, fs.pending, fs.key
+            (fsb.cam, fsb.n, fsb.workspace, fsb.capacity, fsb.tile_cap, fsb.instances, fsb.image_state,
+             fsb.key) = fs.cam, fs.n, fs.workspace, fs.capacity, fs.tile_cap, fs.instances, ctx.state, fs.key
             gb = _run_backward(fsb, means_cam, dcol, opac, scales, rot, depth_sil, g_ds)
             g_dcol = gb[2]
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
@@ -95,15 +94,18 @@ class _RenderFrame(torch.autograd.Function):
         g_logit = new(n, 1) if want_a else None
         g_ls = new(n, 1) if want_a else None
         rows = int(_lib.vtgs_pose_partial_rows(n))
-        partials = new(rows, 12) if want_p else None
-        _check(_lib.vtgs_prepare_frame_backward(
-            n, flags, means3D.data_ptr(), logit_op.data_ptr(), log_scales.data_ptr(), unnorm_rot.data_ptr(),
-            cam_q.data_ptr(), cam_t.data_ptr(), depth_w2c.data_ptr(), ga[0].data_ptr(), ptr(gb[0]), g_dcol.data_ptr(),
-            ga[3].data_ptr(), ptr(gb[3]), ga[4].data_ptr(), ptr(gb[4]), ga[5].data_ptr(), ptr(gb[5]),
-            ptr(g_means3D), ptr(g_logit), ptr(g_ls), ptr(g_ur), ptr(partials), _stream_ptr(dev)),
-            "vtgs_prepare_frame_backward")
+        partials = new(max(rows, 1), 12) if want_p else None
+        if n > 0:
+            _check(_lib.vtgs_prepare_frame_backward(
+                n, flags, means3D.data_ptr(), logit_op.data_ptr(), log_scales.data_ptr(), unnorm_rot.data_ptr(),
+                cam_q.data_ptr(), cam_t.data_ptr(), depth_w2c.data_ptr(), ga[0].data_ptr(), ptr(gb[0]), g_dcol.data_ptr(),
+                ga[3].data_ptr(), ptr(gb[3]), ga[4].data_ptr(), ptr(gb[4]), ga[5].data_ptr(), ptr(gb[5]),
+                ptr(g_means3D), ptr(g_logit), ptr(g_ls), ptr(g_ur), ptr(partials), _stream_ptr(dev)),
+                "vtgs_prepare_frame_backward")
         g_q = g_t = None
-        if want_p:                                                # 12 partial sums per workgroup -> dL/dq, dL/dt
+        if want_p and n == 0:                                     # nothing rendered: zero pose gradient, no launch
+            g_q, g_t = torch.zeros(4, device=dev), torch.zeros(3, device=dev)
+        elif want_p:                                              # 12 partial sums per workgroup -> dL/dq, dL/dt
             g_q, g_t = new(4), new(3)
             _check(_lib.vtgs_pose_gradient(partials.data_ptr(), rows, cam_q.data_ptr(), g_q.data_ptr(), g_t.data_ptr(),
                                            _stream_ptr(dev)), "vtgs_pose_gradient")
