@@ -93,8 +93,9 @@ typedef struct VtgsForwardInfo {
                                 /* `info` is not device-mapped.                                                       */
 
 uint32_t    vtgs_abi_version(void);
-/* Implementation switches (tests and ablations): "VTGS_FWD_IMPL" / "VTGS_BWD_IMPL" (2 = lane-per-pixel matrix-core
- * composites, default; 1 = pixel x splat-quad form; 0 = scalar kernels), "VTGS_BIN_IMPL" (1 = LDS-binned slot
+/* Implementation switches (tests and ablations): "VTGS_FWD_IMPL" (3 = per-quadrant splat queues, default) and
+ * "VTGS_FWD_IMPL" / "VTGS_BWD_IMPL" (2 = lane-per-pixel matrix-core composites, the backward's default; 1 = pixel x
+ * splat-quad form; 0 = scalar kernels), "VTGS_BIN_IMPL" (1 = LDS-binned slot
  * reservation where the tile table fits, 0 = global atomics), "VTGS_SORT_PACKED" (1 = payload in the key's low bits for
  * N <= 2^21).  Defaults come from the environment variables of the same names, read ONCE at first use.
  * vtgs_set_option returns VTGS_ERR_INVALID_ARGUMENT for an unknown name; value < 0 restores the default.           */
@@ -253,15 +254,21 @@ int vtgs_silhouette_sweep(const float* im, const float* silhouette, const float*
  * forward: 2-3 launches; out5 (device) = {loss, mask count, sum |d im|, sum |d depth|, mean SSIM}; scratch =
  * vtgs_loss_scratch_floats(H, W) floats; ssim_grad_maps = 9*H*W floats (mode 1 with a backward to follow, else NULL).
  * backward: 1-2 launches writing g_im [3,H,W] and g_depth_sil [3,H,W] = upstream[0] * dloss/d(.) with `upstream` a
- * DEVICE scalar (the gradient arriving at the loss): no host wait, no element-wise multiplies afterwards.            */
+ * DEVICE scalar (the gradient arriving at the loss): no host wait, no element-wise multiplies afterwards.
+ * The TUM / ScanNet / ScanNet++ branches (src/vtgaussian_slam.py:511-611) add detached per-pixel masks to the same sums:
+ * extra_mask [H*W] floats (NULL = none; 0 = pixel excluded) is ANDed into the depth / tracking-colour mask -- the caller
+ * forms it from the visibility mask (:536-584, :376-404), the far-depth filter (:586-588) and the 50 x median outlier
+ * mask (:525-528); color_weight [3*H*W] (mapping only, NULL = none) = 10 * additional_mask + 0.8 replaces the constant
+ * 0.8 of the colour L1 term (:609-611, l1_loss_v1_mask).                                                             */
 size_t vtgs_loss_scratch_floats(int32_t height, int32_t width);
 int vtgs_slam_loss_forward(int32_t mode, const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth,
                            int32_t height, int32_t width, float sil_thres, float w_im, float w_depth, float* scratch,
-                           float* ssim_grad_maps, float* out5, void* stream);
+                           float* ssim_grad_maps, float* out5, const float* extra_mask, const float* color_weight,
+                           void* stream);
 int vtgs_slam_loss_backward(int32_t mode, const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth,
                             int32_t height, int32_t width, float sil_thres, float w_im, float w_depth,
                             const float* ssim_grad_maps, const float* fwd_out5, const float* upstream, float* g_im,
-                            float* g_depth_sil, void* stream);
+                            float* g_depth_sil, const float* extra_mask, const float* color_weight, void* stream);
 
 /* ---- Adam over the parameter groups ------------------------------------------------------------------
  * Replaces torch.optim.Adam as the reference configures it (src/vtgaussian_slam.py:180-187: one group per tensor with its

@@ -6,6 +6,9 @@
 //   v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 blocks, block = L>>2):
 //        D[v] of lane L = A(lane 4*(L>>2) + v) * B(lane L)                 (row v from the block's lanes, column = L&3)
 //   the same with cbsz=4/abid=g:  D[v] of lane L = A(lane 4*g + v) * B(lane L)      (all blocks share block g's A rows)
+//   the same with cbsz=2/abid=g:  D[v] of lane L = A(lane 16*(L>>4) + 4*g + v) * B(lane L)
+//        (the four blocks of each 16-lane group share the A rows of the group's block g: one 4x4 pixel quadrant per group,
+//         each quadrant with its OWN four splats -- what the quadrant-queue composites are built on)
 // Exit code 0 = layout as assumed.  Build: hipcc --offload-arch=gfx950 mfma_layout.hip -o mfma_layout.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -64,6 +67,25 @@ static int check4x4_bcast(float* d) {
   if (bad) printf("4x4x1_16b cbsz=4 abid=%d: %d mismatches (lane 9: %g %g %g %g)\n", ABID, bad, h[36], h[37], h[38], h[39]);
   return bad;
 }
+template <int ABID>
+__global__ void k4x4_group(float* out) {
+  const int l = threadIdx.x;
+  f32x4 d = {0, 0, 0, 0};
+  d = __builtin_amdgcn_mfma_f32_4x4x1f32((float)(1 + l), (float)(3 + l), d, 2, ABID, 0);
+  for (int r = 0; r < 4; ++r) out[l * 4 + r] = d[r];
+}
+template <int ABID>
+static int check4x4_group(float* d) {
+  float h[64 * 4];
+  k4x4_group<ABID><<<1, 64>>>(d);
+  if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return 1000;
+  int bad = 0;
+  for (int l = 0; l < 64; ++l)
+    for (int v = 0; v < 4; ++v)
+      if (h[l * 4 + v] != (float)(1 + 16 * (l >> 4) + 4 * ABID + v) * (float)(3 + l)) ++bad;
+  if (bad) printf("4x4x1_16b cbsz=2 abid=%d: %d mismatches (lane 21: %g %g %g %g)\n", ABID, bad, h[84], h[85], h[86], h[87]);
+  return bad;
+}
 #define CK(x) do { if ((x) != hipSuccess) { printf("HIP error line %d\n", __LINE__); return 2; } } while (0)
 
 template <int ABID>
@@ -120,6 +142,7 @@ int main() {
   if (bad4) printf("4x4x1_16b: %d mismatches (lane 5: %g %g %g %g)\n", bad4, h[20], h[21], h[22], h[23]);
   bad += bad4;
   bad += check4x4_bcast<0>(d) + check4x4_bcast<5>(d) + check4x4_bcast<15>(d);
+  bad += check4x4_group<0>(d) + check4x4_group<1>(d) + check4x4_group<2>(d) + check4x4_group<3>(d);
   printf(bad ? "MFMA layout DIFFERS from what the kernels assume (%d)\n" : "mfma layouts ok\n", bad);
   return bad ? 1 : 0;
 }

@@ -161,8 +161,13 @@ def oracle_instances_8x8(sp, opacities, cam, rel_slack=0.0, abs_slack=0.0, rows8
 # discrete decision of the composite -- a pair whose alpha is within float32 rounding of 1/255 (counted or skipped), or a
 # transmittance within rounding of the 1e-4 stop -- as seen in the ORACLE's own per-pair values.  Anything else fails.
 # ---------------------------------------------------------------------------------------------------------------
-LN_ALPHA_MARGIN = 1e-4      # |ln alpha - ln(1/255)|: float32 exponent rounding is ~1e-5 absolute (deviation 3)
-T_STOP_MARGIN = 5e-4        # |T (1 - alpha) / 1e-4 - 1|: a product of up to ~100 float32 factors
+# |ln alpha - ln(1/255)| a float32 implementation cannot resolve: 5e-5 for the exponent arithmetic itself (DESIGN.md 2,
+# deviation 3) plus the float32 representation of the splat centre -- u, v are O(W) pixels, so they carry an absolute
+# error of a few half-ulps of max(W, H) (6e-5 px at 1024, the published CUDA operator has the same), which moves the
+# exponent by |grad_centre q| times that: up to ~3 per pixel at the rim of a sigma ~ 1 px splat.
+LN_ALPHA_MARGIN = 5e-5
+CENTRE_HALF_ULPS = 4.0
+T_STOP_MARGIN = 1e-3        # |T (1 - alpha) / 1e-4 - 1|: a product of up to ~100 float32 factors, each with the above
 
 
 def audit_outliers(ref, got, aux, opacities, cam, tol=1e-4, max_report=5000):
@@ -182,6 +187,7 @@ def audit_outliers(ref, got, aux, opacities, cam, tol=1e-4, max_report=5000):
     gx = (int(cam.image_width) + 15) // 16
     op_all = opacities.reshape(-1).double()
     ln_min = float(torch.log(torch.tensor(go.ALPHA_MIN, dtype=torch.float64)))
+    delta = CENTRE_HALF_ULPS * 2.0 ** -24 * max(int(cam.image_width), int(cam.image_height))
     for y, x in zip(ys.tolist(), xs.tolist()):
         t = (y // 16) * gx + x // 16
         out["tiles"].add(t)
@@ -197,7 +203,8 @@ def audit_outliers(ref, got, aux, opacities, cam, tol=1e-4, max_report=5000):
         stopped = torch.cumsum((Tcum < go.T_STOP).int(), 0) > 0
         reach = ~torch.cat([torch.zeros(1, dtype=torch.bool), stopped[:-1]])      # pairs the pixel still looks at
         ln_a = torch.log(torch.clamp(a_raw, min=1e-300))
-        m_alpha = (ln_a - ln_min).abs()[reach & (power <= 0)]
+        gq = torch.sqrt((con[:, 0] * dx + con[:, 1] * dy) ** 2 + (con[:, 2] * dy + con[:, 1] * dx) ** 2)   # |d power / d centre|
+        m_alpha = ((ln_a - ln_min).abs() - gq * delta)[reach & (power <= 0)]
         m_T = (Tcum / go.T_STOP - 1.0).abs()[reach & valid]
         ok = (m_alpha.numel() and float(m_alpha.min()) <= LN_ALPHA_MARGIN) or (m_T.numel() and float(m_T.min()) <= T_STOP_MARGIN)
         if ok:

@@ -68,8 +68,8 @@ def _check_grads(ref, got, taint=None):
             assert mx <= 5 * GRAD_TOL and p999 <= GRAD_TOL, f"grad {k}: max {mx:.2e}, p99.9 rel {p999:.2e}"
             continue
         scale = ref[k].abs().max().item()
-        if scale == 0:
-            assert got[k].abs().max().item() <= 1e-12
+        if scale == 0:             # isotropic scenes: dL/drotations is exactly zero; the kernel's is float32 noise around it
+            assert got[k].abs().max().item() <= 1e-4 * max(ref["scales"].abs().max().item(), 1e-30), k
             continue
         d = (ref[k].double() - got[k].double()).abs() / scale
         clean, dirty = d[~taint], d[taint]
@@ -524,3 +524,41 @@ def test_odd_shapes_default_kernels_vs_scalar_kernels(gpu_device, monkeypatch, s
         d = (r - o).abs()
         p99 = torch.quantile((d / (r.abs() + 1e-3 * scale)).reshape(-1), 0.99).item()
         assert (d.max() / scale).item() <= 5e-3 and p99 <= 2e-3, (seed, k, (d.max() / scale).item(), p99)
+
+
+def _quadrant_scenes():
+    yield "view_tied_dense", SCENES["view_tied_dense"]()
+    yield "random_aniso", SCENES["random_aniso"]()
+    yield "wide_fov_aniso", SCENES["wide_fov_aniso"]()
+    scene, cam = go.view_tied_scene(20000, 48, 32, seed=77)                   # saturating: every pixel stops mid-list
+    yield "saturating", (scene, cam)
+    scene, cam = go.view_tied_scene(20000, 48, 32, seed=78)
+    scene["opacities"] = torch.full_like(scene["opacities"], 0.995)           # clamp + early termination everywhere
+    yield "opaque", (scene, cam)
+    for seed in range(8):                                                     # awkward sizes, giant and sub-pixel splats
+        g = torch.Generator().manual_seed(1000 + seed)
+        W = int(torch.randint(1, 70, (1,), generator=g)); H = int(torch.randint(1, 50, (1,), generator=g))
+        n = [1, 2, 63, 65, 257, 1500, 4000, 9000][seed]
+        scene, cam = go.random_scene(n, W, H, seed=seed, anisotropic=bool(seed & 1), w2c=_w2c(seed))
+        if seed % 4 == 1:
+            scene["scales"] = scene["scales"] * 6.0
+        if seed % 4 == 2:
+            scene["scales"] = scene["scales"] * 0.05
+        yield f"odd{seed}", (scene, cam)
+
+
+def test_quadrant_queue_forward_is_bit_identical(gpu_device):
+    """composite_forward_q (per-quadrant splat queues, colour on the matrix cores) skips only pairs whose alpha is below
+    1/255 in the whole 4x4 quadrant and keeps every k-ordered fmaf chain: colour, depth and the per-pixel final
+    transmittance (through the backward that consumes it) are BIT-IDENTICAL to the lane = pixel kernel."""
+    for name, (scene, cam) in _quadrant_scenes():
+        g = torch.Generator().manual_seed(5)
+        grad_color = torch.rand(3, cam.image_height, cam.image_width, generator=g) * 2 - 1
+        _opt("VTGS_FWD_IMPL", 2)
+        ref = run_hip(scene, cam, gpu_device, grad_color)
+        _opt("VTGS_FWD_IMPL", 3)
+        got = run_hip(scene, cam, gpu_device, grad_color)
+        assert torch.equal(ref[0], got[0]), f"{name}: colour differs, max {(ref[0] - got[0]).abs().max().item():.3e}"
+        assert torch.equal(ref[2], got[2]) and torch.equal(ref[1], got[1]), name
+        for k in GRAD_KEYS:                                                   # same final T -> same backward, bit for bit
+            assert torch.equal(ref[3][k], got[3][k]), (name, k)

@@ -26,6 +26,10 @@ template <int WAVES, bool DUAL>
 __global__ void composite_forward_px(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                      const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*,
                                      float*);
+template <bool DUAL>
+__global__ void composite_forward_q(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
+                                    const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*,
+                                    float*);
 __global__ void composite_backward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                    const uint32_t*, const GeomRec*, const float*, const float*, const float*,
                                    const float*, float*, const Counters*);
@@ -140,7 +144,7 @@ size_t vtgs_backward_dual_scratch_bytes(int32_t n, uint64_t instances) {
 #include <time.h>
 // Implementation switches: defaults from the environment, read once; vtgs_set_option overrides them at run time.
 struct Option { const char* name; int dflt; int value; };
-static Option g_options[] = {{"VTGS_FWD_IMPL", 2, -1}, {"VTGS_BWD_IMPL", 2, -1}, {"VTGS_BIN_IMPL", 1, -1}, {"VTGS_SORT_PACKED", 1, -1}};
+static Option g_options[] = {{"VTGS_FWD_IMPL", 3, -1}, {"VTGS_BWD_IMPL", 2, -1}, {"VTGS_BIN_IMPL", 1, -1}, {"VTGS_SORT_PACKED", 1, -1}};
 enum { OPT_FWD_IMPL = 0, OPT_BWD_IMPL, OPT_BIN_IMPL, OPT_SORT_PACKED, OPT_COUNT };
 static bool g_options_ready = false;
 static void options_init() {
@@ -179,7 +183,17 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
                                                            // matrix-core kernel, 0 = scalar kernel (read per call)
   {
     ProfScope ps__(colors_b ? "composite_forward_dual" : "composite_forward", st);
-    if (colors_b && impl != 1)
+    if (impl == 3 && colors_b)                              // quadrant queues (vtgs_composite_q.hip)
+      hipLaunchKernelGGL((composite_forward_q<true>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
+                         (const GeomRec*)(ws + L.geom), colors, out_color, (float*)nullptr, image_state,
+                         (const Counters*)(ws + L.counters), colors_b, out_color_b);
+    else if (impl == 3)
+      hipLaunchKernelGGL((composite_forward_q<false>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
+                         (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
+                         (const Counters*)(ws + L.counters), (const float*)nullptr, (float*)nullptr);
+    else if (colors_b && impl != 1)
       hipLaunchKernelGGL((composite_forward_px<4, true>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const GeomRec*)(ws + L.geom), colors, out_color, (float*)nullptr, image_state,
@@ -223,6 +237,7 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   if (!band_of(cam, &r8b, &r8e, &rows16, &row16_0)) return VTGS_ERR_INVALID_ARGUMENT;
   const WsLayout L = make_layout(n, cam->image_width, cam->image_height, instance_capacity, tile_capacity);
   if (workspace_bytes < L.total) return VTGS_ERR_WORKSPACE_TOO_SMALL;
+  if ((uint64_t)L.tiles8 * L.tile_cap >= (1ull << 32)) return VTGS_ERR_INVALID_ARGUMENT;   // bin offsets are 32-bit in the composites
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
   const CamScalars cs = scalars_of(cam, r8b, r8e);

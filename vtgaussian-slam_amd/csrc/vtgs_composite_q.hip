@@ -1,0 +1,351 @@
+// vtgs_composite_q.hip -- composites with per-quadrant splat queues (gfx950, wave64).
+//
+// The lane = pixel kernels of vtgs_composite.hip evaluate every splat of an 8x8 tile's list at all 64 pixels; at view-tied
+// densities (sigma ~ 1 px) a splat's alpha >= 1/255 footprint covers ~2 of the tile's four 4x4 quadrants, so about half of
+// those (pixel, splat) rows are dead by construction.  Here one wavefront is still one 8x8 tile and one lane one pixel, but
+// the 16 lanes of a 4x4 QUADRANT walk their own list:
+//
+//   * lane L <-> pixel (x, y) = (4 (q & 1) + (i & 3), 4 (q >> 1) + (i >> 2)),  q = L >> 4 the quadrant, i = L & 15;
+//   * per 64-entry chunk of the tile's depth-sorted list, lane L gathers splat L, derives from the bounding box of its
+//     alpha >= 1/255 ellipse which quadrants it can reach (4 bits), and the wavefront compacts the chunk into four FIFO
+//     queues in LDS with __ballot + mbcnt ranks ("wavefront-ballot compaction" of the LDS-staged list).  The order inside
+//     a queue is the list order, so every pixel still sees its contributors front to back;
+//   * a STEP pops up to 16 entries from every queue: v_mfma_f32_4x4x1_16b_f32 with cbsz = 2 / abid = g multiplies, in each
+//     16-lane group, the four splats held by the group's lanes 4g..4g+3 with the group's own 16 pixels -- four MFMAs per
+//     rank-1 term give every lane its pixel x 16 splats OF ITS OWN QUADRANT (tests/micro/mfma_layout.hip checks the
+//     layout).  Steps run while some queue holds 16; what is left (< 16 per queue) waits for the next chunk and is always
+//     consumed by the first step after it (a step pops min(16, count) from EVERY queue), so a table ring of two chunks
+//     is enough;
+//   * colour accumulation is a rank-1 update per splat as well, C[ch][pixel] += c[ch][k] w[k][pixel], and runs on the
+//     same MFMA (A = the splat's four channels transposed onto the lanes of block g, B = the lane's w_k): no payload
+//     reads in the inner loop.  An exact-f32 MFMA is a k-ordered fmaf chain, and a skipped pair has w = 0 exactly, so
+//     images are BIT-IDENTICAL to composite_forward_px (tests/test_gpu_parity.py).
+//
+// Where the time goes (profiles/r2_forward_study.md).  A step costs ~1,100 cycles of one wavefront's time and 520-660
+// cycles of the SIMD's at 3-8 resident wavefronts; more than half of that is the vector sweep (exp, threshold, weight,
+// transmittance: 290 cycles per 16 splats, independent of occupancy), the 24 exponent MFMAs take ~120 and the 16 colour
+// MFMAs ~125.  MFMAs and vector instructions are kept in separate groups (sched_group_barrier): alternating one by one
+// they cost 1.5x the sum of their parts.  The gather is software-pipelined two chunks deep.  With the prefetch registers
+// the kernel needs ~120 VGPRs (4 wavefronts per SIMD); the 64-register form without prefetch runs no faster at 6.
+//
+// Semantics per pixel: SURVEY.md Appendix A3 (see vtgs_composite.hip).
+#include "vtgs_internal.h"
+#include "vtgs_composite_common.h"
+
+namespace vtgs {
+
+constexpr int kQRing = 128;                 // table / queue ring: two 64-entry chunks
+constexpr int kQDummy = kQRing;             // table slot 128: a splat that reaches nothing (popped past the end of a queue)
+
+struct QuadCoord { int tile, px, py, q, i; bool tile_ok, inside; };
+
+__device__ __forceinline__ QuadCoord quad_coord(const CamScalars& cs, uint32_t nblk, int gx16, int gx8, int gy8) {
+  const uint32_t b = xcd_swizzle(blockIdx.x, nblk);
+  const int l = lane_id();
+  const int row16_0 = cs.row8_begin >> 1;
+  const int t16x = (int)(b % (uint32_t)gx16), t16y = row16_0 + (int)(b / (uint32_t)gx16);
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // workgroup = the 2x2 tiles of a 16x16 block
+  const int t8x = 2 * t16x + (w & 1), t8y = 2 * t16y + (w >> 1);
+  QuadCoord qc;
+  qc.q = l >> 4; qc.i = l & 15;
+  qc.tile_ok = t8x < gx8 && t8y < gy8 && t8y >= cs.row8_begin && t8y < cs.row8_end;
+  qc.tile = t8y * gx8 + t8x;
+  qc.px = t8x * kSubTile + 4 * (qc.q & 1) + (qc.i & 3);
+  qc.py = t8y * kSubTile + 4 * (qc.q >> 1) + (qc.i >> 2);
+  qc.inside = qc.tile_ok && qc.px < cs.W && qc.py < cs.H;
+  return qc;
+}
+
+// Quadrants (bit q) the splat's alpha >= 1/255 region can reach: bounding box of the ellipse {q <= tau}, tau = ln(255 o) with
+// the binning's conservative slack -- a quadrant outside the box holds no pixel with alpha >= 1/255.  (sx, sy) = splat
+// centre relative to the tile centre; the quadrants' pixel centres are X, Y in {-3.5..-0.5} and {0.5..3.5}.
+__device__ __forceinline__ uint32_t quadrant_mask(const float4& g0, const float4& g1, float sx, float sy) {
+  float tau = (__log2f(g1.y) + 7.99435344f) * 0.69314718f;               // ln(255 o)
+  tau += 1e-4f * tau + 1e-4f;
+  const float idet = 1.f / fmaxf(g0.z * g1.x - g0.w * g0.w, 1e-30f);
+  const float k2 = 2.f * fmaxf(tau, 0.f) * idet;
+  const float hx = sqrtf(k2 * g1.x) * 1.000001f + 1e-5f, hy = sqrtf(k2 * g0.z) * 1.000001f + 1e-5f;
+  const bool left = sx - hx <= -0.5f && sx + hx >= -3.5f, right = sx + hx >= 0.5f && sx - hx <= 3.5f;
+  const bool top = sy - hy <= -0.5f && sy + hy >= -3.5f, bottom = sy + hy >= 0.5f && sy - hy <= 3.5f;
+  return (left && top ? 1u : 0u) | (right && top ? 2u : 0u) | (left && bottom ? 4u : 0u) | (right && bottom ? 8u : 0u);
+}
+
+// exponents of the lane's pixel x the four splats held by lanes 4g..4g+3 of the lane's OWN 16-lane group
+template <int G>
+__device__ __forceinline__ f32x4 q_exponents(const float (&K)[6], const float (&Phi)[6]) {
+  f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < 6; ++m) d = __builtin_amdgcn_mfma_f32_4x4x1f32(K[m], Phi[m], d, 2, G, 0);
+  return d;
+}
+
+template <int R>
+__device__ __forceinline__ f32x4 q_colour(float pt, float w, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(pt, w, c, 2, R, 0);        // C[ch] += c[ch][splat 4j + R] * w
+}
+
+template <bool CLAMP>
+__device__ __forceinline__ float q_alpha(float d) {
+  const float g = __builtin_amdgcn_exp2f(d);
+  const float al = CLAMP ? fminf(kAlphaMax, g) : g;                     // CLAMP == false: no splat in flight can reach 0.99
+  return (al >= kAlphaMin) ? al : 0.f;
+}
+
+// One step for the lane's pixel: 16 splats of its quadrant's queue.  T: transmittance in front of the next splat, frozen once
+// the pixel has ended; `done`: ended / off-image; `exact` (wave-uniform): go straight to the exact sweep while pixels keep
+// ending (the policy of composite_forward_px).  PT[G]: lane (q, 4r + ch) holds channel ch of splat 4G + r.
+//
+// THREE PHASES, kept apart with sched_barrier: (A) the 24 exponent MFMAs back to back, (B) the vector sweep -- alpha, weight
+// and transmittance of the 16 splats -- with no matrix instruction in it, (C) the 16 colour MFMAs back to back.
+// tests/micro/mix_rate.hip: an f32 MFMA and a vector instruction that alternate in one wavefront's stream cost 1.5x the sum
+// of their separate issue times at every occupancy (1 MFMA : 3 v_fma), while groups of 24 : 72 cost the plain sum; left
+// to itself the scheduler interleaves them one by one to hide the MFMA latency, which is exactly the wrong thing here.
+#ifndef VTGS_Q_STEP_ABL
+#define VTGS_Q_STEP_ABL 0      // tests/micro/step_rate.hip only: 1 = no exponent MFMAs, 2 = no colour MFMAs, 4 = no vector sweep
+#endif
+template <bool DUAL, bool CLAMP, bool EXACT_FIRST>
+__device__ __forceinline__ void q_forward_step(float& T, bool& done, bool& exact, f32x4& C, f32x4& C2,
+                                               const float4* ka, const float2* kb, int slot, const float (&Phi)[6],
+                                               const float (&PT)[4], const float (&PT2)[4]) {
+  float v[16];                                                  // exponents, then (in place) the weights w = alpha T
+  auto exponents = [&]() {
+    const float4 a4 = ka[slot];
+    const float2 b2 = kb[slot];
+    const float K[6] = {a4.x, a4.y, a4.z, a4.w, b2.x, b2.y};
+    if constexpr ((VTGS_Q_STEP_ABL & 1) != 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { v[r] = K[r % 6] + Phi[r % 5]; asm volatile("" : "+v"(v[r])); }
+      return;
+    }
+    // term by term across the four splat groups: consecutive MFMAs belong to different accumulation chains (a dependent
+    // v_mfma_f32_4x4x1 issues every ~6 cycles, independent ones every ~3: tests/micro/mix_rate.hip)
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0, d2 = d0, d3 = d0;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+      d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(K[m], Phi[m], d0, 2, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(K[m], Phi[m], d1, 2, 1, 0);
+      d2 = __builtin_amdgcn_mfma_f32_4x4x1f32(K[m], Phi[m], d2, 2, 2, 0);
+      d3 = __builtin_amdgcn_mfma_f32_4x4x1f32(K[m], Phi[m], d3, 2, 3, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[r] = d0[r]; v[4 + r] = d1[r]; v[8 + r] = d2[r]; v[12 + r] = d3[r]; }
+  };
+  exponents();
+  bool swept = false;
+  if constexpr ((VTGS_Q_STEP_ABL & 4) != 0) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(v[k]));
+    swept = true;
+  } else
+  if constexpr (!EXACT_FIRST) {
+    float Tn = done ? 0.f : T;                                  // optimistic sweep: no stop test
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      v[k] = q_alpha<CLAMP>(v[k]) * Tn;
+      Tn = Tn - v[k];
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);         // the 24 exponent MFMAs as one group ...
+    __builtin_amdgcn_sched_group_barrier(0x002, 96, 0);         // ... then the vector sweep
+    if (__ballot(!done && Tn < kTStop) == 0ull) { T = done ? T : Tn; swept = true; }
+  }
+  if (!swept) {
+    // exact sweep: the first splat with T (1 - alpha) < 1e-4 ends the pixel BEFORE it is added.  After an optimistic sweep
+    // the coefficients are read and the exponents produced AGAIN (24 MFMAs on the rare path) instead of being kept alive
+    // next to the weights that replaced them: ~20 registers less on the common path.
+    if constexpr (!EXACT_FIRST) {
+      asm volatile("" : "+v"(slot));                            // not the same loads as far as CSE is concerned
+      exponents();
+    }
+    const bool was_done = done;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float wk = q_alpha<CLAMP>(v[k]) * T;
+      const float tn = T - wk;
+      const bool stop = tn < kTStop;
+      const bool live = !done && !stop;
+      v[k] = live ? wk : 0.f;
+      T = live ? tn : T;
+      done = done || stop;
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 24, 1);
+    __builtin_amdgcn_sched_group_barrier(0x002, 160, 1);
+    exact = __builtin_popcountll(__ballot(done && !was_done)) >= kExactFirstEndings;
+  }
+  if constexpr ((VTGS_Q_STEP_ABL & 2) != 0) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("" :: "v"(v[k]));
+    return;
+  }
+  // colour: C[ch] += c[ch][k] w[k], a rank-1 update per splat on the matrix cores (k-ordered fmaf chain: bit-identical to
+  // the lane = pixel kernel; four independent accumulators would issue ~20 % faster at 8 waves per SIMD, tests/micro/
+  // step_rate.hip, but cost 12 registers, which at this kernel's occupancy is the scarcer resource)
+#define VTGS_Q_COLOUR(G)                                                                       \
+  C = q_colour<0>(PT[G], v[4 * G + 0], C); C = q_colour<1>(PT[G], v[4 * G + 1], C);            \
+  C = q_colour<2>(PT[G], v[4 * G + 2], C); C = q_colour<3>(PT[G], v[4 * G + 3], C);            \
+  if constexpr (DUAL) {                                                                        \
+    C2 = q_colour<0>(PT2[G], v[4 * G + 0], C2); C2 = q_colour<1>(PT2[G], v[4 * G + 1], C2);    \
+    C2 = q_colour<2>(PT2[G], v[4 * G + 2], C2); C2 = q_colour<3>(PT2[G], v[4 * G + 3], C2);    \
+  }
+  VTGS_Q_COLOUR(0) VTGS_Q_COLOUR(1) VTGS_Q_COLOUR(2) VTGS_Q_COLOUR(3)
+#undef VTGS_Q_COLOUR
+  __builtin_amdgcn_sched_group_barrier(0x008, DUAL ? 32 : 16, 2);
+}
+
+#ifndef VTGS_Q_WAVES
+#define VTGS_Q_WAVES 4
+#endif
+template <bool DUAL>
+__global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forward_q(
+    CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
+    const uint32_t* __restrict__ tile_cnt, uint32_t tile_cap, const uint32_t* __restrict__ sorted_gid,
+    const GeomRec* __restrict__ geom, const float* __restrict__ colors,
+    float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
+    const Counters* __restrict__ ctr, const float* __restrict__ colors_b, float* __restrict__ out_color_b) {
+  // per wavefront: the table of the ring's entries (+ one dummy slot) and the four queues of table slots.  Queue bytes are
+  // stored twice, 128 apart, so a pop reads [head & 127, head & 127 + 16) without wrapping.
+  __shared__ float4 lds_ka[4][kQRing + 1];                      // K0..K3
+  __shared__ float2 lds_kb[4][kQRing + 1];                      // K4, K5
+  __shared__ float4 lds_pa[4][kQRing + 1];                      // c0 c1 c2 depth   (dual: c0 c1 c2 c3)
+  __shared__ float4 lds_pb[DUAL ? 4 : 1][DUAL ? kQRing + 1 : 1];//                   (dual: c4 c5 0 0)
+  __shared__ uint8_t lds_q[4][4][2 * kQRing];
+  if (ctr->overflow) return;                                    // bins hold unwritten slots after an overflow
+  const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
+  const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
+  const QuadCoord qc = quad_coord(cs, nblk, gx16, gx8, gy8);
+  if (!qc.tile_ok) return;
+  const int l = lane_id();
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float4* ka = lds_ka[wv];
+  float2* kb = lds_kb[wv];
+  float4* pa = lds_pa[wv];
+  float4* pb = lds_pb[DUAL ? wv : 0];
+  const int q = qc.q, i = qc.i;
+  const uint8_t* myq = lds_q[wv][q];
+  const int lx = 4 * (q & 1) + (i & 3), ly = 4 * (q >> 1) + (i >> 2);
+  const float cx = (float)(qc.px - lx) + 3.5f, cy = (float)(qc.py - ly) + 3.5f;
+  const float X = (float)lx - 3.5f, Y = (float)ly - 3.5f;
+  const float Phi[6] = {1.f, X, Y, X * X, X * Y, Y * Y};
+  const uint32_t s = (uint32_t)qc.tile * tile_cap, e = s + min(tile_cnt[qc.tile], tile_cap);
+  // dummy slot + queue bytes start defined (a pop past the end of a queue reads bytes that were never written)
+  ka[kQDummy] = make_float4(-1e30f, 0.f, 0.f, 0.f);
+  kb[kQDummy] = make_float2(0.f, 0.f);
+  pa[kQDummy] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (DUAL) pb[kQDummy] = make_float4(0.f, 0.f, 0.f, 0.f);
+  reinterpret_cast<uint32_t*>(lds_q[wv][0])[l] = 0u;            // 4 queues x 256 bytes = 256 dwords per wavefront
+  reinterpret_cast<uint32_t*>(lds_q[wv][0])[64 + l] = 0u;
+  reinterpret_cast<uint32_t*>(lds_q[wv][0])[128 + l] = 0u;
+  reinterpret_cast<uint32_t*>(lds_q[wv][0])[192 + l] = 0u;
+
+  float T = 1.f;
+  f32x4 C = {0.f, 0.f, 0.f, 0.f}, C2 = {0.f, 0.f, 0.f, 0.f};
+  bool done = !qc.inside, exact = false;
+  int head_v = 0, cnt_v = 0;                                    // ring state of the lane's OWN queue (uniform per 16-lane group)
+  bool hot_prev = false, hot_cur = false;
+  uint32_t base = s, chunk = 0;
+  // Two-deep software pipeline of the gather: while chunk c is composited the list entry of chunk c+2 and the geometry
+  // record + colours of chunk c+1 are in flight (two dependent trips to L2 / Infinity Cache per chunk otherwise sit on the
+  // wavefront's critical path: gather + compaction alone is 35 us of this kernel, profiles/r2_forward_ablation.md).
+  // Loads are unconditional -- a lane past the end of the list reads entry 0 of its own bin -- and masked afterwards.
+  auto entry = [&](uint32_t b) { const uint32_t p = b + (uint32_t)l; return sorted_gid[p < e ? p : s]; };
+  uint32_t gid_cur = 0u, gid_nxt = 0u;
+  float4 g0n = make_float4(0.f, 0.f, 0.f, 0.f), g1n = g0n;
+  float c0n = 0.f, c1n = 0.f, c2n = 0.f, d0n = 0.f, d1n = 0.f, d2n = 0.f;
+  auto fetch = [&](uint32_t gid) {
+    const float4* gp = reinterpret_cast<const float4*>(geom + gid);
+    g0n = gp[0]; g1n = gp[1];
+    c0n = colors[3 * gid]; c1n = colors[3 * gid + 1]; c2n = colors[3 * gid + 2];
+    if (DUAL) { d0n = colors_b[3 * gid]; d1n = colors_b[3 * gid + 1]; d2n = colors_b[3 * gid + 2]; }
+  };
+  if (s < e) {
+    gid_cur = entry(s);
+    gid_nxt = entry(s + 64u);
+    fetch(gid_cur);
+  }
+
+  for (;;) {
+    const bool full = __ballot(cnt_v >= 16) != 0ull;
+    if (!full && base < e) {
+      // ---- append the next 64-entry chunk: gather, table, wavefront-ballot compaction into the four queues ----------
+      if (__ballot(!done) == 0ull) break;
+      const uint32_t pos = base + (uint32_t)l;
+      const bool in = pos < e;
+      const float4 g0 = g0n, g1 = g1n;                             // this chunk's data, requested one chunk ago
+      const int slot = (int)((chunk & 1u) << 6) + l;
+      {
+        float K[6];
+        tile_coefficients(g0, g1, cx, cy, K);
+        ka[slot] = make_float4(K[0], K[1], K[2], K[3]);
+        kb[slot] = make_float2(K[4], K[5]);
+        pa[slot] = make_float4(c0n, c1n, c2n, DUAL ? d0n : g1.z);
+        if (DUAL) pb[slot] = make_float4(d1n, d2n, 0.f, 0.f);
+      }
+      gid_cur = gid_nxt;
+      gid_nxt = entry(base + 128u);
+      fetch(gid_cur);                                               // next chunk's data: in flight during this chunk's steps
+      hot_prev = hot_cur;
+      hot_cur = __ballot(in && g1.y > kClampGuard) != 0ull;
+      const uint32_t mask = in ? quadrant_mask(g0, g1, g0.x - cx, g0.y - cy) : 0u;
+      const int tail_v = head_v + cnt_v;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const bool in_q = (mask >> qq) & 1u;
+        const unsigned long long bal = __ballot(in_q);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        const int tail = __builtin_amdgcn_readlane(tail_v, 16 * qq);
+        if (in_q) {
+          const int p = (tail + rank) & (kQRing - 1);
+          lds_q[wv][qq][p] = (uint8_t)slot;
+          lds_q[wv][qq][p + kQRing] = (uint8_t)slot;
+        }
+        const int add = (int)__builtin_popcountll(bal);
+        cnt_v = (q == qq) ? cnt_v + add : cnt_v;
+      }
+      base += 64u; ++chunk;
+#if defined(VTGS_Q_ABL) && VTGS_Q_ABL == 1                                 // ablation: gather + compaction only, no steps
+      asm volatile("" :: "v"(cnt_v), "v"(mask));
+      head_v += cnt_v; cnt_v = 0;
+#endif
+      continue;
+    }
+    if (__ballot(cnt_v > 0) == 0ull) break;                       // list and queues exhausted
+    if (__ballot(!done) == 0ull) break;                           // every pixel of the tile has ended
+    // ---- one step: pop min(16, count) entries from every queue ---------------------------------------------------------
+    const int avail = min(16, cnt_v);
+    const int hm = head_v & (kQRing - 1);
+    int sl[5];
+    sl[4] = (int)myq[hm + i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sl[j] = (int)myq[hm + 4 * j + (i >> 2)];
+    sl[4] = (i < avail) ? sl[4] : kQDummy;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sl[j] = (4 * j + (i >> 2) < avail) ? sl[j] : kQDummy;
+    float PT[4], PT2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      PT[j] = reinterpret_cast<const float*>(pa)[4 * sl[j] + (i & 3)];
+      PT2[j] = DUAL ? reinterpret_cast<const float*>(pb)[4 * sl[j] + (i & 3)] : 0.f;
+    }
+    head_v += avail; cnt_v -= avail;
+    if (exact) q_forward_step<DUAL, true, true>(T, done, exact, C, C2, ka, kb, sl[4], Phi, PT, PT2);
+    else if (hot_prev || hot_cur) q_forward_step<DUAL, true, false>(T, done, exact, C, C2, ka, kb, sl[4], Phi, PT, PT2);
+    else q_forward_step<DUAL, false, false>(T, done, exact, C, C2, ka, kb, sl[4], Phi, PT, PT2);
+  }
+  if (qc.inside) {
+    const size_t P = (size_t)cs.W * cs.H, pix = (size_t)qc.py * cs.W + qc.px;
+    out_color[pix] = C[0] + T * bg[0];
+    out_color[P + pix] = C[1] + T * bg[1];
+    out_color[2 * P + pix] = C[2] + T * bg[2];
+    if constexpr (DUAL) {
+      out_color_b[pix] = C[3] + T * bg[0];
+      out_color_b[P + pix] = C2[0] + T * bg[1];
+      out_color_b[2 * P + pix] = C2[1] + T * bg[2];
+    } else {
+      out_depth[pix] = C[3];
+    }
+    final_T[pix] = T;
+  }
+}
+template __global__ void composite_forward_q<false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*);
+template __global__ void composite_forward_q<true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*);
+
+}  // namespace vtgs

@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256) void ssim_forward_kernel(const float* __restri
 __global__ __launch_bounds__(256) void ssim_backward_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
                                                             const float* __restrict__ gmaps, const float* __restrict__ upstream,
                                                             int C, int H, int W, int tiles_x, int tiles_y,
-                                                            float* __restrict__ g_img1, float ssim_coef, float l1_coef) {
+                                                            float* __restrict__ g_img1, float ssim_coef, float l1_coef,
+                                                            const float* __restrict__ l1_weight = nullptr) {
   __shared__ float pm[3][kSP * kSP];
   __shared__ float hz[3][kSP * kST];
   float w[11];
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(256) void ssim_backward_kernel(const float* __restr
     }
     const size_t o = plane + (size_t)gy * W + gx;
     const float x = img1[o], y = img2[o];
-    g_img1[o] = scale * (s0 + 2.f * x * s1 + y * s2) + ((x > y) ? l1s : (x < y) ? -l1s : 0.f);
+    const float lw = l1_weight ? l1s * l1_weight[o] : l1s;
+    g_img1[o] = scale * (s0 + 2.f * x * s1 + y * s2) + ((x > y) ? lw : (x < y) ? -lw : 0.f);
   }
 }
 
@@ -153,7 +155,9 @@ __global__ __launch_bounds__(256) void ssim_backward_kernel(const float* __restr
 __global__ __launch_bounds__(256) void masked_l1_kernel(const float* __restrict__ im, const float* __restrict__ ds,
                                                         const float* __restrict__ gt_im, const float* __restrict__ gt_depth,
                                                         int P, float sil_thres, int mode, float* __restrict__ partial,
-                                                        float* __restrict__ g_im, float* __restrict__ g_ds) {
+                                                        float* __restrict__ g_im, float* __restrict__ g_ds,
+                                                        const float* __restrict__ extra_mask = nullptr,
+                                                        const float* __restrict__ color_weight = nullptr) {
   __shared__ float red[4][3];
   float s_im = 0.f, s_d = 0.f, cnt = 0.f;
   for (int i = (int)(blockIdx.x * 256u + threadIdx.x); i < P; i += (int)(gridDim.x * 256u)) {
@@ -161,6 +165,7 @@ __global__ __launch_bounds__(256) void masked_l1_kernel(const float* __restrict_
     const float gd = gt_depth[i];
     bool m = gd > 0.f && depth == depth && unc == unc;
     if (mode == 0) m = m && sil > sil_thres;
+    if (extra_mask) m = m && extra_mask[i] != 0.f;           // visibility / far-depth / outlier masks of the other datasets
     const bool mc = (mode == 0) ? m : true;
     float d = gd - depth;
     s_d += m ? fabsf(d) : 0.f;
@@ -172,8 +177,9 @@ __global__ __launch_bounds__(256) void masked_l1_kernel(const float* __restrict_
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float e = gt_im[(size_t)c * P + i] - im[(size_t)c * P + i];
-      s_im += mc ? fabsf(e) : 0.f;
-      if (g_im) g_im[(size_t)c * P + i] = mc ? (e > 0.f ? -1.f : (e < 0.f ? 1.f : 0.f)) : 0.f;
+      const float cw = color_weight ? color_weight[(size_t)c * P + i] : 1.f;   // mapping: 10 additional_mask + 0.8
+      s_im += mc ? fabsf(e) * cw : 0.f;
+      if (g_im) g_im[(size_t)c * P + i] = mc ? (e > 0.f ? -cw : (e < 0.f ? cw : 0.f)) : 0.f;
     }
   }
   s_im = wave_sum(s_im); s_d = wave_sum(s_d); cnt = wave_sum(cnt);
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamLaunch a) {
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ l1_partial, uint32_t l1_rows,
                                                             const float* __restrict__ ssim_partial, uint32_t ssim_rows,
                                                             int mode, float w_im, float w_depth, float numel_im,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, float l1_coef = 0.8f) {
   __shared__ float red[4][4];
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   for (uint32_t r = threadIdx.x; r < l1_rows; r += 256u) { a0 += l1_partial[3 * r]; a1 += l1_partial[3 * r + 1]; a2 += l1_partial[3 * r + 2]; }
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     const float ssim = (red[0][3] + red[1][3] + red[2][3] + red[3][3]) / numel_im;
     float loss;
     if (mode == 0) loss = w_im * s_im + w_depth * s_d;                                   // tracking: masked SUMS
-    else loss = w_im * (0.8f * s_im / numel_im + 0.2f * (1.f - ssim)) + w_depth * s_d / cnt;   // mapping: means + SSIM
+    else loss = w_im * (l1_coef * s_im / numel_im + 0.2f * (1.f - ssim)) + w_depth * s_d / cnt;   // mapping: means + SSIM
     out[0] = loss; out[1] = cnt; out[2] = s_im; out[3] = s_d; out[4] = ssim;
   }
 }
@@ -271,7 +277,8 @@ __global__ __launch_bounds__(256) void loss_backward_kernel(const float* __restr
                                                             const float* __restrict__ gt_im, const float* __restrict__ gt_depth,
                                                             int P, float sil_thres, int mode, float w_im, float w_depth,
                                                             const float* __restrict__ upstream, const float* __restrict__ fwd_out,
-                                                            float* __restrict__ g_im, float* __restrict__ g_ds) {
+                                                            float* __restrict__ g_im, float* __restrict__ g_ds,
+                                                            const float* __restrict__ extra_mask = nullptr) {
   const float up = upstream[0];
   const float cd = (mode == 0) ? up * w_depth : up * w_depth / fwd_out[1];
   const float ci = up * w_im;
@@ -280,6 +287,7 @@ __global__ __launch_bounds__(256) void loss_backward_kernel(const float* __restr
     const float gd = gt_depth[i];
     bool m = gd > 0.f && depth == depth && unc == unc;
     if (mode == 0) m = m && sil > sil_thres;
+    if (extra_mask) m = m && extra_mask[i] != 0.f;
     const float d = gd - depth;
     g_ds[i] = m ? (d > 0.f ? -cd : (d < 0.f ? cd : 0.f)) : 0.f;
     g_ds[P + i] = 0.f; g_ds[2 * (size_t)P + i] = 0.f;
@@ -384,7 +392,8 @@ size_t vtgs_loss_scratch_floats(int32_t height, int32_t width) {
 
 int vtgs_slam_loss_forward(int32_t mode, const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth,
                            int32_t height, int32_t width, float sil_thres, float w_im, float w_depth, float* scratch,
-                           float* ssim_grad_maps, float* out5, void* stream) {
+                           float* ssim_grad_maps, float* out5, const float* extra_mask, const float* color_weight,
+                           void* stream) {
   if ((mode != 0 && mode != 1) || !im || !depth_sil || !gt_im || !gt_depth || !scratch || !out5 || height <= 0 || width <= 0)
     return VTGS_ERR_INVALID_ARGUMENT;
   const int32_t P = height * width;
@@ -392,7 +401,7 @@ int vtgs_slam_loss_forward(int32_t mode, const float* im, const float* depth_sil
   float* ssim_partial = scratch + (size_t)l1_rows * 3;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(masked_l1_kernel, dim3(l1_rows), dim3(256), 0, st, im, depth_sil, gt_im, gt_depth, P, sil_thres, mode,
-                     scratch, (float*)nullptr, (float*)nullptr);
+                     scratch, (float*)nullptr, (float*)nullptr, extra_mask, mode == 1 ? color_weight : (const float*)nullptr);
   uint32_t ssim_rows = 0;
   if (mode == 1) {
     const int tx = (width + kST - 1) / kST, ty = (height + kST - 1) / kST;
@@ -401,25 +410,26 @@ int vtgs_slam_loss_forward(int32_t mode, const float* im, const float* depth_sil
                        ssim_partial, ssim_grad_maps);
   }
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, l1_rows, ssim_partial, ssim_rows, mode, w_im,
-                     w_depth, (float)((size_t)3 * P), out5);
+                     w_depth, (float)((size_t)3 * P), out5, (mode == 1 && color_weight) ? 1.0f : 0.8f);
   return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
 }
 
 int vtgs_slam_loss_backward(int32_t mode, const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth,
                             int32_t height, int32_t width, float sil_thres, float w_im, float w_depth,
                             const float* ssim_grad_maps, const float* fwd_out5, const float* upstream, float* g_im,
-                            float* g_depth_sil, void* stream) {
+                            float* g_depth_sil, const float* extra_mask, const float* color_weight, void* stream) {
   if ((mode != 0 && mode != 1) || !im || !depth_sil || !gt_im || !gt_depth || !fwd_out5 || !upstream || !g_im || !g_depth_sil ||
       height <= 0 || width <= 0 || (mode == 1 && !ssim_grad_maps))
     return VTGS_ERR_INVALID_ARGUMENT;
   const int32_t P = height * width;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(loss_backward_kernel, dim3(vtgs_masked_l1_partial_rows(P)), dim3(256), 0, st, im, depth_sil, gt_im,
-                     gt_depth, P, sil_thres, mode, w_im, w_depth, upstream, fwd_out5, g_im, g_depth_sil);
+                     gt_depth, P, sil_thres, mode, w_im, w_depth, upstream, fwd_out5, g_im, g_depth_sil, extra_mask);
   if (mode == 1) {
     const int tx = (width + kST - 1) / kST, ty = (height + kST - 1) / kST;
     hipLaunchKernelGGL(ssim_backward_kernel, dim3(3 * tx * ty), dim3(256), 0, st, im, gt_im, ssim_grad_maps, upstream, 3,
-                       height, width, tx, ty, g_im, -0.2f * w_im, 0.8f * w_im / (float)((size_t)3 * P));
+                       height, width, tx, ty, g_im, -0.2f * w_im, (color_weight ? 1.0f : 0.8f) * w_im / (float)((size_t)3 * P),
+                       color_weight);
   }
   return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
 }

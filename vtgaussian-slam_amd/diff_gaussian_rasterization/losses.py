@@ -88,10 +88,11 @@ class _MaskedL1(torch.autograd.Function):
 
 _lib.vtgs_loss_scratch_floats.restype, _lib.vtgs_loss_scratch_floats.argtypes = ctypes.c_size_t, [_I32, _I32]
 _lib.vtgs_slam_loss_forward.restype = ctypes.c_int
-_lib.vtgs_slam_loss_forward.argtypes = [_I32, _P, _P, _P, _P, _I32, _I32, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P]
+_lib.vtgs_slam_loss_forward.argtypes = [_I32, _P, _P, _P, _P, _I32, _I32, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P,
+                                        _P, _P, _P]
 _lib.vtgs_slam_loss_backward.restype = ctypes.c_int
 _lib.vtgs_slam_loss_backward.argtypes = [_I32, _P, _P, _P, _P, _I32, _I32, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P,
-                                         _P, _P, _P]
+                                         _P, _P, _P, _P, _P]
 
 
 class _SlamLoss(torch.autograd.Function):
@@ -99,7 +100,8 @@ class _SlamLoss(torch.autograd.Function):
     upstream gradient is read on the device).  mode 0 = tracking, 1 = mapping."""
 
     @staticmethod
-    def forward(ctx, im, depth_sil, gt_im, gt_depth, mode: int, sil_thres: float, w_im: float, w_depth: float):
+    def forward(ctx, im, depth_sil, gt_im, gt_depth, mode: int, sil_thres: float, w_im: float, w_depth: float,
+                extra_mask=None, color_weight=None):
         if not im.is_cuda:
             raise RuntimeError("the fused losses need tensors on a HIP device (torch 'cuda'); no CPU path exists")
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
@@ -107,6 +109,10 @@ class _SlamLoss(torch.autograd.Function):
         if a.shape[-3] != 3 or d.shape[-3] != 3:
             raise ValueError("im and depth_sil must be [3,H,W]")
         H, W = a.shape[-2], a.shape[-1]
+        em = None if extra_mask is None else extra_mask.detach().to(device=a.device, dtype=torch.float32).reshape(-1).contiguous()
+        cw = None if color_weight is None else color_weight.detach().to(device=a.device, dtype=torch.float32).expand(3, H, W).contiguous()
+        if em is not None and em.numel() != H * W:
+            raise ValueError("extra_mask must have H*W elements")
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         scratch = torch.empty(int(_lib.vtgs_loss_scratch_floats(H, W)), dtype=torch.float32, device=a.device)
         gmaps = torch.empty((3, 3, H, W), dtype=torch.float32, device=a.device) if (mode == 1 and need) else None
@@ -114,7 +120,9 @@ class _SlamLoss(torch.autograd.Function):
         _check(_lib.vtgs_slam_loss_forward(mode, a.data_ptr(), d.data_ptr(), ga.data_ptr(), gd.data_ptr(), H, W,
                                            float(sil_thres), float(w_im), float(w_depth), scratch.data_ptr(),
                                            None if gmaps is None else gmaps.data_ptr(), out.data_ptr(),
+                                           None if em is None else em.data_ptr(), None if cw is None else cw.data_ptr(),
                                            _stream_ptr(a.device)), "vtgs_slam_loss_forward")
+        ctx.em, ctx.cw = em, cw
         ctx.save_for_backward(a, d, ga, gd, out, gmaps if gmaps is not None else out)
         ctx.cfg = (mode, float(sil_thres), float(w_im), float(w_depth), need, gmaps is not None)
         ctx.set_materialize_grads(False)
@@ -124,26 +132,78 @@ class _SlamLoss(torch.autograd.Function):
     def backward(ctx, g):
         mode, sil_thres, w_im, w_depth, need, has_maps = ctx.cfg
         if g is None or not need:
-            return (None,) * 8
+            return (None,) * 10
         a, d, ga, gd, out, gmaps = ctx.saved_tensors
         H, W = a.shape[-2], a.shape[-1]
         up = g.detach().to(torch.float32).reshape(1).contiguous()
         g_im, g_ds = torch.empty_like(a), torch.empty_like(d)
         _check(_lib.vtgs_slam_loss_backward(mode, a.data_ptr(), d.data_ptr(), ga.data_ptr(), gd.data_ptr(), H, W, sil_thres,
                                             w_im, w_depth, gmaps.data_ptr() if has_maps else None, out.data_ptr(),
-                                            up.data_ptr(), g_im.data_ptr(), g_ds.data_ptr(), _stream_ptr(a.device)),
+                                            up.data_ptr(), g_im.data_ptr(), g_ds.data_ptr(),
+                                            None if ctx.em is None else ctx.em.data_ptr(),
+                                            None if ctx.cw is None else ctx.cw.data_ptr(), _stream_ptr(a.device)),
                "vtgs_slam_loss_backward")
-        return g_im, g_ds, None, None, None, None, None, None
+        return g_im, g_ds, None, None, None, None, None, None, None, None
 
 
-def tracking_loss(im, depth_sil, gt_im, gt_depth, sil_thres: float, w_im: float = 0.5, w_depth: float = 0.025):
-    """Replica tracking loss: w_im * masked L1 SUM of colour + w_depth * masked L1 SUM of depth."""
-    return _SlamLoss.apply(im, depth_sil, gt_im, gt_depth, 0, sil_thres, w_im, w_depth)
+def tracking_loss(im, depth_sil, gt_im, gt_depth, sil_thres: float, w_im: float = 0.5, w_depth: float = 0.025,
+                  extra_mask=None):
+    """Tracking loss of get_loss (src/vtgaussian_slam.py:519-605): w_im * masked L1 SUM of colour + w_depth * masked L1
+    SUM of depth over gt_depth > 0 & finite & silhouette > sil_thres [& extra_mask].  `extra_mask` [H,W] / [1,H,W]
+    (bool or float, detached) carries the masks of the TUM / ScanNet / ScanNet++ branches -- build it with
+    `visibility_mask`, `far_depth_mask`, `outlier_depth_mask` below and AND them together."""
+    return _SlamLoss.apply(im, depth_sil, gt_im, gt_depth, 0, sil_thres, w_im, w_depth, extra_mask, None)
 
 
-def mapping_loss(im, depth_sil, gt_im, gt_depth, w_im: float = 1.0, w_depth: float = 1.0):
-    """Mapping loss: w_depth * masked L1 MEAN of depth + w_im * (0.8 * L1 mean + 0.2 * (1 - SSIM)) of colour."""
-    return _SlamLoss.apply(im, depth_sil, gt_im, gt_depth, 1, 0.0, w_im, w_depth)
+def mapping_loss(im, depth_sil, gt_im, gt_depth, w_im: float = 1.0, w_depth: float = 1.0, extra_mask=None,
+                 additional_mask=None):
+    """Mapping loss (src/vtgaussian_slam.py:592-611): w_depth * masked L1 MEAN of depth + w_im * (0.8 * L1 mean + 0.2 *
+    (1 - SSIM)) of colour; with `additional_mask` the colour L1 becomes mean(|im - gt| * (10 * additional_mask + 0.8))
+    (l1_loss_v1_mask, utils/slam_helpers.py:8-9).  `extra_mask`: the outlier-depth mask when ignore_outlier_depth_loss."""
+    cw = None if additional_mask is None else 10.0 * additional_mask.to(torch.float32) + 0.8
+    return _SlamLoss.apply(im, depth_sil, gt_im, gt_depth, 1, 0.0, w_im, w_depth, extra_mask, cw)
+
+
+# ---- detached masks of the TUM / ScanNet / ScanNet++ branches (device-side torch ops: plumbing, no gradients) ----------
+def outlier_depth_mask(gt_depth, depth):
+    """src/vtgaussian_slam.py:525-528 (ignore_outlier_depth_loss): |gt - depth| (0 where gt <= 0) below 50 x its median,
+    and gt > 0.  gt_depth, depth: [1,H,W]."""
+    err = torch.abs(gt_depth - depth.detach()) * (gt_depth > 0)
+    return (err < 50 * err.median()) & (gt_depth > 0)
+
+
+def far_depth_mask(gt_depth, far_depth_filter_thres: float):
+    """src/vtgaussian_slam.py:586-588: gt_depth < far_depth_filter_thres."""
+    return gt_depth < far_depth_filter_thres
+
+
+def visibility_mask(gt_depth, intrinsics, curr_w2c, overlaps, vis_mask_thres: float = 0.05):
+    """src/vtgaussian_slam.py:536-584 with get_vis_mask (:376-404): every pixel (gt_depth >= 0) is back-projected with
+    the current pose estimate, projected into each overlapping base frame (w2c, gt depth [1,H,W]) and kept if the
+    bilinearly sampled depth there agrees with its own depth in that frame to vis_mask_thres (relative to the smaller of
+    the two); the masks of the overlapping frames are ORed (one frame for TUM, first / mid / last for ScanNet(++)).
+    Returns [H,W] bool on gt_depth's device."""
+    import torch.nn.functional as F
+    H, W = gt_depth.shape[-2], gt_depth.shape[-1]
+    dev = gt_depth.device
+    k = intrinsics.to(dev, torch.float32)
+    ys, xs = torch.where(gt_depth[0] >= 0)
+    z = gt_depth[0, ys, xs]
+    pts_cam = torch.stack(((xs - k[0, 2]) / k[0, 0] * z, (ys - k[1, 2]) / k[1, 1] * z, z), dim=-1)
+    pts4 = torch.cat([pts_cam, torch.ones_like(pts_cam[:, :1])], dim=1)
+    pts = (torch.inverse(curr_w2c.to(dev, torch.float32)) @ pts4.T).T[:, :3]
+    out = None
+    for w2c, gd in overlaps:
+        p4 = torch.cat([pts, torch.ones_like(pts[:, :1])], dim=1)
+        tp = (w2c.to(dev, torch.float32) @ p4.T).T[:, :3]
+        p2 = (k @ tp.T).T
+        pz = p2[:, 2:] + 1e-5
+        uv = (p2 / pz)[:, :2]
+        grid = torch.stack((uv[:, 0] / (W - 1) * 2.0 - 1.0, uv[:, 1] / (H - 1) * 2.0 - 1.0), dim=-1).reshape(1, 1, -1, 2)
+        samp = F.grid_sample(gd.to(dev, torch.float32).reshape(1, 1, H, W), grid, padding_mode="zeros", align_corners=True).reshape(-1)
+        vis = (torch.abs(samp - pz[:, 0]) < vis_mask_thres * torch.minimum(samp, pz[:, 0])).reshape(H, W)
+        out = vis if out is None else (out | vis)
+    return out
 
 
 _lib.vtgs_silhouette_sweep.restype = ctypes.c_int
