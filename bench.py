@@ -203,8 +203,7 @@ def main():
     # algorithm, E_effective = 64 x (8x8 tile instances) evaluated here after the exact ellipse-vs-tile culling
     if roofline is not None:
         comp_us = sum(kern[k]["avg_us"] for k in kern if k.startswith("composite_"))
-        scale_r = (r_rank / r16) if r16 else 1.0
-        e_all, e_eff = 256 * r_rank, int(64 * info["instances"] * (scale_r if world > 1 else 1.0))
+        e_all, e_eff = 256 * r_rank, 64 * info["instances"]          # (the instance count is already this rank's band)
         floor_us = e_eff * FLOP_PER_EVAL_FWD_BWD / (FP32_PEAK_TFLOPS * 1e12) * 1e6
         roofline["valu"] = {"E": e_all, "E_effective": e_eff, "flop_per_eval_fwd_bwd": FLOP_PER_EVAL_FWD_BWD,
                             "peak_tflops": FP32_PEAK_TFLOPS, "valu_floor_us": round(floor_us, 2),

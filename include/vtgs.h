@@ -287,6 +287,21 @@ typedef struct VtgsAdamGroup {
 } VtgsAdamGroup;
 int vtgs_adam_step(const VtgsAdamGroup* groups, int32_t n_groups, int32_t step, float beta1, float beta2, void* stream);
 
+/* ---- Point-to-plane consistency of two depth frames -----------------------------------------------
+ * Replaces the host path of compute_point2plane_dist (src/vtgaussian_slam.py:1070-1155: kornia normals, numpy, Open3D
+ * KD-tree) that the reference runs per tracking iteration at base-frame boundaries (:1929, :1956, :2158, :2185).
+ * depth_target = the latest (reference) frame, depth_source = the current frame, both [H*W] floats on the device;
+ * mask_* optional [H*W] bytes (the `varmask`s); intrinsics [9], w2c_* [16] row-major DEVICE pointers (the poses are slices
+ * of parameters); threshold = max correspondence distance (0.02 in the reference); frustum = keep only points the other
+ * camera sees.  out_dist[H*W] = n_target . (p_source - p_nearest_target) per source pixel, out_matched[H*W] = 1 where a
+ * target point lies within threshold (nearest neighbour found exactly by a bounded window search, csrc/vtgs_p2p.hip).
+ * The caller reduces: sum of squares ('sum'), max |.| ('max'), mean of the 100 largest |.| ('max100').             */
+size_t vtgs_point2plane_scratch_bytes(int32_t width, int32_t height);
+int vtgs_point2plane(int32_t width, int32_t height, const float* depth_target, const float* depth_source,
+                     const uint8_t* mask_target, const uint8_t* mask_source, const float* intrinsics, const float* w2c_target,
+                     const float* w2c_source, float threshold, int32_t frustum, void* scratch, size_t scratch_bytes,
+                     float* out_dist, uint8_t* out_matched, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on (used by bench.py for
  * the roofline of the dominant kernel).  While enabled, every kernel launch of the library is bracketed by two
  * events; vtgs_profile_collect synchronises the device, sums elapsed time per kernel name since enabling and

@@ -204,6 +204,72 @@ def main():
     np.savez_compressed(os.path.join(OUT, "get_loss.npz"), **store)
     print("wrote get_loss.npz", {k: v.shape for k, v in store.items() if hasattr(v, "shape") and v.ndim > 0})
 
+    # ---- f4: submap bookkeeping (src/vtgaussian_slam.py:884-1020) and the torch pieces of compute_point2plane_dist
+    #      (get_pointcloud :76-128 with factor=1, get_frustum_mask :1046-1065, trans_normal_c2w :1158-1178) ---------------
+    d = {}
+    sizes = [37, 52, 41, 29]
+    keys5 = ["means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"]
+    dims = {"means3D": 3, "rgb_colors": 3, "unnorm_rotations": 4, "logit_opacities": 1, "log_scales": 1}
+    vkeys = ["max_2D_radius", "means2D_gradient_accum", "denom", "timestep"]
+    params_ls, variables_ls = [], []
+    for i, m in enumerate(sizes):
+        pr = {kk: torch.randn(m, dims[kk], generator=g) for kk in keys5}
+        pr["cam_unnorm_rots"] = torch.randn(1, 4, 12, generator=g)
+        pr["cam_trans"] = torch.randn(1, 3, 12, generator=g)
+        params_ls.append(pr)
+        vr = {kk: torch.rand(m, generator=g) for kk in vkeys}
+        vr["scene_radius"] = torch.tensor(2.0 + i)
+        variables_ls.append(vr)
+        for kk, vv in {**pr, **vr}.items():
+            d[f"in{i}_{kk}"] = vv.numpy().copy()
+    selected = [3, 11, 4, 9]                 # frames -> base frames {0, 1, 2} with 4 frames per base frame
+    nfe = 4
+    d["selected_time_idx"] = np.array(selected)
+    d["num_frames_each_base_frame"] = np.int64(nfe)
+    d["quantized"] = np.array(ref.quantize_selected_time_idx(selected, nfe))
+    cat_p, cat_v, num_gs = ref.concat_keyframes_params_base_frame(params_ls, variables_ls, selected, nfe)
+    d["cat_num_gs"] = np.array(num_gs)
+    for kk, vv in cat_p.items():
+        d["cat_p_" + kk] = vv.detach().numpy().copy()
+    for kk, vv in cat_v.items():
+        d["cat_v_" + kk] = vv.detach().numpy().copy()
+    glob_p = {kk: torch.randn(23, dims[kk], generator=g) for kk in keys5}
+    glob_v = {kk: torch.rand(23, generator=g) for kk in vkeys}
+    for kk, vv in {**glob_p, **glob_v}.items():
+        d["glob_" + kk] = vv.numpy().copy()
+    gp, gv, gnum = ref.concat_global(cat_p, cat_v, list(num_gs), glob_p, glob_v)
+    d["global_num_gs"] = np.array(gnum)
+    for kk, vv in gp.items():
+        d["global_p_" + kk] = vv.detach().numpy().copy()
+    for kk, vv in gv.items():
+        d["global_v_" + kk] = vv.detach().numpy().copy()
+    # after an "optimisation" (perturbed copies), write back into the per-base-frame lists
+    new_p = {kk: (vv.detach() + 0.5) for kk, vv in cat_p.items()}
+    new_v = {kk: (vv.detach() * 2.0) for kk, vv in cat_v.items()}
+    upd_p = ref.update_params_ls([dict(x) for x in params_ls], selected, new_p, list(num_gs), nfe)
+    upd_v = ref.update_variables_ls([dict(x) for x in variables_ls], selected, new_v, list(num_gs), nfe)
+    for i in range(len(sizes)):
+        for kk in keys5:
+            d[f"upd{i}_{kk}"] = upd_p[i][kk].numpy().copy()
+        for kk in vkeys:
+            d[f"upd{i}_{kk}"] = upd_v[i][kk].numpy().copy()
+    # point-to-plane pieces
+    Hp, Wp = 40, 52
+    kp = torch.tensor([[45.0, 0, Wp / 2 - 0.3], [0, 44.0, Hp / 2 + 0.2], [0, 0, 1.0]])
+    depth0 = 2.0 + 0.4 * torch.rand(1, Hp, Wp, generator=g)
+    depth0[:, :3, :5] = 0.0
+    col0 = torch.rand(3, Hp, Wp, generator=g)
+    w2c_a, w2c_b = pose(0.02, [0.03, -0.01, 0.02]), pose(0.03, [-0.02, 0.04, 0.01])
+    mask0 = (depth0 > 0).reshape(-1)
+    pc = ref.get_pointcloud(col0, depth0, kp, w2c_a, mask=mask0, factor=1)
+    nrm_cam = torch.nn.functional.normalize(torch.randn(int(mask0.sum()), 3, generator=g), dim=1)
+    d.update(p2p_depth0=depth0.numpy(), p2p_color0=col0.numpy(), p2p_k=kp.numpy(), p2p_w2c_a=w2c_a.numpy(), p2p_w2c_b=w2c_b.numpy(),
+             p2p_pointcloud=pc.numpy(), p2p_normals_cam=nrm_cam.numpy(),
+             p2p_normals_world=ref.trans_normal_c2w(nrm_cam.numpy(), w2c_a),
+             p2p_frustum=ref.get_frustum_mask(w2c_b, kp, pc[:, :3], Hp, Wp).numpy())
+    np.savez_compressed(os.path.join(OUT, "driver_helpers.npz"), **d)
+    print("wrote driver_helpers.npz", len(d), "arrays")
+
 
 if __name__ == "__main__":
     main()

@@ -82,3 +82,83 @@ def test_two_rank_band_render_matches_full_frame(tmp_path):
     gm = leaves["means3D"].grad
     pose = torch.cat([gm.sum(0), torch.cross(leaves["means3D"].detach(), gm, dim=1).sum(0), gm[:, 2:3].sum(0)])
     assert (got["pose"] - pose).abs().max().item() <= 1e-3 * pose.abs().max().item()
+
+
+# ---- mapping mode: per-Gaussian gradient all-reduce, SSIM halo rows, global mask count and median ------------------------
+def _mapping_problem():
+    """A small scene with trainable appearance parameters (the mapping loop's), its ground truth and the full-frame loss."""
+    import slam_callers as sc
+    scene, cam = go.view_tied_scene(1800, 96, 112, seed=21)               # 7 tile rows: bands of 4 and 3 rows
+    H, W = cam.image_height, cam.image_width
+    g = torch.Generator().manual_seed(9)
+    z = scene["means3D"][:, 2:3]
+    with torch.no_grad():
+        gt_im, _, _ = go.rasterize(cam=cam, **scene)
+        gt_ds, _, _ = go.rasterize(cam=cam, **dict(scene, colors_precomp=torch.cat([z, torch.ones_like(z), z * z], 1)))
+    gt_im = (gt_im + 0.05 * torch.randn(3, H, W, generator=g)).clamp(0, 1)
+    gt_depth = (gt_ds[0:1] / gt_ds[1:2].clamp(min=1e-6)) * (1 + 0.02 * torch.randn(1, H, W, generator=g))
+    gt_depth[:, 40:46, 10:30] = 0.0
+    gt_depth[:, 70:74, 60:80] *= 40.0                                     # outliers for the 50 x median mask
+
+    def params():
+        gg = torch.Generator().manual_seed(4)
+        return {"rgb_colors": (scene["colors_precomp"] + 0.1 * torch.randn(scene["colors_precomp"].shape, generator=gg)).requires_grad_(True),
+                "logit_opacities": (torch.logit(scene["opacities"]) + 0.3 * torch.randn(scene["opacities"].shape, generator=gg)).requires_grad_(True),
+                "log_scales": (torch.log(scene["scales"][:, :1]) + 0.05 * torch.randn(scene["scales"][:, :1].shape, generator=gg)).requires_grad_(True)}
+
+    def render(p, band):
+        common = dict(means3D=scene["means3D"], means2D=scene["means2D"], opacities=torch.sigmoid(p["logit_opacities"]),
+                      scales=torch.exp(p["log_scales"]).repeat(1, 3), rotations=scene["rotations"], cam=cam, tile_rows=band)
+        im, _, _ = go.rasterize(colors_precomp=p["rgb_colors"], **common)
+        ds, _, _ = go.rasterize(colors_precomp=torch.cat([z, torch.ones_like(z), z * z], 1), **common)
+        return im, ds
+    return scene, cam, gt_im, gt_depth, params, render, sc
+
+
+def _mapping_worker(rank, world, port, out, outlier):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from diff_gaussian_rasterization import partition as pt
+    scene, cam, gt_im, gt_depth, params, render, sc = _mapping_problem()
+    H = cam.image_height
+    p = params()
+    band = band_for_rank(H, world, rank)
+    im, ds = render(p, band)
+    share = pt.band_mapping_loss(im, ds, gt_im, gt_depth, band, rank, world, w_im=0.5, w_depth=1.0,
+                                 ignore_outlier_depth_loss=outlier)
+    share.backward()
+    nbytes = pt.allreduce_param_grads(p)
+    total = share.detach().clone()
+    dist.all_reduce(total)
+    y0, y1 = pixel_rows(band, H)
+    err = (torch.abs(gt_depth[:, y0:y1] - ds.detach()[0:1, y0:y1]) * (gt_depth[:, y0:y1] > 0))
+    med = pt.global_median(err)
+    if rank == 0:
+        torch.save({"loss": total, "median": med, "bytes": nbytes, **{k: v.grad for k, v in p.items()}}, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("outlier", [False, True])
+def test_two_rank_mapping_loss_and_gradients_match_full_frame(tmp_path, outlier):
+    out = str(tmp_path / "m0.pt")
+    mp.spawn(_mapping_worker, args=(2, _free_port(), out, outlier), nprocs=2, join=True)
+    got = torch.load(out)
+    scene, cam, gt_im, gt_depth, params, render, sc = _mapping_problem()
+    p = params()
+    im, ds = render(p, None)
+    depth = ds[0:1]
+    err = torch.abs(gt_depth - depth.detach()) * (gt_depth > 0)
+    if outlier:                                  # full-frame form of src/vtgaussian_slam.py:525-528, then the mapping branch
+        mask = (err < 50 * err.median()) & (gt_depth > 0)
+        l_depth = (gt_depth - depth).abs()[mask].mean()
+        loss = 0.5 * (0.8 * sc.l1_loss_v1(im, gt_im) + 0.2 * (1.0 - sc.calc_ssim(im, gt_im))) + 1.0 * l_depth
+    else:
+        loss = sc.mapping_loss(im, ds, gt_im, gt_depth, w_im=0.5, w_depth=1.0)
+    loss.backward()
+    assert got["bytes"] == 20 * scene["means3D"].shape[0]                 # rgb 3 + opacity 1 + log-scale 1, float32
+    assert abs(got["median"].item() - err.median().item()) == 0.0
+    assert abs(got["loss"].item() - loss.item()) <= 2e-6 * abs(loss.item())
+    for k, v in p.items():
+        ref = v.grad
+        assert (got[k] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-9, k

@@ -1,5 +1,6 @@
 """Tile-row image partition for multi-GPU rendering: contiguous bands of 16-pixel tile rows,
-Gaussians replicated, one band per rank.  Pure Python, no device work."""
+Gaussians replicated, one band per rank; the collectives of the tracking loop (7-float pose gradient) and of the mapping
+loop (per-Gaussian gradients, SSIM halo rows, global mask count and median)."""
 from typing import List, Tuple
 
 
@@ -50,3 +51,167 @@ def pose7_reduce(points, g_points):
     _check(_lib.vtgs_pose7_reduce(n, p.data_ptr(), g.data_ptr(), partials.data_ptr(), out.data_ptr(), _stream_ptr(p.device)),
            "vtgs_pose7_reduce")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Mapping mode of the tile-row partition ("non-additive pieces").  Tracking needs one 7-float all-reduce per
+# iteration (pose7_reduce above); mapping optimises the Gaussians themselves, so
+#   * the trainable per-Gaussian gradients (rgb 3 + opacity 1 + log-scale 1 = 20 B per Gaussian; means and rotations have
+#     learning rate 0, configs/replica/room0.py:100-102) are summed over the ranks in ONE flat all-reduce per iteration;
+#   * the SSIM term has an 11x11 window (utils/slam_external.py:78-87): a band needs 5 rendered pixel rows of each
+#     neighbour (HaloExchange: a differentiable send/recv pair, the halo's gradient flows back to the rank that rendered it);
+#   * the depth term is a masked MEAN: every rank divides its partial sum by the GLOBAL mask count (src/vtgaussian_slam.py:
+#     592-597), and the 50 x median outlier mask (:525-528, :754) needs the median over the whole frame (global_median).
+# All of it is torch + torch.distributed on whatever device the tensors live on: RCCL (backend "nccl") on the GPUs, gloo in
+# the CPU tests (tests/test_band_partition_gloo.py, world_size 2).
+# ---------------------------------------------------------------------------------------------------------------------
+SSIM_HALO = 5                      # rows a band needs from each neighbour: (11 - 1) / 2
+
+
+def allreduce_param_grads(params, keys=("rgb_colors", "logit_opacities", "log_scales"), group=None):
+    """Sum `.grad` of the listed parameters over the ranks with one flat all-reduce (20 B per Gaussian for the default
+    keys).  Parameters without a gradient on this rank (no Gaussian of theirs met the band) count as zero."""
+    import torch
+    import torch.distributed as dist
+    ref = params[keys[0]]
+    parts = [(params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])).reshape(-1) for k in keys]
+    flat = torch.cat(parts).to(ref.device)
+    dist.all_reduce(flat, group=group)
+    o = 0
+    for k, p in zip(keys, parts):
+        n = p.numel()
+        g = flat[o:o + n].reshape(params[k].shape)
+        if params[k].grad is None:
+            params[k].grad = g.clone()
+        else:
+            params[k].grad.copy_(g)
+        o += n
+    return flat.numel() * flat.element_size()
+
+
+def _halo_autograd():
+    import torch
+    import torch.distributed as dist
+
+    class HaloExchange(torch.autograd.Function):
+        """img [C,H,W] holds this rank's pixel rows [y0, y1) (anything elsewhere is ignored).  Returns a copy whose rows
+        [y0 - halo, y0) and [y1, y1 + halo) hold what the neighbouring ranks rendered there.  Backward: the gradient
+        that lands on a halo row is sent to the rank that rendered it and added to that rank's own-row gradient."""
+
+        @staticmethod
+        def forward(ctx, img, y0: int, y1: int, halo: int, rank: int, world: int, group):
+            H = img.shape[-2]
+            out = img.clone()
+            up, down = rank - 1, rank + 1                       # bands are ordered top to bottom by rank
+            lo0, hi1 = max(y0 - halo, 0), min(y1 + halo, H)
+            ops, recv_up, recv_down = [], None, None
+            if up >= 0:
+                send = img[:, y0:min(y0 + halo, y1)].contiguous()
+                recv_up = torch.empty_like(img[:, lo0:y0])
+                ops += [dist.P2POp(dist.isend, send, up, group), dist.P2POp(dist.irecv, recv_up, up, group)]
+            if down < world:
+                send = img[:, max(y1 - halo, y0):y1].contiguous()
+                recv_down = torch.empty_like(img[:, y1:hi1])
+                ops += [dist.P2POp(dist.isend, send, down, group), dist.P2POp(dist.irecv, recv_down, down, group)]
+            if ops:
+                for r in dist.batch_isend_irecv(ops):
+                    r.wait()
+            if recv_up is not None:
+                out[:, lo0:y0] = recv_up
+            if recv_down is not None:
+                out[:, y1:hi1] = recv_down
+            ctx.cfg = (y0, y1, halo, rank, world, group, H)
+            return out
+
+        @staticmethod
+        def backward(ctx, g):
+            y0, y1, halo, rank, world, group, H = ctx.cfg
+            up, down = rank - 1, rank + 1
+            lo0, hi1 = max(y0 - halo, 0), min(y1 + halo, H)
+            gi = torch.zeros_like(g)
+            gi[:, y0:y1] = g[:, y0:y1]
+            ops, recv_up, recv_down = [], None, None
+            if up >= 0:                                         # my top halo was rendered by `up`; `up`'s bottom halo by me
+                send = g[:, lo0:y0].contiguous()
+                recv_up = torch.empty_like(g[:, y0:min(y0 + halo, y1)])
+                ops += [dist.P2POp(dist.isend, send, up, group), dist.P2POp(dist.irecv, recv_up, up, group)]
+            if down < world:
+                send = g[:, y1:hi1].contiguous()
+                recv_down = torch.empty_like(g[:, max(y1 - halo, y0):y1])
+                ops += [dist.P2POp(dist.isend, send, down, group), dist.P2POp(dist.irecv, recv_down, down, group)]
+            if ops:
+                for r in dist.batch_isend_irecv(ops):
+                    r.wait()
+            if recv_up is not None:
+                gi[:, y0:min(y0 + halo, y1)] += recv_up
+            if recv_down is not None:
+                gi[:, max(y1 - halo, y0):y1] += recv_down
+            return gi, None, None, None, None, None, None
+    return HaloExchange
+
+
+def halo_exchange(img, band: Tuple[int, int], image_height: int, rank: int, world: int, halo: int = SSIM_HALO, group=None):
+    """Differentiable exchange of `halo` pixel rows with the neighbouring bands (see HaloExchange)."""
+    y0, y1 = pixel_rows(band, image_height)
+    if y1 - y0 < halo and world > 1:
+        raise ValueError(f"a band of {y1 - y0} pixel rows cannot serve a {halo}-row halo; use fewer ranks")
+    return _halo_autograd().apply(img, y0, y1, halo, rank, world, group)
+
+
+def global_median(local_values, group=None):
+    """torch.median (the lower median, as the reference's depth_error.median()) of the concatenation of every rank's values."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    v = local_values.detach().reshape(-1)
+    counts = [torch.zeros(1, dtype=torch.long, device=v.device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([v.numel()], dtype=torch.long, device=v.device), group=group)
+    m = int(max(int(c) for c in counts))
+    pad = torch.full((m,), float("nan"), dtype=v.dtype, device=v.device)
+    pad[:v.numel()] = v
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([b[:int(c)] for b, c in zip(bufs, counts)]).median()
+
+
+def band_mapping_loss(im, depth_sil, gt_im, gt_depth, band: Tuple[int, int], rank: int, world: int, w_im: float = 1.0,
+                      w_depth: float = 1.0, ignore_outlier_depth_loss: bool = False, group=None):
+    """This rank's share of the mapping loss of get_loss (src/vtgaussian_slam.py:519-611): the shares of all ranks sum to the
+    full-frame loss and the gradients of the shares, summed over the ranks (allreduce_param_grads), are the full-frame
+    gradients.  im / depth_sil: [3,H,W] renders whose rows of `band` are this rank's (GaussianRasterizer(tile_rows=band));
+    gt_im / gt_depth: full frames (every rank holds the ground truth)."""
+    import torch
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    H, W = im.shape[-2], im.shape[-1]
+    y0, y1 = pixel_rows(band, H)
+    rows = slice(y0, y1)
+    depth = depth_sil[0:1, rows]
+    unc = (depth_sil[2:3, rows] - depth ** 2).detach()
+    gd = gt_depth[:, rows]
+    if ignore_outlier_depth_loss:
+        err = torch.abs(gd - depth.detach()) * (gd > 0)
+        mask = (err < 50 * global_median(err, group)) & (gd > 0)
+    else:
+        mask = gd > 0
+    mask = (mask & ~torch.isnan(depth) & ~torch.isnan(unc)).detach()
+    stats = torch.stack([mask.sum().to(torch.float32)])
+    dist.all_reduce(stats, group=group)                       # global mask count: the depth term is a MEAN over the frame
+    l_depth = torch.abs(gd - depth)[mask].sum() / stats[0]
+    numel = float(3 * H * W)
+    l1 = torch.abs(im[:, rows] - gt_im[:, rows]).sum() / numel
+    # SSIM map of this band: blur needs SSIM_HALO rows of context on both sides, rendered by the neighbours
+    full = halo_exchange(im, band, H, rank, world, SSIM_HALO, group)
+    c0, c1 = max(y0 - SSIM_HALO, 0), min(y1 + SSIM_HALO, H)
+    a, b = full[None, :, c0:c1], gt_im[None, :, c0:c1]
+    g1 = torch.tensor([__import__("math").exp(-(i - 5) ** 2 / (2 * 1.5 ** 2)) for i in range(11)], dtype=a.dtype, device=a.device)
+    g1 = g1 / g1.sum()
+    win = (g1[:, None] @ g1[None, :]).expand(3, 1, 11, 11).contiguous()
+    blur = lambda t: F.conv2d(t, win, padding=5, groups=3)     # zero padding: at the frame border like calc_ssim, and at the
+    mu1, mu2 = blur(a), blur(b)                                # crop's artificial borders only inside the discarded halo rows
+    s11, s22, s12 = blur(a * a) - mu1 * mu1, blur(b * b) - mu2 * mu2, blur(a * b) - mu1 * mu2
+    c_1, c_2 = 0.01 ** 2, 0.03 ** 2
+    smap = ((2 * mu1 * mu2 + c_1) * (2 * s12 + c_2)) / ((mu1 * mu1 + mu2 * mu2 + c_1) * (s11 + s22 + c_2))
+    ssim_share = smap[0, :, y0 - c0:y1 - c0].sum() / numel
+    const = 0.2 if rank == 0 else 0.0                          # the "1" of (1 - SSIM) belongs to one rank
+    return w_im * (0.8 * l1 + const - 0.2 * ssim_share) + w_depth * l_depth
