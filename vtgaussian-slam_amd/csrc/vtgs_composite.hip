@@ -25,6 +25,19 @@
 #include "vtgs_internal.h"
 #include "vtgs_composite_common.h"
 
+// Scheduling groups (profiles/r2_issue_rates.md 2: an MFMA and a vector instruction that alternate one by one cost 1.5x the
+// sum of their parts).  Measured on the headline scene: backward sweeps + contraction grouped 190.6 us against 197.8 us
+// ungrouped; the same grouping in the lane = pixel FORWARD raises its register pressure and slows it down, so it stays off.
+#ifndef VTGS_PX_GROUP
+#define VTGS_PX_GROUP 1
+#endif
+#ifndef VTGS_PX_GROUP2
+#define VTGS_PX_GROUP2 1
+#endif
+#ifndef VTGS_PX_GROUP_FWD
+#define VTGS_PX_GROUP_FWD 0
+#endif
+
 namespace vtgs {
 
 // Scalar ("readlane") forward composite: lane = pixel, splats broadcast one at a time.  Kept as an independent
@@ -330,7 +343,7 @@ __device__ __forceinline__ void px_forward_batch(float& T, bool& done, bool& exa
       }
       Tn = Tn - w;                                               // T (1 - alpha), with the product already at hand
     }
-#ifdef VTGS_PX_GROUP
+#if VTGS_PX_GROUP_FWD
     // keep the 24 exponent MFMAs together, ahead of the vector sweep (tests/micro/mix_rate.hip: MFMA and vector
     // instructions alternating one by one cost 1.5x the sum of their separate issue times)
     __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
@@ -803,7 +816,7 @@ __device__ __forceinline__ void px_backward_batch(PxBwdState& st, bool& exact, c
       Pn = fmaf(gcv[k >> 2][k & 3], w, Pn);
       Tn = Tn - w;
     }
-#ifdef VTGS_PX_GROUP
+#if VTGS_PX_GROUP
     __builtin_amdgcn_sched_group_barrier(0x008, DUAL ? 48 : 36, 0);
     __builtin_amdgcn_sched_group_barrier(0x302, 400, 0);
 #endif
@@ -1017,6 +1030,10 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
           if constexpr (DUAL) Pw2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], gbv[e4], Pw2, 0, 0, 0);
         }
       }
+#if VTGS_PX_GROUP2
+      __builtin_amdgcn_sched_group_barrier(0x100, DUAL ? 24 : 16, 1);   // the image / Phi reads first ...
+      __builtin_amdgcn_sched_group_barrier(0x008, DUAL ? 64 : 48, 1);   // ... then the contraction MFMAs back to back
+#endif
       // lane (cj, sg, rho = l >> 4) ends up with the totals of splat 4 sg + rho
       const float Fa = quarter_sum(Pa), Fb = quarter_sum(Pb), Fw = quarter_sum(Pw);
       const float Fw2 = DUAL ? quarter_sum(Pw2) : 0.f;           // cross-lane: must run with all lanes active

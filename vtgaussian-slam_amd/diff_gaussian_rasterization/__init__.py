@@ -205,6 +205,26 @@ class _Camera:
         self.band = (b, e)
 
 
+_camera_cache: dict = {}
+
+
+def _camera_for(settings, device, radius_rule: int, tile_rows) -> "_Camera":
+    """The reference builds its settings record once per run (src/vtgaussian_slam.py:209) and hands the same object to every
+    render: keep the ctypes record per (settings object, device, rule, band) while the three camera tensors are unchanged
+    (same storage and `_version`; an in-place edit misses)."""
+    key = (id(settings), device, radius_rule, tile_rows)
+    ver = tuple((t.data_ptr(), t._version) if isinstance(t, torch.Tensor) else None
+                for t in (settings.bg, settings.viewmatrix, settings.projmatrix))
+    hit = _camera_cache.get(key)
+    if hit is not None and hit[0] is settings and hit[1] == ver and None not in ver:
+        return hit[2]
+    cam = _Camera(settings, device, radius_rule, tile_rows)
+    if len(_camera_cache) > 64:
+        _camera_cache.clear()
+    _camera_cache[key] = (settings, ver, cam)
+    return cam
+
+
 def _stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -226,10 +246,12 @@ class _ForwardState:
 _info_slots: dict = {}       # device index -> pinned, device-mapped 64-byte slot the forward writes its result record to
 
 
-def _info_slot(device) -> torch.Tensor:
+def _info_slot(device):
+    """(pinned tensor, its address, a ctypes view of the record in it) -- the view reads the pinned bytes in place."""
     slot = _info_slots.get(device.index)
     if slot is None:
-        slot = torch.zeros((64,), dtype=torch.uint8).pin_memory()
+        t = torch.zeros((64,), dtype=torch.uint8).pin_memory()
+        slot = (t, t.data_ptr(), _VtgsForwardInfo.from_address(t.data_ptr()))
         _info_slots[device.index] = slot
     return slot
 
@@ -288,22 +310,23 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
     device = means3D.device
     n = means3D.shape[0]
     H, W = cam.H, cam.W
-    color = torch.empty((3, H, W), dtype=torch.float32, device=device)
-    depth = torch.empty((3 if colors_b is not None else 1, H, W), dtype=torch.float32, device=device)
+    nd = 3 if colors_b is not None else 1
+    images = torch.empty((3 + nd, H, W), dtype=torch.float32, device=device)      # one allocation for both images
+    color, depth = images[:3], images[3:]
     radii = torch.empty((n,), dtype=torch.int32, device=device)
-    slot = _info_slot(device)
+    _slot_tensor, slot_ptr, info = _info_slot(device)
     stream = _stream_ptr(device)
 
     def launch(workspace, nbytes, capacity, tile_cap):
         if colors_b is None:
             return _lib.vtgs_forward(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
                                      scales.data_ptr(), rotations.data_ptr(), color.data_ptr(), depth.data_ptr(),
-                                     radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, tile_cap, slot.data_ptr(),
+                                     radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, tile_cap, slot_ptr,
                                      VTGS_FORWARD_CHECKED, stream)
         return _lib.vtgs_forward_dual(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), colors_b.data_ptr(),
                                       opacities.data_ptr(), scales.data_ptr(), rotations.data_ptr(), color.data_ptr(),
                                       depth.data_ptr(), radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, tile_cap,
-                                      slot.data_ptr(), VTGS_FORWARD_CHECKED, stream)
+                                      slot_ptr, VTGS_FORWARD_CHECKED, stream)
 
     key = (device.index, n, W, H, cam.band)
     capacity, tile_cap = _choose_capacities(key, n)
@@ -313,7 +336,6 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
         for _attempt in range(6):
             nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
             st = launch(workspace, nbytes, capacity, tile_cap)
-            info = _VtgsForwardInfo.from_buffer_copy(bytes(slot[:ctypes.sizeof(_VtgsForwardInfo)].numpy()))
             if st == VTGS_ERR_INSTANCE_OVERFLOW:          # the record says what is needed: grow whichever was short
                 if info.overflow & 1:
                     capacity = int(info.instances_needed * 1.5) + 4096
@@ -352,12 +374,9 @@ def _device_guard(device):
 def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotations, out_color, grad_color):
     device = means3D.device
     n = fs.n
-    g_means3D = torch.empty((n, 3), dtype=torch.float32, device=device)
-    g_means2D = torch.empty((n, 3), dtype=torch.float32, device=device)
-    g_colors = torch.empty((n, 3), dtype=torch.float32, device=device)
-    g_opac = torch.empty((n, 1), dtype=torch.float32, device=device)
-    g_scales = torch.empty((n, 3), dtype=torch.float32, device=device)
-    g_rot = torch.empty((n, 4), dtype=torch.float32, device=device)
+    flat = torch.empty((17 * n,), dtype=torch.float32, device=device)             # one allocation, six contiguous arrays
+    g_means3D, g_means2D, g_colors = flat[:3 * n].view(n, 3), flat[3 * n:6 * n].view(n, 3), flat[6 * n:9 * n].view(n, 3)
+    g_opac, g_scales, g_rot = flat[9 * n:10 * n].view(n, 1), flat[10 * n:13 * n].view(n, 3), flat[13 * n:].view(n, 4)
     if n == 0:
         return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
     sbytes = _lib.vtgs_backward_scratch_bytes(n, fs.instances)
@@ -513,7 +532,7 @@ class GaussianRasterizer(nn.Module):
                                       "scales + rotations (utils/slam_helpers.py:152-159)")
         if not means3D.is_cuda:
             raise RuntimeError("GaussianRasterizer needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
-        cam = _Camera(self.raster_settings, means3D.device, self._rule, self._tile_rows)
+        cam = _camera_for(self.raster_settings, means3D.device, self._rule, self._tile_rows)
         color, radii, depth, fs = _RasterizeGaussians.apply(means3D, means2D, None, colors_precomp, opacities, scales,
                                                             rotations, None, cam, None)
         self._last_state = fs
