@@ -1,7 +1,7 @@
 """Per-kernel timing of the fwd+bwd step at the headline shape (HIP events inside the library).
 
     python tools/kernel_timing.py            # env: ABL_N (Gaussians), ABL_BWD=0 forward only, ABL_TAG label,
-                                             #      VTGS_FWD_IMPL / VTGS_BWD_IMPL = 0 scalar kernels, 1 matrix-core kernels; ABL_W / ABL_H image size; ABL_OPACITY constant opacity
+                                             #      VTGS_FWD_IMPL / VTGS_BWD_IMPL = 0 scalar kernels, 1 matrix-core kernels; ABL_W / ABL_H image size; ABL_OPACITY constant opacity; ABL_BAND=r/w one band of a w-way partition
 """
 import sys, os, time, torch
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +15,11 @@ W=int(os.environ.get('ABL_W','1200')); H=int(os.environ.get('ABL_H','680'))
 scene,cam=go.view_tied_scene(N,W,H,seed=0)
 if 'ABL_OPACITY' in os.environ: scene['opacities']=torch.full_like(scene['opacities'], float(os.environ['ABL_OPACITY']))   # saturating scenes
 leaves={k:v.to(dev).requires_grad_(True) for k,v in scene.items()}
-rast=dgr.GaussianRasterizer(raster_settings=to_settings(cam,dev))
+band=None
+if 'ABL_BAND' in os.environ:                                   # "r/w": time rank r's band of a w-way tile-row partition
+    from diff_gaussian_rasterization.partition import band_for_rank
+    r_,w_=os.environ['ABL_BAND'].split('/'); band=band_for_rank(H,int(w_),int(r_))
+rast=dgr.GaussianRasterizer(raster_settings=to_settings(cam,dev),tile_rows=band)
 g=torch.rand(3,H,W,device=dev)
 bwd=os.environ.get('ABL_BWD','1')=='1'
 def step():

@@ -198,10 +198,13 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
   const uint32_t inst_base = wave_base + incl - cnt;
 
   if (valid) {
-    GeomRec g;
-    g.u = sp.u; g.v = sp.v; g.A = sp.A; g.B = sp.B; g.C = sp.C; g.opacity = op; g.depth = sp.depth; g.pad = 0.f;
-    if (!vis) { g.u = g.v = g.A = g.B = g.C = g.depth = 0.f; }
-    geom[gid] = g;
+    // the geometry record is only ever reached through a tile list: a splat without instances (culled, or outside this
+    // call's band of tile rows -- 7/8 of them on each rank of an 8-way partition) does not need one
+    if (cnt) {
+      GeomRec g;
+      g.u = sp.u; g.v = sp.v; g.A = sp.A; g.B = sp.B; g.C = sp.C; g.opacity = op; g.depth = sp.depth; g.pad = 0.f;
+      geom[gid] = g;
+    }
     gaux[gid] = GaussAux{inst_base, cnt};
   }
 
@@ -336,16 +339,58 @@ constexpr int kSortLds = 2048;
 constexpr int kWaveSortMax = 1024;
 
 // HASV = false sorts the keys alone (the payload travels in their low bits, see wave_sort_tile): a third less to move.
+//
+// Code size matters more than the exchange instruction here: fully unrolled, the five list-length variants of this network
+// came to ~35 K instructions (~250 KB), far beyond the instruction cache that the CUs share, and the kernel took the same
+// 27-45 us whether it sorted 1,600 or 12,750 lists and whether lanes exchanged through ds_bpermute or DPP -- it was
+// fetching instructions.  So only what must be unrolled is (register indices: the in-lane comparators); the merge levels
+// and the cross-lane half-cleaners are real loops over a run-time lane mask.
+template <int E, bool HASV>
+__device__ __forceinline__ void in_lane_cleaners(unsigned long long (&k)[E], uint32_t (&v)[E]) {   // partner = e ^ j, j = E/2 .. 1
+#pragma unroll
+  for (int j = E >> 1; j > 0; j >>= 1) {
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      if (!(r & j)) {
+        const int p = r | j;
+        const bool sw = k[r] > k[p];
+        const unsigned long long a = k[r], b = k[p];
+        const uint32_t va = v[r], vb = v[p];
+        k[r] = sw ? b : a; k[p] = sw ? a : b;
+        if (HASV) { v[r] = sw ? vb : va; v[p] = sw ? va : vb; }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned long long lane_fetch64(unsigned long long x, int byte_addr) {   // x of lane byte_addr / 4
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(uint32_t)x);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(uint32_t)(x >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 template <int E, bool HASV>
 __device__ __forceinline__ void wave_sort_regs(unsigned long long (&k)[E], uint32_t (&v)[E], int lane) {
+  // levels inside a lane (k2 <= E): compile-time register pairs
 #pragma unroll
-  for (int k2 = 2; k2 <= 64 * E; k2 <<= 1) {
-    // ---- mirror step: partner = e ^ (k2 - 1)
-    if (k2 <= E) {
+  for (int k2 = 2; k2 <= E; k2 <<= 1) {
+#pragma unroll
+    for (int r = 0; r < E; ++r) {                                // mirror step: partner = r ^ (k2 - 1)
+      const int p = r ^ (k2 - 1);
+      if (r < p) {
+        const bool sw = k[r] > k[p];
+        const unsigned long long a = k[r], b = k[p];
+        const uint32_t va = v[r], vb = v[p];
+        k[r] = sw ? b : a; k[p] = sw ? a : b;
+        if (HASV) { v[r] = sw ? vb : va; v[p] = sw ? va : vb; }
+      }
+    }
+#pragma unroll
+    for (int j = k2 >> 2; j > 0; j >>= 1) {
 #pragma unroll
       for (int r = 0; r < E; ++r) {
-        const int p = r ^ (k2 - 1);
-        if (r < p) {
+        if (!(r & j)) {
+          const int p = r | j;
           const bool sw = k[r] > k[p];
           const unsigned long long a = k[r], b = k[p];
           const uint32_t va = v[r], vb = v[p];
@@ -353,14 +398,19 @@ __device__ __forceinline__ void wave_sort_regs(unsigned long long (&k)[E], uint3
           if (HASV) { v[r] = sw ? vb : va; v[p] = sw ? va : vb; }
         }
       }
-    } else {
-      const int M = k2 / E - 1;                                  // lane mask; in-lane index mirrors (E-1-r)
+    }
+  }
+  // levels across lanes: lane mask M = 1, 3, 7, .. 63 (k2 = 2E .. 64E)
+#pragma unroll 1
+  for (int M = 1; M < 64; M = 2 * M + 1) {
+    {                                                            // mirror step: lane ^ M, in-lane index mirrored
+      const int addr = (lane ^ M) << 2;
       const bool lower = (lane & ((M + 1) >> 1)) == 0;
       unsigned long long pk[E]; uint32_t pv[E];
 #pragma unroll
       for (int r = 0; r < E; ++r) {
-        pk[r] = (unsigned long long)__shfl_xor((long long)k[E - 1 - r], M, 64);
-        pv[r] = HASV ? (uint32_t)__shfl_xor((int)v[E - 1 - r], M, 64) : 0u;
+        pk[r] = lane_fetch64(k[E - 1 - r], addr);
+        pv[r] = HASV ? (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[E - 1 - r]) : 0u;
       }
 #pragma unroll
       for (int r = 0; r < E; ++r) {
@@ -369,34 +419,20 @@ __device__ __forceinline__ void wave_sort_regs(unsigned long long (&k)[E], uint3
         if (HASV) v[r] = take ? pv[r] : v[r];
       }
     }
-    // ---- half-cleaners: partner = e ^ j
+#pragma unroll 1
+    for (int m = (M + 1) >> 2; m > 0; m >>= 1) {                 // half-cleaners across lanes: lane ^ m
+      const int addr = (lane ^ m) << 2;
+      const bool lower = (lane & m) == 0;
 #pragma unroll
-    for (int j = k2 >> 2; j > 0; j >>= 1) {
-      if (j < E) {
-#pragma unroll
-        for (int r = 0; r < E; ++r) {
-          if (!(r & j)) {
-            const int p = r | j;
-            const bool sw = k[r] > k[p];
-            const unsigned long long a = k[r], b = k[p];
-            const uint32_t va = v[r], vb = v[p];
-            k[r] = sw ? b : a; k[p] = sw ? a : b;
-          if (HASV) { v[r] = sw ? vb : va; v[p] = sw ? va : vb; }
-          }
-        }
-      } else {
-        const int m = j / E;
-        const bool lower = (lane & m) == 0;
-#pragma unroll
-        for (int r = 0; r < E; ++r) {
-          const unsigned long long pk = (unsigned long long)__shfl_xor((long long)k[r], m, 64);
-          const uint32_t pv = HASV ? (uint32_t)__shfl_xor((int)v[r], m, 64) : 0u;
-          const bool take = lower ? (pk < k[r]) : (pk > k[r]);
-          k[r] = take ? pk : k[r];
-          if (HASV) v[r] = take ? pv : v[r];
-        }
+      for (int r = 0; r < E; ++r) {
+        const unsigned long long pk = lane_fetch64(k[r], addr);
+        const uint32_t pv = HASV ? (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[r]) : 0u;
+        const bool take = lower ? (pk < k[r]) : (pk > k[r]);
+        k[r] = take ? pk : k[r];
+        if (HASV) v[r] = take ? pv : v[r];
       }
     }
+    in_lane_cleaners<E, HASV>(k, v);
   }
 }
 
@@ -464,11 +500,13 @@ __device__ __forceinline__ void sort_network(unsigned long long* k, uint32_t* v,
   }
 }
 
-// grid = ceil(tiles/4) workgroups of 4 wavefronts; wavefront w of workgroup b owns tile 4*b' + w (b' XCD-swizzled)
+// grid = ceil(tiles/4) workgroups of 4 wavefronts; wavefront w of workgroup b owns tile tile_first + 4*b' + w (b' XCD-swizzled)
+// (tile_first, tiles) = the call's band of tiles: the grid covers only those, so that a band (multi-GPU partition) still
+// spreads over all eight XCDs instead of landing in the one XCD whose share of a full-frame grid it would be.
 __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ tile_cnt, unsigned long long* __restrict__ keys,
                                                   uint32_t* __restrict__ vals, uint32_t* __restrict__ sorted_gid,
-                                                  uint32_t* __restrict__ sorted_inst, uint32_t tiles, uint32_t tile_cap,
-                                                  const Counters* __restrict__ ctr, int packed) {
+                                                  uint32_t* __restrict__ sorted_inst, uint32_t tile_first, uint32_t tiles,
+                                                  uint32_t tile_cap, const Counters* __restrict__ ctr, int packed) {
   __shared__ unsigned long long sk[kSortLds];
   __shared__ uint32_t sv[kSortLds];
   if (ctr->overflow) return;                    // some bin slots were never written: nothing valid to sort
@@ -477,8 +515,8 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = lane_id();
   {
-    const uint32_t tile = 4u * b + (uint32_t)wv;
-    if (tile < tiles) {
+    const uint32_t tile = tile_first + 4u * b + (uint32_t)wv;
+    if (4u * b + (uint32_t)wv < tiles) {
       const size_t s = (size_t)tile * tile_cap;
       const uint32_t L = min(tile_cnt[tile], tile_cap);
       if (L == 1u) {
@@ -501,8 +539,8 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
   // long lists: the whole workgroup takes them one at a time (workgroup-uniform control flow)
   const uint32_t t = threadIdx.x;
   for (uint32_t q = 0; q < 4u; ++q) {
-    const uint32_t tile = 4u * b + q;
-    if (tile >= tiles) break;
+    const uint32_t tile = tile_first + 4u * b + q;
+    if (4u * b + q >= tiles) break;
     const size_t s = (size_t)tile * tile_cap;
     const uint32_t L = min(tile_cnt[tile], tile_cap);
     if (L <= (uint32_t)kWaveSortMax) continue;
