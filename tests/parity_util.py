@@ -215,6 +215,16 @@ def audit_outliers(ref, got, aux, opacities, cam, tol=1e-4, max_report=5000):
     return out
 
 
+def tiles_of(aux, sel, cam):
+    """16x16 tile ids under the oracle rectangles of the selected Gaussians."""
+    gx = (int(cam.image_width) + 15) // 16
+    out = set()
+    for i in torch.nonzero(sel).reshape(-1).tolist():
+        x0, y0, x1, y1 = aux["splats"].rect[i].tolist()
+        out.update(ty * gx + tx for ty in range(y0, y1) for tx in range(x0, x1))
+    return out
+
+
 def tainted_gaussians(aux, tiles, n):
     """[n] bool: Gaussians in the 16x16 tile list of a tile that holds an audited outlier pixel (their gradients carry
     that pixel's flipped decision)."""

@@ -13,7 +13,8 @@ import pytest
 import torch
 
 from oracle import gs_oracle as go
-from parity_util import (GRAD_KEYS, audit_outliers, grad_error, image_error, run_hip, run_oracle, tainted_gaussians)
+from parity_util import (GRAD_KEYS, audit_outliers, grad_error, image_error, run_hip, run_oracle, tainted_gaussians,
+                         tiles_of)
 
 pytestmark = pytest.mark.gpu
 
@@ -101,18 +102,8 @@ def test_forward_backward_parity(gpu_device, name):
     assert ((ref_r > 0) != (got_r > 0)).sum().item() <= 2
     taint = _check_images(ref_c, ref_d, got_c, got_d, audit=(aux, scene["opacities"], cam))
     # a radius on the other side of float32 ceil() moves a whole tile rectangle: not a rounding-level difference
-    taint |= tainted_gaussians(aux, _tiles_of(aux, diff, cam), diff.numel())
+    taint |= tainted_gaussians(aux, tiles_of(aux, diff, cam), diff.numel())
     _check_grads(ref_g, got_g, taint)
-
-
-def _tiles_of(aux, sel, cam):
-    """16x16 tile ids under the oracle rectangles of the selected Gaussians."""
-    gx = (int(cam.image_width) + 15) // 16
-    out = set()
-    for i in torch.nonzero(sel).reshape(-1).tolist():
-        x0, y0, x1, y1 = aux["splats"].rect[i].tolist()
-        out.update(ty * gx + tx for ty in range(y0, y1) for tx in range(x0, x1))
-    return out
 
 
 def test_cfg_a_synthetic_10k_320x240(gpu_device):
@@ -124,7 +115,7 @@ def test_cfg_a_synthetic_10k_320x240(gpu_device):
     got_c, got_r, got_d, got_g = run_hip(scene, cam, gpu_device, grad_color)
     assert torch.equal(ref_r > 0, got_r > 0)
     taint = _check_images(ref_c, ref_d, got_c, got_d, audit=(aux, scene["opacities"], cam))
-    taint |= tainted_gaussians(aux, _tiles_of(aux, ref_r != got_r, cam), ref_r.numel())
+    taint |= tainted_gaussians(aux, tiles_of(aux, ref_r != got_r, cam), ref_r.numel())
     _check_grads(ref_g, got_g, taint)
 
 
@@ -152,7 +143,7 @@ def test_background_and_gradient_through_bg(gpu_device):
     ref_c, ref_r, ref_d, ref_g, aux = run_oracle(scene, cam_bg, grad_color)
     got_c, got_r, got_d, got_g = run_hip(scene, cam_bg, gpu_device, grad_color)
     taint = _check_images(ref_c, ref_d, got_c, got_d, audit=(aux, scene["opacities"], cam_bg))
-    taint |= tainted_gaussians(aux, _tiles_of(aux, ref_r != got_r, cam_bg), ref_r.numel())
+    taint |= tainted_gaussians(aux, tiles_of(aux, ref_r != got_r, cam_bg), ref_r.numel())
     _check_grads(ref_g, got_g, taint)
 
 
@@ -403,7 +394,7 @@ def test_saturating_scene_exercises_the_stop_rule(gpu_device, opacity_scale):
         _opt("VTGS_FWD_IMPL", impl); _opt("VTGS_BWD_IMPL", impl)
         got_c, got_r, got_d, got_g = run_hip(scene, cam, gpu_device, grad_color)
         taint = _check_images(ref_c, ref_d, got_c, got_d, audit=(aux, scene["opacities"], cam))
-        taint |= tainted_gaussians(aux, _tiles_of(aux, ref_r != got_r, cam), ref_r.numel())
+        taint |= tainted_gaussians(aux, tiles_of(aux, ref_r != got_r, cam), ref_r.numel())
         _check_grads(ref_g, got_g, taint)
 
 
@@ -425,7 +416,7 @@ def test_giant_splats_and_long_lists(gpu_device):
     assert int(got_r[:k].max()) > 2 * max(cam.image_width, cam.image_height) // 4      # really frame-sized splats
     assert ((ref_r > 0) != (got_r > 0)).sum().item() == 0
     taint = _check_images(ref_c, ref_d, got_c, got_d, audit=(aux, scene["opacities"], cam))
-    taint |= tainted_gaussians(aux, _tiles_of(aux, ref_r != got_r, cam), ref_r.numel())
+    taint |= tainted_gaussians(aux, tiles_of(aux, ref_r != got_r, cam), ref_r.numel())
     _check_grads(ref_g, got_g, taint)
 
 

@@ -12,7 +12,7 @@ tag = sys.argv[1]
 
 
 def kname(full):
-    return full.replace("void ", "").split("(")[0].replace("vtgs::", "").split("<")[0].replace("_mx", "").replace("_px", "")
+    return full.replace("void ", "").split("(")[0].replace("vtgs::", "").split("<")[0].replace("_mx", "").replace("_px", "").replace("forward_q", "forward")
 
 
 def find(dirname, suffix):
@@ -79,7 +79,7 @@ try:
 except SystemExit:
     sq = None
 if sq:
-    occ = {"composite_backward": 3, "composite_forward": 3, "project_and_bin": 8, "gather_splat_grads": 3, "sort_tiles": 4}
+    occ = {"composite_backward": 3, "composite_forward": 4, "project_and_bin": 8, "gather_splat_grads": 3, "sort_tiles": 6}
     with open(f"profiles/{tag}_sq_counters.md", "w") as fo:
         fo.write(f"# SQ counters per kernel, {tag} (rocprofv3 --pmc, two passes of `bench.py --steps 3 --warmup 2 "
                  "--no-cpu-baseline`, N=1M, 1200x680)\n\nPercentages are of SQ_WAVE_CYCLES (all SQ_* cycle counters share the "

@@ -1088,6 +1088,19 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
   float cb0 = 0.f, cb1 = 0.f, cb2 = 0.f;         // dual: dL/d(second render's colours)
   const GaussAux ga = gaux[gid];
   if (ga.inst_cnt) {
+    // The records are read with everything else: their addresses only need gaux, so the first kGatherAhead of them (a
+    // splat has 3.5 on average at the headline shape) are in flight together with the inputs of the projection instead
+    // of behind its arithmetic -- this kernel is bound by how many loads it keeps outstanding at 3 waves per SIMD.
+    constexpr int RV = (DUAL ? kGradRecDual : kGradRec) / 4;       // float4 per record
+    constexpr uint32_t kGatherAhead = 4;
+    const float4* rec = reinterpret_cast<const float4*>(grad_inst) + (size_t)ga.inst_base * RV;
+    float4 pa[kGatherAhead], pb[kGatherAhead], pc[kGatherAhead], pd[kGatherAhead];
+#pragma unroll
+    for (uint32_t i = 0; i < kGatherAhead; ++i) {
+      const uint32_t ii = min(i, ga.inst_cnt - 1u);                // past the end: the last record again (a cache hit), unused
+      pa[i] = rec[RV * ii]; pb[i] = rec[RV * ii + 1]; pc[i] = rec[RV * ii + 2];
+      if constexpr (DUAL) pd[i] = rec[RV * ii + 3]; else pd[i] = pc[i];
+    }
     const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
     const float sc[3] = {scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
     const float4 q4 = reinterpret_cast<const float4*>(rotations)[gid];
@@ -1097,14 +1110,11 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     if (project_splat(cam, mean, sc, q, op, sp, aux)) {
       SplatMoments mo;
       for (int k = 0; k < 9; ++k) mo.m[k] = 0.f;
-      constexpr int RV = (DUAL ? kGradRecDual : kGradRec) / 4;       // float4 per record
-      const float4* rec = reinterpret_cast<const float4*>(grad_inst) + (size_t)ga.inst_base * RV;
-      for (uint32_t i = 0; i < ga.inst_cnt; ++i) {
-        const float4 a = rec[RV * i], b = rec[RV * i + 1], c = rec[RV * i + 2];
-        // record = tile-local moments (U0, UX, UY, UXX, UXY, UYY), colour sums (3 or 6), tile id
+      // record = tile-local moments (U0, UX, UY, UXX, UXY, UYY), colour sums (3 or 6), tile id
+      auto add_record = [&](float4 a, float4 b, float4 c, float4 d) {
         uint32_t tile;
         if constexpr (DUAL) {
-          tile = __float_as_uint(rec[RV * i + 3].x);
+          tile = __float_as_uint(d.x);
           cb0 += c.y; cb1 += c.z; cb2 += c.w;
         } else {
           tile = __float_as_uint(c.y);
@@ -1119,6 +1129,15 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
         mo.m[4] += sx * sy * U0 - sx * UY - sy * UX + UXY;
         mo.m[5] += sy * sy * U0 - 2.f * sy * UY + UYY;
         mo.m[6] += b.z; mo.m[7] += b.w; mo.m[8] += c.x;
+      };
+#pragma unroll
+      for (uint32_t i = 0; i < kGatherAhead; ++i)
+        if (i < ga.inst_cnt) add_record(pa[i], pb[i], pc[i], pd[i]);
+      for (uint32_t i = kGatherAhead; i < ga.inst_cnt; ++i) {
+        const float4 a = rec[RV * i], b = rec[RV * i + 1], c = rec[RV * i + 2];
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (DUAL) d = rec[RV * i + 3];
+        add_record(a, b, c, d);
       }
       if (moments_scaled_by_opacity) {        // the matrix-core backward accumulates u' = o*u
         const float io = 1.f / op;
