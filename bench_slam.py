@@ -79,7 +79,8 @@ def main():
         from diff_gaussian_rasterization.optim import FusedAdam
         track_loss = lambda im, ds, gi, gd, thr: fl.tracking_loss(im, ds, gi, gd, thr)
         map_loss = lambda im, ds, gi, gd: fl.mapping_loss(im, ds, gi, gd)
-        pick_threshold, make_adam = fl.best_silhouette_threshold, FusedAdam
+        import functools
+        pick_threshold, make_adam = fl.best_silhouette_threshold, functools.partial(FusedAdam, skip_frozen=True)
     else:                                             # exactly the reference's PyTorch formulation
         track_loss = lambda im, ds, gi, gd, thr: sc.tracking_loss(im, ds, gi, gd, thr)
         map_loss = lambda im, ds, gi, gd: sc.mapping_loss(im, ds, gi, gd)

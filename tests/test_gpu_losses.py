@@ -122,3 +122,16 @@ def test_fused_adam_matches_torch_adam(gpu_device, eps):
         moved = (a - init[k].to(dev)).abs().max().item()
         assert (a - b).abs().max().item() <= 1e-5 * max(moved, 1e-12) + 1e-7, k
     assert torch.equal(pb["cam_unnorm_rots"].detach().cpu(), init["cam_unnorm_rots"])      # lr 0 leaves it untouched
+    # skip_frozen: groups with lr 0 are not streamed at all; everything else comes out bit-identical
+    pc = {k: v.clone().to(dev).requires_grad_(True) for k, v in init.items()}
+    pd = {k: v.clone().to(dev).requires_grad_(True) for k, v in init.items()}
+    full, lean = FusedAdam(groups(pc), lr=0.0, eps=eps), FusedAdam(groups(pd), lr=0.0, eps=eps, skip_frozen=True)
+    g2 = torch.Generator().manual_seed(5)
+    for it in range(6):
+        for k in shapes:
+            gr = torch.randn(*shapes[k], generator=g2).to(dev)
+            pc[k].grad, pd[k].grad = gr.clone(), gr.clone()
+        full.step(); lean.step()
+    for k in shapes:
+        assert torch.equal(pc[k].detach(), pd[k].detach()), k
+    assert pd["cam_unnorm_rots"] not in lean.state and pc["cam_unnorm_rots"] in full.state

@@ -14,6 +14,7 @@ __global__ void project_and_bin(CamScalars, const float*, const float*, int, con
                                 Counters*, BlockStats*, unsigned long long, uint32_t);
 __global__ void finalize_forward(const uint32_t*, uint32_t, Counters*, unsigned long long, uint32_t, const BlockStats*,
                                  uint32_t, VtgsForwardInfo*);
+template <bool WIDE>
 __global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t,
                            const Counters*, int);
 __global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
@@ -304,10 +305,19 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
 
   const uint32_t gx8 = (uint32_t)((cam->image_width + kSubTile - 1) / kSubTile);
   const uint32_t band_first = (uint32_t)r8b * gx8, band_tiles = (uint32_t)(r8e - r8b) * gx8;
-  { ProfScope ps__("sort_tiles", st); hipLaunchKernelGGL(sort_tiles, dim3((band_tiles + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
-                     (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
-                     (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr,
-                     (n <= (1 << 21) && option(OPT_SORT_PACKED) == 1) ? 1 : 0); }
+  {
+    ProfScope ps__("sort_tiles", st);
+    const int packed = (n <= (1 << 21) && option(OPT_SORT_PACKED) == 1) ? 1 : 0;
+    // lists cannot be longer than the bin capacity: the wide (32 keys per lane) form is only worth its registers beyond 1024
+    if (packed && L.tile_cap > 1024u)
+      hipLaunchKernelGGL(sort_tiles<true>, dim3((band_tiles + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
+                         (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
+                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed);
+    else
+      hipLaunchKernelGGL(sort_tiles<false>, dim3((band_tiles + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
+                         (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
+                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed);
+  }
   VTGS_HIP(hipGetLastError());
   int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st,
                                     dual ? colors_b : nullptr, dual ? out_color_b : nullptr);

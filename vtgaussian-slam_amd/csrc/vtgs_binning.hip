@@ -336,7 +336,8 @@ __global__ __launch_bounds__(1024) void finalize_forward(const uint32_t* __restr
 // Slow path (longer lists): the whole workgroup cooperates, in LDS up to kSortLds entries, else in place in global
 // memory (L2-resident) with the same network.
 constexpr int kSortLds = 2048;
-constexpr int kWaveSortMax = 1024;
+constexpr int kWaveSortMax = 1024;        // key + value form: 16 keys per lane
+constexpr int kWaveSortMaxPacked = 2048;  // packed form (payload in the key): 32 keys per lane still fit the register budget
 
 // HASV = false sorts the keys alone (the payload travels in their low bits, see wave_sort_tile): a third less to move.
 //
@@ -404,19 +405,28 @@ __device__ __forceinline__ void wave_sort_regs(unsigned long long (&k)[E], uint3
 #pragma unroll 1
   for (int M = 1; M < 64; M = 2 * M + 1) {
     {                                                            // mirror step: lane ^ M, in-lane index mirrored
+      // registers r and E-1-r trade places with their mirror images in the partner lane: done pair by pair, so that only two
+      // fetched keys are live at a time (a [E] array of them doubles the register footprint of the E = 32 form)
       const int addr = (lane ^ M) << 2;
       const bool lower = (lane & ((M + 1) >> 1)) == 0;
-      unsigned long long pk[E]; uint32_t pv[E];
 #pragma unroll
-      for (int r = 0; r < E; ++r) {
-        pk[r] = lane_fetch64(k[E - 1 - r], addr);
-        pv[r] = HASV ? (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[E - 1 - r]) : 0u;
-      }
-#pragma unroll
-      for (int r = 0; r < E; ++r) {
-        const bool take = lower ? (pk[r] < k[r]) : (pk[r] > k[r]);
-        k[r] = take ? pk[r] : k[r];
-        if (HASV) v[r] = take ? pv[r] : v[r];
+      for (int r = 0; r < E / 2 + (E == 1 ? 1 : 0); ++r) {
+        const int m2 = E - 1 - r;
+        const unsigned long long pa = lane_fetch64(k[m2], addr);          // partner's mirror of r
+        const uint32_t va = HASV ? (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[m2]) : 0u;
+        unsigned long long pb = 0ull; uint32_t vb = 0u;
+        if (m2 != r) {
+          pb = lane_fetch64(k[r], addr);                                   // partner's mirror of E-1-r
+          vb = HASV ? (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[r]) : 0u;
+        }
+        const bool ta = lower ? (pa < k[r]) : (pa > k[r]);
+        k[r] = ta ? pa : k[r];
+        if (HASV) v[r] = ta ? va : v[r];
+        if (m2 != r) {
+          const bool tb = lower ? (pb < k[m2]) : (pb > k[m2]);
+          k[m2] = tb ? pb : k[m2];
+          if (HASV) v[m2] = tb ? vb : v[m2];
+        }
       }
     }
 #pragma unroll 1
@@ -503,6 +513,10 @@ __device__ __forceinline__ void sort_network(unsigned long long* k, uint32_t* v,
 // grid = ceil(tiles/4) workgroups of 4 wavefronts; wavefront w of workgroup b owns tile tile_first + 4*b' + w (b' XCD-swizzled)
 // (tile_first, tiles) = the call's band of tiles: the grid covers only those, so that a band (multi-GPU partition) still
 // spreads over all eight XCDs instead of landing in the one XCD whose share of a full-frame grid it would be.
+// WIDE adds the 32-keys-per-lane register form for packed lists of 1025..2048 entries (dense maps: 2 M Gaussians at 640x480
+// average ~1,300 per tile; one wavefront per list instead of the whole workgroup going through them one at a time: 192 ->
+// ~40 us there).  It costs 125 instead of 80 VGPRs, so the host launches it only when the bin capacity allows such lists.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ tile_cnt, unsigned long long* __restrict__ keys,
                                                   uint32_t* __restrict__ vals, uint32_t* __restrict__ sorted_gid,
                                                   uint32_t* __restrict__ sorted_inst, uint32_t tile_first, uint32_t tiles,
@@ -527,6 +541,7 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
         else if (L <= 256u) wave_sort_tile<4, true>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
         else if (L <= 512u) wave_sort_tile<8, true>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
         else if (L <= (uint32_t)kWaveSortMax) wave_sort_tile<16, true>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
+        else if (WIDE && L <= (uint32_t)kWaveSortMaxPacked) { if constexpr (WIDE) wave_sort_tile<32, true>(keys, vals, sorted_gid, sorted_inst, s, L, lane); }
       } else {
         if (L <= 64u) { if (L) wave_sort_tile<1, false>(keys, vals, sorted_gid, sorted_inst, s, L, lane); }
         else if (L <= 128u) wave_sort_tile<2, false>(keys, vals, sorted_gid, sorted_inst, s, L, lane);
@@ -543,7 +558,7 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
     if (4u * b + q >= tiles) break;
     const size_t s = (size_t)tile * tile_cap;
     const uint32_t L = min(tile_cnt[tile], tile_cap);
-    if (L <= (uint32_t)kWaveSortMax) continue;
+    if (L <= (uint32_t)((WIDE && packed) ? kWaveSortMaxPacked : kWaveSortMax)) continue;
     uint32_t n2 = 1;
     while (n2 < L) n2 <<= 1;
     __syncthreads();
@@ -558,5 +573,8 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
     }
   }
 }
+
+template __global__ void sort_tiles<false>(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, const Counters*, int);
+template __global__ void sort_tiles<true>(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, const Counters*, int);
 
 }  // namespace vtgs
