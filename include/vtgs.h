@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VTGS_ABI_VERSION 8
+#define VTGS_ABI_VERSION 9
 
 typedef enum VtgsStatus {
   VTGS_OK = 0,
@@ -216,6 +216,23 @@ int vtgs_prepare_frame_backward(int32_t n, uint32_t flags, const float* means3D,
                                 const float* g_scales_a, const float* g_scales_b, const float* g_rot_a, const float* g_rot_b,
                                 float* g_means3D, float* g_logit_opacities, float* g_log_scales, float* g_unnorm_rotations,
                                 float* pose_partials, void* stream);
+
+/* vtgs_backward_dual followed by vtgs_prepare_frame_backward, in ONE pass over the Gaussians: the adjoint of
+ * vtgs_prepare_frame is applied to each Gaussian's operator gradients while they are still in registers (same formulas
+ * and reduction order as vtgs_prepare_frame_backward; results agree to float32 rounding), so the six dense [N, .] gradient arrays
+ * of vtgs_backward_dual are never written or read back.  Inputs as vtgs_backward_dual (means_cam, opacities, scales,
+ * rotations, colors_b = the outputs of vtgs_prepare_frame) plus means3D / unnorm_rotations / cam_q / cam_t / depth_w2c
+ * as given to vtgs_prepare_frame; flags as vtgs_prepare_frame_backward.  Outputs (each may be NULL when its flag is
+ * clear): bit 0 g_means3D [N,3], g_unnorm_rotations [N,4]; bit 1 pose_partials [vtgs_pose_partial_rows(n)][12];
+ * bit 2 g_rgb_colors [N,3], g_logit_opacities [N], g_log_scales [N].  No screen-space (means2D) gradient.          */
+int vtgs_backward_dual_frame(const VtgsCamera* cam, int32_t n, const float* means_cam, const float* colors_a, const float* colors_b,
+                             const float* opacities, const float* scales, const float* rotations, const float* out_color_a,
+                             const float* out_color_b, const float* grad_color_a, const float* grad_color_b,
+                             const void* workspace, size_t workspace_bytes, uint64_t instance_capacity,
+                             uint32_t tile_capacity, void* scratch, size_t scratch_bytes, uint32_t flags,
+                             const float* means3D, const float* unnorm_rotations, const float* cam_q, const float* cam_t,
+                             const float* depth_w2c, float* g_rgb_colors, float* g_means3D, float* g_logit_opacities,
+                             float* g_log_scales, float* g_unnorm_rotations, float* pose_partials, void* stream);
 
 /* ---- SSIM of the mapping loss ------------------------------------------------------------------
  * Replaces utils/slam_external.py:66-97 (calc_ssim): mean SSIM of two [C,H,W] images with the 11x11 Gaussian window

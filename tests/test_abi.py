@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_version_strings_and_sizes(lib):
     lib.vtgs_abi_version.restype = ctypes.c_uint32
-    assert lib.vtgs_abi_version() == 8
+    assert lib.vtgs_abi_version() == 9
     lib.vtgs_strerror.restype = ctypes.c_char_p
     assert lib.vtgs_strerror(0) == b"ok" and b"instance" in lib.vtgs_strerror(3)
     lib.vtgs_workspace_bytes.restype = ctypes.c_size_t

@@ -124,6 +124,78 @@ def test_dual_composite_equals_two_renders(gpu_device, monkeypatch, shape, n, op
         assert (a - b).abs().max().item() <= 2e-4 * scale + 1e-7, (k, (a - b).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("gaussians_grad,camera_grad", [(False, True), (True, False), (True, True)])
+def test_frame_epilogue_in_the_gather_kernel_matches_the_two_kernel_route(gpu_device, monkeypatch, gaussians_grad, camera_grad):
+    """vtgs_backward_dual_frame (adjoint of vtgs_prepare_frame applied inside gather_splat_grads, default) against
+    vtgs_backward_dual + vtgs_prepare_frame_backward (VTGS_FRAME_EPILOGUE=0): same formulas, same reduction order; what is
+    left is float32 rounding (the compiler contracts multiply-adds differently in the two instantiations of the gather
+    kernel): 4e-6 of the largest gradient of each tensor."""
+    from diff_gaussian_rasterization.fused import render_frame
+    dev = gpu_device
+    params, cam = _params(dev, 30000, 200, 136, seed=11)
+    st = to_settings(cam, dev)
+    w2c = torch.eye(4, device=dev)
+    w2c[:3, 3] = torch.tensor([0.02, -0.01, 0.03], device=dev)
+    g = torch.Generator().manual_seed(6)
+    g1 = (torch.rand(3, 136, 200, generator=g) * 2 - 1).to(dev)
+    g2 = (torch.rand(3, 136, 200, generator=g) * 2 - 1).to(dev)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VTGS_FRAME_EPILOGUE", mode)
+        for v in params.values():
+            v.grad = None
+        im, ds, _ = render_frame(params, 1, st, w2c, gaussians_grad, camera_grad)
+        ((im * g1).sum() + (ds * g2).sum()).backward()
+        res[mode] = {k: (None if v.grad is None else v.grad.clone()) for k, v in params.items()}
+    for k in params:
+        a, b = res["0"][k], res["1"][k]
+        assert (a is None) == (b is None), k
+        if a is not None:
+            scale = a.abs().max().item()
+            if k == "unnorm_rotations":                   # isotropic map: float noise around an exact zero in both routes
+                scale = res["0"]["log_scales"].abs().max().item()
+            assert (a - b).abs().max().item() <= 4e-6 * scale + 1e-12, (k, (a - b).abs().max().item(), scale)
+
+
+def test_render_frame_bands_add_up_to_the_full_frame(gpu_device):
+    """Tile-row partition of the fused operator: the band images tile the frame bit-exactly and the band
+    gradients -- pose gradient and appearance gradients -- sum to the full-frame ones (float32 summation order)."""
+    from diff_gaussian_rasterization.fused import render_frame
+    from diff_gaussian_rasterization.partition import all_bands, pixel_rows
+    dev = gpu_device
+    W, H = 200, 136
+    params, cam = _params(dev, 30000, W, H, seed=13)
+    st = to_settings(cam, dev)
+    w2c = torch.eye(4, device=dev)
+    g = torch.Generator().manual_seed(8)
+    g1 = (torch.rand(3, H, W, generator=g) * 2 - 1).to(dev)
+    g2 = (torch.rand(3, H, W, generator=g) * 2 - 1).to(dev)
+    keys = ("rgb_colors", "logit_opacities", "log_scales", "cam_unnorm_rots", "cam_trans")
+
+    def run(band):
+        for v in params.values():
+            v.grad = None
+        im, ds, radii = render_frame(params, 1, st, w2c, False, True, tile_rows=band)
+        ((im * g1).sum() + (ds * g2).sum()).backward()
+        return im.detach().clone(), ds.detach().clone(), radii.clone(), {k: params[k].grad.clone() for k in keys}
+    im_f, ds_f, r_f, g_f = run(None)
+    im_s, ds_s = torch.zeros_like(im_f), torch.zeros_like(ds_f)
+    g_s = {k: torch.zeros_like(v) for k, v in g_f.items()}
+    for band in all_bands(H, 3):
+        im, ds, r, gb = run(band)
+        y0, y1 = pixel_rows(band, H)
+        assert float(im[:, :y0].abs().max() if y0 else 0) == 0 and float(im[:, y1:].abs().max() if y1 < H else 0) == 0
+        assert torch.equal(im[:, y0:y1], im_f[:, y0:y1]) and torch.equal(ds[:, y0:y1], ds_f[:, y0:y1])
+        assert torch.equal(r, r_f)                                   # every rank projects every Gaussian: radii complete
+        im_s += im; ds_s += ds
+        for k in keys:
+            g_s[k] += gb[k]
+    assert torch.equal(im_s, im_f) and torch.equal(ds_s, ds_f)
+    for k in keys:
+        scale = g_f[k].abs().max().item()
+        assert (g_s[k] - g_f[k]).abs().max().item() <= 2e-5 * scale + 1e-9, (k, (g_s[k] - g_f[k]).abs().max().item(), scale)
+
+
 def test_pose7_reduce_matches_torch(gpu_device):
     """vtgs_pose7_reduce (what each rank of the tile-row partition all-reduces) against the plain tensor expressions."""
     from diff_gaussian_rasterization.partition import pose7_reduce

@@ -38,10 +38,10 @@ template <int WAVES, bool DUAL, bool PX>
 __global__ void composite_backward_mx(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                       const uint32_t*, const GeomRec*, const float*, const float*, const float*,
                                       const float*, float*, const Counters*, const float*, const float*, const float*);
-template <bool DUAL>
+template <bool DUAL, bool FRAME>
 __global__ void gather_splat_grads(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
                                    const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*,
-                                   float*, const Counters*, float*);
+                                   float*, const Counters*, float*, FrameEpilogue);
 __global__ void mark_visible_kernel(const float*, int, const float*, uint8_t*);
 }  // namespace vtgs
 
@@ -404,13 +404,21 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
                          const void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
                          const float* image_state, void* scratch, size_t scratch_bytes, float* g_means3D, float* g_means2D,
                          float* g_colors, float* g_colors_b, float* g_opacities, float* g_scales, float* g_rotations,
-                         void* stream, bool dual) {
+                         void* stream, bool dual, const FrameEpilogue* frame = nullptr) {
   if (!cam_ok(cam) || n < 0 || !out_color || !grad_color || !workspace || !scratch || instance_capacity == 0 ||
-      instance_capacity > 0xFFFFFFFFull || tile_capacity == 0 || (dual && (!out_color_b || !grad_color_b)))
+      instance_capacity > 0xFFFFFFFFull || tile_capacity == 0 || (dual && (!out_color_b || !grad_color_b)) || (frame && !dual))
     return VTGS_ERR_INVALID_ARGUMENT;
-  if (n > 0 && (!means3D || !colors || !opacities || !scales || !rotations || !g_means3D || !g_means2D || !g_colors ||
-                !g_opacities || !g_scales || !g_rotations || (dual && (!colors_b || !g_colors_b))))
+  if (n > 0 && (!means3D || !colors || !opacities || !scales || !rotations || (dual && !colors_b)))
     return VTGS_ERR_INVALID_ARGUMENT;
+  if (n > 0 && !frame && (!g_means3D || !g_means2D || !g_colors || !g_opacities || !g_scales || !g_rotations || (dual && !g_colors_b)))
+    return VTGS_ERR_INVALID_ARGUMENT;
+  if (n > 0 && frame) {                                      // the gradients leave through the frame epilogue instead
+    const FrameEpilogue& f = *frame;
+    if (!f.means3D_world || !f.cam_q || !f.cam_t || !f.depth_w2c) return VTGS_ERR_INVALID_ARGUMENT;
+    if ((f.flags & 1u) && (!f.unnorm_rot || !f.g_means3D || !f.g_unnorm_rot)) return VTGS_ERR_INVALID_ARGUMENT;
+    if ((f.flags & 2u) && !f.pose_partials) return VTGS_ERR_INVALID_ARGUMENT;
+    if ((f.flags & 4u) && (!f.g_rgb || !f.g_logit || !f.g_log_scales)) return VTGS_ERR_INVALID_ARGUMENT;
+  }
   int r8b, r8e, rows16, row16_0;
   if (!band_of(cam, &r8b, &r8e, &rows16, &row16_0)) return VTGS_ERR_INVALID_ARGUMENT;
   if (n == 0) return VTGS_OK;
@@ -460,16 +468,21 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
   VTGS_HIP(hipGetLastError());
   {
     ProfScope ps__(dual ? "gather_splat_grads_dual" : "gather_splat_grads", st);
-    if (dual)
-      hipLaunchKernelGGL(gather_splat_grads<true>, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+    if (dual && frame)
+      hipLaunchKernelGGL((gather_splat_grads<true, true>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+                         means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, 1,
+                         (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                         (const Counters*)(ws + L.counters), (float*)nullptr, *frame);
+    else if (dual)
+      hipLaunchKernelGGL((gather_splat_grads<true, false>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
                          means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, 1,
                          g_means3D, g_means2D, g_colors, g_opacities, g_scales, g_rotations,
-                         (const Counters*)(ws + L.counters), g_colors_b);
+                         (const Counters*)(ws + L.counters), g_colors_b, FrameEpilogue{});
     else
-      hipLaunchKernelGGL(gather_splat_grads<false>, dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+      hipLaunchKernelGGL((gather_splat_grads<false, false>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
                          means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, bwd_impl != 0 ? 1 : 0,
                          g_means3D, g_means2D, g_colors, g_opacities, g_scales, g_rotations,
-                         (const Counters*)(ws + L.counters), (float*)nullptr);
+                         (const Counters*)(ws + L.counters), (float*)nullptr, FrameEpilogue{});
   }
   VTGS_HIP(hipGetLastError());
   return VTGS_OK;
@@ -495,6 +508,24 @@ int vtgs_backward_dual(const VtgsCamera* cam, int32_t n, const float* means3D, c
                        grad_color_a, grad_color_b, workspace, workspace_bytes, instance_capacity, tile_capacity, nullptr,
                        scratch, scratch_bytes, g_means3D, g_means2D, g_colors_a, g_colors_b, g_opacities, g_scales,
                        g_rotations, stream, true);
+}
+
+int vtgs_backward_dual_frame(const VtgsCamera* cam, int32_t n, const float* means_cam, const float* colors_a, const float* colors_b,
+                             const float* opacities, const float* scales, const float* rotations, const float* out_color_a,
+                             const float* out_color_b, const float* grad_color_a, const float* grad_color_b,
+                             const void* workspace, size_t workspace_bytes, uint64_t instance_capacity,
+                             uint32_t tile_capacity, void* scratch, size_t scratch_bytes, uint32_t flags,
+                             const float* means3D, const float* unnorm_rotations, const float* cam_q, const float* cam_t,
+                             const float* depth_w2c, float* g_rgb_colors, float* g_means3D, float* g_logit_opacities,
+                             float* g_log_scales, float* g_unnorm_rotations, float* pose_partials, void* stream) {
+  FrameEpilogue f;
+  f.flags = flags;
+  f.means3D_world = means3D; f.unnorm_rot = unnorm_rotations; f.cam_q = cam_q; f.cam_t = cam_t; f.depth_w2c = depth_w2c;
+  f.g_rgb = g_rgb_colors; f.g_means3D = g_means3D; f.g_logit = g_logit_opacities; f.g_log_scales = g_log_scales;
+  f.g_unnorm_rot = g_unnorm_rotations; f.pose_partials = pose_partials;
+  return backward_impl(cam, n, means_cam, colors_a, colors_b, opacities, scales, rotations, out_color_a, out_color_b,
+                       grad_color_a, grad_color_b, workspace, workspace_bytes, instance_capacity, tile_capacity, nullptr,
+                       scratch, scratch_bytes, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream, true, &f);
 }
 
 int vtgs_profile_enable(int on) {

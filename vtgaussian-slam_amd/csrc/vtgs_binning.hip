@@ -448,7 +448,7 @@ __device__ __forceinline__ void wave_sort_regs(unsigned long long (&k)[E], uint3
 
 // PACKED (Gaussian ids below 2^21, list positions below 2^11 -- the host decides): the low key word becomes
 // (gid << 11 | bin slot); the order (depth, gid) is unchanged, the instance id is fetched from its slot afterwards.
-constexpr uint32_t kSlotBits = 11u, kPackedGidLimit = 1u << 21;
+constexpr uint32_t kSlotBits = 11u;            // (the host sends ids below 2^21 only: 21 + 11 bits)
 
 template <int E, bool PACKED>
 __device__ __forceinline__ void wave_sort_tile(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,

@@ -1068,8 +1068,12 @@ template __global__ void composite_backward_mx<4, true, false>(CamScalars, const
 template __global__ void composite_backward_mx<4, false, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*);
 template __global__ void composite_backward_mx<4, true, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*);
 
-// one thread per Gaussian: re-centre and sum its instance records (fixed order), then the projection backward
-template <bool DUAL>
+// one thread per Gaussian: re-centre and sum its instance records (fixed order), then the projection backward.
+// FRAME (dual render of the fused caller chain): the adjoint of vtgs_prepare_frame runs here, on the gradients while they
+// are still in registers -- same formulas and the same block reduction as prepare_frame_backward_kernel (vtgs_frame.hip);
+// the results agree to float32 rounding -- instead of writing six dense [N, .] arrays for that kernel to read back
+// (~160 bytes per Gaussian less traffic, one launch less; on a rank of the tile-row partition no dense zero arrays at all).
+template <bool DUAL, bool FRAME = false>
 __global__ __launch_bounds__(256) void gather_splat_grads(
     CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
     const float* __restrict__ means3D, const float* __restrict__ opacities,
@@ -1077,16 +1081,17 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     const GaussAux* __restrict__ gaux, const float* __restrict__ grad_inst, int moments_scaled_by_opacity,
     float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_colors,
     float* __restrict__ g_opacities, float* __restrict__ g_scales, float* __restrict__ g_rotations,
-    const Counters* __restrict__ ctr, float* __restrict__ g_colors_b) {
+    const Counters* __restrict__ ctr, float* __restrict__ g_colors_b, FrameEpilogue fe = FrameEpilogue{}) {
   if (ctr->overflow) return;                     // the forward did not complete: nothing valid to differentiate
   const CamParams cam = load_cam(cs, Vp, PVp);
   const int gid = (int)(blockIdx.x * 256u + threadIdx.x);
-  if (gid >= n) return;
+  if (!FRAME && gid >= n) return;                // (FRAME: every thread takes part in the block reduction)
+  const bool live = gid < n;
   SplatGrads g;
   for (int i = 0; i < 3; ++i) { g.mean3D[i] = g.mean2D[i] = g.color[i] = g.scale[i] = 0.f; }
   g.opacity = 0.f; g.rot[0] = g.rot[1] = g.rot[2] = g.rot[3] = 0.f;
   float cb0 = 0.f, cb1 = 0.f, cb2 = 0.f;         // dual: dL/d(second render's colours)
-  const GaussAux ga = gaux[gid];
+  const GaussAux ga = live ? gaux[gid] : GaussAux{0u, 0u};
   if (ga.inst_cnt) {
     // The records are read with everything else: their addresses only need gaux, so the first kGatherAhead of them (a
     // splat has 3.5 on average at the headline shape) are in flight together with the inputs of the projection instead
@@ -1146,6 +1151,56 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
       splat_backward(cam, sc, q, op, sp, aux, mo, g);
     }
   }
+  if constexpr (FRAME) {
+    __shared__ float red[4][12];
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    if (live) {
+      const FramePose P = load_pose(fe.cam_q, fe.cam_t, fe.depth_w2c);
+      const float x = fe.means3D_world[3 * gid], y = fe.means3D_world[3 * gid + 1], z = fe.means3D_world[3 * gid + 2];
+      const float cx = P.R[0] * x + P.R[1] * y + P.R[2] * z + P.t[0];
+      const float cy = P.R[3] * x + P.R[4] * y + P.R[5] * z + P.t[1];
+      const float cz = P.R[6] * x + P.R[7] * y + P.R[8] * z + P.t[2];
+      const float zz = P.zr[0] * cx + P.zr[1] * cy + P.zr[2] * cz + P.zr[3];
+      const float dz = cb0 + 2.f * zz * cb2;                                   // colours of the second render: [z, 1, z^2]
+      const float g0 = g.mean3D[0] + dz * P.zr[0], g1 = g.mean3D[1] + dz * P.zr[1], g2 = g.mean3D[2] + dz * P.zr[2];
+      if (fe.flags & 1u) {
+        fe.g_means3D[3 * gid] = P.R[0] * g0 + P.R[3] * g1 + P.R[6] * g2;
+        fe.g_means3D[3 * gid + 1] = P.R[1] * g0 + P.R[4] * g1 + P.R[7] * g2;
+        fe.g_means3D[3 * gid + 2] = P.R[2] * g0 + P.R[5] * g1 + P.R[8] * g2;
+        const float4 u = reinterpret_cast<const float4*>(fe.unnorm_rot)[gid];
+        const float un = rsqrtf(fmaxf(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w, 1e-24f));
+        const float r[4] = {u.x * un, u.y * un, u.z * un, u.w * un};
+        const float dot = r[0] * g.rot[0] + r[1] * g.rot[1] + r[2] * g.rot[2] + r[3] * g.rot[3];
+        reinterpret_cast<float4*>(fe.g_unnorm_rot)[gid] = make_float4((g.rot[0] - r[0] * dot) * un, (g.rot[1] - r[1] * dot) * un,
+                                                                       (g.rot[2] - r[2] * dot) * un, (g.rot[3] - r[3] * dot) * un);
+      }
+      if (fe.flags & 4u) {
+        const float o = opacities[gid];                                        // = sigmoid(logit), the forward's value
+        fe.g_logit[gid] = g.opacity * o * (1.f - o);
+        fe.g_log_scales[gid] = scales[3 * gid] * (g.scale[0] + g.scale[1] + g.scale[2]);
+        fe.g_rgb[3 * gid] = g.color[0]; fe.g_rgb[3 * gid + 1] = g.color[1]; fe.g_rgb[3 * gid + 2] = g.color[2];
+      }
+      if (fe.flags & 2u) {
+        acc[0] = g0; acc[1] = g1; acc[2] = g2;
+        acc[3] = g0 * x; acc[4] = g0 * y; acc[5] = g0 * z;
+        acc[6] = g1 * x; acc[7] = g1 * y; acc[8] = g1 * z;
+        acc[9] = g2 * x; acc[10] = g2 * y; acc[11] = g2 * z;
+      }
+    }
+    if (fe.flags & 2u) {                               // fixed-order block reduction, as in prepare_frame_backward_kernel
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc[k] = wave_sum(acc[k]);
+      const int wv = (int)(threadIdx.x >> 6), l = lane_id();
+      if (l == 0)
+        for (int k = 0; k < 12; ++k) red[wv][k] = acc[k];
+      __syncthreads();
+      if (threadIdx.x < 12) fe.pose_partials[(size_t)blockIdx.x * 12 + threadIdx.x] =
+          red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    }
+    return;
+  }
   for (int i = 0; i < 3; ++i) {
     g_means3D[3 * gid + i] = g.mean3D[i];
     g_means2D[3 * gid + i] = g.mean2D[i];
@@ -1156,8 +1211,9 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
   reinterpret_cast<float4*>(g_rotations)[gid] = make_float4(g.rot[0], g.rot[1], g.rot[2], g.rot[3]);
   if constexpr (DUAL) { g_colors_b[3 * gid] = cb0; g_colors_b[3 * gid + 1] = cb1; g_colors_b[3 * gid + 2] = cb2; }
 }
-template __global__ void gather_splat_grads<false>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*);
-template __global__ void gather_splat_grads<true>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*);
+template __global__ void gather_splat_grads<false>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*, FrameEpilogue);
+template __global__ void gather_splat_grads<true>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*, FrameEpilogue);
+template __global__ void gather_splat_grads<true, true>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*, FrameEpilogue);
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(const float* __restrict__ Vp, int n,
                                                            const float* __restrict__ means3D, uint8_t* __restrict__ out) {

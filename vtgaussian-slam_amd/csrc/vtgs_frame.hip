@@ -11,19 +11,6 @@
 
 namespace vtgs {
 
-struct FramePose { float R[9]; float t[3]; float zr[4]; };   // rotation from the normalised quaternion, translation, depth row
-
-__device__ __forceinline__ FramePose load_pose(const float* __restrict__ q, const float* __restrict__ t,
-                                               const float* __restrict__ w2c) {
-  FramePose p;
-  const float n = rsqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  const float qq[4] = {q[0] * n, q[1] * n, q[2] * n, q[3] * n};
-  quat_to_R(qq, p.R);
-  p.t[0] = t[0]; p.t[1] = t[1]; p.t[2] = t[2];
-  p.zr[0] = w2c[8]; p.zr[1] = w2c[9]; p.zr[2] = w2c[10]; p.zr[3] = w2c[11];    // row 2 of the row-major 4x4
-  return p;
-}
-
 __global__ __launch_bounds__(256) void prepare_frame_kernel(
     int n, const float* __restrict__ means3D, const float* __restrict__ logit_op, const float* __restrict__ log_scales,
     const float* __restrict__ unnorm_rot, const float* __restrict__ cam_q, const float* __restrict__ cam_t,

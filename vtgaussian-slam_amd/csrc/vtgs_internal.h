@@ -143,4 +143,26 @@ __device__ __forceinline__ uint32_t xcd_swizzle(uint32_t bid, uint32_t nblk) {
 }
 #endif  // __HIPCC__
 
+// ---- pose transform of the fused caller chain (vtgs_frame.hip; also the epilogue of gather_splat_grads<.., FRAME>) --------
+struct FramePose { float R[9]; float t[3]; float zr[4]; };   // rotation from the normalised quaternion, translation, depth row
+
+__device__ __forceinline__ FramePose load_pose(const float* __restrict__ q, const float* __restrict__ t,
+                                               const float* __restrict__ w2c) {
+  FramePose p;
+  const float n = rsqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float qq[4] = {q[0] * n, q[1] * n, q[2] * n, q[3] * n};
+  quat_to_R(qq, p.R);
+  p.t[0] = t[0]; p.t[1] = t[1]; p.t[2] = t[2];
+  p.zr[0] = w2c[8]; p.zr[1] = w2c[9]; p.zr[2] = w2c[10]; p.zr[3] = w2c[11];    // row 2 of the row-major 4x4
+  return p;
+}
+
+// What vtgs_prepare_frame_backward needs besides the operator gradients, for the backward that runs it in the gather
+// kernel (vtgs_backward_dual_frame): flags as there (bit 0 geometry, bit 1 pose, bit 2 appearance).
+struct FrameEpilogue {
+  uint32_t flags;
+  const float* means3D_world; const float* unnorm_rot; const float* cam_q; const float* cam_t; const float* depth_w2c;
+  float* g_rgb; float* g_means3D; float* g_logit; float* g_log_scales; float* g_unnorm_rot; float* pose_partials;
+};
+
 }  // namespace vtgs

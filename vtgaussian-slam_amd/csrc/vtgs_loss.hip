@@ -47,43 +47,61 @@ __global__ __launch_bounds__(256) void ssim_forward_kernel(const float* __restri
     py[i] = in ? img2[o] : 0.f;
   }
   __syncthreads();
-  for (int i = t; i < kSP * kST; i += 256) {                          // rows: 42 x 32 outputs
-    const int r = i / kST, q = i - r * kST;
-    float m1 = 0.f, m2 = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
+  // Both passes slide the window in registers: a work item produces FOUR adjacent outputs from 14 staged values instead of
+  // 4 x 11 (the kernel was bound by its LDS reads: 86 K per workgroup).  Every output still accumulates its 11 taps in the
+  // same order, so the values are the ones of the one-output-per-item form.
+  for (int i = t; i < kSP * (kST / 4); i += 256) {                    // rows: 42 x 32 outputs, 4 per item
+    const int r = i / (kST / 4), q = 4 * (i - r * (kST / 4));
+    float a[14], d[14];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float a = px[r * kSP + q + k], d = py[r * kSP + q + k];
-      m1 = fmaf(w[k], a, m1); m2 = fmaf(w[k], d, m2);
-      xx = fmaf(w[k], a * a, xx); yy = fmaf(w[k], d * d, yy); xy = fmaf(w[k], a * d, xy);
+    for (int k = 0; k < 14; ++k) { a[k] = px[r * kSP + q + k]; d[k] = py[r * kSP + q + k]; }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float m1 = 0.f, m2 = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const float av = a[o + k], dv = d[o + k];
+        m1 = fmaf(w[k], av, m1); m2 = fmaf(w[k], dv, m2);
+        xx = fmaf(w[k], av * av, xx); yy = fmaf(w[k], dv * dv, yy); xy = fmaf(w[k], av * dv, xy);
+      }
+      const int j = r * kST + q + o;
+      hz[0][j] = m1; hz[1][j] = m2; hz[2][j] = xx; hz[3][j] = yy; hz[4][j] = xy;
     }
-    hz[0][i] = m1; hz[1][i] = m2; hz[2][i] = xx; hz[3][i] = yy; hz[4][i] = xy;
   }
   __syncthreads();
   float acc = 0.f;
   const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
-  for (int i = t; i < kST * kST; i += 256) {                          // columns: 32 x 32 outputs
-    const int r = i / kST, q = i - r * kST;
-    const int gy = ty * kST + r, gx = tx * kST + q;
-    float m1 = 0.f, m2 = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
+  {                                                                   // columns: 32 x 32 outputs, 4 rows per item
+    const int q = t & (kST - 1), r0 = 4 * (t >> 5);                   // 256 items = 8 row groups x 32 columns
+    float h[5][14];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const int j = (r + k) * kST + q;
-      m1 = fmaf(w[k], hz[0][j], m1); m2 = fmaf(w[k], hz[1][j], m2);
-      xx = fmaf(w[k], hz[2][j], xx); yy = fmaf(w[k], hz[3][j], yy); xy = fmaf(w[k], hz[4][j], xy);
-    }
-    if (gy < H && gx < W) {
-      const float s11 = xx - m1 * m1, s22 = yy - m2 * m2, s12 = xy - m1 * m2;
-      const float a1 = 2.f * m1 * m2 + c1, a2 = 2.f * s12 + c2, b1 = m1 * m1 + m2 * m2 + c1, b2 = s11 + s22 + c2;
-      const float ib = 1.f / (b1 * b2);
-      const float ssim = a1 * a2 * ib;
-      acc += ssim;
-      if (gmaps) {
-        const float d_mu1 = 2.f * m2 * a2 * ib - ssim * 2.f * m1 / b1;
-        const float d_s11 = -ssim / b2, d_s12 = 2.f * a1 * ib;
-        const size_t o = plane + (size_t)gy * W + gx, P3 = (size_t)C * H * W;
-        gmaps[o] = d_mu1 - 2.f * m1 * d_s11 - m2 * d_s12;
-        gmaps[P3 + o] = d_s11;
-        gmaps[2 * P3 + o] = d_s12;
+    for (int m = 0; m < 5; ++m)
+#pragma unroll
+      for (int k = 0; k < 14; ++k) h[m][k] = hz[m][(r0 + k) * kST + q];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int r = r0 + o;
+      const int gy = ty * kST + r, gx = tx * kST + q;
+      float m1 = 0.f, m2 = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        m1 = fmaf(w[k], h[0][o + k], m1); m2 = fmaf(w[k], h[1][o + k], m2);
+        xx = fmaf(w[k], h[2][o + k], xx); yy = fmaf(w[k], h[3][o + k], yy); xy = fmaf(w[k], h[4][o + k], xy);
+      }
+      if (gy < H && gx < W) {
+        const float s11 = xx - m1 * m1, s22 = yy - m2 * m2, s12 = xy - m1 * m2;
+        const float a1 = 2.f * m1 * m2 + c1, a2 = 2.f * s12 + c2, b1 = m1 * m1 + m2 * m2 + c1, b2 = s11 + s22 + c2;
+        const float ib = 1.f / (b1 * b2);
+        const float ssim = a1 * a2 * ib;
+        acc += ssim;
+        if (gmaps) {
+          const float d_mu1 = 2.f * m2 * a2 * ib - ssim * 2.f * m1 / b1;
+          const float d_s11 = -ssim / b2, d_s12 = 2.f * a1 * ib;
+          const size_t o2 = plane + (size_t)gy * W + gx, P3 = (size_t)C * H * W;
+          gmaps[o2] = d_mu1 - 2.f * m1 * d_s11 - m2 * d_s12;
+          gmaps[P3 + o2] = d_s11;
+          gmaps[2 * P3 + o2] = d_s12;
+        }
       }
     }
   }
@@ -116,34 +134,49 @@ __global__ __launch_bounds__(256) void ssim_backward_kernel(const float* __restr
     pm[0][i] = in ? gmaps[o] : 0.f; pm[1][i] = in ? gmaps[P3 + o] : 0.f; pm[2][i] = in ? gmaps[2 * P3 + o] : 0.f;
   }
   __syncthreads();
-  for (int i = t; i < kSP * kST; i += 256) {
-    const int r = i / kST, q = i - r * kST;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int i = t; i < kSP * (kST / 4); i += 256) {                    // rows, four outputs per item (see the forward)
+    const int r = i / (kST / 4), q = 4 * (i - r * (kST / 4));
+    float v[3][14];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const int j = r * kSP + q + k;
-      s0 = fmaf(w[k], pm[0][j], s0); s1 = fmaf(w[k], pm[1][j], s1); s2 = fmaf(w[k], pm[2][j], s2);
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int k = 0; k < 14; ++k) v[m][k] = pm[m][r * kSP + q + k];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        s0 = fmaf(w[k], v[0][o + k], s0); s1 = fmaf(w[k], v[1][o + k], s1); s2 = fmaf(w[k], v[2][o + k], s2);
+      }
+      const int j = r * kST + q + o;
+      hz[0][j] = s0; hz[1][j] = s1; hz[2][j] = s2;
     }
-    hz[0][i] = s0; hz[1][i] = s1; hz[2][i] = s2;
   }
   __syncthreads();
   // dL/dimg1 = upstream * ( ssim_coef * d(mean SSIM)/dimg1 + l1_coef * sign(img1 - img2) )   (plain SSIM: 1, 0)
   const float scale = upstream[0] * ssim_coef / (float)((size_t)C * H * W);
   const float l1s = upstream[0] * l1_coef;
-  for (int i = t; i < kST * kST; i += 256) {
-    const int r = i / kST, q = i - r * kST;
-    const int gy = ty * kST + r, gx = tx * kST + q;
-    if (gy >= H || gx >= W) continue;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  {                                                                   // columns, four rows per item
+    const int q = t & (kST - 1), r0 = 4 * (t >> 5);
+    float h[3][14];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const int j = (r + k) * kST + q;
-      s0 = fmaf(w[k], hz[0][j], s0); s1 = fmaf(w[k], hz[1][j], s1); s2 = fmaf(w[k], hz[2][j], s2);
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int k = 0; k < 14; ++k) h[m][k] = hz[m][(r0 + k) * kST + q];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int gy = ty * kST + r0 + o, gx = tx * kST + q;
+      if (gy >= H || gx >= W) continue;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        s0 = fmaf(w[k], h[0][o + k], s0); s1 = fmaf(w[k], h[1][o + k], s1); s2 = fmaf(w[k], h[2][o + k], s2);
+      }
+      const size_t o2 = plane + (size_t)gy * W + gx;
+      const float x = img1[o2], y = img2[o2];
+      const float lw = l1_weight ? l1s * l1_weight[o2] : l1s;
+      g_img1[o2] = scale * (s0 + 2.f * x * s1 + y * s2) + ((x > y) ? lw : (x < y) ? -lw : 0.f);
     }
-    const size_t o = plane + (size_t)gy * W + gx;
-    const float x = img1[o], y = img2[o];
-    const float lw = l1_weight ? l1s * l1_weight[o] : l1s;
-    g_img1[o] = scale * (s0 + 2.f * x * s1 + y * s2) + ((x > y) ? lw : (x < y) ? -lw : 0.f);
   }
 }
 

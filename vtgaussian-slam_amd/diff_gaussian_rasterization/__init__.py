@@ -49,7 +49,7 @@ class _VtgsProfileEntry(ctypes.Structure):
 
 
 VTGS_OK, VTGS_ERR_INSTANCE_OVERFLOW = 0, 3
-ABI_VERSION = 8
+ABI_VERSION = 9
 VTGS_FORWARD_SYNC, VTGS_FORWARD_ASYNC, VTGS_FORWARD_CHECKED = 0, 1, 2
 _P, _U64, _I32, _SZ = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
 
@@ -72,6 +72,8 @@ _SIGNATURES = {
                                          ctypes.c_uint32, _P, ctypes.c_uint32, _P]),
     "vtgs_backward_dual": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32] + [_P] * 11 + [_SZ, _U64, ctypes.c_uint32, _P, _SZ]
                            + [_P] * 8),
+    "vtgs_backward_dual_frame": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32] + [_P] * 11 + [_SZ, _U64, ctypes.c_uint32, _P, _SZ,
+                                                ctypes.c_uint32] + [_P] * 12),
     "vtgs_mark_visible": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P]),
     "vtgs_debug_layout": (ctypes.c_int, [_I32, _I32, _I32, _U64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]),
     "vtgs_profile_enable": (ctypes.c_int, [ctypes.c_int]),

@@ -76,6 +76,9 @@ class _RenderFrame(torch.autograd.Function):
         dev, n, flags, fs = means3D.device, ctx.n, ctx.flags, ctx.fs
         g_im = torch.zeros_like(im) if g_im is None else g_im.to(torch.float32).contiguous()
         g_ds = torch.zeros_like(depth_sil) if g_ds is None else g_ds.to(torch.float32).contiguous()
+        if ctx.dual and os.environ.get("VTGS_FRAME_EPILOGUE", "1") != "0":
+            # one pass, and the adjoint of vtgs_prepare_frame applied in the gather kernel: no dense operator gradients
+            return _RenderFrame._backward_fused(ctx, g_im, g_ds)
         if ctx.dual:                                                # one pass; the geometry gradients arrive summed
             ga = _run_backward_dual(fs, means_cam, rgb, dcol, opac, scales, rot, im, depth_sil, g_im, g_ds)
             g_dcol, gb = ga[6], (None,) * 6
@@ -112,10 +115,49 @@ class _RenderFrame(torch.autograd.Function):
         return (g_means3D, ga[2] if want_a else None, g_ur, g_logit, g_ls, g_q, g_t, None, None, None)
 
 
+def _backward_fused(ctx, g_im, g_ds):
+    (means3D, rgb, unnorm_rot, logit_op, log_scales, cam_q, cam_t, depth_w2c,
+     means_cam, opac, scales, rot, dcol, im, depth_sil) = ctx.saved_tensors
+    dev, n, flags, fs = means3D.device, ctx.n, ctx.flags, ctx.fs
+    new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    want_g, want_p, want_a = bool(flags & 1), bool(flags & 2), bool(flags & 4)
+    g_means3D = new(n, 3) if want_g else None
+    g_ur = new(n, 4) if want_g else None
+    g_rgb = new(n, 3) if want_a else None
+    g_logit = new(n, 1) if want_a else None
+    g_ls = new(n, 1) if want_a else None
+    rows = int(_lib.vtgs_pose_partial_rows(n))
+    partials = new(max(rows, 1), 12) if want_p else None
+    g_q = g_t = None
+    if n > 0:
+        sbytes = _lib.vtgs_backward_dual_scratch_bytes(n, fs.instances)
+        scratch = torch.empty((sbytes,), dtype=torch.uint8, device=dev)
+        _check(_lib.vtgs_backward_dual_frame(
+            ctypes.byref(fs.cam.c), n, means_cam.data_ptr(), rgb.data_ptr(), dcol.data_ptr(), opac.data_ptr(),
+            scales.data_ptr(), rot.data_ptr(), im.data_ptr(), depth_sil.data_ptr(), g_im.data_ptr(), g_ds.data_ptr(),
+            fs.workspace.data_ptr(), fs.workspace.numel(), fs.capacity, fs.tile_cap, scratch.data_ptr(), sbytes, flags,
+            means3D.data_ptr(), unnorm_rot.data_ptr(), cam_q.data_ptr(), cam_t.data_ptr(), depth_w2c.data_ptr(),
+            ptr(g_rgb), ptr(g_means3D), ptr(g_logit), ptr(g_ls), ptr(g_ur), ptr(partials), _stream_ptr(dev)),
+            "vtgs_backward_dual_frame")
+        if want_p:                                                # 12 partial sums per workgroup -> dL/dq, dL/dt
+            g_q, g_t = new(4), new(3)
+            _check(_lib.vtgs_pose_gradient(partials.data_ptr(), rows, cam_q.data_ptr(), g_q.data_ptr(), g_t.data_ptr(),
+                                           _stream_ptr(dev)), "vtgs_pose_gradient")
+    elif want_p:                                                  # nothing rendered: zero pose gradient, no launch
+        g_q, g_t = torch.zeros(4, device=dev), torch.zeros(3, device=dev)
+    return (g_means3D, g_rgb, g_ur, g_logit, g_ls, g_q, g_t, None, None, None)
+
+
+_RenderFrame._backward_fused = staticmethod(_backward_fused)
+
+
 def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings, first_frame_w2c: torch.Tensor,
-                 gaussians_grad: bool, camera_grad: bool, radius_rule: Optional[str] = None):
+                 gaussians_grad: bool, camera_grad: bool, radius_rule: Optional[str] = None, tile_rows=None):
     """RGB render + [z,1,z^2] render of frame `time_idx` (see module docstring).  Returns (im [3,H,W],
-    depth_sil [3,H,W], radii [N] int32)."""
+    depth_sil [3,H,W], radii [N] int32).  `tile_rows=(begin, end)`: this rank's band of 16-pixel tile rows (multi-GPU
+    partition, `partition.band_for_rank`): pixels outside the band come back as zero and the gradients are the band's
+    share -- the pose gradient of a rank is then 7 floats to all-reduce, with no dense per-Gaussian array behind it."""
     if params["log_scales"].shape[1] != 1:
         raise NotImplementedError("render_frame covers isotropic maps (log_scales [N,1]) -- what every reference config "
                                   "uses; anisotropic maps go through transform_to_frame + GaussianRasterizer")
@@ -124,7 +166,7 @@ def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings
         raise RuntimeError("render_frame needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
     import os
     rule = _RADIUS_RULES[radius_rule or os.environ.get("VTGS_RADIUS_RULE", "3sigma")]
-    cam = _Camera(raster_settings, dev, rule, None)
+    cam = _Camera(raster_settings, dev, rule, tile_rows)
     q = params["cam_unnorm_rots"][0, :, time_idx]
     t = params["cam_trans"][0, :, time_idx]
     if not camera_grad:
