@@ -32,7 +32,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (= f32 MFMA) rate
 # SURVEY.md 8(d) secondary bound: per (pixel, Gaussian) evaluation the forward costs ~14 flop + 1 exp, the backward ~3x
-# that; v_exp_f32 occupies the issue slot of three v_fma_f32 (tests/micro/issue_rate.hip, profiles/r2_issue_rate.md) = 6 flop.
+# that; v_exp_f32 occupies the issue slot of three v_fma_f32 (tests/micro/issue_rate.hip, profiles/r2_issue_rates.md) = 6 flop.
 FLOP_PER_EVAL_FWD_BWD = 4 * (14 + 6)
 
 
