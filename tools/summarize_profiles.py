@@ -55,7 +55,7 @@ with open(f"profiles/{tag}_kernel_stats.csv", "w") as fo:
     fo.write(open(find(f"prof_{tag}", "kernel_stats.csv")).read())
 with open(f"profiles/{tag}_kernel_stats.md", "w") as fo:
     fo.write(f"# rocprofv3 --kernel-trace --stats, {tag}\n\ncommand: `rocprofv3 --kernel-trace --stats --output-format csv -- "
-             f"python bench.py --steps 10 --warmup 3 --no-cpu-baseline` (N=1M, 1200x680); bench line of the same build: "
+             f"python bench.py --steps 50 --warmup 10 --no-cpu-baseline` (N=1M, 1200x680; the default step counts, so that both runs see the same clocks); bench line of the same build: "
              f"{b['ms_per_step']} ms/step, {b['value']:.4g} {b['unit']}\n\n| kernel | calls | avg us | % |\n|---|---|---|---|\n")
     for r in rows[:12]:
         fo.write(f"| {r['Name'].split('(')[0][:70]} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {r['Percentage']} |\n")
