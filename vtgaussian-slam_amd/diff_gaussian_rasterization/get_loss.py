@@ -1,0 +1,126 @@
+"""`get_loss` of the reference with its own signature (src/vtgaussian_slam.py:407-689), on the fused operators.
+
+The reference's tracking and mapping loops call ONE function per iteration:
+
+    loss, variables, losses = get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_for_loss,
+                                       sil_thres, use_l1, ignore_outlier_depth_loss, tracking=True, ...)
+
+A maintainer who replaces that function by this one (`from diff_gaussian_rasterization.get_loss import get_loss`) gets the
+fused caller chain without touching the loops: pose transform + render-variable builders + both renders as the dual
+composite (`fused.render_frame`), the masks of every dataset branch (`losses.visibility_mask`, `far_depth_mask`,
+`outlier_depth_mask`), the threshold sweep of Replica's tracking iteration 0 and the whole loss as one autograd node.
+Same arguments, same return value (`loss, variables, weighted_losses[, presence_sil_mask_mse_ls, sil_thres_ls]`), same
+bookkeeping of `variables['seen']` / `['max_2D_radius']` and of the two threshold lists.
+
+Differences, all outside what the shipped configurations use:
+  * `variables['means2D']` is not set: the dual backward sums the geometry gradients of both renders, so there is no
+    colour-render-only screen-space gradient (utils/slam_external.py:100-103 reads it only when
+    `use_gaussian_splatting_densification` is on; every config has it off);
+  * `use_l1=False` and tracking with neither `use_sil_for_loss` nor `ignore_outlier_depth_loss` (the unmasked colour sum,
+    :601-602) raise NotImplementedError; `visualize_tracking_loss` is ignored (plots);
+  * the entries of `weighted_losses` other than 'loss' are detached (the loops only log them).
+HIP only: no CPU path.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import losses as _l
+from .fused import render_frame
+
+__all__ = ["get_loss"]
+
+
+def _cuda_f32(v):
+    t = v if isinstance(v, torch.Tensor) else torch.tensor(v)
+    return t.cuda().float().contiguous()
+
+
+def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_for_loss,
+             sil_thres, use_l1, ignore_outlier_depth_loss, tracking=False,
+             mapping=False, do_ba=False, plot_dir=None, visualize_tracking_loss=False,
+             tracking_iteration=None, additional_mask=None, dataset_name=None,
+             presence_sil_mask_mse_ls=None, sil_thres_ls=None, far_depth_filter_thres=None, vis_mask_thres=0.05,
+             curr_w2c=None, overlap_w2c=None, overlap_gtdepth=None, overlap_last_w2c=None, overlap_last_gtdepth=None,
+             overlap_mid_w2c=None, overlap_mid_gtdepth=None):
+    # :416-426 -- everything on the device, float32, contiguous (a no-op for tensors that already are)
+    for k, v in params.items():
+        params[k] = _cuda_f32(v)
+    for k, v in variables.items():
+        variables[k] = _cuda_f32(v)
+    if not use_l1:
+        raise NotImplementedError("use_l1=False leaves the depth term out (src/vtgaussian_slam.py:591-596); no shipped "
+                                  "configuration does that")
+    # :428-449 -- who gets a gradient
+    if tracking:
+        gaussians_grad, camera_grad = False, True
+    elif mapping and do_ba:
+        gaussians_grad, camera_grad = True, True
+    else:
+        gaussians_grad, camera_grad = True, False
+    # :451-468 -- both renders
+    im, depth_sil, radius = render_frame(params, iter_time_idx, curr_data["cam"], curr_data["w2c"], gaussians_grad, camera_grad)
+    gt_im, gt_depth = curr_data["im"], curr_data["depth"]
+    depth = depth_sil[0:1].detach()
+
+    # :470-514 -- the silhouette threshold of the presence mask
+    thr = None
+    if dataset_name == "replica":
+        if tracking and use_sil_for_loss:
+            if tracking_iteration == 0:
+                thr, mse = _l.best_silhouette_threshold(im.detach(), depth_sil.detach()[1], gt_im, gt_depth, return_mse=True)
+                presence_sil_mask_mse_ls.append(mse)
+                sil_thres_ls.append(thr)
+            else:
+                thr = sil_thres_ls[-1]
+    elif dataset_name in ("tum", "scannet", "scannetpp"):
+        thr = sil_thres
+    if tracking and use_sil_for_loss and thr is None:
+        raise ValueError(f"get_loss: no presence mask is defined for dataset_name={dataset_name!r} "
+                         "(src/vtgaussian_slam.py:470-514 knows replica, tum, scannet, scannetpp)")
+
+    # :523-588 -- detached masks beyond gt_depth > 0 & finite (those two live in the loss node)
+    masks = []
+    if ignore_outlier_depth_loss:
+        masks.append(_l.outlier_depth_mask(gt_depth, depth))
+    if tracking and overlap_w2c is not None and dataset_name != "replica":
+        if dataset_name == "tum":
+            overlaps = [(overlap_w2c, overlap_gtdepth)]
+        elif dataset_name in ("scannet", "scannetpp"):
+            overlaps = [(overlap_w2c, overlap_gtdepth), (overlap_mid_w2c, overlap_mid_gtdepth),
+                        (overlap_last_w2c, overlap_last_gtdepth)]
+        else:
+            raise ValueError(f"get_loss: visibility mask undefined for dataset_name={dataset_name!r}")
+        masks.append(_l.visibility_mask(gt_depth, curr_data["intrinsics"], curr_w2c, overlaps, vis_mask_thres)[None])
+    if tracking and far_depth_filter_thres is not None and dataset_name not in ("replica", "scannetpp"):
+        masks.append(_l.far_depth_mask(gt_depth, far_depth_filter_thres))
+    extra = None
+    for m in masks:
+        extra = m if extra is None else (extra & m)
+
+    # :590-611 -- the loss
+    w_im, w_depth = float(loss_weights["im"]), float(loss_weights["depth"])
+    numel = float(gt_im.numel())
+    if tracking:
+        if not (use_sil_for_loss or ignore_outlier_depth_loss):
+            raise NotImplementedError("tracking with neither use_sil_for_loss nor ignore_outlier_depth_loss sums the colour "
+                                      "error over ALL pixels (src/vtgaussian_slam.py:601-602); no shipped configuration does that")
+        loss, terms = _l.tracking_loss(im, depth_sil, gt_im, gt_depth, thr if use_sil_for_loss else float("-inf"),
+                                       w_im=w_im, w_depth=w_depth, extra_mask=extra, return_terms=True)
+        l_im, l_depth = terms[2], terms[3]                                  # masked SUMS
+    else:
+        loss, terms = _l.mapping_loss(im, depth_sil, gt_im, gt_depth, w_im=w_im, w_depth=w_depth, extra_mask=extra,
+                                      additional_mask=additional_mask, return_terms=True)
+        l1_coef = 0.8 if additional_mask is None else 1.0                   # (the weights 10 m + 0.8 carry the 0.8 themselves)
+        l_im = l1_coef * terms[2] / numel + 0.2 * (1.0 - terms[4])
+        l_depth = terms[3] / terms[1]                                       # masked MEAN
+    weighted_losses = {"im": w_im * l_im, "depth": w_depth * l_depth}
+
+    # :681-689 -- bookkeeping
+    seen = radius > 0
+    variables["max_2D_radius"][seen] = torch.max(radius[seen].to(variables["max_2D_radius"].dtype), variables["max_2D_radius"][seen])
+    variables["seen"] = seen
+    weighted_losses["loss"] = loss
+    if presence_sil_mask_mse_ls is not None:
+        return loss, variables, weighted_losses, presence_sil_mask_mse_ls, sil_thres_ls
+    return loss, variables, weighted_losses

@@ -126,10 +126,11 @@ class _SlamLoss(torch.autograd.Function):
         ctx.save_for_backward(a, d, ga, gd, out, gmaps if gmaps is not None else out)
         ctx.cfg = (mode, float(sil_thres), float(w_im), float(w_depth), need, gmaps is not None)
         ctx.set_materialize_grads(False)
-        return out[0]
+        ctx.mark_non_differentiable(out)
+        return out[0], out              # out = {loss, mask count, sum |gt_im - im| (weighted), sum |gt_depth - depth|, mean SSIM}
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g_terms=None):
         mode, sil_thres, w_im, w_depth, need, has_maps = ctx.cfg
         if g is None or not need:
             return (None,) * 10
@@ -147,21 +148,24 @@ class _SlamLoss(torch.autograd.Function):
 
 
 def tracking_loss(im, depth_sil, gt_im, gt_depth, sil_thres: float, w_im: float = 0.5, w_depth: float = 0.025,
-                  extra_mask=None):
+                  extra_mask=None, return_terms: bool = False):
     """Tracking loss of get_loss (src/vtgaussian_slam.py:519-605): w_im * masked L1 SUM of colour + w_depth * masked L1
     SUM of depth over gt_depth > 0 & finite & silhouette > sil_thres [& extra_mask].  `extra_mask` [H,W] / [1,H,W]
     (bool or float, detached) carries the masks of the TUM / ScanNet / ScanNet++ branches -- build it with
-    `visibility_mask`, `far_depth_mask`, `outlier_depth_mask` below and AND them together."""
-    return _SlamLoss.apply(im, depth_sil, gt_im, gt_depth, 0, sil_thres, w_im, w_depth, extra_mask, None)
+    `visibility_mask`, `far_depth_mask`, `outlier_depth_mask` below and AND them together.
+    return_terms: also the detached device vector {loss, mask count, colour sum, depth sum, -}."""
+    loss, terms = _SlamLoss.apply(im, depth_sil, gt_im, gt_depth, 0, sil_thres, w_im, w_depth, extra_mask, None)
+    return (loss, terms) if return_terms else loss
 
 
 def mapping_loss(im, depth_sil, gt_im, gt_depth, w_im: float = 1.0, w_depth: float = 1.0, extra_mask=None,
-                 additional_mask=None):
+                 additional_mask=None, return_terms: bool = False):
     """Mapping loss (src/vtgaussian_slam.py:592-611): w_depth * masked L1 MEAN of depth + w_im * (0.8 * L1 mean + 0.2 *
     (1 - SSIM)) of colour; with `additional_mask` the colour L1 becomes mean(|im - gt| * (10 * additional_mask + 0.8))
     (l1_loss_v1_mask, utils/slam_helpers.py:8-9).  `extra_mask`: the outlier-depth mask when ignore_outlier_depth_loss."""
     cw = None if additional_mask is None else 10.0 * additional_mask.to(torch.float32) + 0.8
-    return _SlamLoss.apply(im, depth_sil, gt_im, gt_depth, 1, 0.0, w_im, w_depth, extra_mask, cw)
+    loss, terms = _SlamLoss.apply(im, depth_sil, gt_im, gt_depth, 1, 0.0, w_im, w_depth, extra_mask, cw)
+    return (loss, terms) if return_terms else loss
 
 
 # ---- detached masks of the TUM / ScanNet / ScanNet++ branches (device-side torch ops: plumbing, no gradients) ----------
@@ -229,9 +233,11 @@ def silhouette_sweep(im, silhouette, gt_im, gt_depth, candidates):
     return partial.sum(0, dtype=torch.float64)
 
 
-def best_silhouette_threshold(im, silhouette, gt_im, gt_depth, candidates=(0.990, 0.993, 0.995, 0.997, 0.999)) -> float:
+def best_silhouette_threshold(im, silhouette, gt_im, gt_depth, candidates=(0.990, 0.993, 0.995, 0.997, 0.999),
+                              return_mse: bool = False):
     """Tracking iteration 0 of the Replica branch: the candidate with the smallest masked colour MSE, first one on ties
-    (src/vtgaussian_slam.py:472-510) -- one kernel and one host read instead of five masked gathers and five .item()."""
+    (src/vtgaussian_slam.py:472-510) -- one kernel and one host read instead of five masked gathers and five .item().
+    return_mse: (threshold, its MSE), the pair the reference appends to sil_thres_ls / presence_sil_mask_mse_ls."""
     sums = silhouette_sweep(im, silhouette, gt_im, gt_depth, candidates).cpu()
     best, best_mse = candidates[0], float("inf")
     for k, c in enumerate(candidates):
@@ -239,4 +245,4 @@ def best_silhouette_threshold(im, silhouette, gt_im, gt_depth, candidates=(0.990
         mse = float(sums[k, 0]) / (3.0 * cnt) if cnt > 0 else float("inf")      # an empty mask gives NaN in the reference
         if mse < best_mse:
             best, best_mse = c, mse
-    return best
+    return (best, best_mse) if return_mse else best
