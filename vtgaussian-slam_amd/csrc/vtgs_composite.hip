@@ -37,6 +37,9 @@
 #ifndef VTGS_PX_GROUP_FWD
 #define VTGS_PX_GROUP_FWD 0
 #endif
+#ifndef VTGS_BWD_PREFETCH
+#define VTGS_BWD_PREFETCH 1
+#endif
 
 namespace vtgs {
 
@@ -978,12 +981,24 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   const int col_w2 = (cj == 3) ? 15 : 9 + cj;
 
   uint32_t base = s;
+#if VTGS_BWD_PREFETCH
+  // the list entries of the NEXT chunk are requested while this one is composited: one of the two dependent trips to
+  // L2 / Infinity Cache per chunk leaves the wavefront's critical path (a lane past the end reads entry 0 of its own bin)
+  auto entry = [&](const uint32_t* __restrict__ list, uint32_t b) { const uint32_t p = b + (uint32_t)l; return list[p < e ? p : s]; };
+  uint32_t gid_nxt = entry(sorted_gid, s), inst_nxt = entry(sorted_inst, s);
+#endif
   for (; base < e; base += 64u) {
     const bool alive = PXL ? !ps.done : (st.Tb[0].x > 0.f || st.Tb[0].y > 0.f || st.Tb[1].x > 0.f || st.Tb[1].y > 0.f);
     if (__ballot(alive) == 0ull) break;
     const int n = (int)min(64u, e - base);
+#if VTGS_BWD_PREFETCH
+    const MxSplat m = mx_gather_gid<DUAL>(gid_nxt, geom, colors, l < n, cx, cy, colors_b);
+    const uint32_t my_inst = (l < n) ? inst_nxt : 0u;
+    gid_nxt = entry(sorted_gid, base + 64u); inst_nxt = entry(sorted_inst, base + 64u);
+#else
     const MxSplat m = mx_gather<DUAL>(sorted_gid, geom, colors, base + (uint32_t)l, l < n, cx, cy, colors_b);
     const uint32_t my_inst = (l < n) ? sorted_inst[base + (uint32_t)l] : 0u;
+#endif
     const bool hot = __ballot(m.hot) != 0ull;                 // wave-uniform: some splat of the chunk may hit the 0.99 clamp
     const bool chunk_exact = px_exact;                        // exact sweep first for this chunk (pixels kept ending before it)
 #pragma unroll

@@ -87,16 +87,15 @@ __device__ __forceinline__ void tile_coefficients(const float4& g0, const float4
 // DUAL: two renders over the same geometry in one pass -- the second render's colours ride along
 // as channels 3..5; the depth image (which the fused caller discards) is not produced.
 template <bool DUAL = false>
-__device__ __forceinline__ MxSplat mx_gather(const uint32_t* __restrict__ sorted_gid, const GeomRec* __restrict__ geom,
-                                             const float* __restrict__ colors, uint32_t pos, bool in, float cx, float cy,
-                                             const float* __restrict__ colors_b = nullptr) {
+__device__ __forceinline__ MxSplat mx_gather_gid(uint32_t gid, const GeomRec* __restrict__ geom,
+                                                 const float* __restrict__ colors, bool in, float cx, float cy,
+                                                 const float* __restrict__ colors_b = nullptr) {
   MxSplat m;
   m.K[0] = -1e30f; m.K[1] = m.K[2] = m.K[3] = m.K[4] = m.K[5] = 0.f;
   m.pay = make_float4(0.f, 0.f, 0.f, 0.f);
   m.pay2 = make_float2(0.f, 0.f);
   m.hot = false;
   if (in) {
-    const uint32_t gid = sorted_gid[pos];
     const float4* gp = reinterpret_cast<const float4*>(geom + gid);
     const float4 g0 = gp[0], g1 = gp[1];
     tile_coefficients(g0, g1, cx, cy, m.K);
@@ -105,6 +104,12 @@ __device__ __forceinline__ MxSplat mx_gather(const uint32_t* __restrict__ sorted
     if (DUAL) m.pay2 = make_float2(colors_b[3 * gid + 1], colors_b[3 * gid + 2]);
   }
   return m;
+}
+template <bool DUAL = false>
+__device__ __forceinline__ MxSplat mx_gather(const uint32_t* __restrict__ sorted_gid, const GeomRec* __restrict__ geom,
+                                             const float* __restrict__ colors, uint32_t pos, bool in, float cx, float cy,
+                                             const float* __restrict__ colors_b = nullptr) {
+  return mx_gather_gid<DUAL>(in ? sorted_gid[pos] : 0u, geom, colors, in, cx, cy, colors_b);
 }
 
 constexpr int kExactFirstEndings = 3;   // pixels (of 64) ending in a batch that make the next batch skip the optimistic sweep
