@@ -579,9 +579,9 @@ __global__ __launch_bounds__(256) void composite_backward(
     const int n = (int)min(64u, e - base);
     if (l < n) {
       const uint32_t inst = sorted_inst[base + (uint32_t)l];
-      float4* p = reinterpret_cast<float4*>(grad_inst + (size_t)inst * kGradRec);
-      p[0] = p[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-      p[2] = make_float4(0.f, __uint_as_float(tile_bits), 0.f, 0.f);
+      float2* p = reinterpret_cast<float2*>(grad_inst + (size_t)inst * kGradRec);
+      p[0] = p[1] = p[2] = p[3] = make_float2(0.f, 0.f);
+      p[4] = make_float2(0.f, __uint_as_float(tile_bits));
     }
   }
 }
@@ -976,7 +976,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   const uint32_t tile_bits = (uint32_t)tc.tile;
   // record columns: chain a -> 0..3, chain b -> 4,5 and two pad columns, chain w -> 6..8 and the tile id
   // (dual: w -> 6..8 + tile id in 12, w2 -> 9..11 + pad 15)
-  const int col_b = (cj < 2) ? 4 + cj : (REC == 12 ? 8 : 11) + cj;   // pads: 10, 11 (REC 12) / 13, 14 (REC 16): no lane shares a word
+  const int col_b = (cj < 2) ? 4 + cj : 11 + cj;             // dual: lanes cj = 2, 3 store into the pad words 13, 14; single
+  const bool b_live = DUAL || cj < 2;                         // render (10-float record, no pad): they store nothing
   const int col_w = (DUAL && cj == 3) ? 12 : 6 + cj;
   const int col_w2 = (cj == 3) ? 15 : 9 + cj;
 
@@ -1057,7 +1058,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
       if (srow < nb) {
         float* __restrict__ rec = grad_inst + (size_t)inst * REC;
         rec[cj] = Fa;
-        rec[col_b] = Fb;
+        if (b_live) rec[col_b] = Fb;
         rec[col_w] = (cj == 3) ? __uint_as_float(tile_bits) : Fw;
         if constexpr (DUAL) rec[col_w2] = Fw2;
       }
@@ -1067,13 +1068,14 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     const int n = (int)min(64u, e - base);
     if (l < n) {
       const uint32_t inst = sorted_inst[base + (uint32_t)l];
-      float4* p = reinterpret_cast<float4*>(grad_inst + (size_t)inst * REC);
-      p[0] = p[1] = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (DUAL) {
-        p[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4* p = reinterpret_cast<float4*>(grad_inst + (size_t)inst * REC);
+        p[0] = p[1] = p[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         p[3] = make_float4(__uint_as_float(tile_bits), 0.f, 0.f, 0.f);
       } else {
-        p[2] = make_float4(0.f, __uint_as_float(tile_bits), 0.f, 0.f);
+        float2* p = reinterpret_cast<float2*>(grad_inst + (size_t)inst * REC);
+        p[0] = p[1] = p[2] = p[3] = make_float2(0.f, 0.f);
+        p[4] = make_float2(0.f, __uint_as_float(tile_bits));
       }
     }
   }
@@ -1111,16 +1113,23 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     // The records are read with everything else: their addresses only need gaux, so the first kGatherAhead of them (a
     // splat has 3.5 on average at the headline shape) are in flight together with the inputs of the projection instead
     // of behind its arithmetic -- this kernel is bound by how many loads it keeps outstanding at 3 waves per SIMD.
-    constexpr int RV = (DUAL ? kGradRecDual : kGradRec) / 4;       // float4 per record
     constexpr uint32_t kGatherAhead = 4;
-    const float4* rec = reinterpret_cast<const float4*>(grad_inst) + (size_t)ga.inst_base * RV;
+    // dual: 16 floats = four float4; single render: 10 floats = five float2 (40-byte stride, 8-byte aligned)
+    auto load_record = [&](uint32_t i, float4& a, float4& b, float4& c, float4& d) {
+      if constexpr (DUAL) {
+        const float4* rec = reinterpret_cast<const float4*>(grad_inst) + ((size_t)ga.inst_base + i) * (kGradRecDual / 4);
+        a = rec[0]; b = rec[1]; c = rec[2]; d = rec[3];
+      } else {
+        const float2* rec = reinterpret_cast<const float2*>(grad_inst) + ((size_t)ga.inst_base + i) * (kGradRec / 2);
+        const float2 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3 = rec[3], f4 = rec[4];
+        a = make_float4(f0.x, f0.y, f1.x, f1.y); b = make_float4(f2.x, f2.y, f3.x, f3.y);
+        c = make_float4(f4.x, f4.y, 0.f, 0.f); d = c;
+      }
+    };
     float4 pa[kGatherAhead], pb[kGatherAhead], pc[kGatherAhead], pd[kGatherAhead];
 #pragma unroll
-    for (uint32_t i = 0; i < kGatherAhead; ++i) {
-      const uint32_t ii = min(i, ga.inst_cnt - 1u);                // past the end: the last record again (a cache hit), unused
-      pa[i] = rec[RV * ii]; pb[i] = rec[RV * ii + 1]; pc[i] = rec[RV * ii + 2];
-      if constexpr (DUAL) pd[i] = rec[RV * ii + 3]; else pd[i] = pc[i];
-    }
+    for (uint32_t i = 0; i < kGatherAhead; ++i)            // past the end: the last record again (a cache hit), unused
+      load_record(min(i, ga.inst_cnt - 1u), pa[i], pb[i], pc[i], pd[i]);
     const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
     const float sc[3] = {scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
     const float4 q4 = reinterpret_cast<const float4*>(rotations)[gid];
@@ -1154,9 +1163,8 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
       for (uint32_t i = 0; i < kGatherAhead; ++i)
         if (i < ga.inst_cnt) add_record(pa[i], pb[i], pc[i], pd[i]);
       for (uint32_t i = kGatherAhead; i < ga.inst_cnt; ++i) {
-        const float4 a = rec[RV * i], b = rec[RV * i + 1], c = rec[RV * i + 2];
-        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (DUAL) d = rec[RV * i + 3];
+        float4 a, b, c, d;
+        load_record(i, a, b, c, d);
         add_record(a, b, c, d);
       }
       if (moments_scaled_by_opacity) {        // the matrix-core backward accumulates u' = o*u
