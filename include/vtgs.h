@@ -164,7 +164,7 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n,
  * computed once; out_color_a / out_color_b are bit-identical to vtgs_forward + vtgs_forward_shared.  No depth image
  * (the reference discards it at both call sites).  vtgs_backward_dual differentiates both images at once:
  * grad_color_a/b in, ONE set of geometry gradients (= the sum over the two renders, as autograd would accumulate
- * it) plus g_colors_a / g_colors_b out.  Scratch: vtgs_backward_dual_scratch_bytes (64-byte records).            */
+ * it) plus g_colors_a / g_colors_b out.  Scratch: vtgs_backward_dual_scratch_bytes (56-byte records).            */
 size_t vtgs_backward_dual_scratch_bytes(int32_t n, uint64_t instances);
 int vtgs_forward_dual(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors_a, const float* colors_b,
                       const float* opacities, const float* scales, const float* rotations, float* out_color_a,

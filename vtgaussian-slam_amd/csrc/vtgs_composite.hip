@@ -974,12 +974,12 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   const float4* __restrict__ PhiA4 = reinterpret_cast<const float4*>(lds_phi + pq * kPhiQuarter + cj * kImgRow);
   const float4* __restrict__ PhiB4 = reinterpret_cast<const float4*>(lds_phi + pq * kPhiQuarter + (4 + cj) * kImgRow);
   const uint32_t tile_bits = (uint32_t)tc.tile;
-  // record columns: chain a -> 0..3, chain b -> 4,5 and two pad columns, chain w -> 6..8 and the tile id
-  // (dual: w -> 6..8 + tile id in 12, w2 -> 9..11 + pad 15)
-  const int col_b = (cj < 2) ? 4 + cj : 11 + cj;             // dual: lanes cj = 2, 3 store into the pad words 13, 14; single
-  const bool b_live = DUAL || cj < 2;                         // render (10-float record, no pad): they store nothing
+  // record columns: chain a -> 0..3, chain b -> 4, 5 (its lanes cj = 2, 3 hold padding and store nothing), chain w -> 6..8
+  // and the tile id in 9 (dual: w -> 6..8 + tile id in 12, w2 -> 9..11, its lane cj = 3 stores nothing)
+  const int col_b = 4 + cj;
+  const bool b_live = cj < 2;
   const int col_w = (DUAL && cj == 3) ? 12 : 6 + cj;
-  const int col_w2 = (cj == 3) ? 15 : 9 + cj;
+  const int col_w2 = 9 + cj;
 
   uint32_t base = s;
 #if VTGS_BWD_PREFETCH
@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
         rec[cj] = Fa;
         if (b_live) rec[col_b] = Fb;
         rec[col_w] = (cj == 3) ? __uint_as_float(tile_bits) : Fw;
-        if constexpr (DUAL) rec[col_w2] = Fw2;
+        if constexpr (DUAL) { if (cj < 3) rec[col_w2] = Fw2; }
       }
     }
   }
@@ -1069,9 +1069,9 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     if (l < n) {
       const uint32_t inst = sorted_inst[base + (uint32_t)l];
       if constexpr (DUAL) {
-        float4* p = reinterpret_cast<float4*>(grad_inst + (size_t)inst * REC);
-        p[0] = p[1] = p[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        p[3] = make_float4(__uint_as_float(tile_bits), 0.f, 0.f, 0.f);
+        float2* p = reinterpret_cast<float2*>(grad_inst + (size_t)inst * REC);
+        p[0] = p[1] = p[2] = p[3] = p[4] = p[5] = make_float2(0.f, 0.f);
+        p[6] = make_float2(__uint_as_float(tile_bits), 0.f);
       } else {
         float2* p = reinterpret_cast<float2*>(grad_inst + (size_t)inst * REC);
         p[0] = p[1] = p[2] = p[3] = make_float2(0.f, 0.f);
@@ -1114,11 +1114,13 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     // splat has 3.5 on average at the headline shape) are in flight together with the inputs of the projection instead
     // of behind its arithmetic -- this kernel is bound by how many loads it keeps outstanding at 3 waves per SIMD.
     constexpr uint32_t kGatherAhead = 4;
-    // dual: 16 floats = four float4; single render: 10 floats = five float2 (40-byte stride, 8-byte aligned)
+    // dual: 14 floats = seven float2 (56-byte stride); single render: 10 floats = five float2 (40-byte stride)
     auto load_record = [&](uint32_t i, float4& a, float4& b, float4& c, float4& d) {
       if constexpr (DUAL) {
-        const float4* rec = reinterpret_cast<const float4*>(grad_inst) + ((size_t)ga.inst_base + i) * (kGradRecDual / 4);
-        a = rec[0]; b = rec[1]; c = rec[2]; d = rec[3];
+        const float2* rec = reinterpret_cast<const float2*>(grad_inst) + ((size_t)ga.inst_base + i) * (kGradRecDual / 2);
+        const float2 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3 = rec[3], f4 = rec[4], f5 = rec[5], f6 = rec[6];
+        a = make_float4(f0.x, f0.y, f1.x, f1.y); b = make_float4(f2.x, f2.y, f3.x, f3.y);
+        c = make_float4(f4.x, f4.y, f5.x, f5.y); d = make_float4(f6.x, 0.f, 0.f, 0.f);
       } else {
         const float2* rec = reinterpret_cast<const float2*>(grad_inst) + ((size_t)ga.inst_base + i) * (kGradRec / 2);
         const float2 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3 = rec[3], f4 = rec[4];

@@ -48,7 +48,7 @@ struct alignas(8) GaussAux { uint32_t inst_base, inst_cnt; };
 struct alignas(16) BlockStats { uint32_t visible, pad; unsigned long long r16; };
 
 constexpr int kGradRec = 10;       // floats per instance gradient record: 6 moments, 3 colour sums, tile id (40-byte stride, float2 access)
-constexpr int kGradRecDual = 16;   // dual render: 6 moments + 6 colour sums + tile id, 64-byte stride
+constexpr int kGradRecDual = 14;   // dual render: 6 moments + 6 colour sums + tile id + one pad word (56-byte stride, float2 access)
 
 struct WsLayout {
   size_t counters, geom, gaux, block_stats, tile_cnt, keys, vals, sorted_gid, sorted_inst, final_T, total;
