@@ -158,3 +158,23 @@ def test_get_loss_mirror_equals_the_unfused_composition(gpu_device, dataset, tra
     seen = radius > 0
     assert torch.equal(variables_out["seen"], seen)
     assert torch.equal(variables_out["max_2D_radius"], torch.where(seen, radius.float(), torch.zeros_like(radius, dtype=torch.float32)))
+
+
+@pytest.mark.gpu
+def test_get_loss_mirror_refuses_what_it_does_not_cover(gpu_device):
+    """The branches no shipped configuration takes fail loudly instead of computing something else."""
+    from diff_gaussian_rasterization.get_loss import get_loss
+    dev = gpu_device
+    params, st, K, go = _scene(dev, 2000, 64, 48, seed=3)
+    curr = {"cam": st, "im": torch.rand(3, 48, 64, device=dev), "depth": torch.rand(1, 48, 64, device=dev) + 1.0,
+            "w2c": torch.eye(4, device=dev), "intrinsics": K.to(dev), "id": 0}
+    variables = {"max_2D_radius": torch.zeros(2000, device=dev)}
+    w = {"im": 0.5, "depth": 1.0}
+    with pytest.raises(NotImplementedError):                 # use_l1 = False
+        get_loss(params, curr, variables, 0, w, True, 0.9, False, False, tracking=True, dataset_name="tum")
+    with pytest.raises(NotImplementedError):                 # tracking without any mask on the colour term
+        get_loss(params, curr, variables, 0, w, False, 0.9, True, False, tracking=True, dataset_name="tum")
+    with pytest.raises(ValueError):                          # a dataset the reference has no presence mask for
+        get_loss(params, curr, variables, 0, w, True, 0.9, True, False, tracking=True, dataset_name="kitti")
+    loss, variables, wl = get_loss(params, curr, variables, 0, w, True, 0.9, True, False, mapping=True, dataset_name="tum")
+    assert torch.isfinite(loss) and set(wl) == {"im", "depth", "loss"} and "seen" in variables
