@@ -180,6 +180,9 @@ def main():
             loss.backward()
             opt.step(); opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize(); map_ms.append((time.perf_counter() - t0) * 1e3 / args.mapping_iters)
+        if os.environ.get("VTGS_SLAM_VERBOSE"):
+            print(f"[bench_slam] frame {t}: tracking {track_ms[-1]:.3f} ms/it, mapping {map_ms[-1]:.3f} ms/it, "
+                  f"instances {dgr.last_forward_info().get('instances')}, longest tile list {dgr.last_forward_info().get('max_tile_list')}", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     total = time.perf_counter() - t_all
     out = {

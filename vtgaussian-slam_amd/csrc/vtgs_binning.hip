@@ -97,6 +97,31 @@ __device__ __forceinline__ bool tile_reached(const CamParams& cam, const Splat& 
 
 constexpr int kProjBlock = 1024;     // threads per workgroup: one allocation atomic per 1024 Gaussians
 
+// A Gaussian whose candidate walk exceeds kBigArea tiles (a splat that has grown over a hole of the map can cover
+// thousands) is not walked by its own lane -- one thread iterating over 3,000 tiles held project_and_bin for up to 2 ms in
+// a long mapping run -- but by the whole wavefront, 64 tiles at a time, at the END of the kernel: it takes its instance ids
+// with an atomic of its own and its bin slots straight from the global per-tile counters, so the common path above does
+// not know it exists (inlined between the two passes, the mere presence of these loops cost the common path 13 us).
+// Same tiles, instances in raster order of the walk, same results.
+constexpr int kBigArea = 64;
+
+struct BigWalk {            // wave-uniform copy of one lane's walk and reach test
+  TileWalk w; Splat sp; ReachForm rf; float tau; int area;
+};
+__device__ __forceinline__ BigWalk broadcast_walk(const TileWalk& w, const Splat& sp, const ReachForm& rf, float tau, int area,
+                                                  int src) {
+  BigWalk b;
+  auto bi = [&](int v) { return __builtin_amdgcn_readlane(v, src); };
+  auto bf = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+  b.w.cx0 = bi(w.cx0); b.w.cy0 = bi(w.cy0); b.w.cw = bi(w.cw); b.w.ch = bi(w.ch);
+  b.sp = Splat{};
+  b.sp.u = bf(sp.u); b.sp.v = bf(sp.v); b.sp.A = bf(sp.A); b.sp.B = bf(sp.B); b.sp.C = bf(sp.C);
+  b.rf.hA = bf(rf.hA); b.rf.B = bf(rf.B); b.rf.hC = bf(rf.hC); b.rf.kx = bf(rf.kx); b.rf.ky = bf(rf.ky);
+  b.rf.regular = bi(rf.regular ? 1 : 0) != 0;
+  b.tau = bf(tau); b.area = bi(area);
+  return b;
+}
+
 // LDSBINS (tile count fits the LDS table): the workgroup first histograms its instances per tile in LDS, then takes ONE
 // global slot range per touched tile -- all those device-scope atomics are in flight together, so their round trip
 // (microseconds: they execute at the memory side) is paid once per workgroup instead of once per step of the lock-step
@@ -154,7 +179,9 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     if (x1 > x0 && y1 > y0) { w.cx0 = x0; w.cy0 = y0; w.cw = x1 - x0; w.ch = y1 - y0; }
     else { w.cw = 0; w.ch = 0; }
   }
-  const int area = w.cw * w.ch;
+  const int area_all = w.cw * w.ch;
+  const bool big = area_all > kBigArea;                        // left to the wavefront, at the end of the kernel
+  const int area = big ? 0 : area_all;
 
   // pass 1: which candidate tiles does this splat really reach (remembered as a bitmask for the first 64)
   uint32_t cnt = 0;
@@ -197,7 +224,7 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
   for (int k = 0; k < wv; ++k) wave_base += s_wave_cnt[k];
   const uint32_t inst_base = wave_base + incl - cnt;
 
-  if (valid) {
+  if (valid && !big) {
     // the geometry record is only ever reached through a tile list: a splat without instances (culled, or outside this
     // call's band of tile rows -- 7/8 of them on each rank of an 8-way partition) does not need one
     if (cnt) {
@@ -230,8 +257,7 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
       }
       if (++tx == w.cw) { tx = 0; ++ty; }
     }
-    return;
-  }
+  } else {
   Reservation pend;
   pend.base = 0; pend.head_lane = 0; pend.rank = 0; pend.act = false; pend.tile = -1;
   auto consume = [&](const Reservation& r) {                  // all 64 lanes call it
@@ -280,6 +306,52 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
       }
       consume(pend);
       pend = cur;
+    }
+  }
+  }  // (global-atomic form)
+
+  // ---- the big splats of this wavefront, one after the other, every lane a tile --------------------------------------------
+  for (unsigned long long rest = __ballot(big); rest; rest &= rest - 1ull) {      // wave-uniform
+    const int src = __builtin_ctzll(rest);
+    const BigWalk b = broadcast_walk(w, sp, rf, tau, area_all, src);
+    uint32_t total = 0;
+    for (int i0 = 0; i0 < b.area; i0 += 64) {
+      const int i = i0 + l;
+      const int ty = i / b.w.cw, tx = i - ty * b.w.cw;
+      const bool hit = i < b.area && tile_reached(cam, b.sp, b.rf, b.tau, b.w.cx0 + tx, b.w.cy0 + ty);
+      total += (uint32_t)__builtin_popcountll(__ballot(hit));
+    }
+    uint32_t base = 0;
+    if (l == src && total) base = atomicAdd(&ctr->inst_total, total);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, src);
+    const unsigned long long key_src = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), src) << 32) |
+                                       (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, src);
+    uint32_t done = 0;
+    for (int i0 = 0; i0 < b.area; i0 += 64) {
+      const int i = i0 + l;
+      const int ty = i / b.w.cw, tx = i - ty * b.w.cw;
+      const bool hit = i < b.area && tile_reached(cam, b.sp, b.rf, b.tau, b.w.cx0 + tx, b.w.cy0 + ty);
+      const unsigned long long hb = __ballot(hit);
+      if (hit) {
+        const int tile = (b.w.cy0 + ty) * cam.gx8 + b.w.cx0 + tx;
+        const uint32_t slot = atomicAdd(&tile_cnt[tile], 1u);
+        const uint32_t rank = (uint32_t)__builtin_popcountll(hb & ((1ull << l) - 1ull));
+        const unsigned long long id = (unsigned long long)base + done + rank;            // raster order of the walk
+        if (id < capacity && slot < tile_cap) {
+          const size_t pos = (size_t)tile * tile_cap + slot;
+          keys[pos] = key_src;
+          vals[pos] = (uint32_t)id;
+        }
+      }
+      done += (uint32_t)__builtin_popcountll(hb);
+    }
+    if (l == src) {
+      if (total) {
+        GeomRec g;
+        g.u = sp.u; g.v = sp.v; g.A = sp.A; g.B = sp.B; g.C = sp.C; g.opacity = op; g.depth = sp.depth; g.pad = 0.f;
+        geom[gid] = g;
+      }
+      gaux[gid] = GaussAux{base, total};
     }
   }
 }

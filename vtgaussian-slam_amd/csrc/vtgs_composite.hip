@@ -1102,79 +1102,106 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
   if (ctr->overflow) return;                     // the forward did not complete: nothing valid to differentiate
   const CamParams cam = load_cam(cs, Vp, PVp);
   const int gid = (int)(blockIdx.x * 256u + threadIdx.x);
-  if (!FRAME && gid >= n) return;                // (FRAME: every thread takes part in the block reduction)
-  const bool live = gid < n;
+  const bool live = gid < n;                     // nobody leaves: the wavefront sums the records of its big splats together
   SplatGrads g;
   for (int i = 0; i < 3; ++i) { g.mean3D[i] = g.mean2D[i] = g.color[i] = g.scale[i] = 0.f; }
   g.opacity = 0.f; g.rot[0] = g.rot[1] = g.rot[2] = g.rot[3] = 0.f;
   float cb0 = 0.f, cb1 = 0.f, cb2 = 0.f;         // dual: dL/d(second render's colours)
   const GaussAux ga = live ? gaux[gid] : GaussAux{0u, 0u};
+  // A Gaussian with more than kBigInst instances (a splat grown over a hole of the map has thousands) is summed by the whole
+  // wavefront, 64 records at a time, instead of by its own lane in a loop that held this kernel for up to 1 ms.
+  constexpr uint32_t kBigInst = 32;
+  constexpr uint32_t kGatherAhead = 4;
+  const bool big = ga.inst_cnt > kBigInst;
+  // dual: 14 floats = seven float2 (56-byte stride); single render: 10 floats = five float2 (40-byte stride)
+  auto load_record = [&](uint32_t inst, float4& a, float4& b, float4& c, float4& d) {
+    if constexpr (DUAL) {
+      const float2* rec = reinterpret_cast<const float2*>(grad_inst) + (size_t)inst * (kGradRecDual / 2);
+      const float2 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3 = rec[3], f4 = rec[4], f5 = rec[5], f6 = rec[6];
+      a = make_float4(f0.x, f0.y, f1.x, f1.y); b = make_float4(f2.x, f2.y, f3.x, f3.y);
+      c = make_float4(f4.x, f4.y, f5.x, f5.y); d = make_float4(f6.x, 0.f, 0.f, 0.f);
+    } else {
+      const float2* rec = reinterpret_cast<const float2*>(grad_inst) + (size_t)inst * (kGradRec / 2);
+      const float2 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3 = rec[3], f4 = rec[4];
+      a = make_float4(f0.x, f0.y, f1.x, f1.y); b = make_float4(f2.x, f2.y, f3.x, f3.y);
+      c = make_float4(f4.x, f4.y, 0.f, 0.f); d = c;
+    }
+  };
+  // record = tile-local moments (U0, UX, UY, UXX, UXY, UYY), colour sums (3 or 6), tile id; (u, v) = the splat's centre
+  auto add_record = [&](SplatMoments& M, float& c0, float& c1, float& c2, float4 a, float4 b, float4 c, float4 d, float u, float v) {
+    uint32_t tile;
+    if constexpr (DUAL) {
+      tile = __float_as_uint(d.x);
+      c0 += c.y; c1 += c.z; c2 += c.w;
+    } else {
+      tile = __float_as_uint(c.y);
+    }
+    const int ty = (int)(tile / (uint32_t)cam.gx8), tx = (int)(tile - (uint32_t)ty * (uint32_t)cam.gx8);
+    const float sx = u - ((float)(tx * kSubTile) + 3.5f), sy = v - ((float)(ty * kSubTile) + 3.5f);
+    const float U0 = a.x, UX = a.y, UY = a.z, UXX = a.w, UXY = b.x, UYY = b.y;
+    M.m[0] += U0;
+    M.m[1] += sx * U0 - UX;                                     // d = centre - pixel = s - X
+    M.m[2] += sy * U0 - UY;
+    M.m[3] += sx * sx * U0 - 2.f * sx * UX + UXX;
+    M.m[4] += sx * sy * U0 - sx * UY - sy * UX + UXY;
+    M.m[5] += sy * sy * U0 - 2.f * sy * UY + UYY;
+    M.m[6] += b.z; M.m[7] += b.w; M.m[8] += c.x;
+  };
+  float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, op = 0.f;
+  Splat sp{}; SplatAux aux{};
+  SplatMoments mo;
+  for (int k = 0; k < 9; ++k) mo.m[k] = 0.f;
+  bool ok = false;
   if (ga.inst_cnt) {
     // The records are read with everything else: their addresses only need gaux, so the first kGatherAhead of them (a
     // splat has 3.5 on average at the headline shape) are in flight together with the inputs of the projection instead
     // of behind its arithmetic -- this kernel is bound by how many loads it keeps outstanding at 3 waves per SIMD.
-    constexpr uint32_t kGatherAhead = 4;
-    // dual: 14 floats = seven float2 (56-byte stride); single render: 10 floats = five float2 (40-byte stride)
-    auto load_record = [&](uint32_t i, float4& a, float4& b, float4& c, float4& d) {
-      if constexpr (DUAL) {
-        const float2* rec = reinterpret_cast<const float2*>(grad_inst) + ((size_t)ga.inst_base + i) * (kGradRecDual / 2);
-        const float2 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3 = rec[3], f4 = rec[4], f5 = rec[5], f6 = rec[6];
-        a = make_float4(f0.x, f0.y, f1.x, f1.y); b = make_float4(f2.x, f2.y, f3.x, f3.y);
-        c = make_float4(f4.x, f4.y, f5.x, f5.y); d = make_float4(f6.x, 0.f, 0.f, 0.f);
-      } else {
-        const float2* rec = reinterpret_cast<const float2*>(grad_inst) + ((size_t)ga.inst_base + i) * (kGradRec / 2);
-        const float2 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3 = rec[3], f4 = rec[4];
-        a = make_float4(f0.x, f0.y, f1.x, f1.y); b = make_float4(f2.x, f2.y, f3.x, f3.y);
-        c = make_float4(f4.x, f4.y, 0.f, 0.f); d = c;
-      }
-    };
     float4 pa[kGatherAhead], pb[kGatherAhead], pc[kGatherAhead], pd[kGatherAhead];
 #pragma unroll
     for (uint32_t i = 0; i < kGatherAhead; ++i)            // past the end: the last record again (a cache hit), unused
-      load_record(min(i, ga.inst_cnt - 1u), pa[i], pb[i], pc[i], pd[i]);
+      load_record(ga.inst_base + min(i, ga.inst_cnt - 1u), pa[i], pb[i], pc[i], pd[i]);
     const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
-    const float sc[3] = {scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
+    sc[0] = scales[3 * gid]; sc[1] = scales[3 * gid + 1]; sc[2] = scales[3 * gid + 2];
     const float4 q4 = reinterpret_cast<const float4*>(rotations)[gid];
-    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-    const float op = opacities[gid];
-    Splat sp; SplatAux aux;
-    if (project_splat(cam, mean, sc, q, op, sp, aux)) {
-      SplatMoments mo;
-      for (int k = 0; k < 9; ++k) mo.m[k] = 0.f;
-      // record = tile-local moments (U0, UX, UY, UXX, UXY, UYY), colour sums (3 or 6), tile id
-      auto add_record = [&](float4 a, float4 b, float4 c, float4 d) {
-        uint32_t tile;
-        if constexpr (DUAL) {
-          tile = __float_as_uint(d.x);
-          cb0 += c.y; cb1 += c.z; cb2 += c.w;
-        } else {
-          tile = __float_as_uint(c.y);
-        }
-        const int ty = (int)(tile / (uint32_t)cam.gx8), tx = (int)(tile - (uint32_t)ty * (uint32_t)cam.gx8);
-        const float sx = sp.u - ((float)(tx * kSubTile) + 3.5f), sy = sp.v - ((float)(ty * kSubTile) + 3.5f);
-        const float U0 = a.x, UX = a.y, UY = a.z, UXX = a.w, UXY = b.x, UYY = b.y;
-        mo.m[0] += U0;
-        mo.m[1] += sx * U0 - UX;                                     // d = centre - pixel = s - X
-        mo.m[2] += sy * U0 - UY;
-        mo.m[3] += sx * sx * U0 - 2.f * sx * UX + UXX;
-        mo.m[4] += sx * sy * U0 - sx * UY - sy * UX + UXY;
-        mo.m[5] += sy * sy * U0 - 2.f * sy * UY + UYY;
-        mo.m[6] += b.z; mo.m[7] += b.w; mo.m[8] += c.x;
-      };
+    q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+    op = opacities[gid];
+    ok = project_splat(cam, mean, sc, q, op, sp, aux);
+    if (ok && !big) {
 #pragma unroll
       for (uint32_t i = 0; i < kGatherAhead; ++i)
-        if (i < ga.inst_cnt) add_record(pa[i], pb[i], pc[i], pd[i]);
+        if (i < ga.inst_cnt) add_record(mo, cb0, cb1, cb2, pa[i], pb[i], pc[i], pd[i], sp.u, sp.v);
       for (uint32_t i = kGatherAhead; i < ga.inst_cnt; ++i) {
         float4 a, b, c, d;
-        load_record(i, a, b, c, d);
-        add_record(a, b, c, d);
+        load_record(ga.inst_base + i, a, b, c, d);
+        add_record(mo, cb0, cb1, cb2, a, b, c, d, sp.u, sp.v);
       }
-      if (moments_scaled_by_opacity) {        // the matrix-core backward accumulates u' = o*u
-        const float io = 1.f / op;
-        for (int k = 0; k < 6; ++k) mo.m[k] *= io;
-      }
-      splat_backward(cam, sc, q, op, sp, aux, mo, g);
     }
+  }
+  for (unsigned long long rest = __ballot(ok && big); rest; rest &= rest - 1ull) {     // wave-uniform
+    const int src = __builtin_ctzll(rest);
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)ga.inst_base, src);
+    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)ga.inst_cnt, src);
+    const float u = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sp.u), src));
+    const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sp.v), src));
+    SplatMoments part;
+    for (int k = 0; k < 9; ++k) part.m[k] = 0.f;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    for (uint32_t i = (uint32_t)lane_id(); i < cnt; i += 64u) {   // lane-strided partial sums, then a butterfly: fixed order
+      float4 a, b, c, d;
+      load_record(base + i, a, b, c, d);
+      add_record(part, p0, p1, p2, a, b, c, d, u, v);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) part.m[k] = wave_sum(part.m[k]);
+    if constexpr (DUAL) { p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2); }
+    if (lane_id() == src) { mo = part; cb0 = p0; cb1 = p1; cb2 = p2; }
+  }
+  if (ok) {
+    if (moments_scaled_by_opacity) {        // the matrix-core backward accumulates u' = o*u
+      const float io = 1.f / op;
+      for (int k = 0; k < 6; ++k) mo.m[k] *= io;
+    }
+    splat_backward(cam, sc, q, op, sp, aux, mo, g);
   }
   if constexpr (FRAME) {
     __shared__ float red[4][12];
@@ -1226,6 +1253,7 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     }
     return;
   }
+  if (!live) return;
   for (int i = 0; i < 3; ++i) {
     g_means3D[3 * gid + i] = g.mean3D[i];
     g_means2D[3 * gid + i] = g.mean2D[i];
