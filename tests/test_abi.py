@@ -48,7 +48,7 @@ def test_version_strings_and_sizes(lib):
     assert lib.vtgs_workspace_bytes(10, 640, 480, 8, 0) == 0
     lib.vtgs_backward_scratch_bytes.restype = ctypes.c_size_t
     lib.vtgs_backward_scratch_bytes.argtypes = [ctypes.c_int32, ctypes.c_uint64]
-    assert lib.vtgs_backward_scratch_bytes(10, 100) >= 100 * 48
+    assert lib.vtgs_backward_scratch_bytes(10, 100) >= 100 * 40                 # 10-float records
 
 
 def test_invalid_arguments_are_rejected_before_any_device_work(lib):
@@ -115,3 +115,20 @@ def test_option_api_without_a_gpu(lib):
         assert lib.vtgs_set_option(name, 0) == 0 and lib.vtgs_get_option(name) == 0
         assert lib.vtgs_set_option(name, -1) == 0 and lib.vtgs_get_option(name) == dflt
     assert lib.vtgs_set_option(b"VTGS_NO_SUCH_SWITCH", 1) == 1 and lib.vtgs_get_option(b"VTGS_NO_SUCH_SWITCH") == -1
+
+
+def test_header_is_plain_c99_and_links(tmp_path):
+    """include/vtgs.h is the boundary a C / cgo / JNI caller binds: it must compile as C99 (no C++, no torch types) and a C
+    program must link against libvtgs.so with nothing but the header."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "vtgaussian-slam_amd", "lib")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "vtgs.h"\n#include <stdio.h>\n'
+                   'int main(void) { printf("%u %s\\n", vtgs_abi_version(), vtgs_strerror(VTGS_ERR_INSTANCE_OVERFLOW)); '
+                   'return vtgs_get_option("VTGS_FWD_IMPL") < 0; }\n')
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src),
+                    "-L", lib_dir, "-lvtgs", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out[0] == "9"
