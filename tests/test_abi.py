@@ -109,7 +109,7 @@ def test_option_api_without_a_gpu(lib):
     rejected (no HIP call involved)."""
     lib.vtgs_set_option.restype, lib.vtgs_set_option.argtypes = ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]
     lib.vtgs_get_option.restype, lib.vtgs_get_option.argtypes = ctypes.c_int, [ctypes.c_char_p]
-    for name in (b"VTGS_FWD_IMPL", b"VTGS_BWD_IMPL", b"VTGS_BIN_IMPL", b"VTGS_SORT_PACKED"):
+    for name in (b"VTGS_FWD_IMPL", b"VTGS_BWD_IMPL", b"VTGS_BIN_IMPL", b"VTGS_SORT_PACKED", b"VTGS_SORT_FUSED"):
         dflt = lib.vtgs_get_option(name)
         assert dflt >= 0
         assert lib.vtgs_set_option(name, 0) == 0 and lib.vtgs_get_option(name) == 0

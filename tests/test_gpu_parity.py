@@ -479,6 +479,34 @@ def test_packed_key_sort_matches_the_key_value_sort(gpu_device, monkeypatch):
         assert torch.equal(res["1"][3][k], res["0"][3][k]), k
 
 
+@pytest.mark.parametrize("packed", ["1", "0"])
+def test_sort_inside_the_forward_equals_the_sort_kernel(gpu_device, packed):
+    """VTGS_SORT_FUSED: the quadrant-queue forward sorts its own tile's list (bins of <= 1024 entries) instead of a
+    sort_tiles launch before it -- same network, so the lists, the images and the gradients are bit-identical; lists up to
+    the 16-keys-per-lane form are exercised, with exact depth ties."""
+    import diff_gaussian_rasterization as dgr
+    from parity_util import to_settings
+    scene, cam = go.view_tied_scene(60000, 152, 104, seed=29)
+    scene["means3D"][:, 2] = (scene["means3D"][:, 2] * 8).round() / 8       # many exact depth ties -> the id breaks them
+    g = torch.Generator().manual_seed(3)
+    grad_color = torch.rand(3, cam.image_height, cam.image_width, generator=g) * 2 - 1
+    _opt("VTGS_SORT_PACKED", packed)
+    res, lists = {}, {}
+    for mode in ("1", "0"):
+        _opt("VTGS_SORT_FUSED", mode)
+        res[mode] = run_hip(scene, cam, gpu_device, grad_color)
+        rast = dgr.GaussianRasterizer(raster_settings=to_settings(cam, gpu_device))
+        with torch.no_grad():
+            rast(**{k: v.to(gpu_device) for k, v in scene.items()})
+        lists[mode] = dgr.debug_tile_lists(rast)[:2]
+        assert dgr.last_forward_info()["max_tile_list"] > 256           # several register forms in play
+    assert torch.equal(lists["1"][0], lists["0"][0]) and torch.equal(lists["1"][1], lists["0"][1])
+    for a, b in zip(res["1"][:3], res["0"][:3]):
+        assert torch.equal(a, b)
+    for k in GRAD_KEYS:
+        assert torch.equal(res["1"][3][k], res["0"][3][k]), k
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_odd_shapes_default_kernels_vs_scalar_kernels(gpu_device, monkeypatch, seed):
     """Small random configurations at awkward sizes (1-pixel-wide images, one Gaussian, everything opaque, huge and tiny

@@ -28,9 +28,9 @@ __global__ void composite_forward_px(CamScalars, const float*, uint32_t, const u
                                      const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*,
                                      float*);
 template <bool DUAL>
-__global__ void composite_forward_q(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
+__global__ void composite_forward_q(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*,
                                     const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*,
-                                    float*);
+                                    float*, int, const unsigned long long*, const uint32_t*, uint32_t*);
 __global__ void composite_backward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                    const uint32_t*, const GeomRec*, const float*, const float*, const float*,
                                    const float*, float*, const Counters*);
@@ -145,8 +145,9 @@ size_t vtgs_backward_dual_scratch_bytes(int32_t n, uint64_t instances) {
 #include <time.h>
 // Implementation switches: defaults from the environment, read once; vtgs_set_option overrides them at run time.
 struct Option { const char* name; int dflt; int value; };
-static Option g_options[] = {{"VTGS_FWD_IMPL", 3, -1}, {"VTGS_BWD_IMPL", 2, -1}, {"VTGS_BIN_IMPL", 1, -1}, {"VTGS_SORT_PACKED", 1, -1}};
-enum { OPT_FWD_IMPL = 0, OPT_BWD_IMPL, OPT_BIN_IMPL, OPT_SORT_PACKED, OPT_COUNT };
+static Option g_options[] = {{"VTGS_FWD_IMPL", 3, -1}, {"VTGS_BWD_IMPL", 2, -1}, {"VTGS_BIN_IMPL", 1, -1}, {"VTGS_SORT_PACKED", 1, -1},
+                             {"VTGS_SORT_FUSED", 1, -1}};
+enum { OPT_FWD_IMPL = 0, OPT_BWD_IMPL, OPT_BIN_IMPL, OPT_SORT_PACKED, OPT_SORT_FUSED, OPT_COUNT };
 static bool g_options_ready = false;
 static void options_init() {
   if (g_options_ready) return;
@@ -177,7 +178,7 @@ int vtgs_get_option(const char* name) {
 static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs, int rows16, const WsLayout& L,
                                     char* ws, const float* colors, float* out_color, float* out_depth,
                                     float* image_state, hipStream_t st, const float* colors_b = nullptr,
-                                    float* out_color_b = nullptr) {
+                                    float* out_color_b = nullptr, int sort_mode = 0) {
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   const uint32_t nblk = (uint32_t)(gx16 * rows16);
   const int impl = option(OPT_FWD_IMPL);                     // 2 = lane-per-pixel matrix-core kernel (default), 1 = pixel x splat-quad
@@ -186,14 +187,16 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
     ProfScope ps__(colors_b ? "composite_forward_dual" : "composite_forward", st);
     if (impl == 3 && colors_b)                              // quadrant queues (vtgs_composite_q.hip)
       hipLaunchKernelGGL((composite_forward_q<true>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
-                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (uint32_t*)(ws + L.sorted_gid),
                          (const GeomRec*)(ws + L.geom), colors, out_color, (float*)nullptr, image_state,
-                         (const Counters*)(ws + L.counters), colors_b, out_color_b);
+                         (const Counters*)(ws + L.counters), colors_b, out_color_b, sort_mode,
+                         (const unsigned long long*)(ws + L.keys), (const uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_inst));
     else if (impl == 3)
       hipLaunchKernelGGL((composite_forward_q<false>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
-                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (uint32_t*)(ws + L.sorted_gid),
                          (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
-                         (const Counters*)(ws + L.counters), (const float*)nullptr, (float*)nullptr);
+                         (const Counters*)(ws + L.counters), (const float*)nullptr, (float*)nullptr, sort_mode,
+                         (const unsigned long long*)(ws + L.keys), (const uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_inst));
     else if (colors_b && impl != 1)
       hipLaunchKernelGGL((composite_forward_px<4, true>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
@@ -305,9 +308,12 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
 
   const uint32_t gx8 = (uint32_t)((cam->image_width + kSubTile - 1) / kSubTile);
   const uint32_t band_first = (uint32_t)r8b * gx8, band_tiles = (uint32_t)(r8e - r8b) * gx8;
-  {
+  const int packed = (n <= (1 << 21) && option(OPT_SORT_PACKED) == 1) ? 1 : 0;
+  // The quadrant-queue forward sorts its own tile's list when no bin can hold more than the 1024 entries one wavefront
+  // takes (VTGS_SORT_FUSED, default 1): no sort launch at all.
+  const bool fused_sort = option(OPT_FWD_IMPL) == 3 && option(OPT_SORT_FUSED) == 1 && L.tile_cap <= 1024u;
+  if (!fused_sort) {
     ProfScope ps__("sort_tiles", st);
-    const int packed = (n <= (1 << 21) && option(OPT_SORT_PACKED) == 1) ? 1 : 0;
     // lists cannot be longer than the bin capacity: the wide (32 keys per lane) form is only worth its registers beyond 1024
     if (packed && L.tile_cap > 1024u)
       hipLaunchKernelGGL(sort_tiles<true>, dim3((band_tiles + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
@@ -320,7 +326,8 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   }
   VTGS_HIP(hipGetLastError());
   int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st,
-                                    dual ? colors_b : nullptr, dual ? out_color_b : nullptr);
+                                    dual ? colors_b : nullptr, dual ? out_color_b : nullptr,
+                                    fused_sort ? (packed ? 1 : 2) : 0);
   if (rc != VTGS_OK) return rc;
   // result record: assembled on the device by finalize_forward at byte 64 of the counters block
   static_assert(sizeof(VtgsForwardInfo) == 40, "VtgsForwardInfo layout is mirrored in Counters");

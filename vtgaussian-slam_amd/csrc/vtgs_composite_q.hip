@@ -31,6 +31,7 @@
 // Semantics per pixel: SURVEY.md Appendix A3 (see vtgs_composite.hip).
 #include "vtgs_internal.h"
 #include "vtgs_composite_common.h"
+#include "vtgs_sort_common.h"
 
 namespace vtgs {
 
@@ -197,10 +198,12 @@ __device__ __forceinline__ void q_forward_step(float& T, bool& done, bool& exact
 template <bool DUAL>
 __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forward_q(
     CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
-    const uint32_t* __restrict__ tile_cnt, uint32_t tile_cap, const uint32_t* __restrict__ sorted_gid,
+    const uint32_t* __restrict__ tile_cnt, uint32_t tile_cap, uint32_t* sorted_gid,
     const GeomRec* __restrict__ geom, const float* __restrict__ colors,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
-    const Counters* __restrict__ ctr, const float* __restrict__ colors_b, float* __restrict__ out_color_b) {
+    const Counters* __restrict__ ctr, const float* __restrict__ colors_b, float* __restrict__ out_color_b,
+    int sort_mode, const unsigned long long* __restrict__ bin_keys, const uint32_t* __restrict__ bin_vals,
+    uint32_t* sorted_inst) {
   // per wavefront: the table of the ring's entries (+ one dummy slot) and the four queues of table slots.  Queue bytes are
   // stored twice, 128 apart, so a pop reads [head & 127, head & 127 + 16) without wrapping.
   __shared__ float4 lds_ka[4][kQRing + 1];                      // K0..K3
@@ -226,6 +229,33 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
   const float X = (float)lx - 3.5f, Y = (float)ly - 3.5f;
   const float Phi[6] = {1.f, X, Y, X * X, X * Y, Y * Y};
   const uint32_t s = (uint32_t)qc.tile * tile_cap, e = s + min(tile_cnt[qc.tile], tile_cap);
+  // sort_mode != 0 (the host picks it when no bin can hold more than 1024 entries): the wavefront sorts its own tile's list
+  // here -- 1 = payload packed into the key, 2 = key + value -- instead of a sort kernel before this one: one launch less,
+  // and the list's trip through memory overlaps with the other wavefronts' compositing.  The sorted list still goes to
+  // global memory (the backward and a second render read it) and is re-read below after the fence.
+  if (sort_mode) {
+    const uint32_t L = e - s;
+    const size_t sz = (size_t)s;
+    if (L == 1u) {
+      if (l == 0) { sorted_gid[s] = (uint32_t)bin_keys[s]; sorted_inst[s] = bin_vals[s]; }
+    } else if (sort_mode == 1) {
+      if (L <= 64u) { if (L) wave_sort_tile<1, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l); }
+      else if (L <= 128u) wave_sort_tile<2, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l);
+      else if (L <= 256u) wave_sort_tile<4, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l);
+      else if (L <= 512u) wave_sort_tile<8, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l);
+      else wave_sort_tile<16, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l);
+    } else {
+      if (L <= 64u) { if (L) wave_sort_tile<1, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l); }
+      else if (L <= 128u) wave_sort_tile<2, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l);
+      else if (L <= 256u) wave_sort_tile<4, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l);
+      else if (L <= 512u) wave_sort_tile<8, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l);
+      else wave_sort_tile<16, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l);
+    }
+    // the wavefront's own stores before its own loads: program order within one wavefront, no cache maintenance (a
+    // device-scope fence here writes L2 back for every tile: 590 us instead of 90)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0);
+  }
   // dummy slot + queue bytes start defined (a pop past the end of a queue reads bytes that were never written)
   ka[kQDummy] = make_float4(-1e30f, 0.f, 0.f, 0.f);
   kb[kQDummy] = make_float2(0.f, 0.f);
@@ -345,7 +375,7 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     final_T[pix] = T;
   }
 }
-template __global__ void composite_forward_q<false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*);
-template __global__ void composite_forward_q<true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*);
+template __global__ void composite_forward_q<false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*, int, const unsigned long long*, const uint32_t*, uint32_t*);
+template __global__ void composite_forward_q<true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*, int, const unsigned long long*, const uint32_t*, uint32_t*);
 
 }  // namespace vtgs

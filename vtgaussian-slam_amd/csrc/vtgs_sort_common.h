@@ -1,0 +1,165 @@
+// vtgs_sort_common.h -- the one-wavefront-per-list register sort, shared by sort_tiles (vtgs_binning.hip) and by the
+// quadrant-queue forward composite, which sorts its own tile's list when the bins cannot hold lists above 1024 entries.
+#pragma once
+#include "vtgs_internal.h"
+
+namespace vtgs {
+
+// Per-tile depth sort.  Network: the all-ascending form of the bitonic sorter -- each merge level starts with a
+// mirror step (e <-> e ^ (k2-1)) followed by half-cleaners (e <-> e ^ j).  Every comparator puts the smaller key at
+// the lower index, so a list of any length behaves as if padded with +inf up to the next power of two.
+//
+// Fast path (lists <= 1024, i.e. practically all of them): ONE WAVEFRONT PER TILE, keys in registers.  Blocked
+// layout, element e = lane*E + r with E = n2/64 registers per lane: strides below E are in-lane compare-exchanges,
+// strides >= E are lane-xor exchanges (DPP / ds_bpermute), no LDS traffic and no barriers.
+// Slow path (longer lists): the whole workgroup cooperates, in LDS up to kSortLds entries, else in place in global
+// memory (L2-resident) with the same network.
+constexpr int kSortLds = 2048;
+constexpr int kWaveSortMax = 1024;        // key + value form: 16 keys per lane
+constexpr int kWaveSortMaxPacked = 2048;  // packed form (payload in the key): 32 keys per lane still fit the register budget
+
+// HASV = false sorts the keys alone (the payload travels in their low bits, see wave_sort_tile): a third less to move.
+//
+// Code size matters more than the exchange instruction here: fully unrolled, the five list-length variants of this network
+// came to ~35 K instructions (~250 KB), far beyond the instruction cache that the CUs share, and the kernel took the same
+// 27-45 us whether it sorted 1,600 or 12,750 lists and whether lanes exchanged through ds_bpermute or DPP -- it was
+// fetching instructions.  So only what must be unrolled is (register indices: the in-lane comparators); the merge levels
+// and the cross-lane half-cleaners are real loops over a run-time lane mask.
+template <int E, bool HASV>
+__device__ __forceinline__ void in_lane_cleaners(unsigned long long (&k)[E], uint32_t (&v)[E]) {   // partner = e ^ j, j = E/2 .. 1
+#pragma unroll
+  for (int j = E >> 1; j > 0; j >>= 1) {
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      if (!(r & j)) {
+        const int p = r | j;
+        const bool sw = k[r] > k[p];
+        const unsigned long long a = k[r], b = k[p];
+        const uint32_t va = v[r], vb = v[p];
+        k[r] = sw ? b : a; k[p] = sw ? a : b;
+        if (HASV) { v[r] = sw ? vb : va; v[p] = sw ? va : vb; }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned long long lane_fetch64(unsigned long long x, int byte_addr) {   // x of lane byte_addr / 4
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(uint32_t)x);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(uint32_t)(x >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int E, bool HASV>
+__device__ __forceinline__ void wave_sort_regs(unsigned long long (&k)[E], uint32_t (&v)[E], int lane) {
+  // levels inside a lane (k2 <= E): compile-time register pairs
+#pragma unroll
+  for (int k2 = 2; k2 <= E; k2 <<= 1) {
+#pragma unroll
+    for (int r = 0; r < E; ++r) {                                // mirror step: partner = r ^ (k2 - 1)
+      const int p = r ^ (k2 - 1);
+      if (r < p) {
+        const bool sw = k[r] > k[p];
+        const unsigned long long a = k[r], b = k[p];
+        const uint32_t va = v[r], vb = v[p];
+        k[r] = sw ? b : a; k[p] = sw ? a : b;
+        if (HASV) { v[r] = sw ? vb : va; v[p] = sw ? va : vb; }
+      }
+    }
+#pragma unroll
+    for (int j = k2 >> 2; j > 0; j >>= 1) {
+#pragma unroll
+      for (int r = 0; r < E; ++r) {
+        if (!(r & j)) {
+          const int p = r | j;
+          const bool sw = k[r] > k[p];
+          const unsigned long long a = k[r], b = k[p];
+          const uint32_t va = v[r], vb = v[p];
+          k[r] = sw ? b : a; k[p] = sw ? a : b;
+          if (HASV) { v[r] = sw ? vb : va; v[p] = sw ? va : vb; }
+        }
+      }
+    }
+  }
+  // levels across lanes: lane mask M = 1, 3, 7, .. 63 (k2 = 2E .. 64E)
+#pragma unroll 1
+  for (int M = 1; M < 64; M = 2 * M + 1) {
+    {                                                            // mirror step: lane ^ M, in-lane index mirrored
+      // registers r and E-1-r trade places with their mirror images in the partner lane: done pair by pair, so that only two
+      // fetched keys are live at a time (a [E] array of them doubles the register footprint of the E = 32 form)
+      const int addr = (lane ^ M) << 2;
+      const bool lower = (lane & ((M + 1) >> 1)) == 0;
+#pragma unroll
+      for (int r = 0; r < E / 2 + (E == 1 ? 1 : 0); ++r) {
+        const int m2 = E - 1 - r;
+        const unsigned long long pa = lane_fetch64(k[m2], addr);          // partner's mirror of r
+        const uint32_t va = HASV ? (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[m2]) : 0u;
+        unsigned long long pb = 0ull; uint32_t vb = 0u;
+        if (m2 != r) {
+          pb = lane_fetch64(k[r], addr);                                   // partner's mirror of E-1-r
+          vb = HASV ? (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[r]) : 0u;
+        }
+        const bool ta = lower ? (pa < k[r]) : (pa > k[r]);
+        k[r] = ta ? pa : k[r];
+        if (HASV) v[r] = ta ? va : v[r];
+        if (m2 != r) {
+          const bool tb = lower ? (pb < k[m2]) : (pb > k[m2]);
+          k[m2] = tb ? pb : k[m2];
+          if (HASV) v[m2] = tb ? vb : v[m2];
+        }
+      }
+    }
+#pragma unroll 1
+    for (int m = (M + 1) >> 2; m > 0; m >>= 1) {                 // half-cleaners across lanes: lane ^ m
+      const int addr = (lane ^ m) << 2;
+      const bool lower = (lane & m) == 0;
+#pragma unroll
+      for (int r = 0; r < E; ++r) {
+        const unsigned long long pk = lane_fetch64(k[r], addr);
+        const uint32_t pv = HASV ? (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[r]) : 0u;
+        const bool take = lower ? (pk < k[r]) : (pk > k[r]);
+        k[r] = take ? pk : k[r];
+        if (HASV) v[r] = take ? pv : v[r];
+      }
+    }
+    in_lane_cleaners<E, HASV>(k, v);
+  }
+}
+
+// PACKED (Gaussian ids below 2^21, list positions below 2^11 -- the host decides): the low key word becomes
+// (gid << 11 | bin slot); the order (depth, gid) is unchanged, the instance id is fetched from its slot afterwards.
+constexpr uint32_t kSlotBits = 11u;            // (the host sends ids below 2^21 only: 21 + 11 bits)
+
+template <int E, bool PACKED>
+__device__ __forceinline__ void wave_sort_tile(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                               uint32_t* __restrict__ sorted_gid, uint32_t* __restrict__ sorted_inst,
+                                               size_t s, uint32_t L, int lane) {
+  unsigned long long k[E]; uint32_t v[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const uint32_t e = (uint32_t)lane * E + r;
+    k[r] = (e < L) ? keys[s + e] : ~0ull;
+    if (PACKED) {
+      if (e < L) k[r] = (k[r] & 0xFFFFFFFF00000000ull) | (unsigned long long)((((uint32_t)k[r]) << kSlotBits) | e);
+      v[r] = 0u;
+    } else {
+      v[r] = (e < L) ? vals[s + e] : 0u;
+    }
+  }
+  wave_sort_regs<E, !PACKED>(k, v, lane);
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const uint32_t e = (uint32_t)lane * E + r;
+    if (e < L) {
+      if (PACKED) {
+        const uint32_t lo = (uint32_t)k[r];
+        sorted_gid[s + e] = lo >> kSlotBits;
+        sorted_inst[s + e] = vals[s + (lo & ((1u << kSlotBits) - 1u))];
+      } else {
+        sorted_gid[s + e] = (uint32_t)k[r]; sorted_inst[s + e] = v[r];
+      }
+    }
+  }
+}
+
+
+}  // namespace vtgs

@@ -148,7 +148,7 @@ def profile_collect() -> dict:
     return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches) for i in range(n.value)}
 
 
-_OPTION_NAMES = ("VTGS_FWD_IMPL", "VTGS_BWD_IMPL", "VTGS_BIN_IMPL", "VTGS_SORT_PACKED")
+_OPTION_NAMES = ("VTGS_FWD_IMPL", "VTGS_BWD_IMPL", "VTGS_BIN_IMPL", "VTGS_SORT_PACKED", "VTGS_SORT_FUSED")
 
 
 def set_option(name: str, value: int) -> None:
