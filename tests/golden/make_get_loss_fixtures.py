@@ -1,4 +1,4 @@
-"""Generates tests/golden/get_loss_*.npz by running the reference's OWN `get_loss` and `get_vis_mask`
+"""Generates tests/golden/get_loss.npz and tests/golden/driver_helpers.npz by running the reference's OWN `get_loss` and `get_vis_mask`
 (src/vtgaussian_slam.py:376-404, 407-689) in the build container -- the loss glue of the four dataset branches
 (Replica silhouette sweep, TUM / ScanNet / ScanNet++ visibility mask, far-depth filter, 50 x median outlier mask,
 `additional_mask`) is captured from the reference instead of being restated.
@@ -12,7 +12,10 @@ hard-coded 'cuda' device to the CPU (as make_helper_fixtures.py does), and puts 
 (oracle/gs_oracle.py, test infrastructure) behind `diff_gaussian_rasterization.GaussianRasterizer`, the operator this
 repository replaces.  What is stored: the operator outputs get_loss saw (im, depth_sil), its other inputs, and what it
 returned -- the loss, the per-term weighted losses, d loss / d im and d loss / d depth_sil (captured with tensor hooks) and
-the masks of get_vis_mask.  No reference source text is stored; the reference never travels to the GPU box.
+the masks of get_vis_mask.  driver_helpers.npz holds, captured the same way, the submap bookkeeping functions
+(quantize_selected_time_idx, concat_keyframes_params_base_frame, concat_global, update_params_ls, update_variables_ls,
+:884-1020) and the reference's own pieces of compute_point2plane_dist (get_pointcloud, the frustum mask, trans_normal_c2w,
+:1070-1155).  No reference source text is stored; the reference never travels to the GPU box.
 """
 import importlib.util
 import os
