@@ -30,7 +30,7 @@ __global__ void composite_forward_px(CamScalars, const float*, uint32_t, const u
 template <bool DUAL>
 __global__ void composite_forward_q(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*,
                                     const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*,
-                                    float*, int, const unsigned long long*, const uint32_t*, uint32_t*);
+                                    float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs);
 __global__ void composite_backward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                    const uint32_t*, const GeomRec*, const float*, const float*, const float*,
                                    const float*, float*, const Counters*);
@@ -178,7 +178,7 @@ int vtgs_get_option(const char* name) {
 static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs, int rows16, const WsLayout& L,
                                     char* ws, const float* colors, float* out_color, float* out_depth,
                                     float* image_state, hipStream_t st, const float* colors_b = nullptr,
-                                    float* out_color_b = nullptr, int sort_mode = 0) {
+                                    float* out_color_b = nullptr, int sort_mode = 0, FinalizeArgs fin = FinalizeArgs{}) {
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   const uint32_t nblk = (uint32_t)(gx16 * rows16);
   const int impl = option(OPT_FWD_IMPL);                     // 2 = lane-per-pixel matrix-core kernel (default), 1 = pixel x splat-quad
@@ -190,13 +190,13 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (uint32_t*)(ws + L.sorted_gid),
                          (const GeomRec*)(ws + L.geom), colors, out_color, (float*)nullptr, image_state,
                          (const Counters*)(ws + L.counters), colors_b, out_color_b, sort_mode,
-                         (const unsigned long long*)(ws + L.keys), (const uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_inst));
+                         (const unsigned long long*)(ws + L.keys), (const uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_inst), fin);
     else if (impl == 3)
       hipLaunchKernelGGL((composite_forward_q<false>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (uint32_t*)(ws + L.sorted_gid),
                          (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
                          (const Counters*)(ws + L.counters), (const float*)nullptr, (float*)nullptr, sort_mode,
-                         (const unsigned long long*)(ws + L.keys), (const uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_inst));
+                         (const unsigned long long*)(ws + L.keys), (const uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_inst), fin);
     else if (colors_b && impl != 1)
       hipLaunchKernelGGL((composite_forward_px<4, true>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
@@ -301,17 +301,24 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
     if (hipHostGetDevicePointer(&dp, info, 0) == hipSuccess) host_record = (VtgsForwardInfo*)dp;
     else (void)hipGetLastError();                               // not mapped: fall back to the copy below
   }
-  { ProfScope ps__("finalize_forward", st); hipLaunchKernelGGL(finalize_forward, dim3(1), dim3(1024), 0, st, (const uint32_t*)(ws + L.tile_cnt), L.tiles8, ctr,
-                     (unsigned long long)instance_capacity, L.tile_cap, (const BlockStats*)(ws + L.block_stats),
-                     (uint32_t)((n + 1023) / 1024), host_record); }
-  VTGS_HIP(hipGetLastError());
-
   const uint32_t gx8 = (uint32_t)((cam->image_width + kSubTile - 1) / kSubTile);
   const uint32_t band_first = (uint32_t)r8b * gx8, band_tiles = (uint32_t)(r8e - r8b) * gx8;
   const int packed = (n <= (1 << 21) && option(OPT_SORT_PACKED) == 1) ? 1 : 0;
   // The quadrant-queue forward sorts its own tile's list when no bin can hold more than the 1024 entries one wavefront
-  // takes (VTGS_SORT_FUSED, default 1): no sort launch at all.
+  // takes (VTGS_SORT_FUSED, default 1), and its first workgroup does finalize_forward's job: nothing is launched between
+  // the binning and the composite.
   const bool fused_sort = option(OPT_FWD_IMPL) == 3 && option(OPT_SORT_FUSED) == 1 && L.tile_cap <= 1024u;
+  FinalizeArgs fin;
+  fin.tile_cnt = (const uint32_t*)(ws + L.tile_cnt); fin.tiles = L.tiles8; fin.ctr = ctr;
+  fin.capacity = (unsigned long long)instance_capacity; fin.tile_cap = L.tile_cap;
+  fin.block_stats = (const BlockStats*)(ws + L.block_stats); fin.nblocks = (uint32_t)((n + 1023) / 1024);
+  fin.host_record = host_record;
+  if (!fused_sort) {
+    ProfScope ps__("finalize_forward", st);
+    hipLaunchKernelGGL(finalize_forward, dim3(1), dim3(1024), 0, st, fin.tile_cnt, fin.tiles, ctr, fin.capacity, fin.tile_cap,
+                       fin.block_stats, fin.nblocks, host_record);
+  }
+  VTGS_HIP(hipGetLastError());
   if (!fused_sort) {
     ProfScope ps__("sort_tiles", st);
     // lists cannot be longer than the bin capacity: the wide (32 keys per lane) form is only worth its registers beyond 1024
@@ -327,7 +334,7 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   VTGS_HIP(hipGetLastError());
   int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st,
                                     dual ? colors_b : nullptr, dual ? out_color_b : nullptr,
-                                    fused_sort ? (packed ? 1 : 2) : 0);
+                                    fused_sort ? (packed ? 1 : 2) : 0, fin);
   if (rc != VTGS_OK) return rc;
   // result record: assembled on the device by finalize_forward at byte 64 of the counters block
   static_assert(sizeof(VtgsForwardInfo) == 40, "VtgsForwardInfo layout is mirrored in Counters");

@@ -361,42 +361,13 @@ template __global__ void project_and_bin<false>(CamScalars, const float*, const 
 template __global__ void project_and_bin<true>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
 
 // One workgroup right after the binning: longest tile list, statistics, overflow flags and the image of the
-// host-visible VtgsForwardInfo.
+// host-visible VtgsForwardInfo (finalize_block, vtgs_internal.h; the quadrant-queue forward runs it in its first workgroup
+// instead when it also sorts the lists -- then nothing is launched between the binning and the composite).
 __global__ __launch_bounds__(1024) void finalize_forward(const uint32_t* __restrict__ tile_cnt, uint32_t tiles,
                                                          Counters* __restrict__ ctr, unsigned long long capacity,
                                                          uint32_t tile_cap, const BlockStats* __restrict__ block_stats,
                                                          uint32_t nblocks, VtgsForwardInfo* host_record) {
-  __shared__ uint32_t wmax[16], svis[16];
-  __shared__ unsigned long long sr16[16];
-  const uint32_t t = threadIdx.x;
-  uint32_t mx = 0;
-  for (uint32_t i = t; i < tiles; i += 1024u) mx = max(mx, tile_cnt[i]);
-  mx = (uint32_t)wave_max_i((int)mx);
-  uint32_t vis = 0; unsigned long long r16 = 0;
-  for (uint32_t i = t; i < nblocks; i += 1024u) { vis += block_stats[i].visible; r16 += block_stats[i].r16; }
-  for (int m = 1; m < 64; m <<= 1) {
-    vis += (uint32_t)__shfl_xor((int)vis, m, 64);
-    r16 += (unsigned long long)__shfl_xor((long long)r16, m, 64);
-  }
-  if ((t & 63u) == 0) { wmax[t >> 6] = mx; svis[t >> 6] = vis; sr16[t >> 6] = r16; }
-  __syncthreads();
-  if (t == 0) {
-    uint32_t m = 0, v = 0; unsigned long long r = 0;
-    for (int i = 0; i < 16; ++i) { m = max(m, wmax[i]); v += svis[i]; r += sr16[i]; }
-    const uint32_t total = ctr->inst_total;
-    const uint32_t ovf = (((unsigned long long)total > capacity) ? 1u : 0u) | ((m > tile_cap) ? 2u : 0u);
-    ctr->overflow = ovf;
-    ctr->info_instances = ovf ? 0ull : (unsigned long long)total;
-    ctr->info_needed = total; ctr->info_r16 = r;
-    ctr->info_visible = v; ctr->info_max_list = m; ctr->info_overflow = ovf; ctr->info_complete = 1u;
-    if (host_record) {                         // asynchronous mode: the caller's pinned record, device-addressable
-      host_record->instances = ovf ? 0ull : (unsigned long long)total;
-      host_record->instances_needed = total; host_record->tiles16_touched = r;
-      host_record->visible = v; host_record->max_tile_list = m; host_record->overflow = ovf;
-      __threadfence_system();
-      host_record->complete = 1u;              // last: the host treats the record as landed once this is set
-    }
-  }
+  finalize_block<1024>(tile_cnt, tiles, ctr, capacity, tile_cap, block_stats, nblocks, host_record);
 }
 
 __device__ __forceinline__ void order_pair(unsigned long long* k, uint32_t* v, uint32_t i, uint32_t p) {

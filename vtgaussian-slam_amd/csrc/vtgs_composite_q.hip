@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
     const Counters* __restrict__ ctr, const float* __restrict__ colors_b, float* __restrict__ out_color_b,
     int sort_mode, const unsigned long long* __restrict__ bin_keys, const uint32_t* __restrict__ bin_vals,
-    uint32_t* sorted_inst) {
+    uint32_t* sorted_inst, FinalizeArgs fin) {
   // per wavefront: the table of the ring's entries (+ one dummy slot) and the four queues of table slots.  Queue bytes are
   // stored twice, 128 apart, so a pop reads [head & 127, head & 127 + 16) without wrapping.
   __shared__ float4 lds_ka[4][kQRing + 1];                      // K0..K3
@@ -211,7 +211,17 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
   __shared__ float4 lds_pa[4][kQRing + 1];                      // c0 c1 c2 depth   (dual: c0 c1 c2 c3)
   __shared__ float4 lds_pb[DUAL ? 4 : 1][DUAL ? kQRing + 1 : 1];//                   (dual: c4 c5 0 0)
   __shared__ uint8_t lds_q[4][4][2 * kQRing];
-  if (ctr->overflow) return;                                    // bins hold unwritten slots after an overflow
+  if (sort_mode) {
+    // Nothing ran between the binning and this kernel: the first workgroup does what finalize_forward does (longest list,
+    // statistics, overflow flags, the host's record -- it is dispatched first, so the record still leaves early), and
+    // every wavefront decides for itself whether its bin is safe to read: slots below min(count, capacity) are all
+    // written unless the INSTANCE capacity overflowed (then an entry may have been dropped after its slot was taken).
+    if (blockIdx.x == 0u) finalize_block<256>(fin.tile_cnt, fin.tiles, fin.ctr, fin.capacity, fin.tile_cap, fin.block_stats,
+                                              fin.nblocks, fin.host_record);
+    if ((unsigned long long)ctr->inst_total > fin.capacity) return;
+  } else if (ctr->overflow) {
+    return;                                                     // bins hold unwritten slots after an overflow
+  }
   const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
   const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
   const QuadCoord qc = quad_coord(cs, nblk, gx16, gx8, gy8);
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     final_T[pix] = T;
   }
 }
-template __global__ void composite_forward_q<false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*, int, const unsigned long long*, const uint32_t*, uint32_t*);
-template __global__ void composite_forward_q<true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*, int, const unsigned long long*, const uint32_t*, uint32_t*);
+template __global__ void composite_forward_q<false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs);
+template __global__ void composite_forward_q<true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs);
 
 }  // namespace vtgs

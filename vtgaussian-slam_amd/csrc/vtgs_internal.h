@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "vtgs_math.h"
+#include "../../include/vtgs.h"
 
 namespace vtgs {
 
@@ -142,6 +143,51 @@ __device__ __forceinline__ uint32_t xcd_swizzle(uint32_t bid, uint32_t nblk) {
   return xcd * q + (xcd < r ? xcd : r) + idx;
 }
 #endif  // __HIPCC__
+
+// ---- what follows the binning: longest list, statistics, overflow flags, the host-visible record -------------------------
+// Run by ONE workgroup of THREADS threads (all of them call it: it contains a barrier).
+struct FinalizeArgs {
+  const uint32_t* tile_cnt; uint32_t tiles; Counters* ctr; unsigned long long capacity; uint32_t tile_cap;
+  const BlockStats* block_stats; uint32_t nblocks; VtgsForwardInfo* host_record;
+};
+template <int THREADS>
+__device__ __forceinline__ void finalize_block(const uint32_t* __restrict__ tile_cnt, uint32_t tiles, Counters* __restrict__ ctr,
+                                               unsigned long long capacity, uint32_t tile_cap,
+                                               const BlockStats* __restrict__ block_stats, uint32_t nblocks,
+                                               VtgsForwardInfo* host_record) {
+  constexpr int kW = THREADS / 64;
+  __shared__ uint32_t wmax[kW], svis[kW];
+  __shared__ unsigned long long sr16[kW];
+  const uint32_t t = threadIdx.x;
+  uint32_t mx = 0;
+  for (uint32_t i = t; i < tiles; i += (uint32_t)THREADS) mx = max(mx, tile_cnt[i]);
+  mx = (uint32_t)wave_max_i((int)mx);
+  uint32_t vis = 0; unsigned long long r16 = 0;
+  for (uint32_t i = t; i < nblocks; i += (uint32_t)THREADS) { vis += block_stats[i].visible; r16 += block_stats[i].r16; }
+  for (int m = 1; m < 64; m <<= 1) {
+    vis += (uint32_t)__shfl_xor((int)vis, m, 64);
+    r16 += (unsigned long long)__shfl_xor((long long)r16, m, 64);
+  }
+  if ((t & 63u) == 0) { wmax[t >> 6] = mx; svis[t >> 6] = vis; sr16[t >> 6] = r16; }
+  __syncthreads();
+  if (t == 0) {
+    uint32_t m = 0, v = 0; unsigned long long r = 0;
+    for (int i = 0; i < kW; ++i) { m = max(m, wmax[i]); v += svis[i]; r += sr16[i]; }
+    const uint32_t total = ctr->inst_total;
+    const uint32_t ovf = (((unsigned long long)total > capacity) ? 1u : 0u) | ((m > tile_cap) ? 2u : 0u);
+    ctr->overflow = ovf;
+    ctr->info_instances = ovf ? 0ull : (unsigned long long)total;
+    ctr->info_needed = total; ctr->info_r16 = r;
+    ctr->info_visible = v; ctr->info_max_list = m; ctr->info_overflow = ovf; ctr->info_complete = 1u;
+    if (host_record) {                         // the caller's pinned record, device-addressable
+      host_record->instances = ovf ? 0ull : (unsigned long long)total;
+      host_record->instances_needed = total; host_record->tiles16_touched = r;
+      host_record->visible = v; host_record->max_tile_list = m; host_record->overflow = ovf;
+      __threadfence_system();
+      host_record->complete = 1u;              // last: the host treats the record as landed once this is set
+    }
+  }
+}
 
 // ---- pose transform of the fused caller chain (vtgs_frame.hip; also the epilogue of gather_splat_grads<.., FRAME>) --------
 struct FramePose { float R[9]; float t[3]; float zr[4]; };   // rotation from the normalised quaternion, translation, depth row
