@@ -178,8 +178,9 @@ def main():
         y0, y1 = tile_rows[0] * 16, min(tile_rows[1] * 16, H)
         p_rank, r_rank = W * (y1 - y0), int(r16 * (tile_rows[1] - tile_rows[0]) / gy16)
     alg = kernel_algorithmic_bytes(N, p_rank, r_rank)
-    if kern and "sort_tiles" not in kern:          # the forward composite sorted its own tile lists (no sort launch)
-        alg["composite_forward"] += alg.pop("sort_tiles")
+    for fused in ("sort_tiles", "finalize_forward"):    # done inside the forward composite (no launch of their own)
+        if kern and fused not in kern:
+            alg["composite_forward"] += alg.pop(fused)
     roofline = None
     if kern:
         dom = max(kern, key=lambda k: kern[k]["avg_us"])

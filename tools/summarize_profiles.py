@@ -40,8 +40,9 @@ alg = {"project_and_bin": 44 * N + 12 * R, "finalize_forward": 8 * R, "sort_tile
        "composite_forward": 12 * N + 4 * R + 16 * P, "composite_backward": 12 * N + 4 * R + 12 * P,
        "gather_splat_grads": 112 * N}
 f = pmc(find("pmc_fetch", "counter_collection.csv"), "FETCH_SIZE")
-if "sort_tiles" not in f:                    # the forward composite sorted its own tile lists (no sort launch)
-    alg["composite_forward"] += alg.pop("sort_tiles")
+for fused in ("sort_tiles", "finalize_forward"):      # done inside the forward composite (no launch of their own)
+    if fused not in f:
+        alg["composite_forward"] += alg.pop(fused)
 w = pmc(find("pmc_write", "counter_collection.csv"), "WRITE_SIZE")
 out = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 5 --warmup 2 "
                 "--no-cpu-baseline`; traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE "
