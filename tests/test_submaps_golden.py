@@ -64,3 +64,32 @@ def test_concat_split_equal_the_reference(fx):
         for v in d.values():
             if isinstance(v, torch.Tensor):
                 assert not v.requires_grad and v._base is None and v.device.type == "cpu"
+
+
+@pytest.mark.gpu
+def test_resident_submaps_on_the_device(fx):
+    """The same bookkeeping with the submaps resident on the GPU: values equal the reference's (which went through the host),
+    nothing leaves the device, and keep_resident accounts the bytes to the device."""
+    dev = torch.device("cuda:0")
+    params_ls, variables_ls = _lists(fx)
+    params_ls = [{k: v.to(dev) for k, v in d.items()} for d in params_ls]
+    variables_ls = [{k: v.to(dev) for k, v in d.items()} for d in variables_ls]
+    sel, nfe = fx["selected_time_idx"].tolist(), int(fx["num_frames_each_base_frame"])
+    cat_p, cat_v, num_gs = submaps.concat_keyframes_params_base_frame(params_ls, variables_ls, sel, nfe)
+    assert num_gs == fx["cat_num_gs"].tolist()
+    for k in KEYS5 + ["cam_unnorm_rots", "cam_trans"]:
+        assert cat_p[k].is_cuda and cat_p[k].requires_grad
+        assert np.array_equal(cat_p[k].detach().cpu().numpy(), fx["cat_p_" + k]), k
+    new_p = {k: v.detach() + 0.5 for k, v in cat_p.items()}
+    new_v = {k: (v.detach() * 2.0 if isinstance(v, torch.Tensor) else v) for k, v in cat_v.items()}
+    upd_p = submaps.update_params_ls([dict(x) for x in params_ls], sel, new_p, list(num_gs), nfe)
+    upd_v = submaps.update_variables_ls([dict(x) for x in variables_ls], sel, new_v, list(num_gs), nfe)
+    for i in range(4):
+        for k in KEYS5:
+            assert np.array_equal(upd_p[i][k].cpu().numpy(), fx[f"upd{i}_{k}"]), (i, k)
+    on_dev, on_host = submaps.keep_resident(upd_p, upd_v)
+    assert on_dev > 0 and on_host == 0
+    for d in upd_p + upd_v:
+        for v in d.values():
+            if isinstance(v, torch.Tensor):
+                assert v.is_cuda and not v.requires_grad and v._base is None
