@@ -47,7 +47,12 @@ def main():
     ap.add_argument("--shared-geometry", action="store_true", help="depth/silhouette pass reuses the RGB pass's binning (8f-2)")
     ap.add_argument("--fused", action="store_true", help="fused pose transform + render variables + both renders (8f-1), "
                                                          "loss kernels, threshold sweep and one-launch Adam (8f-3)")
+    ap.add_argument("--get-loss", action="store_true", help="drive both loops through diff_gaussian_rasterization.get_loss."
+                                                            "get_loss, the function with the reference's own signature "
+                                                            "(implies --fused): what a one-import swap in the driver gives")
     args = ap.parse_args()
+    if args.get_loss:
+        args.fused = True
     assert torch.cuda.is_available(), "bench_slam.py needs an MI355X"
     dev = torch.device("cuda", 0)
 
@@ -127,6 +132,15 @@ def main():
     map_lrs = dict(means3D=0.0, rgb_colors=0.0025, unnorm_rotations=0.0, logit_opacities=0.05, log_scales=0.005,
                    cam_unnorm_rots=1e-8, cam_trans=1e-7)
 
+    mirror_get_loss = None
+    variables = {"max_2D_radius": torch.zeros(N, device=dev), "means2D_gradient_accum": torch.zeros(N, device=dev),
+                 "denom": torch.zeros(N, device=dev)}
+    if args.get_loss:
+        from diff_gaussian_rasterization.get_loss import get_loss as mirror_get_loss
+
+    def curr_data(t):                             # what the driver hands to get_loss for frame t (tracking_curr_data / iter_data of the driver)
+        return {"cam": settings, "im": gts[t][0], "depth": gts[t][1], "id": t, "w2c": first_w2c}
+
     def pose_error(t):
         with torch.no_grad():
             dt = (params["cam_trans"][0, :, t] - gt_trans[0, :, t]).norm().item() * 100          # cm
@@ -157,11 +171,18 @@ def main():
         opt = make_adam([{"params": [v], "name": k, "lr": track_lrs[k]} for k, v in params.items()])
         torch.cuda.synchronize(); t0 = time.perf_counter()
         sil_thres, best = 0.99, (float("inf"), None, None)
+        mse_ls, thr_ls = [], []
         for it in range(args.tracking_iters):
-            im, depth_sil, _ = render_pair(params, t, gaussians_grad=False, camera_grad=True)
-            if it == 0:
-                sil_thres = pick_threshold(im, depth_sil[1], gt_im, gt_depth)
-            loss = track_loss(im, depth_sil, gt_im, gt_depth, sil_thres)
+            if args.get_loss:                      # the call of src/vtgaussian_slam.py:1803-1806, argument for argument
+                loss, variables, _losses, mse_ls, thr_ls = mirror_get_loss(
+                    params, curr_data(t), variables, t, {"im": 0.5, "depth": 0.025}, True, 0.99, True, False, tracking=True,
+                    plot_dir=None, visualize_tracking_loss=False, tracking_iteration=it, dataset_name="replica",
+                    presence_sil_mask_mse_ls=mse_ls, sil_thres_ls=thr_ls)
+            else:
+                im, depth_sil, _ = render_pair(params, t, gaussians_grad=False, camera_grad=True)
+                if it == 0:
+                    sil_thres = pick_threshold(im, depth_sil[1], gt_im, gt_depth)
+                loss = track_loss(im, depth_sil, gt_im, gt_depth, sil_thres)
             loss.backward()
             with torch.no_grad():
                 lv = loss.detach()
@@ -175,8 +196,12 @@ def main():
         opt = make_adam([{"params": [v], "name": k, "lr": map_lrs[k]} for k, v in params.items()], lr=0.0, eps=1e-15)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for it in range(args.mapping_iters):
-            im, depth_sil, _ = render_pair(params, t, gaussians_grad=True, camera_grad=False)
-            loss = map_loss(im, depth_sil, gt_im, gt_depth)
+            if args.get_loss:                      # (the mapping loops call it the same way, without the threshold lists)
+                loss, variables, _losses = mirror_get_loss(params, curr_data(t), variables, t, {"im": 1.0, "depth": 1.0}, False,
+                                                           0.99, True, False, mapping=True, dataset_name="replica")
+            else:
+                im, depth_sil, _ = render_pair(params, t, gaussians_grad=True, camera_grad=False)
+                loss = map_loss(im, depth_sil, gt_im, gt_depth)
             loss.backward()
             opt.step(); opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize(); map_ms.append((time.perf_counter() - t0) * 1e3 / args.mapping_iters)
@@ -191,7 +216,8 @@ def main():
         "data": "synthetic", "dtype": "f32",
         "config": {"workload": f"view-tied submap N={N}, {W}x{H}; {args.tracking_iters} tracking + {args.mapping_iters} "
                                f"mapping iterations per frame, 2 renders fwd+bwd per iteration (configs/replica/room0.py)",
-                   "frames": args.frames, "shared_geometry": bool(args.shared_geometry or args.fused), "fused_callers": bool(args.fused)},
+                   "frames": args.frames, "shared_geometry": bool(args.shared_geometry or args.fused), "fused_callers": bool(args.fused),
+                   "through_get_loss_mirror": bool(args.get_loss)},
         "tracking_ms_per_iter": round(sum(track_ms) / len(track_ms), 3),
         "mapping_ms_per_iter": round(sum(map_ms) / len(map_ms), 3),
         "pose_error_before_tracking_cm_deg": [[round(a, 3), round(b, 4)] for a, b in errs_before],

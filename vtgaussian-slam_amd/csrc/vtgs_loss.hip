@@ -297,10 +297,10 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     const float s_im = red[0][0] + red[1][0] + red[2][0] + red[3][0], s_d = red[0][1] + red[1][1] + red[2][1] + red[3][1];
     const float cnt = red[0][2] + red[1][2] + red[2][2] + red[3][2];
     const float ssim = (red[0][3] + red[1][3] + red[2][3] + red[3][3]) / numel_im;
-    float loss;
-    if (mode == 0) loss = w_im * s_im + w_depth * s_d;                                   // tracking: masked SUMS
-    else loss = w_im * (l1_coef * s_im / numel_im + 0.2f * (1.f - ssim)) + w_depth * s_d / cnt;   // mapping: means + SSIM
-    out[0] = loss; out[1] = cnt; out[2] = s_im; out[3] = s_d; out[4] = ssim;
+    // the two weighted terms the reference's get_loss reports beside their sum (weighted_losses['im'], ['depth'])
+    const float t_im = (mode == 0) ? w_im * s_im : w_im * (l1_coef * s_im / numel_im + 0.2f * (1.f - ssim));
+    const float t_d = (mode == 0) ? w_depth * s_d : w_depth * s_d / cnt;                   // tracking: masked SUMS, mapping: means
+    out[0] = t_im + t_d; out[1] = cnt; out[2] = s_im; out[3] = s_d; out[4] = ssim; out[5] = t_im; out[6] = t_d; out[7] = 0.f;
   }
 }
 

@@ -116,7 +116,7 @@ class _SlamLoss(torch.autograd.Function):
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         scratch = torch.empty(int(_lib.vtgs_loss_scratch_floats(H, W)), dtype=torch.float32, device=a.device)
         gmaps = torch.empty((3, 3, H, W), dtype=torch.float32, device=a.device) if (mode == 1 and need) else None
-        out = torch.empty(5, dtype=torch.float32, device=a.device)
+        out = torch.empty(8, dtype=torch.float32, device=a.device)
         _check(_lib.vtgs_slam_loss_forward(mode, a.data_ptr(), d.data_ptr(), ga.data_ptr(), gd.data_ptr(), H, W,
                                            float(sil_thres), float(w_im), float(w_depth), scratch.data_ptr(),
                                            None if gmaps is None else gmaps.data_ptr(), out.data_ptr(),
@@ -127,7 +127,8 @@ class _SlamLoss(torch.autograd.Function):
         ctx.cfg = (mode, float(sil_thres), float(w_im), float(w_depth), need, gmaps is not None)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(out)
-        return out[0], out              # out = {loss, mask count, sum |gt_im - im| (weighted), sum |gt_depth - depth|, mean SSIM}
+        return out[0], out              # out = {loss, mask count, sum |gt_im - im| (weighted), sum |gt_depth - depth|, mean SSIM,
+                                        #        weighted colour term, weighted depth term, 0}
 
     @staticmethod
     def backward(ctx, g, _g_terms=None):
@@ -153,7 +154,8 @@ def tracking_loss(im, depth_sil, gt_im, gt_depth, sil_thres: float, w_im: float 
     SUM of depth over gt_depth > 0 & finite & silhouette > sil_thres [& extra_mask].  `extra_mask` [H,W] / [1,H,W]
     (bool or float, detached) carries the masks of the TUM / ScanNet / ScanNet++ branches -- build it with
     `visibility_mask`, `far_depth_mask`, `outlier_depth_mask` below and AND them together.
-    return_terms: also the detached device vector {loss, mask count, colour sum, depth sum, -}."""
+    return_terms: also the detached device vector {loss, mask count, colour sum, depth sum, -, w_im * colour term,
+    w_depth * depth term, 0}."""
     loss, terms = _SlamLoss.apply(im, depth_sil, gt_im, gt_depth, 0, sil_thres, w_im, w_depth, extra_mask, None)
     return (loss, terms) if return_terms else loss
 
