@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VTGS_ABI_VERSION 10
+#define VTGS_ABI_VERSION 11
 
 typedef enum VtgsStatus {
   VTGS_OK = 0,
@@ -98,7 +98,8 @@ uint32_t    vtgs_abi_version(void);
  * splat-quad form; 0 = scalar kernels), "VTGS_BIN_IMPL" (1 = LDS-binned slot
  * reservation where the tile table fits, 0 = global atomics), "VTGS_SORT_PACKED" (1 = payload in the key's low bits for
  * N <= 2^21), "VTGS_SORT_FUSED" (1 = the quadrant-queue forward sorts its own tile's list when tile_capacity <= 1024,
- * no sort launch).  Defaults come from the environment variables of the same names, read ONCE at first use.
+ * no sort launch), "VTGS_COUNT_STEPS" (1 = the quadrant-queue forward counts its steps, see vtgs_debug_layout;
+ * measurement only).  Defaults come from the environment variables of the same names, read ONCE at first use.
  * vtgs_set_option returns VTGS_ERR_INVALID_ARGUMENT for an unknown name; value < 0 restores the default.           */
 int         vtgs_set_option(const char* name, int value);
 int         vtgs_get_option(const char* name);   /* current value, or -1 for an unknown name */
@@ -338,9 +339,11 @@ int vtgs_profile_collect(VtgsProfileEntry* out, int32_t max_entries, int32_t* n_
  * out[0..7] = counters, geom (N x 8 f32: u v A B C opacity depth pad), gaux (N x {first instance, count}),
  * tile_counts (tiles8 x u32), sorted_gid (tiles8 x tile_capacity x u32), sorted_inst (same), final_T (P x f32),
  * tiles8 (count, not an offset).  8x8 tiles are numbered row-major over ceil(W/8) x ceil(H/8); tile t owns
- * entries [t * tile_capacity, t * tile_capacity + count[t]).                                             */
+ * entries [t * tile_capacity, t * tile_capacity + count[t]).  out[8] = quadrant masks (tiles8 x tile_capacity x u8, bit q =
+ * the entry's alpha >= 1/255 box reaches 4x4 quadrant q of its tile; written by the default forward), out[9] = 64 x u32
+ * partial sums of the forward's queue steps (only with option VTGS_COUNT_STEPS = 1).                       */
 int vtgs_debug_layout(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity, uint32_t tile_capacity,
-                      uint64_t out[8]);
+                      uint64_t out[10]);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_version_strings_and_sizes(lib):
     lib.vtgs_abi_version.restype = ctypes.c_uint32
-    assert lib.vtgs_abi_version() == 10
+    assert lib.vtgs_abi_version() == 11
     lib.vtgs_strerror.restype = ctypes.c_char_p
     assert lib.vtgs_strerror(0) == b"ok" and b"instance" in lib.vtgs_strerror(3)
     lib.vtgs_workspace_bytes.restype = ctypes.c_size_t
@@ -54,7 +54,7 @@ def test_version_strings_and_sizes(lib):
 def test_invalid_arguments_are_rejected_before_any_device_work(lib):
     assert lib.vtgs_forward(None, 0, *([None] * 9), ctypes.c_size_t(0), ctypes.c_uint64(1), 64, None, 0, None) == 1
     assert lib.vtgs_mark_visible(None, 0, None, None, None) == 1
-    out = (ctypes.c_uint64 * 8)()
+    out = (ctypes.c_uint64 * 10)()
     lib.vtgs_debug_layout.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
     assert lib.vtgs_debug_layout(5, 33, 17, 64, 32, out) == 0
     assert out[7] == 5 * 3 and out[3] == 256            # ceil(33/8) x ceil(17/8) tiles; tile_cnt right after counters
@@ -109,7 +109,7 @@ def test_option_api_without_a_gpu(lib):
     rejected (no HIP call involved)."""
     lib.vtgs_set_option.restype, lib.vtgs_set_option.argtypes = ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]
     lib.vtgs_get_option.restype, lib.vtgs_get_option.argtypes = ctypes.c_int, [ctypes.c_char_p]
-    for name in (b"VTGS_FWD_IMPL", b"VTGS_BWD_IMPL", b"VTGS_BIN_IMPL", b"VTGS_SORT_PACKED", b"VTGS_SORT_FUSED"):
+    for name in (b"VTGS_FWD_IMPL", b"VTGS_BWD_IMPL", b"VTGS_BIN_IMPL", b"VTGS_SORT_PACKED", b"VTGS_SORT_FUSED", b"VTGS_COUNT_STEPS"):
         dflt = lib.vtgs_get_option(name)
         assert dflt >= 0
         assert lib.vtgs_set_option(name, 0) == 0 and lib.vtgs_get_option(name) == 0
@@ -131,4 +131,4 @@ def test_header_is_plain_c99_and_links(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src),
                     "-L", lib_dir, "-lvtgs", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert out[0] == "10"
+    assert out[0] == "11"

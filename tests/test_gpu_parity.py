@@ -566,6 +566,89 @@ def _quadrant_scenes():
         yield f"odd{seed}", (scene, cam)
 
 
+def _central_cross_scene(seed=0, W=16, H=16, n_faint=900, n_norm=500):
+    """Sub-pixel, faint splats (sigma = the 0.55 px dilation floor, opacity 0.4-0.6 %) whose alpha >= 1/255 box lies in the
+    gap between the pixel centres of two 4x4 quadrants -- on the central cross of their 8x8 tile -- so that they are binned
+    into the tile (its continuous pixel-centre rectangle contains them) but reach NO quadrant queue, mixed in depth with
+    ordinary splats.  Tile lists of several hundred entries: the table ring of composite_forward_q is reused many times."""
+    g = torch.Generator().manual_seed(seed)
+    fx = fy = W / 2.0
+    cx, cy = W / 2.0 - 0.5, H / 2.0 - 0.5
+    cam = go.setup_camera(W, H, [[fx, 0, cx], [0, fy, cy], [0, 0, 1]], torch.eye(4))
+    gap = lambda n, size: (torch.randint(0, size // 8, (n,), generator=g) * 8 + 3.4 + 0.2 * torch.rand(n, generator=g))
+    half = n_faint // 2
+    xs = torch.cat([gap(half, W), torch.rand(n_faint - half, generator=g) * (W - 1), torch.rand(n_norm, generator=g) * (W - 1)])
+    ys = torch.cat([torch.rand(half, generator=g) * (H - 1), gap(n_faint - half, H), torch.rand(n_norm, generator=g) * (H - 1)])
+    n = n_faint + n_norm
+    zz = 1.0 + 4.0 * torch.rand(n, generator=g)
+    scale = torch.cat([torch.full((n_faint,), 1e-3), 0.6 + 0.8 * torch.rand(n_norm, generator=g)]) * zz / fx
+    op = torch.cat([0.004 + 0.002 * torch.rand(n_faint, generator=g), 0.05 + 0.6 * torch.rand(n_norm, generator=g)])
+    scene = {
+        "means3D": torch.stack([(xs - cx + 0.5) / fx * zz, (ys - cy + 0.5) / fy * zz, zz], dim=-1).contiguous(),
+        "means2D": torch.zeros(n, 3),
+        "opacities": op[:, None].contiguous(),
+        "colors_precomp": torch.rand(n, 3, generator=g),
+        "scales": scale[:, None].repeat(1, 3).contiguous(),
+        "rotations": torch.tensor([[1.0, 0.0, 0.0, 0.0]]).repeat(n, 1),
+    }
+    return scene, cam
+
+
+def test_quadrant_queue_ring_with_entries_that_reach_no_quadrant(gpu_device):
+    """list entries whose quadrant mask is 0 let every queue stay below 16 after an append; the
+    two-chunk ring of round 2 then overwrote table slots that queued entries still referenced.  The ring now retires a
+    chunk only when all four queues have popped its last entry.  Bit-identical to the lane = pixel kernel, and the scene
+    really contains such entries (checked on the quadrant masks the forward leaves in its workspace)."""
+    import diff_gaussian_rasterization as dgr
+    from parity_util import to_settings
+    for seed in range(3):
+        scene, cam = _central_cross_scene(seed)
+        g = torch.Generator().manual_seed(5)
+        grad_color = torch.rand(3, cam.image_height, cam.image_width, generator=g) * 2 - 1
+        _opt("VTGS_FWD_IMPL", 2)
+        ref = run_hip(scene, cam, gpu_device, grad_color)
+        _opt("VTGS_FWD_IMPL", 3)
+        got = run_hip(scene, cam, gpu_device, grad_color)
+        assert torch.equal(ref[0], got[0]), f"seed {seed}: colour differs, max {(ref[0] - got[0]).abs().max().item():.3e}"
+        assert torch.equal(ref[2], got[2]), seed
+        for k in GRAD_KEYS:
+            assert torch.equal(ref[3][k], got[3][k]), (seed, k)
+        rast = dgr.GaussianRasterizer(raster_settings=to_settings(cam, gpu_device))
+        with torch.no_grad():
+            rast(**{k: v.to(gpu_device) for k, v in scene.items()})
+        offs, _gid, _geom, qmask = dgr.debug_tile_lists(rast, with_qmask=True)
+        counts = offs[1:] - offs[:-1]
+        assert counts.max().item() > 192, "lists must wrap the 192-slot ring"
+        assert (qmask == 0).sum().item() > 100, "the scene must hold entries that reach no quadrant"
+
+
+def test_quadrant_queue_steps_per_tile(gpu_device):
+    """With three chunks queued every quadrant pops full groups of 16 until the list runs out: the step count of a tile is
+    the minimum its queue lengths allow, max_q ceil(len_q / 16), plus at most one partial step per quadrant's tail
+    (<= 8 steps per tile on the headline scene; here the same bound on a small dense scene, from the
+    masks the forward wrote)."""
+    import diff_gaussian_rasterization as dgr
+    from parity_util import to_settings
+    scene, cam = go.view_tied_scene(60000, 160, 96, seed=3)
+    dgr.set_option("VTGS_COUNT_STEPS", 1)
+    rast = dgr.GaussianRasterizer(raster_settings=to_settings(cam, gpu_device))
+    with torch.no_grad():
+        rast(**{k: v.to(gpu_device) for k, v in scene.items()})
+    steps = dgr.debug_forward_steps(rast)
+    offs, _gid, _geom, qmask = dgr.debug_tile_lists(rast, with_qmask=True)
+    tiles = offs.numel() - 1
+    ideal = 0
+    for t in range(tiles):
+        m = qmask[offs[t]:offs[t + 1]].long()
+        if m.numel():
+            ideal += max(int((((m >> q) & 1).sum().item() + 15) // 16) for q in range(4))
+    batches = int(((offs[1:] - offs[:-1] + 15) // 16).sum().item())
+    # not below the bound (no tile of this scene saturates); above it only where the quadrant that dominates changes along
+    # the list -- a quadrant cannot pop entries that the 192-slot ring has not reached yet
+    assert ideal <= steps <= 1.12 * ideal, (steps, ideal, batches)
+    assert steps < 0.62 * batches, (steps, batches)
+
+
 def test_quadrant_queue_forward_is_bit_identical(gpu_device):
     """composite_forward_q (per-quadrant splat queues, colour on the matrix cores) skips only pairs whose alpha is below
     1/255 in the whole 4x4 quadrant and keeps every k-ordered fmaf chain: colour, depth and the per-pixel final

@@ -30,7 +30,7 @@ __global__ void composite_forward_px(CamScalars, const float*, uint32_t, const u
 template <bool DUAL>
 __global__ void composite_forward_q(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*,
                                     const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*,
-                                    float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs);
+                                    float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs, uint8_t*, uint32_t*);
 __global__ void composite_backward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                    const uint32_t*, const GeomRec*, const float*, const float*, const float*,
                                    const float*, float*, const Counters*);
@@ -146,8 +146,8 @@ size_t vtgs_backward_dual_scratch_bytes(int32_t n, uint64_t instances) {
 // Implementation switches: defaults from the environment, read once; vtgs_set_option overrides them at run time.
 struct Option { const char* name; int dflt; int value; };
 static Option g_options[] = {{"VTGS_FWD_IMPL", 3, -1}, {"VTGS_BWD_IMPL", 2, -1}, {"VTGS_BIN_IMPL", 1, -1}, {"VTGS_SORT_PACKED", 1, -1},
-                             {"VTGS_SORT_FUSED", 1, -1}};
-enum { OPT_FWD_IMPL = 0, OPT_BWD_IMPL, OPT_BIN_IMPL, OPT_SORT_PACKED, OPT_SORT_FUSED, OPT_COUNT };
+                             {"VTGS_SORT_FUSED", 1, -1}, {"VTGS_COUNT_STEPS", 0, -1}};
+enum { OPT_FWD_IMPL = 0, OPT_BWD_IMPL, OPT_BIN_IMPL, OPT_SORT_PACKED, OPT_SORT_FUSED, OPT_COUNT_STEPS, OPT_COUNT };
 static bool g_options_ready = false;
 static void options_init() {
   if (g_options_ready) return;
@@ -178,8 +178,14 @@ int vtgs_get_option(const char* name) {
 static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs, int rows16, const WsLayout& L,
                                     char* ws, const float* colors, float* out_color, float* out_depth,
                                     float* image_state, hipStream_t st, const float* colors_b = nullptr,
-                                    float* out_color_b = nullptr, int sort_mode = 0, FinalizeArgs fin = FinalizeArgs{}) {
+                                    float* out_color_b = nullptr, int sort_mode = 0, FinalizeArgs fin = FinalizeArgs{},
+                                    bool write_qmask = false) {
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
+  uint32_t* steps = nullptr;                                 // measurement only: steps of the quadrant-queue forward, 64 partial sums
+  if (option(OPT_COUNT_STEPS) == 1 && write_qmask) {
+    steps = (uint32_t*)(ws + L.dbg);
+    VTGS_HIP(hipMemsetAsync(steps, 0, 256, st));
+  }
   const uint32_t nblk = (uint32_t)(gx16 * rows16);
   const int impl = option(OPT_FWD_IMPL);                     // 2 = lane-per-pixel matrix-core kernel (default), 1 = pixel x splat-quad
                                                            // matrix-core kernel, 0 = scalar kernel (read per call)
@@ -190,13 +196,15 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (uint32_t*)(ws + L.sorted_gid),
                          (const GeomRec*)(ws + L.geom), colors, out_color, (float*)nullptr, image_state,
                          (const Counters*)(ws + L.counters), colors_b, out_color_b, sort_mode,
-                         (const unsigned long long*)(ws + L.keys), (const uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_inst), fin);
+                         (const unsigned long long*)(ws + L.keys), (const uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_inst), fin,
+                         write_qmask ? (uint8_t*)(ws + L.qmask) : (uint8_t*)nullptr, steps);
     else if (impl == 3)
       hipLaunchKernelGGL((composite_forward_q<false>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (uint32_t*)(ws + L.sorted_gid),
                          (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
                          (const Counters*)(ws + L.counters), (const float*)nullptr, (float*)nullptr, sort_mode,
-                         (const unsigned long long*)(ws + L.keys), (const uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_inst), fin);
+                         (const unsigned long long*)(ws + L.keys), (const uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_inst), fin,
+                         write_qmask ? (uint8_t*)(ws + L.qmask) : (uint8_t*)nullptr, steps);
     else if (colors_b && impl != 1)
       hipLaunchKernelGGL((composite_forward_px<4, true>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
@@ -334,7 +342,7 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   VTGS_HIP(hipGetLastError());
   int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st,
                                     dual ? colors_b : nullptr, dual ? out_color_b : nullptr,
-                                    fused_sort ? (packed ? 1 : 2) : 0, fin);
+                                    fused_sort ? (packed ? 1 : 2) : 0, fin, true);
   if (rc != VTGS_OK) return rc;
   // result record: assembled on the device by finalize_forward at byte 64 of the counters block
   static_assert(sizeof(VtgsForwardInfo) == 40, "VtgsForwardInfo layout is mirrored in Counters");
@@ -572,11 +580,11 @@ int vtgs_profile_collect(VtgsProfileEntry* out, int32_t max_entries, int32_t* n_
 }
 
 int vtgs_debug_layout(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity, uint32_t tile_capacity,
-                      uint64_t out[8]) {
+                      uint64_t out[10]) {
   if (n < 0 || width <= 0 || height <= 0 || !out || tile_capacity == 0) return VTGS_ERR_INVALID_ARGUMENT;
   const WsLayout L = make_layout(n, width, height, instance_capacity, tile_capacity);
   out[0] = L.counters; out[1] = L.geom; out[2] = L.gaux; out[3] = L.tile_cnt; out[4] = L.sorted_gid;
-  out[5] = L.sorted_inst; out[6] = L.final_T; out[7] = L.tiles8;
+  out[5] = L.sorted_inst; out[6] = L.final_T; out[7] = L.tiles8; out[8] = L.qmask; out[9] = L.dbg;
   return VTGS_OK;
 }
 

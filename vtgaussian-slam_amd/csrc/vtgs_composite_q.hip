@@ -13,9 +13,12 @@
 //   * a STEP pops up to 16 entries from every queue: v_mfma_f32_4x4x1_16b_f32 with cbsz = 2 / abid = g multiplies, in each
 //     16-lane group, the four splats held by the group's lanes 4g..4g+3 with the group's own 16 pixels -- four MFMAs per
 //     rank-1 term give every lane its pixel x 16 splats OF ITS OWN QUADRANT (tests/micro/mfma_layout.hip checks the
-//     layout).  Steps run while some queue holds 16; what is left (< 16 per queue) waits for the next chunk and is always
-//     consumed by the first step after it (a step pops min(16, count) from EVERY queue), so a table ring of two chunks
-//     is enough;
+//     layout).  Up to three chunks are in flight: the loop appends chunks while the table ring has room and otherwise
+//     steps until every queue has popped the last entry of the OLDEST chunk, whose 64 table slots are then free again
+//     (an explicit invariant -- counted per quadrant and chunk -- not an argument about queue lengths: entries that
+//     reach no quadrant at all exist).  With three chunks queued, every quadrant pops full groups of 16 until the list
+//     runs out: 8.0 steps per tile on the headline scene, the minimum its queue lengths allow, against 9.7 when a step
+//     was taken as soon as ONE queue held 16 (profiles/r3_queue_policy.md);
 //   * colour accumulation is a rank-1 update per splat as well, C[ch][pixel] += c[ch][k] w[k][pixel], and runs on the
 //     same MFMA (A = the splat's four channels transposed onto the lanes of block g, B = the lane's w_k): no payload
 //     reads in the inner loop.  An exact-f32 MFMA is a k-ordered fmaf chain, and a skipped pair has w = 0 exactly, so
@@ -35,8 +38,12 @@
 
 namespace vtgs {
 
-constexpr int kQRing = 128;                 // table / queue ring: two 64-entry chunks
-constexpr int kQDummy = kQRing;             // table slot 128: a splat that reaches nothing (popped past the end of a queue)
+#ifndef VTGS_Q_CHUNKS
+#define VTGS_Q_CHUNKS 3
+#endif
+constexpr int kQChunks = VTGS_Q_CHUNKS;                 // 64-entry chunks of the tile's list in flight at once
+constexpr int kQRing = 64 * kQChunks;       // table / queue ring: 192 slots
+constexpr int kQDummy = kQRing;             // table slot 192: a splat that reaches nothing (popped past the end of a queue)
 
 struct QuadCoord { int tile, px, py, q, i; bool tile_ok, inside; };
 
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ final_T,
     const Counters* __restrict__ ctr, const float* __restrict__ colors_b, float* __restrict__ out_color_b,
     int sort_mode, const unsigned long long* __restrict__ bin_keys, const uint32_t* __restrict__ bin_vals,
-    uint32_t* sorted_inst, FinalizeArgs fin) {
+    uint32_t* sorted_inst, FinalizeArgs fin, uint8_t* __restrict__ qmask, uint32_t* __restrict__ step_counters) {
   // per wavefront: the table of the ring's entries (+ one dummy slot) and the four queues of table slots.  Queue bytes are
   // stored twice, 128 apart, so a pop reads [head & 127, head & 127 + 16) without wrapping.
   __shared__ float4 lds_ka[4][kQRing + 1];                      // K0..K3
@@ -271,17 +278,20 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
   kb[kQDummy] = make_float2(0.f, 0.f);
   pa[kQDummy] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (DUAL) pb[kQDummy] = make_float4(0.f, 0.f, 0.f, 0.f);
-  reinterpret_cast<uint32_t*>(lds_q[wv][0])[l] = 0u;            // 4 queues x 256 bytes = 256 dwords per wavefront
-  reinterpret_cast<uint32_t*>(lds_q[wv][0])[64 + l] = 0u;
-  reinterpret_cast<uint32_t*>(lds_q[wv][0])[128 + l] = 0u;
-  reinterpret_cast<uint32_t*>(lds_q[wv][0])[192 + l] = 0u;
+#pragma unroll
+  for (int k = 0; k < (4 * 2 * kQRing) / 256; ++k)               // 4 queues x 2 x 192 bytes = 384 dwords per wavefront
+    reinterpret_cast<uint32_t*>(lds_q[wv][0])[64 * k + l] = 0u;
 
   float T = 1.f;
   f32x4 C = {0.f, 0.f, 0.f, 0.f}, C2 = {0.f, 0.f, 0.f, 0.f};
   bool done = !qc.inside, exact = false;
-  int head_v = 0, cnt_v = 0;                                    // ring state of the lane's OWN queue (uniform per 16-lane group)
-  bool hot_prev = false, hot_cur = false;
-  uint32_t base = s, chunk = 0;
+  // Ring state of the lane's OWN queue (uniform per 16-lane group): head position 0..kQRing-1 and the number of queued
+  // entries by chunk in flight, oldest first.  A pop takes from the oldest chunk first (the queue is a FIFO in list order), so
+  // "c0 == 0 in every quadrant" says that nothing references the oldest chunk's 64 table slots any more.
+  int head_v = 0, c0 = 0, c1 = 0, c2 = 0;
+  bool hot0 = false, hot1 = false, hot2 = false;                // per chunk in flight: some splat may reach the 0.99 clamp
+  int inflight = 0;                                             // chunks in flight (wave-uniform)
+  uint32_t base = s, wslot = 0u, nsteps = 0u;                   // wslot: first table slot of the next chunk (0, 64, 128)
   // Two-deep software pipeline of the gather: while chunk c is composited the list entry of chunk c+2 and the geometry
   // record + colours of chunk c+1 are in flight (two dependent trips to L2 / Infinity Cache per chunk otherwise sit on the
   // wavefront's critical path: gather + compaction alone is 35 us of this kernel, profiles/r2_forward_ablation.md).
@@ -303,14 +313,13 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
   }
 
   for (;;) {
-    const bool full = __ballot(cnt_v >= 16) != 0ull;
-    if (!full && base < e) {
+    if (inflight < kQChunks && base < e) {
       // ---- append the next 64-entry chunk: gather, table, wavefront-ballot compaction into the four queues ----------
       if (__ballot(!done) == 0ull) break;
       const uint32_t pos = base + (uint32_t)l;
       const bool in = pos < e;
       const float4 g0 = g0n, g1 = g1n;                             // this chunk's data, requested one chunk ago
-      const int slot = (int)((chunk & 1u) << 6) + l;
+      const int slot = (int)wslot + l;
       {
         float K[6];
         tile_coefficients(g0, g1, cx, cy, K);
@@ -322,10 +331,11 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
       gid_cur = gid_nxt;
       gid_nxt = entry(base + 128u);
       fetch(gid_cur);                                               // next chunk's data: in flight during this chunk's steps
-      hot_prev = hot_cur;
-      hot_cur = __ballot(in && g1.y > kClampGuard) != 0ull;
+      const bool hot = __ballot(in && g1.y > kClampGuard) != 0ull;
       const uint32_t mask = in ? quadrant_mask(g0, g1, g0.x - cx, g0.y - cy) : 0u;
-      const int tail_v = head_v + cnt_v;
+      if (qmask && in) qmask[pos] = (uint8_t)mask;                  // kept for the backward (composite_backward_q)
+      const int tail_v = head_v + c0 + c1 + c2;
+      int add_v = 0;
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const bool in_q = (mask >> qq) & 1u;
@@ -333,25 +343,36 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
         const int tail = __builtin_amdgcn_readlane(tail_v, 16 * qq);
         if (in_q) {
-          const int p = (tail + rank) & (kQRing - 1);
+          int p = tail + rank;                                     // tail < 2 kQRing, rank < 64
+          p -= (p >= kQRing) ? kQRing : 0;
+          p -= (p >= kQRing) ? kQRing : 0;
           lds_q[wv][qq][p] = (uint8_t)slot;
           lds_q[wv][qq][p + kQRing] = (uint8_t)slot;
         }
         const int add = (int)__builtin_popcountll(bal);
-        cnt_v = (q == qq) ? cnt_v + add : cnt_v;
+        add_v = (q == qq) ? add : add_v;
       }
-      base += 64u; ++chunk;
+      if (inflight == 0) { c0 += add_v; hot0 = hot; }
+      else if (inflight == 1) { c1 += add_v; hot1 = hot; }
+      else { c2 += add_v; hot2 = hot; }
+      base += 64u; wslot = (wslot == (uint32_t)(kQRing - 64)) ? 0u : wslot + 64u; ++inflight;
 #if defined(VTGS_Q_ABL) && VTGS_Q_ABL == 1                                 // ablation: gather + compaction only, no steps
-      asm volatile("" :: "v"(cnt_v), "v"(mask));
-      head_v += cnt_v; cnt_v = 0;
+      asm volatile("" :: "v"(c0), "v"(mask));
+      head_v += c0 + c1 + c2; head_v -= (head_v >= kQRing) ? kQRing : 0; c0 = c1 = c2 = 0; inflight = 0;
 #endif
       continue;
     }
-    if (__ballot(cnt_v > 0) == 0ull) break;                       // list and queues exhausted
+    if (inflight == 0) break;                                     // list exhausted, every chunk retired
+    if (__ballot(c0 > 0) == 0ull) {                               // the oldest chunk is drained in all four queues: retire it
+      c0 = c1; c1 = c2; c2 = 0;
+      hot0 = hot1; hot1 = hot2; hot2 = false;
+      --inflight;
+      continue;
+    }
     if (__ballot(!done) == 0ull) break;                           // every pixel of the tile has ended
     // ---- one step: pop min(16, count) entries from every queue ---------------------------------------------------------
-    const int avail = min(16, cnt_v);
-    const int hm = head_v & (kQRing - 1);
+    const int avail = min(16, c0 + c1 + c2);
+    const int hm = head_v;
     int sl[5];
     sl[4] = (int)myq[hm + i];
 #pragma unroll
@@ -365,11 +386,19 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
       PT[j] = reinterpret_cast<const float*>(pa)[4 * sl[j] + (i & 3)];
       PT2[j] = DUAL ? reinterpret_cast<const float*>(pb)[4 * sl[j] + (i & 3)] : 0.f;
     }
-    head_v += avail; cnt_v -= avail;
+    head_v += avail; head_v -= (head_v >= kQRing) ? kQRing : 0;
+    {
+      int t = avail;
+      const int d0 = min(t, c0); c0 -= d0; t -= d0;
+      const int d1 = min(t, c1); c1 -= d1; t -= d1;
+      c2 -= t;
+    }
+    ++nsteps;
     if (exact) q_forward_step<DUAL, true, true>(T, done, exact, C, C2, ka, kb, sl[4], Phi, PT, PT2);
-    else if (hot_prev || hot_cur) q_forward_step<DUAL, true, false>(T, done, exact, C, C2, ka, kb, sl[4], Phi, PT, PT2);
+    else if (hot0 || hot1 || hot2) q_forward_step<DUAL, true, false>(T, done, exact, C, C2, ka, kb, sl[4], Phi, PT, PT2);
     else q_forward_step<DUAL, false, false>(T, done, exact, C, C2, ka, kb, sl[4], Phi, PT, PT2);
   }
+  if (step_counters && l == 0) atomicAdd(&step_counters[blockIdx.x & 63u], nsteps);   // measurement only (VTGS_COUNT_STEPS)
   if (qc.inside) {
     const size_t P = (size_t)cs.W * cs.H, pix = (size_t)qc.py * cs.W + qc.px;
     out_color[pix] = C[0] + T * bg[0];
@@ -385,7 +414,7 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     final_T[pix] = T;
   }
 }
-template __global__ void composite_forward_q<false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs);
-template __global__ void composite_forward_q<true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs);
+template __global__ void composite_forward_q<false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs, uint8_t*, uint32_t*);
+template __global__ void composite_forward_q<true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs, uint8_t*, uint32_t*);
 
 }  // namespace vtgs

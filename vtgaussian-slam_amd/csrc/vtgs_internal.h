@@ -21,6 +21,7 @@ namespace vtgs {
 //   sorted_gid   T8 x cap_t x 4   per-tile front-to-back Gaussian ids (tile t: [t*cap_t, t*cap_t + tile_cnt[t]))
 //   sorted_inst  T8 x cap_t x 4   per-tile instance ids (address of the per-instance gradient record)
 //   final_T      P x 4     per-pixel transmittance after the last contributor
+//   qmask        T8 x cap_t x 1   which 4x4 quadrants of its tile a sorted list entry can reach (quadrant-queue composites)
 // Every tile owns a fixed-capacity bin (cap_t, a caller hint like the instance capacity), so binning is one
 // pass: no prefix scan over tiles and no scatter pass.  finalize_forward raises the overflow flags right after the
 // binning (a dropped instance leaves an unwritten bin slot, so sort and composite bail on the flag) and the caller
@@ -52,7 +53,7 @@ constexpr int kGradRec = 10;       // floats per instance gradient record: 6 mom
 constexpr int kGradRecDual = 14;   // dual render: 6 moments + 6 colour sums + tile id + one pad word (56-byte stride, float2 access)
 
 struct WsLayout {
-  size_t counters, geom, gaux, block_stats, tile_cnt, keys, vals, sorted_gid, sorted_inst, final_T, total;
+  size_t counters, geom, gaux, block_stats, tile_cnt, keys, vals, sorted_gid, sorted_inst, final_T, qmask, dbg, total;
   uint32_t tiles8, tile_cap;
 };
 
@@ -76,6 +77,8 @@ inline WsLayout make_layout(int32_t n, int32_t w, int32_t h, uint64_t cap, uint3
   L.sorted_gid = o;  o += align256(slots * 4);
   L.sorted_inst = o; o += align256(slots * 4);
   L.final_T = o;     o += align256((size_t)w * h * 4);
+  L.qmask = o;       o += align256(slots);               // quadrant mask (4 bits) of every sorted list entry, written by composite_forward_q
+  L.dbg = o;         o += 256;                           // 64 step counters (measurement only, VTGS_COUNT_STEPS)
   L.total = o;
   return L;
 }

@@ -49,7 +49,7 @@ class _VtgsProfileEntry(ctypes.Structure):
 
 
 VTGS_OK, VTGS_ERR_INSTANCE_OVERFLOW = 0, 3
-ABI_VERSION = 10
+ABI_VERSION = 11
 VTGS_FORWARD_SYNC, VTGS_FORWARD_ASYNC, VTGS_FORWARD_CHECKED = 0, 1, 2
 _P, _U64, _I32, _SZ = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
 
@@ -91,7 +91,7 @@ def _load_library() -> ctypes.CDLL:
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError here == ABI mismatch, fail loudly
         fn.restype, fn.argtypes = res, args
-    if lib.vtgs_abi_version() != ABI_VERSION:
+    if lib.vtgs_abi_version() != ABI_VERSION and os.environ.get("VTGS_ABI_ANY") != "1":   # (A/B timing of older builds only)
         raise ImportError(f"libvtgs.so ABI {lib.vtgs_abi_version()} != expected {ABI_VERSION}; rebuild it")
     return lib
 
@@ -148,7 +148,7 @@ def profile_collect() -> dict:
     return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches) for i in range(n.value)}
 
 
-_OPTION_NAMES = ("VTGS_FWD_IMPL", "VTGS_BWD_IMPL", "VTGS_BIN_IMPL", "VTGS_SORT_PACKED", "VTGS_SORT_FUSED")
+_OPTION_NAMES = ("VTGS_FWD_IMPL", "VTGS_BWD_IMPL", "VTGS_BIN_IMPL", "VTGS_SORT_PACKED", "VTGS_SORT_FUSED", "VTGS_COUNT_STEPS")
 
 
 def set_option(name: str, value: int) -> None:
@@ -416,11 +416,12 @@ def _run_backward_dual(fs: _ForwardState, means3D, colors_a, colors_b, opacities
     return g_means3D, g_means2D, g_ca, g_opac, g_scales, g_rot, g_cb
 
 
-def debug_tile_lists(rasterizer: "GaussianRasterizer"):
+def debug_tile_lists(rasterizer: "GaussianRasterizer", with_qmask: bool = False):
     """Test hook: (tile_offsets [tiles8+1] int64, sorted_gid [R] int64, geom [N,8] float32) of the last forward
-    of `rasterizer`, copied to the CPU and compacted (tile t = sorted_gid[offsets[t]:offsets[t+1]]).  8x8 tiles, row-major."""
+    of `rasterizer`, copied to the CPU and compacted (tile t = sorted_gid[offsets[t]:offsets[t+1]]).  8x8 tiles, row-major.
+    with_qmask: a fourth value, the quadrant masks [R] uint8 the quadrant-queue forward wrote for the same entries."""
     fs = rasterizer._last_state
-    out = (ctypes.c_uint64 * 8)()
+    out = (ctypes.c_uint64 * 10)()
     _check(_lib.vtgs_debug_layout(fs.n, fs.cam.W, fs.cam.H, fs.capacity, fs.tile_cap, out), "vtgs_debug_layout")
     ws = fs.workspace
     tiles8, cap = int(out[7]), fs.tile_cap
@@ -431,7 +432,19 @@ def debug_tile_lists(rasterizer: "GaussianRasterizer"):
     offs = torch.zeros(tiles8 + 1, dtype=torch.long)
     offs[1:] = torch.cumsum(cnt, 0)
     geom = ws[int(out[1]): int(out[1]) + 32 * fs.n].view(torch.float32).reshape(fs.n, 8).cpu()
+    if with_qmask:
+        qm = ws[int(out[8]): int(out[8]) + tiles8 * cap].reshape(tiles8, cap).cpu()
+        return offs, gid, geom, qm[keep]
     return offs, gid, geom
+
+
+def debug_forward_steps(rasterizer: "GaussianRasterizer") -> int:
+    """Test / measurement hook: queue steps taken by the quadrant-queue forward of the last forward of `rasterizer`, summed
+    over its tiles (needs set_option("VTGS_COUNT_STEPS", 1) before that forward)."""
+    fs = rasterizer._last_state
+    out = (ctypes.c_uint64 * 10)()
+    _check(_lib.vtgs_debug_layout(fs.n, fs.cam.W, fs.cam.H, fs.capacity, fs.tile_cap, out), "vtgs_debug_layout")
+    return int(fs.workspace[int(out[9]): int(out[9]) + 256].view(torch.int32).sum().item())
 
 
 class _RasterizeGaussians(torch.autograd.Function):
