@@ -85,6 +85,10 @@ def main():
     ap.add_argument("--height", type=int, default=680)
     ap.add_argument("--cpu-rows", type=int, default=1000, help="16-px tile rows rendered by the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--audit-rows", default="5,21,38", help="16-px tile rows of the frame audited against the float64 oracle "
+                                                             "('' = skip the parity block)")
+    ap.add_argument("--slam-frames", type=int, default=3, help="frames of the tracking+mapping loop in the `slam` block "
+                                                               "(BASELINE.json metric 2; 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank path with all ranks on one GPU)")
     args = ap.parse_args()
@@ -213,6 +217,18 @@ def main():
                             "composite_us": round(comp_us, 2), "frac": round(floor_us / comp_us, 4) if comp_us else None}
         if "sort_tiles" not in kern:
             roofline["valu"]["note"] = "composite_forward includes the per-tile depth sort (no separate sort launch)"
+        # pairs actually evaluated: the quadrant-queue forward counts its steps on the device (one step = 64 pixels x 16 splats)
+        if dgr.get_option("VTGS_FWD_IMPL") == 3:
+            dgr.set_option("VTGS_COUNT_STEPS", 1)
+            with torch.no_grad():
+                rast(**leaves)
+            steps = dgr.debug_forward_steps(rast)
+            dgr.set_option("VTGS_COUNT_STEPS", 0)
+            tiles8 = ((W + 7) // 8) * (((tile_rows[1] - tile_rows[0]) * 2 if tile_rows else (H + 7) // 8))
+            roofline["valu"]["forward_steps_per_tile"] = round(steps / max(tiles8, 1), 3)
+            roofline["valu"]["pairs_forward"] = steps * 1024
+        bwd_q = dgr.get_option("VTGS_BWD_IMPL") == 3
+        roofline["valu"]["pairs_backward"] = roofline["valu"].get("pairs_forward") if bwd_q and "pairs_forward" in roofline["valu"] else e_eff
 
     cpu_baseline = None
     parity = None
@@ -231,29 +247,75 @@ def main():
                         "cores": torch.get_num_threads(), "kind": "port",
                         "sample": f"float32 PyTorch oracle fwd+bwd, same scene, tile rows {rows[0]}..{rows[1]} "
                                   f"({p_band} of {P} pixels; projection+binning of all N included), {tcpu:.1f} s"}
-        # the checker's frame against the frame the timed path produces (float32 both: discrete alpha / stop decisions can
-        # fall either way on both sides; tests/ hold the audited float64 comparison)
-        y1 = min(rows[1] * 16, H)
+        del cpu_scene, c_cpu
+
+    # ---- parity block: the frame of the timed path against the FLOAT64 oracle on a few tile rows, audited ----------------
+    # (tests/test_gpu_configs.py does the same at every BASELINE shape).  Every pixel above 1e-4 must sit on a discrete
+    # decision of the composite in the oracle's own per-pair values (parity_util.audit_outliers): `unexplained` must be 0.
+    # Gradients: Gaussians that share a 16x16 tile with such a pixel carry its flipped pair and are reported apart.
+    if rank == 0 and world == 1 and args.audit_rows:
+        from parity_util import GRAD_KEYS, audit_outliers, grad_error, oracle_rows, rows_mask, tainted_gaussians
+        rows = [int(r) for r in args.audit_rows.split(",") if r.strip() != "" and int(r) < gy16]
+        print(f"[bench] parity: float64 oracle on tile rows {rows} ...", file=sys.stderr, flush=True)
+        tp0 = time.perf_counter()
+        mask = rows_mask(cam, rows)
+        gsel = grad_color.cpu().clone()
+        gsel[:, ~mask] = 0                                          # the audited loss lives on those rows
+        torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+        ref_c, ref_r, ref_d, ref_g, keep, aux, idx = oracle_rows(scene, cam, rows, gsel)
         for t in leaves.values():
             t.grad = None
-        gband = grad_color.clone()
-        gband[:, y1:] = 0
-        color = rast(**leaves)[0]
-        color.backward(gband)
-        got = color.detach()[:, :y1].cpu().double()
-        ref = c_cpu.detach()[:, :y1].double()
-        scale_img = ref.abs().max().item() + 1e-12
-        d_img = (got - ref).abs() / scale_img
-        parity = {"img_max_rel": float(d_img.max()), "img_frac_gt_1e-4": float((d_img.amax(0) > 1e-4).double().mean())}
-        worst = 0.0
-        for k in ("means3D", "opacities", "colors_precomp", "scales"):
-            r, h = cpu_scene[k].grad.double(), leaves[k].grad.cpu().double()
-            sc = r.abs().max().item()
-            if sc > 0:
-                rel = ((r - h).abs() / (r.abs() + 1e-3 * sc)).reshape(-1)[:4_000_000]
-                worst = max(worst, float(torch.quantile(rel, 0.999)))
-        parity["grad_p999"] = worst
-        parity["note"] = "GPU frame of the timed path vs the float32 CPU oracle on the cpu_baseline sample"
+        color, radii, depth = rast(**leaves)
+        color.backward(gsel.to(dev))
+        got_c, got_d = color.detach().cpu().double(), depth.detach().cpu().double()
+        hc = torch.where(mask[None, :, None], got_c, ref_c)          # outside the rows the oracle image is just the background
+        hd = torch.where(mask[None, :, None], got_d, ref_d)
+        sub_op = scene["opacities"][idx]
+        a_c = audit_outliers(ref_c, hc, aux, sub_op, cam, 1e-4)
+        a_d = audit_outliers(ref_d, hd, aux, sub_op, cam, 1e-4)
+        taint = tainted_gaussians(aux, a_c["tiles"] | a_d["tiles"], idx.numel())
+        rdiff = ref_r != radii.cpu()                                 # float32 ceil() on the other side moves a tile rectangle
+        taint_full = torch.zeros(N, dtype=torch.bool)
+        taint_full[idx[taint]] = True
+        taint_full |= rdiff
+        clean = keep & ~taint_full
+        gmax, gp999, gl2 = 0.0, 0.0, 0.0
+        for k in GRAD_KEYS:
+            if k == "rotations":
+                continue                                            # isotropic scene: exactly zero in exact arithmetic
+            r, h = ref_g[k][clean].double(), leaves[k].grad.cpu()[clean].double()
+            if r.numel() == 0 or ref_g[k].abs().max().item() == 0:
+                continue
+            mx, p999 = grad_error(r, h)
+            gmax, gp999 = max(gmax, mx), max(gp999, p999)
+            gl2 = max(gl2, ((r - h).norm() / (r.norm() + 1e-300)).item())
+        n_px = int(mask.sum()) * W
+        parity = {"oracle": "float64, tile rows " + ",".join(map(str, rows)) + f" ({n_px} pixels, {int(keep.sum())} Gaussians)",
+                  "img_outliers_gt_1e-4": a_c["outliers"] + a_d["outliers"], "img_max_rel": max(a_c["max_rel"], a_d["max_rel"]),
+                  "unexplained": len(a_c["unexplained"]) + len(a_d["unexplained"]),
+                  "radii_differ": int(rdiff.sum()), "gaussians_beside_an_audited_pixel": int(taint_full.sum()),
+                  "grad_p999": gp999, "grad_max_rel": gmax, "grad_rel_l2": gl2,
+                  "seconds": round(time.perf_counter() - tp0, 1),
+                  "note": "colour + depth of the timed path vs the float64 oracle; every pixel above 1e-4 is audited against the "
+                          "oracle's own per-pair values (alpha within float32 reach of 1/255, T within reach of the 1e-4 stop); "
+                          "grad_* over the Gaussians that share no 16x16 tile with an audited pixel: p999 = 99.9th percentile "
+                          "of |d| / (|ref| + 1e-3 max|ref|), max_rel = max|d| / max|ref|"}
+
+    # ---- slam block (BASELINE.json metric 2): a short run of bench_slam.py's loop through the get_loss mirror ---------------
+    slam = None
+    if rank == 0 and world == 1 and args.slam_frames > 0 and (N, W, H) == (1_000_000, 1200, 680):
+        import bench_slam
+        print(f"[bench] slam block: {args.slam_frames} frames of the tracking+mapping loop ...", file=sys.stderr, flush=True)
+        del leaves, rast
+        torch.cuda.empty_cache()
+        rec = bench_slam.run(bench_slam.parse_args(["--frames", str(args.slam_frames), "--get-loss"]))
+        slam = {"metric": "SLAM frames/s, tracking+mapping loop", "value": rec["value"], "unit": "frames/s",
+                "frames": args.slam_frames, "tracking_ms_per_iter": rec["tracking_ms_per_iter"],
+                "mapping_ms_per_iter": rec["mapping_ms_per_iter"], "workload": rec["config"]["workload"],
+                "pose_error_after_tracking_cm_deg": rec["pose_error_after_tracking_cm_deg"],
+                "note": "synthetic Replica-room0-like sequence, one submap, one get_loss per mapping iteration (upper bound of "
+                        "the reference's per-frame work; `bench_slam.py --global-submaps 2` adds its second call over the "
+                        "global set, profiles/r3_slam_loop.jsonl)"}
 
     if rank == 0:
         out = {
@@ -265,7 +327,7 @@ def main():
                        "gaussians": N, "width": W, "height": H, "instances_8x8": info["instances"],
                        "tiles16_touched_R": r16, "max_tile_list": info["max_tile_list"],
                        "partition": "none" if world == 1 else f"tile-row bands x{world} + all-reduce(7 floats)"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "slam": slam,
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["avg_us"])},
         }
         print(json.dumps(out))

@@ -36,7 +36,7 @@ def pose_quat_trans(angle_deg: float, axis, trans):
     return torch.cat([torch.tensor([math.cos(a)]), math.sin(a) * ax]), torch.tensor(trans, dtype=torch.float32)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--n", type=int, default=1_000_000)
@@ -50,9 +50,20 @@ def main():
     ap.add_argument("--get-loss", action="store_true", help="drive both loops through diff_gaussian_rasterization.get_loss."
                                                             "get_loss, the function with the reference's own signature "
                                                             "(implies --fused): what a one-import swap in the driver gives")
-    args = ap.parse_args()
+    ap.add_argument("--global-submaps", type=int, default=0,
+                    help="K > 0: every mapping iteration makes the reference's SECOND get_loss call as well, over the global "
+                         "set = K fixed submaps (+) the current one (src/vtgaussian_slam.py:2545-2556, 944-977): (K+1) N "
+                         "Gaussians rendered, gradients to the current submap only (needs --get-loss)")
+    args = ap.parse_args(argv)
     if args.get_loss:
         args.fused = True
+    if args.global_submaps and not args.get_loss:
+        ap.error("--global-submaps needs --get-loss")
+    return args
+
+
+def run(args) -> dict:
+    """One run of the loop; returns the JSON record (bench.py embeds a short run of it as its `slam` block)."""
     assert torch.cuda.is_available(), "bench_slam.py needs an MI355X"
     dev = torch.device("cuda", 0)
 
@@ -132,6 +143,23 @@ def main():
     map_lrs = dict(means3D=0.0, rgb_colors=0.0025, unnorm_rotations=0.0, logit_opacities=0.05, log_scales=0.005,
                    cam_unnorm_rots=1e-8, cam_trans=1e-7)
 
+    # the reference's global set: K earlier ("fixed") submaps that cover the same view, concatenated IN FRONT of the current
+    # one every iteration (concat_global, src/vtgaussian_slam.py:944-977, called at :2510 and again at :2734 after every step)
+    fixed = []
+    for k in range(args.global_submaps):
+        sk, _ = go.view_tied_scene(N, W, H, seed=100 + k)
+        fixed.append({"means3D": sk["means3D"].to(dev), "rgb_colors": sk["colors_precomp"].to(dev),
+                      "unnorm_rotations": sk["rotations"].to(dev), "logit_opacities": torch.full((N, 1), 2.0, device=dev),
+                      "log_scales": torch.log(sk["scales"][:, :1]).to(dev)})
+    variables_global = {"max_2D_radius": torch.zeros(N * (1 + len(fixed)), device=dev),
+                        "means2D_gradient_accum": torch.zeros(N * (1 + len(fixed)), device=dev),
+                        "denom": torch.zeros(N * (1 + len(fixed)), device=dev)}
+
+    def concat_global():
+        out = {k: torch.cat([f[k] for f in fixed] + [params[k]], dim=0) for k in fixed[0]}
+        out["cam_unnorm_rots"], out["cam_trans"] = params["cam_unnorm_rots"], params["cam_trans"]
+        return out
+
     mirror_get_loss = None
     variables = {"max_2D_radius": torch.zeros(N, device=dev), "means2D_gradient_accum": torch.zeros(N, device=dev),
                  "denom": torch.zeros(N, device=dev)}
@@ -199,6 +227,11 @@ def main():
             if args.get_loss:                      # (the mapping loops call it the same way, without the threshold lists)
                 loss, variables, _losses = mirror_get_loss(params, curr_data(t), variables, t, {"im": 1.0, "depth": 1.0}, False,
                                                            0.99, True, False, mapping=True, dataset_name="replica")
+                if fixed:                          # the second call of the reference's mapping iteration (:2551-2556)
+                    loss_global, variables_global, _lg = mirror_get_loss(
+                        concat_global(), curr_data(t), variables_global, t, {"im": 1.0, "depth": 1.0}, False, 0.99, True, False,
+                        mapping=True, dataset_name="replica")
+                    loss = loss + loss_global
             else:
                 im, depth_sil, _ = render_pair(params, t, gaussians_grad=True, camera_grad=False)
                 loss = map_loss(im, depth_sil, gt_im, gt_depth)
@@ -217,7 +250,9 @@ def main():
         "config": {"workload": f"view-tied submap N={N}, {W}x{H}; {args.tracking_iters} tracking + {args.mapping_iters} "
                                f"mapping iterations per frame, 2 renders fwd+bwd per iteration (configs/replica/room0.py)",
                    "frames": args.frames, "shared_geometry": bool(args.shared_geometry or args.fused), "fused_callers": bool(args.fused),
-                   "through_get_loss_mirror": bool(args.get_loss)},
+                   "through_get_loss_mirror": bool(args.get_loss),
+                   "mapping_get_loss_calls_per_iteration": 2 if fixed else 1,
+                   "gaussians_in_global_set": N * (1 + len(fixed)) if fixed else None},
         "tracking_ms_per_iter": round(sum(track_ms) / len(track_ms), 3),
         "mapping_ms_per_iter": round(sum(map_ms) / len(map_ms), 3),
         "pose_error_before_tracking_cm_deg": [[round(a, 3), round(b, 4)] for a, b in errs_before],
@@ -227,7 +262,11 @@ def main():
     out["allocator"] = {"device_allocs": ms.get("num_device_alloc", 0), "device_frees": ms.get("num_device_free", 0),
                         "alloc_retries": ms.get("num_alloc_retries", 0),
                         "reserved_gb": round(torch.cuda.memory_reserved() / 1e9, 2)}
-    print(json.dumps(out))
+    return out
+
+
+def main():
+    print(json.dumps(run(parse_args())))
 
 
 if __name__ == "__main__":

@@ -566,6 +566,56 @@ def _quadrant_scenes():
         yield f"odd{seed}", (scene, cam)
 
 
+def test_forward_runs_ahead_of_its_record_and_settles_after_the_backward(gpu_device):
+    """a grad-mode forward whose predecessor of the same shape left >= 20 % headroom in both capacities
+    returns without waiting for its result record (the host can enqueue the loss and the backward while the device is
+    still busy); the record is read once the backward has been enqueued.  Same bits as the checked mode.  A no-grad
+    forward is always checked.  An overflow in the run-ahead mode cannot be repaired -- the caller holds the image --
+    and raises, after which the next forward fits."""
+    import diff_gaussian_rasterization as dgr
+    from parity_util import to_settings
+    dev = gpu_device
+    scene, cam = go.view_tied_scene(30000, 160, 96, seed=9)
+    st = to_settings(cam, dev)
+    g = torch.Generator().manual_seed(3)
+    grad_color = (torch.rand(3, 96, 160, generator=g) * 2 - 1).to(dev)
+    dgr._capacity_hint.clear(); dgr._caps_in_use.clear(); dgr._tile_cap_hint.clear(); dgr._async_ok.clear()
+
+    def step(sc, mode):
+        dgr._FORWARD_MODE = mode
+        leaves = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+        rast = dgr.GaussianRasterizer(raster_settings=st)
+        c, r, d = rast(**leaves)
+        pending = rast._last_state.pending is not None
+        c.backward(grad_color)
+        assert rast._last_state.pending is None                      # the backward settled it
+        return pending, c.detach().clone(), d.detach().clone(), {k: leaves[k].grad.clone() for k in GRAD_KEYS}
+
+    try:
+        p0, *_ = step(scene, "auto")                 # first forward of the shape: capacities unknown -> checked
+        p1, c1, d1, g1 = step(scene, "auto")         # capacities re-chosen from the observed need -> checked once more
+        p2, c2, d2, g2 = step(scene, "auto")         # same capacities, < 80 % used -> runs ahead
+        p3, c3, d3, g3 = step(scene, "checked")
+        assert (p0, p3) == (False, False) and p2, (p0, p1, p2, p3)
+        assert torch.equal(c2, c3) and torch.equal(d2, d3)
+        for k in GRAD_KEYS:
+            assert torch.equal(g2[k], g3[k]), k
+        dgr._FORWARD_MODE = "auto"
+        with torch.no_grad():                        # no backward will come: always checked
+            rast = dgr.GaussianRasterizer(raster_settings=st)
+            rast(**{k: v.to(dev) for k, v in scene.items()})
+            assert rast._last_state.pending is None
+        big = dict(scene, scales=scene["scales"] * 12.0)             # same shape key, ~100x the instances
+        with pytest.raises(RuntimeError, match="asynchronous mode"):
+            step(big, "auto")
+        p5, c5, d5, _ = step(big, "auto")            # capacities were raised by the failed settle: checked, valid
+        assert not p5
+        ref = run_hip(big, cam, dev)
+        assert torch.equal(c5.cpu(), ref[0])
+    finally:
+        dgr._FORWARD_MODE = os.environ.get("VTGS_FORWARD_MODE", "auto")
+
+
 def _central_cross_scene(seed=0, W=16, H=16, n_faint=900, n_norm=500):
     """Sub-pixel, faint splats (sigma = the 0.55 px dilation floor, opacity 0.4-0.6 %) whose alpha >= 1/255 box lies in the
     gap between the pixel centres of two 4x4 quadrants -- on the central cross of their 8x8 tile -- so that they are binned
@@ -664,3 +714,41 @@ def test_quadrant_queue_forward_is_bit_identical(gpu_device):
         assert torch.equal(ref[2], got[2]) and torch.equal(ref[1], got[1]), name
         for k in GRAD_KEYS:                                                   # same final T -> same backward, bit for bit
             assert torch.equal(ref[3][k], got[3][k]), (name, k)
+
+
+def test_quadrant_queue_backward_agrees_with_the_lane_pixel_backward(gpu_device):
+    """composite_backward_q (VTGS_BWD_IMPL = 3: per-quadrant splat queues, sweeps per group of four, LDS accumulation across
+    quadrants, one record per instance) against composite_backward_mx (= 2) behind the SAME forward: a pair it skips has
+    alpha < 1/255 in its whole quadrant and contributes exactly nothing, so only the float32 summation order differs.
+    Scenes: dense view-tied lists, anisotropic, saturating / opaque (every pixel ends mid-list), awkward sizes, lists that
+    wrap the ring many times with entries that reach no quadrant; plus a forward that leaves no quadrant masks (the
+    kernel then derives them itself)."""
+    scenes = list(_quadrant_scenes()) + [("central_cross", _central_cross_scene(1))]
+    for name, (scene, cam) in scenes:
+        g = torch.Generator().manual_seed(5)
+        grad_color = torch.rand(3, cam.image_height, cam.image_width, generator=g) * 2 - 1
+        for fwd in ((3, 2) if name in ("view_tied_dense", "saturating") else (3,)):
+            _opt("VTGS_FWD_IMPL", fwd)
+            _opt("VTGS_BWD_IMPL", 2)
+            ref = run_hip(scene, cam, gpu_device, grad_color)
+            _opt("VTGS_BWD_IMPL", 3)
+            got = run_hip(scene, cam, gpu_device, grad_color)
+            again = run_hip(scene, cam, gpu_device, grad_color)
+            assert torch.equal(ref[0], got[0]) and torch.equal(ref[2], got[2])
+            for k in GRAD_KEYS:
+                assert torch.equal(got[3][k], again[3][k]), (name, k, "not reproducible run to run")
+                scale = ref[3][k].abs().max().item()
+                if scale == 0.0:
+                    assert got[3][k].abs().max().item() == 0.0, (name, k)
+                    continue
+                if k == "rotations" and not bool((scene["scales"][:, 0] != scene["scales"][:, 1]).any()):
+                    continue                                   # isotropic: float noise around zero
+                mx, p999 = grad_error(ref[3][k], got[3][k])
+                assert mx <= 2e-4 and p999 <= 5e-4, (name, fwd, k, mx, p999)
+
+
+@pytest.mark.parametrize("name", ["view_tied_dense", "random_aniso", "wide_fov_aniso"])
+def test_quadrant_queue_backward_against_the_oracle(gpu_device, name):
+    """The audited HIP-vs-float64-oracle comparison of test_forward_backward_parity with the quadrant-queue backward."""
+    _opt("VTGS_BWD_IMPL", 3)
+    test_forward_backward_parity(gpu_device, name)

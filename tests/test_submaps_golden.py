@@ -33,7 +33,7 @@ def test_concat_split_equal_the_reference(fx):
     params_ls, variables_ls = _lists(fx)
     sel, nfe = fx["selected_time_idx"].tolist(), int(fx["num_frames_each_base_frame"])
     assert submaps.quantize_selected_time_idx(sel, nfe) == fx["quantized"].tolist()
-    cat_p, cat_v, num_gs = submaps.concat_keyframes_params_base_frame(params_ls, variables_ls, sel, nfe)
+    cat_p, cat_v, num_gs = submaps.concat_keyframes_params_base_frame(params_ls, variables_ls, sel, nfe, device="cpu")
     assert num_gs == fx["cat_num_gs"].tolist()
     for k in KEYS5 + ["cam_unnorm_rots", "cam_trans"]:
         assert isinstance(cat_p[k], torch.nn.Parameter) and cat_p[k].requires_grad
@@ -60,10 +60,19 @@ def test_concat_split_equal_the_reference(fx):
     # the shuttle replacement: nothing moves, views become owners, the graph is cut
     on_dev, on_host = submaps.keep_resident(upd_p, upd_v)
     assert on_dev == 0 and on_host > 0
+    before = {(i, k): v.clone() for i, d in enumerate(upd_p) for k, v in d.items() if isinstance(v, torch.Tensor)}
+    for v in new_p.values():                       # the frame's concatenation changes afterwards (the next optimiser step) ...
+        v.add_(1000.0)
+    for i, d in enumerate(upd_p):                  # ... and no kept submap may notice: owners, not views of it
+        for k, v in d.items():
+            if isinstance(v, torch.Tensor) and k in KEYS5:
+                assert torch.equal(v, before[(i, k)]), (i, k)
     for d in upd_p + upd_v:
-        for v in d.values():
+        for k, v in d.items():
             if isinstance(v, torch.Tensor):
-                assert not v.requires_grad and v._base is None and v.device.type == "cpu"
+                assert not v.requires_grad and v.device.type == "cpu"
+                if k in KEYS5 + VKEYS:
+                    assert v.untyped_storage().nbytes() == v.numel() * v.element_size(), k
 
 
 @pytest.mark.gpu
@@ -90,6 +99,8 @@ def test_resident_submaps_on_the_device(fx):
     on_dev, on_host = submaps.keep_resident(upd_p, upd_v)
     assert on_dev > 0 and on_host == 0
     for d in upd_p + upd_v:
-        for v in d.values():
+        for k, v in d.items():
             if isinstance(v, torch.Tensor):
-                assert v.is_cuda and not v.requires_grad and v._base is None
+                assert v.is_cuda and not v.requires_grad
+                if k in KEYS5 + VKEYS:                       # owners: the frame's concatenation can be freed
+                    assert v.untyped_storage().nbytes() == v.numel() * v.element_size(), k

@@ -1,0 +1,53 @@
+"""Where one wavefront of composite_forward_q spends its time (diagnostic build with -DVTGS_Q_STAMPS: s_memtime stamps,
+8 words per tile in the workspace's debug region).
+
+    python vtgaussian-slam_amd/build.py --out vtgaussian-slam_amd/lib/libvtgs_stamps.so -DVTGS_Q_STAMPS
+    VTGS_LIBRARY=.../libvtgs_stamps.so python tools/forward_stamps.py
+"""
+import ctypes, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'vtgaussian-slam_amd'), os.path.join(ROOT, 'tests')]
+from oracle import gs_oracle as go
+from parity_util import to_settings
+import diff_gaussian_rasterization as dgr
+dev = torch.device('cuda:0')
+N = int(os.environ.get('ABL_N', '1000000')); W = int(os.environ.get('ABL_W', '1200')); H = int(os.environ.get('ABL_H', '680'))
+scene, cam = go.view_tied_scene(N, W, H, seed=0)
+dgr.set_option("VTGS_COUNT_STEPS", 1)
+rast = dgr.GaussianRasterizer(raster_settings=to_settings(cam, dev))
+leaves = {k: v.to(dev) for k, v in scene.items()}
+with torch.no_grad():
+    for _ in range(4):
+        rast(**leaves)
+torch.cuda.synchronize()
+fs = rast._last_state
+out = (ctypes.c_uint64 * 10)()
+dgr._lib.vtgs_debug_layout(fs.n, fs.cam.W, fs.cam.H, fs.capacity, fs.tile_cap, out)
+tiles = int(out[7])
+st = fs.workspace[int(out[9]) + 256: int(out[9]) + 256 + 32 * tiles].view(torch.int32).reshape(tiles, 8).cpu().double()
+names = ["sort (entry -> sorted list re-readable)", "first append", "all appends", "all steps", "whole wavefront", "steps", "list length"]
+for i, nm in enumerate(names):
+    c = st[:, i]
+    print(f"{nm:42s} mean {c.mean():10.1f}  median {c.median():10.1f}  p90 {c.quantile(0.9):10.1f}  max {c.max():10.1f}")
+w7 = st[:, 7].long() & 0xFFFFFFFF
+keys_in, network = (w7 & 0xFFFFF).double(), ((w7 >> 20) * 16).double()
+for nm, c in (("  of the sort: entry -> keys in registers", keys_in), ("  of the sort: network", network),
+              ("  of the sort: stores, vals gather, fence", st[:, 0] - keys_in - network)):
+    print(f"{nm:42s} mean {c.mean():10.1f}  median {c.median():10.1f}  p90 {c.quantile(0.9):10.1f}  max {c.max():10.1f}")
+per_step = (st[:, 3] / st[:, 5].clamp(min=1)).median()
+print(f"ticks per step (median tile) {per_step:.0f}")
+# ---- backward (composite_backward_mx writes its own stamps into the same region)
+lv = {k: v.clone().requires_grad_(True) for k, v in leaves.items()}
+g = torch.rand(3, H, W, device=dev)
+for _ in range(3):
+    c, _, _ = rast(**lv)
+    c.backward(g)
+torch.cuda.synchronize()
+fs = rast._last_state
+st = fs.workspace[int(out[9]) + 256: int(out[9]) + 256 + 32 * tiles].view(torch.int32).reshape(tiles, 8).cpu().double()
+print("backward:")
+for i, nm in ((0, "prologue (entry -> list loop)"), (2, "waiting for the chunk gathers"), (3, "batches (sweeps + contraction + records)"),
+              (4, "whole wavefront"), (5, "batches"), (6, "list length")):
+    c = st[:, i]
+    print(f"{nm:42s} mean {c.mean():10.1f}  median {c.median():10.1f}  p90 {c.quantile(0.9):10.1f}  max {c.max():10.1f}")
+print(f"ticks per batch (median tile) {(st[:, 3] / st[:, 5].clamp(min=1)).median():.0f}")

@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", f) for f in ("vtgs_api.hip", "vtgs_binning.hip", "vtgs_composite.hip", "vtgs_composite_q.hip", "vtgs_frame.hip", "vtgs_loss.hip", "vtgs_p2p.hip")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("vtgs_api.hip", "vtgs_binning.hip", "vtgs_composite.hip", "vtgs_composite_q.hip", "vtgs_composite_bq.hip", "vtgs_frame.hip", "vtgs_loss.hip", "vtgs_p2p.hip")]
 HDR = [os.path.join(HERE, "csrc", f) for f in ("vtgs_internal.h", "vtgs_math.h", "vtgs_composite_common.h", "vtgs_sort_common.h")] + \
       [os.path.join(HERE, "..", "include", "vtgs.h")]
 OUT = os.path.join(HERE, "lib", "libvtgs.so")

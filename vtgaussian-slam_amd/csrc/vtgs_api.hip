@@ -5,6 +5,7 @@
 
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 
 namespace vtgs {
 // kernels (vtgs_binning.hip / vtgs_composite.hip)
@@ -37,7 +38,10 @@ __global__ void composite_backward(CamScalars, const float*, uint32_t, const uin
 template <int WAVES, bool DUAL, bool PX>
 __global__ void composite_backward_mx(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                       const uint32_t*, const GeomRec*, const float*, const float*, const float*,
-                                      const float*, float*, const Counters*, const float*, const float*, const float*);
+                                      const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*);
+__global__ void composite_backward_q(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
+                                     const uint32_t*, const uint8_t*, const GeomRec*, const float*, const float*, const float*,
+                                     const float*, float*, const Counters*, uint32_t*);
 template <bool DUAL, bool FRAME>
 __global__ void gather_splat_grads(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
                                    const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*,
@@ -148,15 +152,15 @@ struct Option { const char* name; int dflt; int value; };
 static Option g_options[] = {{"VTGS_FWD_IMPL", 3, -1}, {"VTGS_BWD_IMPL", 2, -1}, {"VTGS_BIN_IMPL", 1, -1}, {"VTGS_SORT_PACKED", 1, -1},
                              {"VTGS_SORT_FUSED", 1, -1}, {"VTGS_COUNT_STEPS", 0, -1}};
 enum { OPT_FWD_IMPL = 0, OPT_BWD_IMPL, OPT_BIN_IMPL, OPT_SORT_PACKED, OPT_SORT_FUSED, OPT_COUNT_STEPS, OPT_COUNT };
-static bool g_options_ready = false;
-static void options_init() {
-  if (g_options_ready) return;
-  for (int i = 0; i < OPT_COUNT; ++i) {
-    const char* v = getenv(g_options[i].name);
-    if (v) g_options[i].dflt = atoi(v);
-    if (g_options[i].value < 0) g_options[i].value = g_options[i].dflt;
-  }
-  g_options_ready = true;
+static std::once_flag g_options_once;
+static void options_init() {                                   // thread-safe: the first caller reads the environment
+  std::call_once(g_options_once, [] {
+    for (int i = 0; i < OPT_COUNT; ++i) {
+      const char* v = getenv(g_options[i].name);
+      if (v) g_options[i].dflt = atoi(v);
+      if (g_options[i].value < 0) g_options[i].value = g_options[i].dflt;
+    }
+  });
 }
 static inline int option(int which) { options_init(); return g_options[which].value; }
 int vtgs_set_option(const char* name, int value) {
@@ -453,8 +457,10 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
   const float* state = image_state ? image_state : (const float*)(ws + L.final_T);
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   const uint32_t nblk16 = (uint32_t)(gx16 * rows16);
+  uint32_t* dbg = option(OPT_COUNT_STEPS) == 1 ? (uint32_t*)(const_cast<char*>(ws) + L.dbg) : nullptr;   // measurement only
   int bwd_impl = option(OPT_BWD_IMPL);                       // 2 = lane-per-pixel matrix-core replay (default), 1 = pixel x splat-quad replay,
   if (dual && bwd_impl == 0) bwd_impl = 1;                   // 0 = scalar kernel (single render only); read per call
+  if (dual && bwd_impl == 3) bwd_impl = 2;                   // 3 = quadrant queues (single render only so far)
   {
     ProfScope ps__(dual ? "composite_backward_dual" : "composite_backward", st);
     if (dual && bwd_impl == 2)
@@ -462,25 +468,30 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
                          grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), colors_b, out_color_b,
-                         grad_color_b);
+                         grad_color_b, dbg);
     else if (dual)
       hipLaunchKernelGGL((composite_backward_mx<4, true, false>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
                          grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), colors_b, out_color_b,
-                         grad_color_b);
+                         grad_color_b, dbg);
+    else if (bwd_impl == 3)                                 // per-quadrant splat queues (vtgs_composite_bq.hip)
+      hipLaunchKernelGGL(composite_backward_q, dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
+                         (const uint32_t*)(ws + L.sorted_inst), (const uint8_t*)(ws + L.qmask), (const GeomRec*)(ws + L.geom), colors,
+                         out_color, grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), dbg);
     else if (bwd_impl == 2)                                 // lane = pixel replay
       hipLaunchKernelGGL((composite_backward_mx<4, false, true>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
                          grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), (const float*)nullptr,
-                         (const float*)nullptr, (const float*)nullptr);
+                         (const float*)nullptr, (const float*)nullptr, dbg);
     else if (bwd_impl == 1)
       hipLaunchKernelGGL((composite_backward_mx<4, false, false>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
                          grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), (const float*)nullptr,
-                         (const float*)nullptr, (const float*)nullptr);
+                         (const float*)nullptr, (const float*)nullptr, dbg);
     else
       hipLaunchKernelGGL(composite_backward, dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),

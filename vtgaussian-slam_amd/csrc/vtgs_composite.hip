@@ -19,8 +19,8 @@
 //     dL/dalpha_k = T_k (g.c_k) - (Cg - P_k + T_final (g.bg)) / (1 - alpha_k)
 // so the list is replayed in the SAME order as the forward (identical skip/stop decisions by construction,
 // no per-pixel contributor count to store) and the per-pixel state is two scalars (T, P).  Per splat the nine
-// sums over the tile's 64 pixels are formed by an f32 MFMA contraction and stored as one 48-byte record per
-// (splat, tile) instance -- plain stores, no float atomics, bitwise reproducible.  gather_splat_grads then
+// sums over the tile's 64 pixels are formed by an f32 MFMA contraction and stored as one 40-byte record per
+// (splat, tile) instance (56 bytes in the dual render) -- plain stores, no float atomics, bitwise reproducible.  gather_splat_grads then
 // re-centres and sums each splat's contiguous run of records and runs splat_backward (vtgs_math.h).
 #include "vtgs_internal.h"
 #include "vtgs_composite_common.h"
@@ -866,8 +866,13 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     const uint32_t* __restrict__ sorted_inst, const GeomRec* __restrict__ geom, const float* __restrict__ colors,
     const float* __restrict__ out_color, const float* __restrict__ grad_color, const float* __restrict__ final_T,
     float* __restrict__ grad_inst, const Counters* __restrict__ ctr, const float* __restrict__ colors_b,
-    const float* __restrict__ out_color_b, const float* __restrict__ grad_color_b) {
+    const float* __restrict__ out_color_b, const float* __restrict__ grad_color_b, uint32_t* __restrict__ dbg) {
   constexpr int NG = DUAL ? 6 : 3;                            // image-gradient channels
+#ifdef VTGS_Q_STAMPS
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+  unsigned long long st_gather = 0ull, st_batch = 0ull, st_loop0 = 0ull;
+  uint32_t nbatches = 0u;
+#endif
   constexpr int REC = DUAL ? kGradRecDual : kGradRec;         // floats per (splat, tile) record
   __shared__ float4 lds_xch_all[WAVES][PXL ? 1 : 128];
   __shared__ __attribute__((aligned(16))) float lds_uw[WAVES][2][kImgFloats];
@@ -982,6 +987,9 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   const int col_w2 = 9 + cj;
 
   uint32_t base = s;
+#ifdef VTGS_Q_STAMPS
+  st_loop0 = __builtin_amdgcn_s_memtime();
+#endif
 #if VTGS_BWD_PREFETCH
   // the list entries of the NEXT chunk are requested while this one is composited: one of the two dependent trips to
   // L2 / Infinity Cache per chunk leaves the wavefront's critical path (a lane past the end reads entry 0 of its own bin)
@@ -992,6 +1000,9 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     const bool alive = PXL ? !ps.done : (st.Tb[0].x > 0.f || st.Tb[0].y > 0.f || st.Tb[1].x > 0.f || st.Tb[1].y > 0.f);
     if (__ballot(alive) == 0ull) break;
     const int n = (int)min(64u, e - base);
+#ifdef VTGS_Q_STAMPS
+    const unsigned long long sg0 = __builtin_amdgcn_s_memtime();
+#endif
 #if VTGS_BWD_PREFETCH
     const MxSplat m = mx_gather_gid<DUAL>(gid_nxt, geom, colors, l < n, cx, cy, colors_b);
     const uint32_t my_inst = (l < n) ? inst_nxt : 0u;
@@ -1001,6 +1012,12 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     const uint32_t my_inst = (l < n) ? sorted_inst[base + (uint32_t)l] : 0u;
 #endif
     const bool hot = __ballot(m.hot) != 0ull;                 // wave-uniform: some splat of the chunk may hit the 0.99 clamp
+#ifdef VTGS_Q_STAMPS
+    asm volatile("" :: "v"(m.K[0]), "v"(m.pay.x));
+    __builtin_amdgcn_s_waitcnt(0x0070);                        // vmcnt(0): the chunk's gathers have arrived
+    const unsigned long long sg1 = __builtin_amdgcn_s_memtime();
+    st_gather += sg1 - sg0;
+#endif
     const bool chunk_exact = px_exact;                        // exact sweep first for this chunk (pixels kept ending before it)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -1062,7 +1079,13 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
         rec[col_w] = (cj == 3) ? __uint_as_float(tile_bits) : Fw;
         if constexpr (DUAL) { if (cj < 3) rec[col_w2] = Fw2; }
       }
+#ifdef VTGS_Q_STAMPS
+      ++nbatches;
+#endif
     }
+#ifdef VTGS_Q_STAMPS
+    st_batch += __builtin_amdgcn_s_memtime() - sg1;
+#endif
   }
   for (; base < e; base += 64u) {
     const int n = (int)min(64u, e - base);
@@ -1079,11 +1102,19 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
       }
     }
   }
+#ifdef VTGS_Q_STAMPS
+  if (dbg && l == 0) {
+    uint32_t* o = dbg + 64 + 8 * tc.tile;
+    const unsigned long long se = __builtin_amdgcn_s_memtime();
+    o[0] = (uint32_t)(st_loop0 - st0); o[1] = 0u; o[2] = (uint32_t)st_gather; o[3] = (uint32_t)st_batch;
+    o[4] = (uint32_t)(se - st0); o[5] = nbatches; o[6] = e - s; o[7] = 0u;
+  }
+#endif
 }
-template __global__ void composite_backward_mx<4, false, false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*);
-template __global__ void composite_backward_mx<4, true, false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*);
-template __global__ void composite_backward_mx<4, false, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*);
-template __global__ void composite_backward_mx<4, true, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*);
+template __global__ void composite_backward_mx<4, false, false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*);
+template __global__ void composite_backward_mx<4, true, false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*);
+template __global__ void composite_backward_mx<4, false, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*);
+template __global__ void composite_backward_mx<4, true, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*);
 
 // one thread per Gaussian: re-centre and sum its instance records (fixed order), then the projection backward.
 // FRAME (dual render of the fused caller chain): the adjoint of vtgs_prepare_frame runs here, on the gradients while they
@@ -1099,9 +1130,36 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_colors,
     float* __restrict__ g_opacities, float* __restrict__ g_scales, float* __restrict__ g_rotations,
     const Counters* __restrict__ ctr, float* __restrict__ g_colors_b, FrameEpilogue fe = FrameEpilogue{}) {
-  if (ctr->overflow) return;                     // the forward did not complete: nothing valid to differentiate
-  const CamParams cam = load_cam(cs, Vp, PVp);
   const int gid = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (ctr->overflow) {
+    // The forward did not complete: nothing valid to differentiate.  The Python layer never gets here (its checked forward
+    // answers an overflow before it returns); a bare C-ABI caller that ignored the overflow of an asynchronous forward
+    // gets DEFINED gradients -- zeros -- instead of whatever the output buffers held.
+    if (gid < n) {
+      if constexpr (FRAME) {
+        if (fe.flags & 1u) {
+          fe.g_means3D[3 * gid] = fe.g_means3D[3 * gid + 1] = fe.g_means3D[3 * gid + 2] = 0.f;
+          reinterpret_cast<float4*>(fe.g_unnorm_rot)[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (fe.flags & 4u) {
+          fe.g_logit[gid] = 0.f; fe.g_log_scales[gid] = 0.f;
+          fe.g_rgb[3 * gid] = fe.g_rgb[3 * gid + 1] = fe.g_rgb[3 * gid + 2] = 0.f;
+        }
+      } else {
+        for (int i = 0; i < 3; ++i) {
+          g_means3D[3 * gid + i] = 0.f; g_means2D[3 * gid + i] = 0.f; g_colors[3 * gid + i] = 0.f; g_scales[3 * gid + i] = 0.f;
+          if constexpr (DUAL) g_colors_b[3 * gid + i] = 0.f;
+        }
+        g_opacities[gid] = 0.f;
+        reinterpret_cast<float4*>(g_rotations)[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    if constexpr (FRAME) {
+      if ((fe.flags & 2u) && threadIdx.x < 12) fe.pose_partials[(size_t)blockIdx.x * 12 + threadIdx.x] = 0.f;
+    }
+    return;
+  }
+  const CamParams cam = load_cam(cs, Vp, PVp);
   const bool live = gid < n;                     // nobody leaves: the wavefront sums the records of its big splats together
   SplatGrads g;
   for (int i = 0; i < 3; ++i) { g.mean3D[i] = g.mean2D[i] = g.color[i] = g.scale[i] = 0.f; }

@@ -1,0 +1,414 @@
+// vtgs_composite_bq.hip -- backward composite with per-quadrant splat queues (gfx950, wave64).
+//
+// composite_backward_mx (vtgs_composite.hip) replays every splat of an 8x8 tile's list at all 64 pixels: 0.18 G
+// (pixel, splat) pairs at the headline shape, ~85 % of them below alpha = 1/255.  Here, as in composite_forward_q, the 16
+// lanes of a 4x4 QUADRANT walk their own queue of the tile's list -- the entries whose alpha >= 1/255 box reaches the
+// quadrant (the 4-bit masks composite_forward_q left in the workspace; recomputed here when another forward ran) -- so a
+// step is 64 pixels x the next 16 splats OF EACH QUADRANT: 8.5 steps per tile instead of 14.4 batches.
+//
+//   * lane L <-> pixel (4 (q & 1) + (i & 3), 4 (q >> 1) + (i >> 2)), q = L >> 4, i = L & 15.  Lane (q, j) also OWNS the j-th
+//     entry its quadrant pops in a step: it gathers that splat's geometry record and colour itself (requested one step
+//     ahead), so the exponent and g.c matrix instructions (v_mfma_f32_4x4x1, cbsz = 2: A from lanes 4g..4g+3 of the
+//     lane's own 16-lane group) read their operands from registers -- no coefficient table in LDS;
+//   * the sweeps run per GROUP of four splats (front to back: alpha, w = alpha T, T, P; anchor A = (CB - P) / T with one
+//     reciprocal per group; back to front: u' = G T (g.c - A), A += alpha (g.c - A)): 16 instead of 64 live per-pair
+//     registers, and a pixel that ends redoes four splats with the exact stop rule, not sixteen;
+//   * the pixel contraction per quadrant: [16 splats x 16 px] x [16 px x 9] on v_mfma_f32_4x4x1 -- the quadrant's four
+//     blocks are its four splat groups -- through ONE 4 KB LDS image per wavefront (XOR-swizzled rows, no padding) that
+//     u' and w use one after the other: w is written while the u' products run;
+//   * a splat's sums arrive from up to four quadrants in different steps: they are added into a per-wavefront LDS table
+//     (ds_add_f32, 9 floats per ring slot) and leave as ONE 40-byte record per (splat, tile) instance -- the format
+//     gather_splat_grads reads -- when the chunk retires: when all four queues have popped its last entry, the same
+//     invariant that frees the chunk's ring slots.  LDS float adds of one instruction are applied in a fixed lane order
+//     and the step sequence of a tile is a function of its list alone, so gradients stay bitwise reproducible run to run.
+//
+// Semantics: SURVEY.md Appendix A4 as restated in vtgs_composite.hip (same recurrences as px_backward_batch, anchored per
+// group of four instead of per sixteen).
+#include "vtgs_internal.h"
+#include "vtgs_composite_common.h"
+
+#ifndef VTGS_BQ_CHUNKS
+#define VTGS_BQ_CHUNKS 2
+#endif
+
+namespace vtgs {
+
+constexpr int kBqChunks = VTGS_BQ_CHUNKS;      // 64-entry chunks of the list in flight
+constexpr int kBqRing = 64 * kBqChunks;        // ring slots (accumulators, ids, queue capacity)
+constexpr int kBqDummy = kBqRing;              // slot of a lane that popped past the end of its queue
+constexpr int kAccRow = 9;                     // floats per accumulator row: 6 moments + 3 colour sums (odd: bank spread)
+
+__device__ __forceinline__ uint32_t quadrant_mask_bq(const float4& g0, const float4& g1, float sx, float sy) {
+  // the same box test as composite_forward_q (vtgs_composite_q.hip): only used when that kernel did not leave its masks
+  float tau = (__log2f(g1.y) + 7.99435344f) * 0.69314718f;               // ln(255 o)
+  tau += 1e-4f * tau + 1e-4f;
+  const float idet = 1.f / fmaxf(g0.z * g1.x - g0.w * g0.w, 1e-30f);
+  const float k2 = 2.f * fmaxf(tau, 0.f) * idet;
+  const float hx = sqrtf(k2 * g1.x) * 1.000001f + 1e-5f, hy = sqrtf(k2 * g0.z) * 1.000001f + 1e-5f;
+  const bool left = sx - hx <= -0.5f && sx + hx >= -3.5f, right = sx + hx >= 0.5f && sx - hx <= 3.5f;
+  const bool top = sy - hy <= -0.5f && sy + hy >= -3.5f, bottom = sy + hy >= 0.5f && sy - hy <= 3.5f;
+  return (left && top ? 1u : 0u) | (right && top ? 2u : 0u) | (left && bottom ? 4u : 0u) | (right && bottom ? 8u : 0u);
+}
+
+// exponents / g.c of the lane's pixel x the four splats held by lanes 4G..4G+3 of the lane's own 16-lane group
+template <int G>
+__device__ __forceinline__ f32x4 bq_exponents(const float (&K)[6], const float (&Phi)[6]) {
+  f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < 6; ++m) d = __builtin_amdgcn_mfma_f32_4x4x1f32(K[m], Phi[m], d, 2, G, 0);
+  return d;
+}
+template <int G>
+__device__ __forceinline__ f32x4 bq_gdotc(const float (&col)[3], const float (&g)[3]) {
+  f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) d = __builtin_amdgcn_mfma_f32_4x4x1f32(col[c], g[c], d, 2, G, 0);
+  return d;
+}
+
+struct BqPixel { float T, P, CB; bool done; };   // T frozen once the pixel has ended (as in the forward)
+
+// One group of four splats for the lane's pixel.  uo / wo: u' = alpha_unclamped dL/dalpha and w = alpha T of the four pairs.
+template <int G, bool CLAMP>
+__device__ __forceinline__ void bq_group(BqPixel& px, const float (&K)[6], const float (&col)[3], const float (&Phi)[6],
+                                         const float (&gown)[3], float (&uo)[4], float (&wo)[4]) {
+  const f32x4 d = bq_exponents<G>(K, Phi);
+  const f32x4 gc = bq_gdotc<G>(col, gown);
+  float a[4], gT[4];
+  float Pn = px.P, Tn = px.done ? 0.f : px.T;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {                                // front to back, optimistic: no stop test
+    const float Gp = __builtin_amdgcn_exp2f(d[r]);
+    if constexpr (CLAMP) {
+      const float al = fminf(kAlphaMax, Gp);
+      const bool valid = al >= kAlphaMin;
+      a[r] = valid ? al : 0.f;
+      gT[r] = valid ? Gp * Tn : 0.f;                           // the 0.99 clamp passes the gradient through
+      wo[r] = a[r] * Tn;
+    } else {                                                   // no splat of this step can reach the clamp
+      a[r] = (Gp >= kAlphaMin) ? Gp : 0.f;
+      wo[r] = a[r] * Tn;
+      gT[r] = wo[r];
+    }
+    Pn = fmaf(gc[r], wo[r], Pn);
+    Tn = Tn - wo[r];
+  }
+  if (__ballot(!px.done && Tn < kTStop) == 0ull) {             // nobody ends inside this group (wave-uniform)
+    px.T = px.done ? px.T : Tn;
+  } else {
+    // exact: the first splat with T (1 - alpha) < 1e-4 ends the pixel BEFORE it is added; from there on alpha = G T = 0
+    Pn = px.P;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float Gp = __builtin_amdgcn_exp2f(d[r]);
+      const float al = CLAMP ? fminf(kAlphaMax, Gp) : Gp;
+      const float av = (al >= kAlphaMin) ? al : 0.f;
+      const float wk = av * px.T;
+      const float tn = px.T - wk;
+      const bool stop = tn < kTStop;                           // a live pixel has T >= 1e-4: alpha = 0 cannot trigger it
+      const bool live = !px.done && !stop;
+      a[r] = live ? av : 0.f;
+      gT[r] = live ? ((al >= kAlphaMin) ? Gp * px.T : 0.f) : 0.f;
+      wo[r] = live ? wk : 0.f;
+      Pn = fmaf(gc[r], wo[r], Pn);
+      px.T = live ? tn : px.T;
+      px.done = px.done || stop;
+    }
+  }
+  // anchor: colour behind the group (behind the ending splat for an ended pixel) per unit of transmittance there; T > 0
+  float A = (px.CB - Pn) * __builtin_amdgcn_rcpf(px.T);
+  px.P = Pn;
+#pragma unroll
+  for (int r = 3; r >= 0; --r) {                               // back to front
+    const float t = gc[r] - A;
+    uo[r] = gT[r] * t;
+    A = fmaf(a[r], t, A);
+  }
+}
+
+// image [quadrant][splat row 0..15][16 px], rows XOR-swizzled in 4-float granules: pixel granule g of row k sits at
+// granule g ^ (k >> 2), which makes the column-wise ds_write_b32 and the row-wise ds_read_b128 conflict-free without padding
+__device__ __forceinline__ int img_write_off(int q, int k, int i) { return q * 256 + k * 16 + 4 * ((i >> 2) ^ (k >> 2)) + (i & 3); }
+__device__ __forceinline__ int img_read_off(int q, int row, int t4) { return q * 256 + row * 16 + 4 * (t4 ^ (row >> 2)); }
+
+constexpr int kPhiRow = 20;                    // Phi table row: 16 pixels + 4 pad (bank spread of the b128 row reads)
+
+__device__ __forceinline__ int bq_wrap(int x) { return x >= kBqRing ? x - kBqRing : x; }   // x < 2 kBqRing
+
+template <int R>
+__device__ __forceinline__ int quad_bcast(int v) {     // value of lane (l & ~3) + R, in every lane of the 4-lane quad
+  return __builtin_amdgcn_mov_dpp(v, R | (R << 2) | (R << 4) | (R << 6), 0xf, 0xf, true);
+}
+
+__global__ __launch_bounds__(256, 3) void composite_backward_q(
+    CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
+    const uint32_t* __restrict__ tile_cnt, uint32_t tile_cap, const uint32_t* __restrict__ sorted_gid,
+    const uint32_t* __restrict__ sorted_inst, const uint8_t* __restrict__ qmask, const GeomRec* __restrict__ geom,
+    const float* __restrict__ colors, const float* __restrict__ out_color, const float* __restrict__ grad_color,
+    const float* __restrict__ final_T, float* __restrict__ grad_inst, const Counters* __restrict__ ctr,
+    uint32_t* __restrict__ step_counters) {
+  __shared__ __attribute__((aligned(16))) float lds_img[4][4 * 256];          // one image per wavefront: u', then w
+  __shared__ float lds_acc[4][(kBqRing + 1) * kAccRow];                       // per ring slot: 6 moments + 3 colour sums
+  __shared__ uint32_t lds_gid[4][kBqRing + 1], lds_inst[4][kBqRing + 1];
+  __shared__ uint8_t lds_q[4][4][kBqRing];
+  __shared__ __attribute__((aligned(16))) float lds_phi[4 * 8 * kPhiRow];     // [quadrant][column 0..7][16 px + 4 pad]
+  // Everything this wavefront needs from memory before its first step is requested HERE, in one go -- the flags, its list
+  // length, its pixels' image values, the first list entries -- and only then are the flags looked at: the prologue was four
+  // dependent round trips to L2 / HBM (flag, length, images, list) and 15 % of the wavefront's life
+  // (profiles/r3_backward_stamps.md).
+  const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
+  const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
+  const uint32_t blk = xcd_swizzle(blockIdx.x, nblk);
+  const int l = lane_id();
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // workgroup = the 2x2 tiles of a 16x16 block
+  const int row16_0 = cs.row8_begin >> 1;
+  const int t8x = 2 * (int)(blk % (uint32_t)gx16) + (wv & 1), t8y = 2 * (row16_0 + (int)(blk / (uint32_t)gx16)) + (wv >> 1);
+  const bool tile_ok = t8x < gx8 && t8y < gy8 && t8y >= cs.row8_begin && t8y < cs.row8_end;   // wave-uniform
+  const int tile = tile_ok ? t8y * gx8 + t8x : 0;
+  const int q = l >> 4, i = l & 15;
+  const int tx0 = t8x * kSubTile, ty0 = t8y * kSubTile;
+  const int lx = 4 * (q & 1) + (i & 3), ly = 4 * (q >> 1) + (i >> 2);
+  const int pxx = tx0 + lx, pyy = ty0 + ly;
+  const bool inside = tile_ok && pxx < cs.W && pyy < cs.H;
+  const size_t P = (size_t)cs.W * cs.H;
+  const uint32_t overflow = ctr->overflow, masks_valid = ctr->qmask_valid;
+  const uint32_t s = (uint32_t)tile * tile_cap;
+  const uint32_t list_len = min(tile_cnt[tile], tile_cap);
+  float gown[3] = {0.f, 0.f, 0.f}, oc[3] = {0.f, 0.f, 0.f}, Tf = 0.f;
+  if (inside) {
+    const size_t pix = (size_t)pyy * cs.W + pxx;
+    gown[0] = grad_color[pix]; gown[1] = grad_color[P + pix]; gown[2] = grad_color[2 * P + pix];
+    oc[0] = out_color[pix]; oc[1] = out_color[P + pix]; oc[2] = out_color[2 * P + pix];
+    Tf = final_T[pix];
+  }
+  const int cj = l & 3, row = l & 15;
+  float Bg[16];                                                 // dL/dcolor channel cj at the quadrant's 16 pixels (cj = 3: 0)
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int qx = tx0 + 4 * (q & 1) + (t & 3), qy = ty0 + 4 * (q >> 1) + (t >> 2);
+    const bool ok = tile_ok && cj < 3 && qx < cs.W && qy < cs.H;
+    Bg[t] = ok ? grad_color[(size_t)cj * P + (size_t)qy * cs.W + qx] : 0.f;
+  }
+  // first list entries (a bin holds at least 64 slots: reading past a short list stays inside the bin; masked later)
+  const bool have_mask_array = qmask != nullptr;
+  uint32_t gid_n = sorted_gid[s + (uint32_t)l], inst_n = sorted_inst[s + (uint32_t)l];
+  uint32_t mask_n = have_mask_array ? (uint32_t)qmask[s + (uint32_t)l] : 0u;
+
+  // Phi table for the contraction's B operands: columns (1, X, Y, X^2, XY, Y^2, 0, 0) at the quadrant's 16 pixels, X, Y
+  // relative to the TILE centre (the records carry tile-centred moments, as composite_backward_mx writes them)
+  for (int idx = (int)threadIdx.x; idx < 4 * 8 * kPhiRow; idx += 256) {
+    const int qq = idx / (8 * kPhiRow), c = (idx - qq * 8 * kPhiRow) / kPhiRow, t = idx - qq * 8 * kPhiRow - c * kPhiRow;
+    const float PX = (float)(4 * (qq & 1) + (t & 3)) - 3.5f, PY = (float)(4 * (qq >> 1) + ((t >> 2) & 3)) - 3.5f;
+    float v = 0.f;
+    v = (c == 0) ? 1.f : v; v = (c == 1) ? PX : v; v = (c == 2) ? PY : v;
+    v = (c == 3) ? PX * PX : v; v = (c == 4) ? PX * PY : v; v = (c == 5) ? PY * PY : v;
+    lds_phi[idx] = (t < 16) ? v : 0.f;
+  }
+  float* __restrict__ img = lds_img[wv];
+  float* __restrict__ acc = lds_acc[wv];
+  uint32_t* __restrict__ tgid = lds_gid[wv];
+  uint32_t* __restrict__ tinst = lds_inst[wv];
+  // ring state: accumulators start at zero (and are zeroed again when a chunk retires); dummy slot included
+  for (int k = l; k < (kBqRing + 1) * kAccRow; k += 64) acc[k] = 0.f;
+  if (l == 0) { tgid[kBqDummy] = 0u; tinst[kBqDummy] = 0u; }
+  __syncthreads();                                              // before any per-wavefront exit
+  if (overflow) return;                                         // uniform over the grid: the forward did not complete
+  if (!tile_ok || list_len == 0u) return;
+  const uint32_t e = s + list_len;
+  const float cx = (float)tx0 + 3.5f, cy = (float)ty0 + 3.5f;
+  const float X = (float)lx - 3.5f, Y = (float)ly - 3.5f;
+  const float Phi[6] = {1.f, X, Y, X * X, X * Y, Y * Y};
+  BqPixel px{1.f, 0.f, 0.f, !inside};
+  {
+    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+    px.CB = gown[0] * (oc[0] - Tf * b0) + gown[1] * (oc[1] - Tf * b1) + gown[2] * (oc[2] - Tf * b2)
+            + Tf * (gown[0] * b0 + gown[1] * b1 + gown[2] * b2);
+  }
+  // Contraction roles: l = cj + 4 sg + 16 q -- column cj of every chain, splat group sg of quadrant q.  A operand: row
+  // (l & 15) = 4 sg + cj of the quadrant's image; B operand: column cj (chain a: Phi 0..3, chain b: Phi 4, 5, chain w: dL/dcolor).
+  const float4* __restrict__ PhiA4 = reinterpret_cast<const float4*>(lds_phi + (8 * q + cj) * kPhiRow);
+  const float4* __restrict__ PhiB4 = reinterpret_cast<const float4*>(lds_phi + (8 * q + 4 + cj) * kPhiRow);
+  const uint32_t tile_bits = (uint32_t)tile;
+  const bool have_masks = have_mask_array && masks_valid != 0u;               // uniform
+
+  int head_v = 0, c0 = 0, c1 = 0, c2 = 0;                        // the lane's OWN queue: head, queued entries by chunk in flight
+  int inflight = 0, n0 = 0, n1 = 0, n2 = 0;                      // chunks in flight and their lengths (wave-uniform)
+  uint32_t base = s, wslot = 0u, rslot = 0u, nsteps = 0u;       // next chunk to append goes to slots wslot.., oldest sits at rslot..
+  // list entries one chunk ahead (a lane past the end reads entry 0 of its own bin)
+  auto lpos = [&](uint32_t b) { const uint32_t p = b + (uint32_t)l; return p < e ? p : s; };
+
+  // the step in flight: cur = popped and gathered, to be computed; nxt = popped, gathers in flight
+  bool have_cur = false;
+  float curK[6] = {-1e30f, 0.f, 0.f, 0.f, 0.f, 0.f}, curC[3] = {0.f, 0.f, 0.f};
+  int cur_slot = kBqDummy, cur_d0 = 0;
+  bool cur_hot = false;
+
+  for (;;) {
+    const bool all_done = __ballot(!px.done) == 0ull;
+    if (all_done) break;                                        // every pixel of the tile has ended: nothing more can contribute
+    if (inflight < kBqChunks && base < e) {
+      // ---- append the next 64-entry chunk: ids into the ring, wavefront-ballot compaction into the four queues ----------
+      const uint32_t pos = base + (uint32_t)l;
+      const bool in = pos < e;
+      const uint32_t gid = gid_n, inst = inst_n;
+      uint32_t mask = mask_n;
+      gid_n = sorted_gid[lpos(base + 64u)]; inst_n = sorted_inst[lpos(base + 64u)];
+      if (have_masks) {
+        mask_n = (uint32_t)qmask[lpos(base + 64u)];
+      } else {                                                  // another forward ran: the box test of composite_forward_q, here
+        const float4* gp = reinterpret_cast<const float4*>(geom + gid);
+        const float4 g0 = gp[0], g1 = gp[1];
+        mask = quadrant_mask_bq(g0, g1, g0.x - cx, g0.y - cy);
+      }
+      mask = in ? mask : 0u;
+      const int slot = (int)wslot + l;
+      tgid[slot] = gid; tinst[slot] = inst;
+      const int tail_v = head_v + c0 + c1 + c2;
+      int add_v = 0;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const bool in_q = (mask >> qq) & 1u;
+        const unsigned long long bal = __ballot(in_q);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        const int tail = __builtin_amdgcn_readlane(tail_v, 16 * qq);
+        if (in_q) lds_q[wv][qq][bq_wrap(bq_wrap(tail + rank))] = (uint8_t)slot;
+        const int add = (int)__builtin_popcountll(bal);
+        add_v = (q == qq) ? add : add_v;
+      }
+      const int len = (int)min(64u, e - base);
+      if (inflight == 0) { c0 += add_v; n0 = len; }
+      else if (inflight == 1) { c1 += add_v; n1 = len; }
+      else { c2 += add_v; n2 = len; }
+      base += 64u; wslot = (wslot == (uint32_t)(kBqRing - 64)) ? 0u : wslot + 64u; ++inflight;
+      continue;
+    }
+    // ---- pop the NEXT step (min(16, count) entries from every queue) and request its splats: lane (q, j) owns entry j ----
+    const int cnt = c0 + c1 + c2;
+    const int avail = min(16, cnt);
+    const bool nxt_valid = i < avail;
+    int nxt_slot = kBqDummy;
+    if (nxt_valid) nxt_slot = (int)lds_q[wv][q][bq_wrap(head_v + i)];
+    const uint32_t ngid = tgid[nxt_slot];
+    const float4* ngp = reinterpret_cast<const float4*>(geom + ngid);
+    const float4 ng0 = ngp[0], ng1 = ngp[1];
+    const float nc0 = colors[3 * ngid], nc1 = colors[3 * ngid + 1], nc2 = colors[3 * ngid + 2];
+    head_v = bq_wrap(head_v + avail);
+    int nxt_d0;
+    {
+      int t = avail;
+      nxt_d0 = min(t, c0); c0 -= nxt_d0; t -= nxt_d0;
+      const int d1 = min(t, c1); c1 -= d1; t -= d1;
+      c2 -= t;
+    }
+    const bool have_nxt = __ballot(nxt_valid) != 0ull;
+
+    if (have_cur) {
+      // ---- compute the current step: four groups of four splats per quadrant ----------------------------------------------
+      ++nsteps;
+      float w[16];
+      const bool hot = __ballot(cur_hot) != 0ull;               // wave-uniform: some splat of this step may hit the 0.99 clamp
+#define VTGS_BQ_GROUP(G)                                                                         \
+      {                                                                                           \
+        float uo[4];                                                                              \
+        if (hot) bq_group<G, true>(px, curK, curC, Phi, gown, uo, *(float(*)[4])(w + 4 * G));     \
+        else bq_group<G, false>(px, curK, curC, Phi, gown, uo, *(float(*)[4])(w + 4 * G));        \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) img[img_write_off(q, 4 * G + r, i)] = uo[r]; \
+      }
+      VTGS_BQ_GROUP(0) VTGS_BQ_GROUP(1) VTGS_BQ_GROUP(2) VTGS_BQ_GROUP(3)
+#undef VTGS_BQ_GROUP
+      // ---- pixel contraction per quadrant: u' x (Phi 0..3 | Phi 4, 5), then w x dL/dcolor --------------------------------
+      f32x4 Pa = {0.f, 0.f, 0.f, 0.f}, Pb = {0.f, 0.f, 0.f, 0.f}, Pw = {0.f, 0.f, 0.f, 0.f};
+      float4 ua[4], pa4[4], pb4[4];
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        ua[t4] = *reinterpret_cast<const float4*>(img + img_read_off(q, row, t4));
+        pa4[t4] = PhiA4[t4]; pb4[t4] = PhiB4[t4];
+      }
+      // (LDS operations of one wavefront execute in order: the w stores below cannot overtake the u' row reads above)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) img[img_write_off(q, k, i)] = w[k];
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const float uav[4] = {ua[t4].x, ua[t4].y, ua[t4].z, ua[t4].w};
+        const float bav[4] = {pa4[t4].x, pa4[t4].y, pa4[t4].z, pa4[t4].w}, bbv[4] = {pb4[t4].x, pb4[t4].y, pb4[t4].z, pb4[t4].w};
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          Pa = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bav[e4], Pa, 0, 0, 0);
+          Pb = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bbv[e4], Pb, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const float4 wa = *reinterpret_cast<const float4*>(img + img_read_off(q, row, t4));
+        const float wav[4] = {wa.x, wa.y, wa.z, wa.w};
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) Pw = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], Bg[4 * t4 + e4], Pw, 0, 0, 0);
+      }
+      // ---- add the quadrant's partial sums to the splats' ring accumulators: lane (q, sg, cj) holds rows 4 sg + 0..3 -----
+      {
+        const int s0 = quad_bcast<0>(cur_slot), s1 = quad_bcast<1>(cur_slot), s2 = quad_bcast<2>(cur_slot), s3 = quad_bcast<3>(cur_slot);
+        const int sl4[4] = {s0, s1, s2, s3};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* a = acc + sl4[r] * kAccRow;
+          __hip_atomic_fetch_add(a + cj, Pa[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (cj < 2) __hip_atomic_fetch_add(a + 4 + cj, Pb[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (cj < 3) __hip_atomic_fetch_add(a + 6 + cj, Pw[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+    // ---- the popped step becomes the current one ----------------------------------------------------------------------------
+    have_cur = have_nxt;
+    cur_slot = nxt_slot; cur_d0 = nxt_d0;
+    cur_hot = nxt_valid && ng1.y > kClampGuard;
+    {
+      float K[6];
+      tile_coefficients(ng0, ng1, cx, cy, K);
+      curK[0] = nxt_valid ? K[0] : -1e30f;
+#pragma unroll
+      for (int m = 1; m < 6; ++m) curK[m] = nxt_valid ? K[m] : 0.f;
+      curC[0] = nxt_valid ? nc0 : 0.f; curC[1] = nxt_valid ? nc1 : 0.f; curC[2] = nxt_valid ? nc2 : 0.f;
+    }
+    // ---- retire: the oldest chunk has left all four queues AND the step still to be computed holds none of its entries ---
+    while (inflight > 0 && __ballot(c0 > 0) == 0ull && __ballot(have_cur && cur_d0 > 0) == 0ull) {
+      const int slot = (int)rslot + l;
+      float v[kAccRow];
+#pragma unroll
+      for (int k = 0; k < kAccRow; ++k) { v[k] = acc[slot * kAccRow + k]; }
+#pragma unroll
+      for (int k = 0; k < kAccRow; ++k) acc[slot * kAccRow + k] = 0.f;
+      if (l < n0) {
+        float2* p = reinterpret_cast<float2*>(grad_inst + (size_t)tinst[slot] * kGradRec);
+        p[0] = make_float2(v[0], v[1]); p[1] = make_float2(v[2], v[3]); p[2] = make_float2(v[4], v[5]);
+        p[3] = make_float2(v[6], v[7]); p[4] = make_float2(v[8], __uint_as_float(tile_bits));
+      }
+      c0 = c1; c1 = c2; c2 = 0; n0 = n1; n1 = n2; n2 = 0;
+      rslot = (rslot == (uint32_t)(kBqRing - 64)) ? 0u : rslot + 64u; --inflight;
+    }
+    if (inflight == 0 && base >= e) break;                      // the list is exhausted and every chunk has retired
+  }
+  // every pixel ended before the end of the list (or the loop ran out): chunks still in flight leave with what they have
+  // gathered so far, entries never appended contributed nothing
+  while (inflight > 0) {
+    const int slot = (int)rslot + l;
+    if (l < n0) {
+      const float* a = acc + slot * kAccRow;
+      float2* p = reinterpret_cast<float2*>(grad_inst + (size_t)tinst[slot] * kGradRec);
+      p[0] = make_float2(a[0], a[1]); p[1] = make_float2(a[2], a[3]); p[2] = make_float2(a[4], a[5]);
+      p[3] = make_float2(a[6], a[7]); p[4] = make_float2(a[8], __uint_as_float(tile_bits));
+    }
+    n0 = n1; n1 = n2; n2 = 0;
+    rslot = (rslot == (uint32_t)(kBqRing - 64)) ? 0u : rslot + 64u; --inflight;
+  }
+  for (; base < e; base += 64u) {
+    const uint32_t pos = base + (uint32_t)l;
+    if (pos < e) {
+      float2* p = reinterpret_cast<float2*>(grad_inst + (size_t)sorted_inst[pos] * kGradRec);
+      p[0] = p[1] = p[2] = p[3] = make_float2(0.f, 0.f);
+      p[4] = make_float2(0.f, __uint_as_float(tile_bits));
+    }
+  }
+  if (step_counters && l == 0) atomicAdd(&step_counters[blockIdx.x & 63u], nsteps);   // measurement only (VTGS_COUNT_STEPS)
+}
+
+}  // namespace vtgs

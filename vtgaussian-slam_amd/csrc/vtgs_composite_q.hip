@@ -218,6 +218,14 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
   __shared__ float4 lds_pa[4][kQRing + 1];                      // c0 c1 c2 depth   (dual: c0 c1 c2 c3)
   __shared__ float4 lds_pb[DUAL ? 4 : 1][DUAL ? kQRing + 1 : 1];//                   (dual: c4 c5 0 0)
   __shared__ uint8_t lds_q[4][4][2 * kQRing];
+#ifdef VTGS_Q_STAMPS
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+  unsigned long long st1 = st0, st2 = st0, st_app = 0ull, st_step = 0ull;
+  unsigned long long st_sort[2] = {st0, st0};
+#define VTGS_SORT_STAMP st_sort
+#else
+#define VTGS_SORT_STAMP nullptr
+#endif
   if (sort_mode) {
     // Nothing ran between the binning and this kernel: the first workgroup does what finalize_forward does (longest list,
     // statistics, overflow flags, the host's record -- it is dispatched first, so the record still leaves early), and
@@ -229,6 +237,7 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
   } else if (ctr->overflow) {
     return;                                                     // bins hold unwritten slots after an overflow
   }
+  if (qmask && blockIdx.x == 0u && threadIdx.x == 0u) fin.ctr->qmask_valid = 1u;
   const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
   const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
   const QuadCoord qc = quad_coord(cs, nblk, gx16, gx8, gy8);
@@ -256,23 +265,26 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     if (L == 1u) {
       if (l == 0) { sorted_gid[s] = (uint32_t)bin_keys[s]; sorted_inst[s] = bin_vals[s]; }
     } else if (sort_mode == 1) {
-      if (L <= 64u) { if (L) wave_sort_tile<1, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l); }
-      else if (L <= 128u) wave_sort_tile<2, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l);
-      else if (L <= 256u) wave_sort_tile<4, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l);
-      else if (L <= 512u) wave_sort_tile<8, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l);
-      else wave_sort_tile<16, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l);
+      if (L <= 64u) { if (L) wave_sort_tile<1, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP); }
+      else if (L <= 128u) wave_sort_tile<2, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
+      else if (L <= 256u) wave_sort_tile<4, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
+      else if (L <= 512u) wave_sort_tile<8, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
+      else wave_sort_tile<16, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
     } else {
-      if (L <= 64u) { if (L) wave_sort_tile<1, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l); }
-      else if (L <= 128u) wave_sort_tile<2, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l);
-      else if (L <= 256u) wave_sort_tile<4, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l);
-      else if (L <= 512u) wave_sort_tile<8, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l);
-      else wave_sort_tile<16, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l);
+      if (L <= 64u) { if (L) wave_sort_tile<1, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP); }
+      else if (L <= 128u) wave_sort_tile<2, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
+      else if (L <= 256u) wave_sort_tile<4, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
+      else if (L <= 512u) wave_sort_tile<8, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
+      else wave_sort_tile<16, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
     }
     // the wavefront's own stores before its own loads: program order within one wavefront, no cache maintenance (a
     // device-scope fence here writes L2 back for every tile: 590 us instead of 90)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_s_waitcnt(0);
   }
+#ifdef VTGS_Q_STAMPS
+  st1 = __builtin_amdgcn_s_memtime();
+#endif
   // dummy slot + queue bytes start defined (a pop past the end of a queue reads bytes that were never written)
   ka[kQDummy] = make_float4(-1e30f, 0.f, 0.f, 0.f);
   kb[kQDummy] = make_float2(0.f, 0.f);
@@ -316,6 +328,9 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     if (inflight < kQChunks && base < e) {
       // ---- append the next 64-entry chunk: gather, table, wavefront-ballot compaction into the four queues ----------
       if (__ballot(!done) == 0ull) break;
+#ifdef VTGS_Q_STAMPS
+      const unsigned long long sa = __builtin_amdgcn_s_memtime();
+#endif
       const uint32_t pos = base + (uint32_t)l;
       const bool in = pos < e;
       const float4 g0 = g0n, g1 = g1n;                             // this chunk's data, requested one chunk ago
@@ -356,6 +371,10 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
       else if (inflight == 1) { c1 += add_v; hot1 = hot; }
       else { c2 += add_v; hot2 = hot; }
       base += 64u; wslot = (wslot == (uint32_t)(kQRing - 64)) ? 0u : wslot + 64u; ++inflight;
+#ifdef VTGS_Q_STAMPS
+      __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): the table / queue writes have landed
+      { const unsigned long long sb = __builtin_amdgcn_s_memtime(); st_app += sb - sa; if (base == s + 64u) st2 = sb; }
+#endif
 #if defined(VTGS_Q_ABL) && VTGS_Q_ABL == 1                                 // ablation: gather + compaction only, no steps
       asm volatile("" :: "v"(c0), "v"(mask));
       head_v += c0 + c1 + c2; head_v -= (head_v >= kQRing) ? kQRing : 0; c0 = c1 = c2 = 0; inflight = 0;
@@ -371,6 +390,9 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     }
     if (__ballot(!done) == 0ull) break;                           // every pixel of the tile has ended
     // ---- one step: pop min(16, count) entries from every queue ---------------------------------------------------------
+#ifdef VTGS_Q_STAMPS
+    const unsigned long long ss = __builtin_amdgcn_s_memtime();
+#endif
     const int avail = min(16, c0 + c1 + c2);
     const int hm = head_v;
     int sl[5];
@@ -397,7 +419,20 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     if (exact) q_forward_step<DUAL, true, true>(T, done, exact, C, C2, ka, kb, sl[4], Phi, PT, PT2);
     else if (hot0 || hot1 || hot2) q_forward_step<DUAL, true, false>(T, done, exact, C, C2, ka, kb, sl[4], Phi, PT, PT2);
     else q_forward_step<DUAL, false, false>(T, done, exact, C, C2, ka, kb, sl[4], Phi, PT, PT2);
+#ifdef VTGS_Q_STAMPS
+    asm volatile("" :: "v"(T), "v"(C[0]));
+    st_step += __builtin_amdgcn_s_memtime() - ss;
+#endif
   }
+#ifdef VTGS_Q_STAMPS
+  if (step_counters && l == 0) {
+    uint32_t* o = step_counters + 64 + 8 * qc.tile;
+    const unsigned long long se = __builtin_amdgcn_s_memtime();
+    o[0] = (uint32_t)(st1 - st0); o[1] = (uint32_t)(st2 - st1); o[2] = (uint32_t)st_app; o[3] = (uint32_t)st_step;
+    o[4] = (uint32_t)(se - st0); o[5] = nsteps; o[6] = e - s;
+    o[7] = (uint32_t)(st_sort[0] - st0) | ((uint32_t)((st_sort[1] - st_sort[0]) >> 4) << 20);   // keys arrived (20 bits) | network / 16
+  }
+#endif
   if (step_counters && l == 0) atomicAdd(&step_counters[blockIdx.x & 63u], nsteps);   // measurement only (VTGS_COUNT_STEPS)
   if (qc.inside) {
     const size_t P = (size_t)cs.W * cs.H, pix = (size_t)qc.py * cs.W + qc.px;

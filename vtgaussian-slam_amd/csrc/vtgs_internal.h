@@ -30,7 +30,8 @@ namespace vtgs {
 struct Counters {
   uint32_t inst_total;      // instances requested (keeps counting past capacity)
   uint32_t overflow;        // bit 0: inst_total > instance capacity, bit 1: a tile list > tile capacity (finalize_forward)
-  uint32_t pad[14];
+  uint32_t qmask_valid;     // composite_forward_q wrote the quadrant masks of this forward's lists (composite_backward_q reads them)
+  uint32_t pad[13];
   // byte 64: image of the public VtgsForwardInfo, written by finalize_forward, copied to the host by vtgs_forward
   unsigned long long info_instances, info_needed, info_r16;
   uint32_t info_visible, info_max_list, info_overflow, info_complete;
@@ -78,7 +79,11 @@ inline WsLayout make_layout(int32_t n, int32_t w, int32_t h, uint64_t cap, uint3
   L.sorted_inst = o; o += align256(slots * 4);
   L.final_T = o;     o += align256((size_t)w * h * 4);
   L.qmask = o;       o += align256(slots);               // quadrant mask (4 bits) of every sorted list entry, written by composite_forward_q
+#ifdef VTGS_Q_STAMPS
+  L.dbg = o;         o += align256(256 + (size_t)L.tiles8 * 32);   // diagnostic build: + 8 words of cycle stamps per tile
+#else
   L.dbg = o;         o += 256;                           // 64 step counters (measurement only, VTGS_COUNT_STEPS)
+#endif
   L.total = o;
   return L;
 }

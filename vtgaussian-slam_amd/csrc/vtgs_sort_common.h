@@ -2,6 +2,7 @@
 // quadrant-queue forward composite, which sorts its own tile's list when the bins cannot hold lists above 1024 entries.
 #pragma once
 #include "vtgs_internal.h"
+#include <type_traits>
 
 namespace vtgs {
 
@@ -43,10 +44,103 @@ __device__ __forceinline__ void in_lane_cleaners(unsigned long long (&k)[E], uin
   }
 }
 
+#ifndef VTGS_SORT_DPP
+#define VTGS_SORT_DPP 1
+#endif
+
 __device__ __forceinline__ unsigned long long lane_fetch64(unsigned long long x, int byte_addr) {   // x of lane byte_addr / 4
   const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(uint32_t)x);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(uint32_t)(x >> 32));
   return ((unsigned long long)hi << 32) | lo;
+}
+
+// x of lane (lane ^ MASK) for the masks the network uses, without the LDS crossbar: DPP row operations inside a 16-lane row,
+// v_permlane16_swap / v_permlane32_swap across rows (semantics: tests/micro/permlane_swap.hip).  When the sort runs at the top
+// of composite_forward_q, at 4 wavefronts per SIMD, it is bound by the latency of its 21 dependent cross-lane stages, not by
+// instruction issue: a ds_bpermute round trip per stage and key cost 19 k of the wavefront's 62 k cycles
+// (profiles/r3_forward_stamps.md); a DPP move has the latency of a vector instruction.
+template <int MASK>
+__device__ __forceinline__ uint32_t lane_xor32(uint32_t x, int lane) {
+  constexpr int kQuad1 = 0xB1, kQuad2 = 0x4E, kQuad3 = 0x1B, kRowMirror = 0x140, kHalfMirror = 0x141, kRor8 = 0x128;
+  auto dpp = [](uint32_t v, auto ctrl) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, decltype(ctrl)::value, 0xf, 0xf, false); };
+  auto x16 = [&](uint32_t v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (lane & 16) ? r[0] : r[1];
+  };
+  auto x32 = [&](uint32_t v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (lane & 32) ? r[0] : r[1];
+  };
+  if constexpr (MASK == 1) return dpp(x, std::integral_constant<int, kQuad1>{});
+  else if constexpr (MASK == 2) return dpp(x, std::integral_constant<int, kQuad2>{});
+  else if constexpr (MASK == 3) return dpp(x, std::integral_constant<int, kQuad3>{});
+  else if constexpr (MASK == 4) return dpp(dpp(x, std::integral_constant<int, kHalfMirror>{}), std::integral_constant<int, kQuad3>{});
+  else if constexpr (MASK == 7) return dpp(x, std::integral_constant<int, kHalfMirror>{});
+  else if constexpr (MASK == 8) return dpp(x, std::integral_constant<int, kRor8>{});
+  else if constexpr (MASK == 15) return dpp(x, std::integral_constant<int, kRowMirror>{});
+  else if constexpr (MASK == 16) return x16(x);
+  else if constexpr (MASK == 31) return x16(dpp(x, std::integral_constant<int, kRowMirror>{}));
+  else if constexpr (MASK == 32) return x32(x);
+  else { static_assert(MASK == 63, "lane mask not used by the network"); return x32(x16(dpp(x, std::integral_constant<int, kRowMirror>{}))); }
+}
+// DPP: lists up to VTGS_SORT_DPP_MAX_E keys per lane (the common ones: 4 keys per lane = 256 entries); the long-list forms
+// keep the LDS crossbar -- with 16 or 32 keys per lane the extra temporaries of the row swaps push them into scratch
+#ifndef VTGS_SORT_DPP_MAX_E
+#define VTGS_SORT_DPP_MAX_E 8
+#endif
+template <int MASK, bool DPP>
+__device__ __forceinline__ unsigned long long lane_xor64(unsigned long long x, int lane) {
+  if constexpr (DPP)
+    return ((unsigned long long)lane_xor32<MASK>((uint32_t)(x >> 32), lane) << 32) | lane_xor32<MASK>((uint32_t)x, lane);
+  else
+    return lane_fetch64(x, (lane ^ MASK) << 2);
+}
+template <int MASK, bool DPP>
+__device__ __forceinline__ uint32_t lane_xor_v(uint32_t x, int lane) {
+  if constexpr (DPP) return lane_xor32<MASK>(x, lane);
+  else return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ MASK) << 2, (int)x);
+}
+
+// mirror step of a merge level: lane ^ M, in-lane index mirrored.  Registers r and E-1-r trade places with their mirror images
+// in the partner lane: done pair by pair, so that only two fetched keys are live at a time (a [E] array of them doubles the
+// register footprint of the E = 32 form)
+template <int E, bool HASV, int M>
+__device__ __forceinline__ void mirror_step(unsigned long long (&k)[E], uint32_t (&v)[E], int lane) {
+  constexpr bool kDpp = VTGS_SORT_DPP != 0 && E <= VTGS_SORT_DPP_MAX_E;
+  const bool lower = (lane & ((M + 1) >> 1)) == 0;
+#pragma unroll
+  for (int r = 0; r < E / 2 + (E == 1 ? 1 : 0); ++r) {
+    const int m2 = E - 1 - r;
+    const unsigned long long pa = lane_xor64<M, kDpp>(k[m2], lane);          // partner's mirror of r
+    const uint32_t va = HASV ? lane_xor_v<M, kDpp>(v[m2], lane) : 0u;
+    unsigned long long pb = 0ull; uint32_t vb = 0u;
+    if (m2 != r) {
+      pb = lane_xor64<M, kDpp>(k[r], lane);                                   // partner's mirror of E-1-r
+      vb = HASV ? lane_xor_v<M, kDpp>(v[r], lane) : 0u;
+    }
+    const bool ta = lower ? (pa < k[r]) : (pa > k[r]);
+    k[r] = ta ? pa : k[r];
+    if (HASV) v[r] = ta ? va : v[r];
+    if (m2 != r) {
+      const bool tb = lower ? (pb < k[m2]) : (pb > k[m2]);
+      k[m2] = tb ? pb : k[m2];
+      if (HASV) v[m2] = tb ? vb : v[m2];
+    }
+  }
+}
+// half-cleaner across lanes: lane ^ m, same register
+template <int E, bool HASV, int m>
+__device__ __forceinline__ void cleaner_step(unsigned long long (&k)[E], uint32_t (&v)[E], int lane) {
+  constexpr bool kDpp = VTGS_SORT_DPP != 0 && E <= VTGS_SORT_DPP_MAX_E;
+  const bool lower = (lane & m) == 0;
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const unsigned long long pk = lane_xor64<m, kDpp>(k[r], lane);
+    const uint32_t pv = HASV ? lane_xor_v<m, kDpp>(v[r], lane) : 0u;
+    const bool take = lower ? (pk < k[r]) : (pk > k[r]);
+    k[r] = take ? pk : k[r];
+    if (HASV) v[r] = take ? pv : v[r];
+  }
 }
 
 template <int E, bool HASV>
@@ -81,44 +175,70 @@ __device__ __forceinline__ void wave_sort_regs(unsigned long long (&k)[E], uint3
     }
   }
   // levels across lanes: lane mask M = 1, 3, 7, .. 63 (k2 = 2E .. 64E)
+  if constexpr (!(VTGS_SORT_DPP != 0 && E <= VTGS_SORT_DPP_MAX_E)) {
+    // long lists: the LDS crossbar with run-time lane masks -- merge levels and cleaners are real loops (code size, above)
 #pragma unroll 1
-  for (int M = 1; M < 64; M = 2 * M + 1) {
-    {                                                            // mirror step: lane ^ M, in-lane index mirrored
-      // registers r and E-1-r trade places with their mirror images in the partner lane: done pair by pair, so that only two
-      // fetched keys are live at a time (a [E] array of them doubles the register footprint of the E = 32 form)
-      const int addr = (lane ^ M) << 2;
-      const bool lower = (lane & ((M + 1) >> 1)) == 0;
+    for (int M = 1; M < 64; M = 2 * M + 1) {
+      {
+        const int addr = (lane ^ M) << 2;
+        const bool lower = (lane & ((M + 1) >> 1)) == 0;
 #pragma unroll
-      for (int r = 0; r < E / 2 + (E == 1 ? 1 : 0); ++r) {
-        const int m2 = E - 1 - r;
-        const unsigned long long pa = lane_fetch64(k[m2], addr);          // partner's mirror of r
-        const uint32_t va = HASV ? (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[m2]) : 0u;
-        unsigned long long pb = 0ull; uint32_t vb = 0u;
-        if (m2 != r) {
-          pb = lane_fetch64(k[r], addr);                                   // partner's mirror of E-1-r
-          vb = HASV ? (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[r]) : 0u;
-        }
-        const bool ta = lower ? (pa < k[r]) : (pa > k[r]);
-        k[r] = ta ? pa : k[r];
-        if (HASV) v[r] = ta ? va : v[r];
-        if (m2 != r) {
-          const bool tb = lower ? (pb < k[m2]) : (pb > k[m2]);
-          k[m2] = tb ? pb : k[m2];
-          if (HASV) v[m2] = tb ? vb : v[m2];
+        for (int r = 0; r < E / 2 + (E == 1 ? 1 : 0); ++r) {
+          const int m2 = E - 1 - r;
+          const unsigned long long pa = lane_fetch64(k[m2], addr);          // partner's mirror of r
+          const uint32_t va = HASV ? (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[m2]) : 0u;
+          unsigned long long pb = 0ull; uint32_t vb = 0u;
+          if (m2 != r) {
+            pb = lane_fetch64(k[r], addr);                                   // partner's mirror of E-1-r
+            vb = HASV ? (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[r]) : 0u;
+          }
+          const bool ta = lower ? (pa < k[r]) : (pa > k[r]);
+          k[r] = ta ? pa : k[r];
+          if (HASV) v[r] = ta ? va : v[r];
+          if (m2 != r) {
+            const bool tb = lower ? (pb < k[m2]) : (pb > k[m2]);
+            k[m2] = tb ? pb : k[m2];
+            if (HASV) v[m2] = tb ? vb : v[m2];
+          }
         }
       }
+#pragma unroll 1
+      for (int m = (M + 1) >> 2; m > 0; m >>= 1) {                 // half-cleaners across lanes: lane ^ m
+        const int addr = (lane ^ m) << 2;
+        const bool lower = (lane & m) == 0;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const unsigned long long pk = lane_fetch64(k[r], addr);
+          const uint32_t pv = HASV ? (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[r]) : 0u;
+          const bool take = lower ? (pk < k[r]) : (pk > k[r]);
+          k[r] = take ? pk : k[r];
+          if (HASV) v[r] = take ? pv : v[r];
+        }
+      }
+      in_lane_cleaners<E, HASV>(k, v);
+    }
+    return;
+  }
+  // short lists: DPP / row-swap exchanges.  The level and the cleaner distance stay loop variables; the exchange needs its
+  // lane mask at compile time, hence the switches.
+#pragma unroll 1
+  for (int lvl = 0; lvl < 6; ++lvl) {
+    switch (lvl) {
+      case 0: mirror_step<E, HASV, 1>(k, v, lane); break;
+      case 1: mirror_step<E, HASV, 3>(k, v, lane); break;
+      case 2: mirror_step<E, HASV, 7>(k, v, lane); break;
+      case 3: mirror_step<E, HASV, 15>(k, v, lane); break;
+      case 4: mirror_step<E, HASV, 31>(k, v, lane); break;
+      default: mirror_step<E, HASV, 63>(k, v, lane); break;
     }
 #pragma unroll 1
-    for (int m = (M + 1) >> 2; m > 0; m >>= 1) {                 // half-cleaners across lanes: lane ^ m
-      const int addr = (lane ^ m) << 2;
-      const bool lower = (lane & m) == 0;
-#pragma unroll
-      for (int r = 0; r < E; ++r) {
-        const unsigned long long pk = lane_fetch64(k[r], addr);
-        const uint32_t pv = HASV ? (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[r]) : 0u;
-        const bool take = lower ? (pk < k[r]) : (pk > k[r]);
-        k[r] = take ? pk : k[r];
-        if (HASV) v[r] = take ? pv : v[r];
+    for (int c = lvl - 1; c >= 0; --c) {                          // half-cleaners: lane ^ 2^c
+      switch (c) {
+        case 0: cleaner_step<E, HASV, 1>(k, v, lane); break;
+        case 1: cleaner_step<E, HASV, 2>(k, v, lane); break;
+        case 2: cleaner_step<E, HASV, 4>(k, v, lane); break;
+        case 3: cleaner_step<E, HASV, 8>(k, v, lane); break;
+        default: cleaner_step<E, HASV, 16>(k, v, lane); break;
       }
     }
     in_lane_cleaners<E, HASV>(k, v);
@@ -132,7 +252,7 @@ constexpr uint32_t kSlotBits = 11u;            // (the host sends ids below 2^21
 template <int E, bool PACKED>
 __device__ __forceinline__ void wave_sort_tile(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                uint32_t* __restrict__ sorted_gid, uint32_t* __restrict__ sorted_inst,
-                                               size_t s, uint32_t L, int lane) {
+                                               size_t s, uint32_t L, int lane, unsigned long long* stamp = nullptr) {
   unsigned long long k[E]; uint32_t v[E];
 #pragma unroll
   for (int r = 0; r < E; ++r) {
@@ -145,7 +265,13 @@ __device__ __forceinline__ void wave_sort_tile(const unsigned long long* __restr
       v[r] = (e < L) ? vals[s + e] : 0u;
     }
   }
+#ifdef VTGS_Q_STAMPS
+  if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[0] = __builtin_amdgcn_s_memtime(); }
+#endif
   wave_sort_regs<E, !PACKED>(k, v, lane);
+#ifdef VTGS_Q_STAMPS
+  if (stamp) { asm volatile("" :: "v"(k[0])); stamp[1] = __builtin_amdgcn_s_memtime(); }
+#endif
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     const uint32_t e = (uint32_t)lane * E + r;

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
+import time
 from typing import NamedTuple, Optional, Tuple
 
 import torch
@@ -127,7 +129,12 @@ _RADIUS_RULES = {"3sigma": 0, "opacity": 1}
 _capacity_hint = {}          # (device index, N, W, H, band) -> instances seen last time
 _tile_cap_hint = {}          # same key -> longest per-tile list seen last time
 _caps_in_use = {}            # same key -> (instance capacity, tile capacity) of the previous forward
+_async_ok = {}               # same key -> the (capacities) of which the last forward of this shape used < 80 %, else None
 _last_info = {}
+# "auto" (default): a forward in grad mode returns without waiting for its result record when the previous forward of the
+# same shape left >= 20 % headroom in both capacities; the record is read after the backward has been enqueued.  "checked":
+# every forward waits for its record (round 2's behaviour).  Forwards in no-grad mode are always checked.
+_FORWARD_MODE = os.environ.get("VTGS_FORWARD_MODE", "auto")
 
 
 def last_forward_info() -> dict:
@@ -242,20 +249,95 @@ def _require(t: torch.Tensor, name: str, shape_tail: int, n: int, device) -> tor
 
 
 class _ForwardState:
-    __slots__ = ("cam", "n", "workspace", "capacity", "tile_cap", "instances", "image_state", "key")
+    """What a backward needs from its forward.  `pending`: the forward ran in the asynchronous mode and its result record has
+    not been looked at yet (`_settle` does, after the backward has been enqueued)."""
+    __slots__ = ("cam", "n", "workspace", "capacity", "tile_cap", "_instances", "image_state", "key", "pending")
+
+    @property
+    def instances(self):
+        if self._instances is None:                # asynchronous forward: the count arrives with the record
+            _settle(self)
+        return self._instances
+
+    @instances.setter
+    def instances(self, v):
+        self._instances = v
 
 
-_info_slots: dict = {}       # device index -> pinned, device-mapped 64-byte slot the forward writes its result record to
+class _SlotPool:
+    """Pinned, device-mapped 64-byte result records, one per forward in flight.  A slot is handed out round-robin and stays
+    with its forward until the record has been read (`_settle`); the pool is per (device, stream) and guarded by a lock, so
+    forwards from several threads or streams never share a record."""
+    SLOTS = 64
+
+    def __init__(self):
+        self.mem = torch.zeros((self.SLOTS * 64,), dtype=torch.uint8).pin_memory()
+        base = self.mem.data_ptr()
+        self.ptr = [base + 64 * i for i in range(self.SLOTS)]
+        self.info = [_VtgsForwardInfo.from_address(a) for a in self.ptr]
+        self.owner = [None] * self.SLOTS           # the _ForwardState whose record is still unread
+        self.next = 0
+
+    def take(self, fs):
+        i = self.next
+        self.next = (i + 1) % self.SLOTS
+        prev = self.owner[i]
+        if prev is not None:                       # 64 forwards later: its record has long landed
+            _settle(prev)
+        self.owner[i] = fs
+        return i
 
 
-def _info_slot(device):
-    """(pinned tensor, its address, a ctypes view of the record in it) -- the view reads the pinned bytes in place."""
-    slot = _info_slots.get(device.index)
-    if slot is None:
-        t = torch.zeros((64,), dtype=torch.uint8).pin_memory()
-        slot = (t, t.data_ptr(), _VtgsForwardInfo.from_address(t.data_ptr()))
-        _info_slots[device.index] = slot
-    return slot
+_slot_pools: dict = {}       # (device index, stream) -> _SlotPool
+_slot_lock = threading.Lock()
+
+
+def _slot_pool(device, stream) -> "_SlotPool":
+    key = (device.index, int(stream))
+    pool = _slot_pools.get(key)
+    if pool is None:
+        pool = _slot_pools[key] = _SlotPool()
+    return pool
+
+
+def _settle(fs) -> None:
+    """Read the result record of an asynchronous forward (waiting for it if the device has not written it yet -- by the time
+    a backward has been enqueued it has: the record leaves right after the binning).  An overflow here means that the image
+    the caller already holds is invalid: raise, after growing the capacities so that the next forward fits."""
+    pend = fs.pending
+    if pend is None:
+        return
+    fs.pending = None
+    pool, i, device = pend
+    info = pool.info[i]
+    if not info.complete:
+        # The device has not reached the end of this forward's binning yet (the host is running ahead of it).  Poll the pinned
+        # record -- NOT a stream synchronisation, which would also wait for everything enqueued behind the forward.
+        t0 = time.perf_counter()
+        spins = 0
+        while not info.complete:
+            spins += 1
+            if spins & 0xFFF == 0:
+                if torch.cuda.current_stream(device).query() and not info.complete:
+                    raise RuntimeError("vtgs_forward: result record never arrived")
+                if time.perf_counter() - t0 > 20.0:
+                    raise RuntimeError("vtgs_forward: timed out waiting for the result record")
+    pool.owner[i] = None
+    key, n = fs.key, fs.n
+    if info.overflow:
+        cap = int(info.instances_needed * 1.5) + 4096 if info.overflow & 1 else fs.capacity
+        tcap = _tile_capacity_for(info.max_tile_list) if info.overflow & 2 else fs.tile_cap
+        _caps_in_use[key] = (cap, tcap)
+        _capacity_hint[key] = max(int(info.instances_needed), 1)
+        _tile_cap_hint[key] = max(int(info.max_tile_list), 1)
+        _async_ok[key] = None
+        raise RuntimeError(
+            "vtgs_forward (asynchronous mode): the workspace of the previous forward overflowed -- the instance count grew by "
+            "more than 25 % between two forwards of the same shape -- so the image it returned is INVALID. The capacities "
+            "have been raised; redo the iteration, or set VTGS_FORWARD_MODE=checked to have every forward verified before "
+            "it returns.")
+    fs._instances = int(info.instances)
+    _record_info(key, n, fs.cam.W, fs.cam.H, fs.capacity, info)
 
 
 def _tile_capacity_for(max_list: int) -> int:
@@ -282,6 +364,9 @@ def _choose_capacities(key, n):
 def _record_info(key, n, W, H, capacity, info):
     _capacity_hint[key] = max(int(info.instances_needed), 1)
     _tile_cap_hint[key] = max(int(info.max_tile_list), 1)
+    cap, tcap = _caps_in_use.get(key, (0, 0))                  # the capacities this forward ran with
+    roomy = bool(cap and tcap and info.instances_needed <= 0.8 * cap and info.max_tile_list <= 0.8 * tcap)
+    _async_ok[key] = (cap, tcap) if roomy else None            # ... are the only ones the next forward may run ahead with
     _last_info.update(instances=int(info.instances), tiles16_touched=int(info.tiles16_touched),
                       visible=int(info.visible), max_tile_list=int(info.max_tile_list), n=n, width=W, height=H,
                       capacity=int(capacity))
@@ -301,12 +386,16 @@ def _workspace(n, W, H, capacity, tile_cap, device):
 
 
 def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, want_async: bool = False, colors_b=None):
-    """One forward through the C ABI.  Every call is CHECKED (include/vtgs.h, VTGS_FORWARD_CHECKED): all kernels are
-    enqueued, then the host waits only for the result record, which the device writes right after the binning -- about a
-    quarter into the forward, while the sort and the composite are still running.  A capacity overflow is therefore
-    answered HERE, by growing the workspace and running again, before the caller ever sees an image: the image this
-    function returns is always valid, in grad mode and in no-grad mode alike, and nothing can fail later in backward.
-    (`want_async` is accepted for the callers of earlier versions and ignored.)
+    """One forward through the C ABI.
+    CHECKED (include/vtgs.h, VTGS_FORWARD_CHECKED; always in no-grad mode, and whenever the previous forward of this shape
+    came within 20 % of a capacity): all kernels are enqueued, then the host waits only for the result record, which the
+    device writes right after the binning -- about a quarter into the forward.  A capacity overflow is answered HERE, by
+    growing the workspace and running again, before the caller sees an image.
+    ASYNCHRONOUS (`want_async`, i.e. grad mode, and >= 20 % headroom last time): the host does not wait at all -- it can
+    enqueue the loss and the backward while the device is still busy with the previous iteration, which is what the
+    host-bound shapes need (three of the five BASELINE configurations) -- and `_settle` reads the
+    record after the backward has been enqueued.  An overflow there cannot be repaired (the caller already holds the
+    image) and raises; it takes a > 25 % jump of the instance count between two forwards of one shape.
     colors_b given: dual render (vtgs_forward_dual) -- the third return value is then the second colour image
     [3,H,W] instead of the depth image."""
     device = means3D.device
@@ -316,41 +405,56 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
     images = torch.empty((3 + nd, H, W), dtype=torch.float32, device=device)      # one allocation for both images
     color, depth = images[:3], images[3:]
     radii = torch.empty((n,), dtype=torch.int32, device=device)
-    _slot_tensor, slot_ptr, info = _info_slot(device)
     stream = _stream_ptr(device)
+    key = (device.index, n, W, H, cam.band)
+    fs = _ForwardState()
+    fs.cam, fs.n, fs.image_state, fs.key, fs.pending = cam, n, None, key, None
 
-    def launch(workspace, nbytes, capacity, tile_cap):
+    def launch(workspace, nbytes, capacity, tile_cap, slot_ptr, flags):
         if colors_b is None:
             return _lib.vtgs_forward(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
                                      scales.data_ptr(), rotations.data_ptr(), color.data_ptr(), depth.data_ptr(),
                                      radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, tile_cap, slot_ptr,
-                                     VTGS_FORWARD_CHECKED, stream)
+                                     flags, stream)
         return _lib.vtgs_forward_dual(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), colors_b.data_ptr(),
                                       opacities.data_ptr(), scales.data_ptr(), rotations.data_ptr(), color.data_ptr(),
                                       depth.data_ptr(), radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, tile_cap,
-                                      slot_ptr, VTGS_FORWARD_CHECKED, stream)
+                                      slot_ptr, flags, stream)
 
-    key = (device.index, n, W, H, cam.band)
-    capacity, tile_cap = _choose_capacities(key, n)
-    fs = _ForwardState()
-    fs.cam, fs.n, fs.image_state, fs.key = cam, n, None, key
-    with _device_guard(device):
-        for _attempt in range(6):
-            nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
-            st = launch(workspace, nbytes, capacity, tile_cap)
-            if st == VTGS_ERR_INSTANCE_OVERFLOW:          # the record says what is needed: grow whichever was short
-                if info.overflow & 1:
-                    capacity = int(info.instances_needed * 1.5) + 4096
-                if info.overflow & 2:
-                    tile_cap = _tile_capacity_for(info.max_tile_list)
-                _caps_in_use[key] = (capacity, tile_cap)
-                continue
-            _check(st, "vtgs_forward")
-            break
-        else:
-            raise RuntimeError("vtgs_forward: instance capacity kept overflowing")
-    _record_info(key, n, W, H, capacity, info)
-    fs.workspace, fs.capacity, fs.tile_cap, fs.instances = workspace, capacity, tile_cap, int(info.instances)
+    with _slot_lock:
+        pool = _slot_pool(device, stream)
+        slot = pool.take(fs)
+        capacity, tile_cap = _choose_capacities(key, n)
+        run_ahead = want_async and _FORWARD_MODE == "auto" and _async_ok.get(key) == (capacity, tile_cap)
+        info = pool.info[slot]
+        with _device_guard(device):
+            if run_ahead:
+                # Asynchronous: everything is enqueued and the host moves on (to the loss, to the backward's launches); the
+                # record -- written by the device right after the binning -- is read by _settle once the backward is queued.
+                nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
+                info.complete = 0
+                _check(launch(workspace, nbytes, capacity, tile_cap, pool.ptr[slot], VTGS_FORWARD_ASYNC), "vtgs_forward")
+                fs.workspace, fs.capacity, fs.tile_cap, fs._instances = workspace, capacity, tile_cap, None
+                fs.pending = (pool, slot, device)
+                return color, radii, depth, fs
+            for _attempt in range(6):
+                nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
+                st = launch(workspace, nbytes, capacity, tile_cap, pool.ptr[slot], VTGS_FORWARD_CHECKED)
+                if st == VTGS_ERR_INSTANCE_OVERFLOW:          # the record says what is needed: grow whichever was short
+                    if info.overflow & 1:
+                        capacity = int(info.instances_needed * 1.5) + 4096
+                    if info.overflow & 2:
+                        tile_cap = _tile_capacity_for(info.max_tile_list)
+                    _caps_in_use[key] = (capacity, tile_cap)
+                    continue
+                _check(st, "vtgs_forward")
+                break
+            else:
+                raise RuntimeError("vtgs_forward: instance capacity kept overflowing")
+        pool.owner[slot] = None
+        _caps_in_use.setdefault(key, (capacity, tile_cap))
+        _record_info(key, n, W, H, capacity, info)
+        fs.workspace, fs.capacity, fs.tile_cap, fs._instances = workspace, capacity, tile_cap, int(info.instances)
     return color, radii, depth, fs
 
 
@@ -373,6 +477,12 @@ def _device_guard(device):
     return torch.cuda.device(device)
 
 
+def _scratch_instances(fs: _ForwardState) -> int:
+    """Instance records the backward needs room for: the forward's count, or -- while the record of an asynchronous forward
+    has not been read -- its instance capacity (an upper bound; the block comes from the caching allocator either way)."""
+    return fs._instances if fs._instances is not None else fs.capacity
+
+
 def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotations, out_color, grad_color):
     device = means3D.device
     n = fs.n
@@ -381,7 +491,7 @@ def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotatio
     g_opac, g_scales, g_rot = flat[9 * n:10 * n].view(n, 1), flat[10 * n:13 * n].view(n, 3), flat[13 * n:].view(n, 4)
     if n == 0:
         return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
-    sbytes = _lib.vtgs_backward_scratch_bytes(n, fs.instances)
+    sbytes = _lib.vtgs_backward_scratch_bytes(n, _scratch_instances(fs))
     scratch = torch.empty((sbytes,), dtype=torch.uint8, device=device)
     state_ptr = fs.image_state.data_ptr() if fs.image_state is not None else None
     with _device_guard(device):
@@ -391,6 +501,7 @@ def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotatio
                                 scratch.data_ptr(), sbytes, g_means3D.data_ptr(), g_means2D.data_ptr(), g_colors.data_ptr(),
                                 g_opac.data_ptr(), g_scales.data_ptr(), g_rot.data_ptr(), _stream_ptr(device))
     _check(st, "vtgs_backward")
+    _settle(fs)                                    # asynchronous forward: its record is read now, behind the backward's launches
     return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
 
 
@@ -404,15 +515,17 @@ def _run_backward_dual(fs: _ForwardState, means3D, colors_a, colors_b, opacities
     g_means3D, g_means2D, g_ca, g_cb, g_opac, g_scales, g_rot = new(n, 3), new(n, 3), new(n, 3), new(n, 3), new(n, 1), new(n, 3), new(n, 4)
     if n == 0:
         return g_means3D, g_means2D, g_ca, g_opac, g_scales, g_rot, g_cb
-    sbytes = _lib.vtgs_backward_dual_scratch_bytes(n, fs.instances)
+    sbytes = _lib.vtgs_backward_dual_scratch_bytes(n, _scratch_instances(fs))
     scratch = torch.empty((sbytes,), dtype=torch.uint8, device=device)
-    st = _lib.vtgs_backward_dual(ctypes.byref(fs.cam.c), n, means3D.data_ptr(), colors_a.data_ptr(), colors_b.data_ptr(),
-                                 opacities.data_ptr(), scales.data_ptr(), rotations.data_ptr(), out_a.data_ptr(),
-                                 out_b.data_ptr(), grad_a.data_ptr(), grad_b.data_ptr(), fs.workspace.data_ptr(),
-                                 fs.workspace.numel(), fs.capacity, fs.tile_cap, scratch.data_ptr(), sbytes,
-                                 g_means3D.data_ptr(), g_means2D.data_ptr(), g_ca.data_ptr(), g_cb.data_ptr(),
-                                 g_opac.data_ptr(), g_scales.data_ptr(), g_rot.data_ptr(), _stream_ptr(device))
+    with _device_guard(device):
+        st = _lib.vtgs_backward_dual(ctypes.byref(fs.cam.c), n, means3D.data_ptr(), colors_a.data_ptr(), colors_b.data_ptr(),
+                                     opacities.data_ptr(), scales.data_ptr(), rotations.data_ptr(), out_a.data_ptr(),
+                                     out_b.data_ptr(), grad_a.data_ptr(), grad_b.data_ptr(), fs.workspace.data_ptr(),
+                                     fs.workspace.numel(), fs.capacity, fs.tile_cap, scratch.data_ptr(), sbytes,
+                                     g_means3D.data_ptr(), g_means2D.data_ptr(), g_ca.data_ptr(), g_cb.data_ptr(),
+                                     g_opac.data_ptr(), g_scales.data_ptr(), g_rot.data_ptr(), _stream_ptr(device))
     _check(st, "vtgs_backward_dual")
+    _settle(fs)
     return g_means3D, g_means2D, g_ca, g_opac, g_scales, g_rot, g_cb
 
 
@@ -463,7 +576,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         scales_c = _require(scales, "scales", 3, n, device)
         rot = _require(rotations, "rotations", 4, n, device)
         if shared_from is None:
-            color, radii, depth, fs = _run_forward(cam, means3D, colors, opac, scales_c, rot)
+            color, radii, depth, fs = _run_forward(cam, means3D, colors, opac, scales_c, rot,
+                                                   want_async=any(ctx.needs_input_grad))
         else:
             base = shared_from
             H, W = cam.H, cam.W
@@ -475,8 +589,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                           base.capacity, base.tile_cap, state.data_ptr(), _stream_ptr(device))
             _check(st, "vtgs_forward_shared")
             fs = _ForwardState()
-            fs.cam, fs.n, fs.workspace, fs.capacity, fs.tile_cap, fs.instances, fs.image_state, fs.key = (
-                base.cam, base.n, base.workspace, base.capacity, base.tile_cap, base.instances, state, base.key)
+            fs.cam, fs.n, fs.workspace, fs.capacity, fs.tile_cap, fs.instances, fs.image_state, fs.key, fs.pending = (
+                base.cam, base.n, base.workspace, base.capacity, base.tile_cap, base.instances, state, base.key, None)
             radii = None
         ctx.fs = fs
         ctx.save_for_backward(means3D, colors, opac, scales_c, rot, color)

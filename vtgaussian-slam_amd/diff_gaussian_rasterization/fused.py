@@ -26,8 +26,8 @@ import torch
 
 import os
 
-from . import (_Camera, _ForwardState, _RADIUS_RULES, _check, _lib, _run_backward, _run_backward_dual, _run_forward,
-               _stream_ptr, _I32, _P)
+from . import (_Camera, _ForwardState, _RADIUS_RULES, _check, _device_guard, _lib, _run_backward, _run_backward_dual,
+               _run_forward, _scratch_instances, _settle, _stream_ptr, _I32, _P)
 
 _lib.vtgs_pose_partial_rows.restype, _lib.vtgs_pose_partial_rows.argtypes = ctypes.c_uint32, [_I32]
 _lib.vtgs_prepare_frame.restype, _lib.vtgs_prepare_frame.argtypes = ctypes.c_int, [_I32] + [_P] * 13
@@ -54,9 +54,10 @@ class _RenderFrame(torch.autograd.Function):
         dual = os.environ.get("VTGS_DUAL", "1") != "0"             # read per call, like the other implementation switches
         state = None
         if dual:
-            im, radii, depth_sil, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot, colors_b=dcol)
+            im, radii, depth_sil, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot, colors_b=dcol,
+                                                    want_async=flags != 0)
         else:
-            im, radii, _, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot)
+            im, radii, _, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot, want_async=flags != 0)
             H, W = cam.H, cam.W
             depth_sil, depth2, state = new(3, H, W), new(1, H, W), new(H * W)
             _check(_lib.vtgs_forward_shared(ctypes.byref(cam.c), n, dcol.data_ptr(), depth_sil.data_ptr(), depth2.data_ptr(),
@@ -86,7 +87,7 @@ class _RenderFrame(torch.autograd.Function):
             ga = _run_backward(fs, means_cam, rgb, opac, scales, rot, im, g_im)
             fsb = _ForwardState()
             (fsb.cam, fsb.n, fsb.workspace, fsb.capacity, fsb.tile_cap, fsb.instances, fsb.image_state,
-             fsb.key) = fs.cam, fs.n, fs.workspace, fs.capacity, fs.tile_cap, fs.instances, ctx.state, fs.key
+             fsb.key, fsb.pending) = fs.cam, fs.n, fs.workspace, fs.capacity, fs.tile_cap, fs.instances, ctx.state, fs.key, None
             gb = _run_backward(fsb, means_cam, dcol, opac, scales, rot, depth_sil, g_ds)
             g_dcol = gb[2]
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
@@ -131,15 +132,17 @@ def _backward_fused(ctx, g_im, g_ds):
     partials = new(max(rows, 1), 12) if want_p else None
     g_q = g_t = None
     if n > 0:
-        sbytes = _lib.vtgs_backward_dual_scratch_bytes(n, fs.instances)
+        sbytes = _lib.vtgs_backward_dual_scratch_bytes(n, _scratch_instances(fs))
         scratch = torch.empty((sbytes,), dtype=torch.uint8, device=dev)
-        _check(_lib.vtgs_backward_dual_frame(
+        with _device_guard(dev):
+          _check(_lib.vtgs_backward_dual_frame(
             ctypes.byref(fs.cam.c), n, means_cam.data_ptr(), rgb.data_ptr(), dcol.data_ptr(), opac.data_ptr(),
             scales.data_ptr(), rot.data_ptr(), im.data_ptr(), depth_sil.data_ptr(), g_im.data_ptr(), g_ds.data_ptr(),
             fs.workspace.data_ptr(), fs.workspace.numel(), fs.capacity, fs.tile_cap, scratch.data_ptr(), sbytes, flags,
             means3D.data_ptr(), unnorm_rot.data_ptr(), cam_q.data_ptr(), cam_t.data_ptr(), depth_w2c.data_ptr(),
             ptr(g_rgb), ptr(g_means3D), ptr(g_logit), ptr(g_ls), ptr(g_ur), ptr(partials), _stream_ptr(dev)),
             "vtgs_backward_dual_frame")
+        _settle(fs)
         if want_p:                                                # 12 partial sums per workgroup -> dL/dq, dL/dt
             g_q, g_t = new(4), new(3)
             _check(_lib.vtgs_pose_gradient(partials.data_ptr(), rows, cam_q.data_ptr(), g_q.data_ptr(), g_t.data_ptr(),

@@ -34,9 +34,12 @@ def _f32(v, device):
 def concat_keyframes_params_base_frame(params_ls, variables_ls, selected_time_idx, num_frames_each_base_frame, device=None):
     """src/vtgaussian_slam.py:900-941: concatenate the selected submaps' Gaussians (and per-Gaussian statistics) into one
     optimisable parameter dict; camera tensors come from the last selected submap.  `device=None`: wherever the first
-    selected submap lives (resident submaps are already on the GPU: the concatenation is a device-side copy)."""
+    selected submap lives (resident submaps are already on the GPU: the concatenation is a device-side copy) -- except that
+    host-resident submaps go to the GPU when there is one, as in the reference; pass device="cpu" to keep them there."""
     q = quantize_selected_time_idx(selected_time_idx, num_frames_each_base_frame)
     dev = device or params_ls[q[0]]["means3D"].device
+    if device is None and torch.device(dev).type == "cpu" and torch.cuda.is_available():
+        dev = torch.device("cuda")             # the reference forces .cuda() here (:913): host-resident submaps are uploaded
     num_gs = [params_ls[idx]["means3D"].shape[0] for idx in q]
     params = {k: torch.cat([_f32(params_ls[idx][k], dev) for idx in q], dim=0) for k in GAUSSIAN_KEYS}
     params["cam_unnorm_rots"] = params_ls[q[-1]]["cam_unnorm_rots"]
@@ -97,9 +100,10 @@ def keep_resident(params_ls: List[Dict], variables_ls: List[Dict]) -> Tuple[int,
         for d in group:
             for k, v in d.items():
                 if isinstance(v, torch.Tensor):
-                    t = v.detach()
-                    if t._base is not None:
-                        t = t.clone()
+                    # a torch.split piece shares the storage of the whole concatenation (detach() of a view reports
+                    # _base None, so compare sizes): copy it out, or every submap would pin -- and alias -- that buffer
+                    owns = v.untyped_storage().nbytes() == v.numel() * v.element_size()
+                    t = v.detach() if owns else v.detach().clone()
                     d[k] = t
                     nbytes = t.numel() * t.element_size()
                     if t.device.type == "cpu":
