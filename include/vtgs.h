@@ -251,7 +251,8 @@ int vtgs_ssim_backward(const float* img1, const float* img2, const float* grad_m
 /* Masked L1 terms of get_loss (src/vtgaussian_slam.py:519-608) with their gradient images, one pass over the pixels.
  * im, gt_im [3,P]; depth_sil [3,P] = the [z,1,z^2] render; gt_depth [P].  mode 0 = tracking (mask: gt_depth > 0, finite
  * depth and uncertainty, silhouette > sil_thres; colour and depth sums over the mask), mode 1 = mapping (depth over the
- * mask without the silhouette test, colour over all pixels).  partial_sums[vtgs_masked_l1_partial_rows(P)][3] =
+ * mask without the silhouette test, colour over all pixels), mode 2 = tracking with the colour sum over ALL pixels
+ * (src/vtgaussian_slam.py:601-602: neither use_sil_for_loss nor ignore_outlier_depth_loss).  partial_sums[vtgs_masked_l1_partial_rows(P)][3] =
  * {sum |gt_im - im|, sum |gt_depth - depth|, mask count} per workgroup; g_im [3,P] and g_depth_sil [3,P] receive the
  * derivatives of the two sums (channels 1 and 2 of depth_sil only feed detached masks: zero).                          */
 uint32_t vtgs_masked_l1_partial_rows(int32_t pixels);
@@ -269,7 +270,9 @@ int vtgs_silhouette_sweep(const float* im, const float* silhouette, const float*
 /* The Replica branch of get_loss as a whole (src/vtgaussian_slam.py:519-608, 678-679).  mode 0 = tracking:
  * w_im * masked sum |gt_im - im| + w_depth * masked sum |gt_depth - depth| (mask: gt_depth > 0, finite depth and
  * uncertainty, silhouette > sil_thres).  mode 1 = mapping: w_im * (0.8 * mean |gt_im - im| + 0.2 * (1 - SSIM)) +
- * w_depth * masked mean |gt_depth - depth| (same mask without the silhouette test).  Images are [3,H,W] / [1,H,W].
+ * w_depth * masked mean |gt_depth - depth| (same mask without the silhouette test).  mode 2 = mode 0 with the colour sum
+ * taken over all pixels (:601-602).  w_depth = 0 gives the loss of use_l1 = False (no depth term, :591-596).  Images are
+ * [3,H,W] / [1,H,W].
  * forward: 2-3 launches; out8 (device, 8 floats) = {loss, mask count, sum |d im|, sum |d depth|, mean SSIM, the weighted
  * colour term, the weighted depth term, 0}; scratch =
  * vtgs_loss_scratch_floats(H, W) floats; ssim_grad_maps = 9*H*W floats (mode 1 with a backward to follow, else NULL).

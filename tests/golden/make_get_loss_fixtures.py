@@ -174,6 +174,13 @@ def main():
         "scannetpp_mapping_additional_mask": dict(loss_weights={"im": 0.5, "depth": 1.0}, use_sil_for_loss=False, sil_thres=0.5,
                                                   use_l1=True, ignore_outlier_depth_loss=False, mapping=True,
                                                   dataset_name="scannetpp", additional_mask=add_mask.clone()),
+        # the two branches no shipped configuration takes (round 3): no depth term at all (:591-596), and the tracking colour
+        # sum over ALL pixels when neither use_sil_for_loss nor ignore_outlier_depth_loss is set (:601-602)
+        "tum_tracking_no_l1": dict(loss_weights={"im": 0.5, "depth": 1.0}, use_sil_for_loss=True, sil_thres=0.9, use_l1=False,
+                                   ignore_outlier_depth_loss=False, tracking=True, tracking_iteration=2, dataset_name="tum"),
+        "tum_tracking_unmasked_colour": dict(loss_weights={"im": 0.5, "depth": 1.0}, use_sil_for_loss=False, sil_thres=0.9,
+                                             use_l1=True, ignore_outlier_depth_loss=False, tracking=True, tracking_iteration=2,
+                                             dataset_name="tum"),
     }
     store = {"W": np.int64(W), "H": np.int64(H), "gt_im": gt_im.numpy(), "gt_depth": gt_depth.numpy(), "intrinsics": intr.numpy(),
              "curr_w2c": curr_w2c.numpy(), "additional_mask": add_mask.numpy(),
@@ -193,7 +200,7 @@ def main():
         store[name + "_g_depth_sil"] = captured["g_depth_sil"].numpy()
         store[name + "_loss"] = np.float64(loss.item())
         store[name + "_loss_im"] = np.float64(weighted["im"].item())
-        store[name + "_loss_depth"] = np.float64(weighted["depth"].item())
+        store[name + "_loss_depth"] = np.float64(weighted["depth"].item()) if "depth" in weighted else np.float64("nan")
         if len(out) == 5:
             store[name + "_sil_thres_chosen"] = np.float64(out[4][-1])
         print(name, "loss", loss.item(), {k: float(v) for k, v in weighted.items()})

@@ -54,6 +54,8 @@ CASES = {   # name: (mode, sil_thres or None (= the sweep), uses additional_mask
     "tum_tracking_vis_far": ("tracking", 0.9, False),
     "scannet_tracking_vis3_outlier": ("tracking", 0.9, False),
     "scannetpp_mapping_additional_mask": ("mapping", 0.5, True),
+    "tum_tracking_no_l1": ("tracking_no_l1", 0.9, False),                 # use_l1 = False: no depth term (:591-596)
+    "tum_tracking_unmasked_colour": ("tracking_unmasked", None, False),   # colour summed over ALL pixels (:601-602)
 }
 
 
@@ -66,12 +68,17 @@ def test_fused_loss_equals_the_reference_get_loss(gpu_device, fx, name):
     im = fx[name + "_im"].to(dev).requires_grad_(True)
     ds = fx[name + "_depth_sil"].to(dev).requires_grad_(True)
     gt_im, gt_depth = fx["gt_im"].to(dev), fx["gt_depth"].to(dev)
-    if sil_thres is None:                                     # Replica, tracking iteration 0: five-candidate sweep
+    if sil_thres is None and mode == "tracking":              # Replica, tracking iteration 0: five-candidate sweep
         sil_thres = losses.best_silhouette_threshold(im.detach(), ds.detach()[1], gt_im, gt_depth)
         assert abs(sil_thres - fx[name + "_sil_thres_chosen"]) < 1e-9
     extra = _masks_for(fx, name, ds.detach()[0:1])
     if mode == "tracking":
         loss = losses.tracking_loss(im, ds, gt_im, gt_depth, sil_thres, w_im=0.5, w_depth=1.0, extra_mask=extra)
+    elif mode == "tracking_no_l1":                            # what get_loss.get_loss passes for use_l1 = False
+        loss = losses.tracking_loss(im, ds, gt_im, gt_depth, sil_thres, w_im=0.5, w_depth=0.0, extra_mask=extra)
+    elif mode == "tracking_unmasked":                         # ... and for use_sil_for_loss = ignore_outlier_depth_loss = False
+        loss = losses.tracking_loss(im, ds, gt_im, gt_depth, float("-inf"), w_im=0.5, w_depth=1.0, extra_mask=extra,
+                                    colour_over_all_pixels=True)
     else:
         loss = losses.mapping_loss(im, ds, gt_im, gt_depth, w_im=0.5, w_depth=1.0,
                                    additional_mask=fx["additional_mask"].to(dev) if use_add else None)
@@ -81,6 +88,9 @@ def test_fused_loss_equals_the_reference_get_loss(gpu_device, fx, name):
     for got, want, what in ((im.grad, fx[name + "_g_im"], "d loss / d im"), (ds.grad, fx[name + "_g_depth_sil"], "d loss / d depth_sil")):
         want = want.to(dev)
         scale = want.abs().max().item()
+        if mode == "tracking_no_l1" and what.endswith("depth_sil"):
+            assert scale == 0 and (got is None or got.abs().max().item() == 0)   # no depth term: no gradient to the second render
+            continue
         assert scale > 0
         err = (got - want).abs().max().item() / scale
         assert err <= 2e-4, f"{name}: {what} differs by {err:.2e} of its maximum"

@@ -161,20 +161,63 @@ def test_get_loss_mirror_equals_the_unfused_composition(gpu_device, dataset, tra
 
 
 @pytest.mark.gpu
-def test_get_loss_mirror_refuses_what_it_does_not_cover(gpu_device):
-    """The branches no shipped configuration takes fail loudly instead of computing something else."""
-    from diff_gaussian_rasterization.get_loss import get_loss
+def test_get_loss_mirror_rare_branches_and_screen_space_gradient(gpu_device):
+    """The branches no shipped configuration takes: use_l1 = False (no depth term, no 'depth' entry), the unmasked tracking
+    colour sum, an unknown dataset (refused BEFORE params / variables are touched), and variables['means2D']: a placeholder
+    that explains itself on the fused route, the colour render's own screen-space tensor (with its gradient after
+    backward, equal to what the plain operator returns) on the two-render route."""
+    import diff_gaussian_rasterization as dgr
+    import slam_callers as sc
+    from diff_gaussian_rasterization import get_loss as gl
+    from diff_gaussian_rasterization import losses
+    get_loss = gl.get_loss
     dev = gpu_device
     params, st, K, go = _scene(dev, 2000, 64, 48, seed=3)
-    curr = {"cam": st, "im": torch.rand(3, 48, 64, device=dev), "depth": torch.rand(1, 48, 64, device=dev) + 1.0,
+    g = torch.Generator().manual_seed(4)
+    curr = {"cam": st, "im": torch.rand(3, 48, 64, generator=g).to(dev), "depth": (torch.rand(1, 48, 64, generator=g) + 1.0).to(dev),
             "w2c": torch.eye(4, device=dev), "intrinsics": K.to(dev), "id": 0}
     variables = {"max_2D_radius": torch.zeros(2000, device=dev)}
     w = {"im": 0.5, "depth": 1.0}
-    with pytest.raises(NotImplementedError):                 # use_l1 = False
-        get_loss(params, curr, variables, 0, w, True, 0.9, False, False, tracking=True, dataset_name="tum")
-    with pytest.raises(NotImplementedError):                 # tracking without any mask on the colour term
-        get_loss(params, curr, variables, 0, w, False, 0.9, True, False, tracking=True, dataset_name="tum")
+
+    def unfused(**kw):
+        tg = sc.transform_to_frame(params, 0, gaussians_grad=False, camera_grad=True)
+        im, _, _ = dgr.GaussianRasterizer(raster_settings=st)(**sc.transformed_params2rendervar(params, tg))
+        ds, _, _ = dgr.GaussianRasterizer(raster_settings=st)(**sc.transformed_params2depthplussilhouette(params, curr["w2c"], tg))
+        return losses.tracking_loss(im, ds, curr["im"], curr["depth"], **kw)
+
+    loss, variables, wl = get_loss(params, curr, variables, 0, w, True, 0.9, False, False, tracking=True, dataset_name="tum")
+    ref = unfused(sil_thres=0.9, w_im=0.5, w_depth=0.0)
+    assert set(wl) == {"im", "loss"} and abs(loss.item() - ref.item()) <= 2e-5 * abs(ref.item())
+    loss, variables, wl = get_loss(params, curr, variables, 0, w, False, 0.9, True, False, tracking=True, dataset_name="tum")
+    ref = unfused(sil_thres=float("-inf"), w_im=0.5, w_depth=1.0, colour_over_all_pixels=True)
+    masked = unfused(sil_thres=float("-inf"), w_im=0.5, w_depth=1.0)
+    assert set(wl) == {"im", "depth", "loss"} and abs(loss.item() - ref.item()) <= 2e-5 * abs(ref.item())
+    assert ref.item() >= masked.item()
+    cpu_params = {k: v.detach().cpu() for k, v in params.items()}
+    snapshot = dict(cpu_params)
     with pytest.raises(ValueError):                          # a dataset the reference has no presence mask for
-        get_loss(params, curr, variables, 0, w, True, 0.9, True, False, tracking=True, dataset_name="kitti")
+        get_loss(cpu_params, curr, variables, 0, w, True, 0.9, True, False, tracking=True, dataset_name="kitti")
+    assert all(cpu_params[k] is snapshot[k] for k in snapshot)              # refused before anything was converted
+    with pytest.raises(RuntimeError, match="SCREEN_SPACE_GRADIENT"):
+        variables["means2D"].grad
+    try:
+        gl.SCREEN_SPACE_GRADIENT = True
+        for v in params.values():
+            v.grad = None
+        loss, variables, wl = get_loss(params, curr, variables, 0, w, True, 0.9, True, False, mapping=True, dataset_name="tum")
+        loss.backward()
+        m2d = variables["means2D"]
+        assert isinstance(m2d, torch.Tensor) and m2d.shape == (2000, 3) and m2d.grad is not None
+        # the same gradient from the plain operator, colour render alone
+        tg = sc.transform_to_frame(params, 0, gaussians_grad=True, camera_grad=False)
+        rv = sc.transformed_params2rendervar(params, tg)
+        rv["means2D"].retain_grad()
+        im, _, _ = dgr.GaussianRasterizer(raster_settings=st)(**rv)
+        ds, _, _ = dgr.GaussianRasterizer(raster_settings=st)(**sc.transformed_params2depthplussilhouette(params, curr["w2c"], tg))
+        losses.mapping_loss(im, ds, curr["im"], curr["depth"], w_im=0.5, w_depth=1.0).backward()
+        scale = rv["means2D"].grad.abs().max().item()
+        assert scale > 0 and (m2d.grad - rv["means2D"].grad).abs().max().item() <= 1e-4 * scale
+    finally:
+        gl.SCREEN_SPACE_GRADIENT = False
     loss, variables, wl = get_loss(params, curr, variables, 0, w, True, 0.9, True, False, mapping=True, dataset_name="tum")
     assert torch.isfinite(loss) and set(wl) == {"im", "depth", "loss"} and "seen" in variables

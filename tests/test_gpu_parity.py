@@ -588,7 +588,8 @@ def test_forward_runs_ahead_of_its_record_and_settles_after_the_backward(gpu_dev
         c, r, d = rast(**leaves)
         pending = rast._last_state.pending is not None
         c.backward(grad_color)
-        assert rast._last_state.pending is None                      # the backward settled it
+        dgr.settle_pending()                                         # (the next forward would do this: read the record now)
+        assert rast._last_state.pending is None
         return pending, c.detach().clone(), d.detach().clone(), {k: leaves[k].grad.clone() for k in GRAD_KEYS}
 
     try:

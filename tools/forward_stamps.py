@@ -46,8 +46,16 @@ torch.cuda.synchronize()
 fs = rast._last_state
 st = fs.workspace[int(out[9]) + 256: int(out[9]) + 256 + 32 * tiles].view(torch.int32).reshape(tiles, 8).cpu().double()
 print("backward:")
-for i, nm in ((0, "prologue (entry -> list loop)"), (2, "waiting for the chunk gathers"), (3, "batches (sweeps + contraction + records)"),
-              (4, "whole wavefront"), (5, "batches"), (6, "list length")):
-    c = st[:, i]
+if dgr.get_option("VTGS_BWD_IMPL") == 3:
+    w7 = st[:, 7].long() & 0xFFFFFFFF
+    cols = (("appends", st[:, 0]), ("pops (queue, ids, gathers requested)", st[:, 1]), ("exponent + g.c MFMAs, front sweep", st[:, 2]),
+            ("colour products, back sweep, u' products", st[:, 3]), ("accumulator adds (waited for)", st[:, 6]),
+            ("promote: tile coefficients of the next step", (w7 & 0xFFFFF).double()), ("retire: records out", ((w7 >> 20) * 16).double()),
+            ("whole wavefront", st[:, 4]), ("steps", st[:, 5]))
+else:
+    cols = (("prologue (entry -> list loop)", st[:, 0]), ("waiting for the chunk gathers", st[:, 2]),
+            ("batches (sweeps + contraction + records)", st[:, 3]), ("whole wavefront", st[:, 4]), ("batches", st[:, 5]),
+            ("list length", st[:, 6]))
+for nm, c in cols:
     print(f"{nm:42s} mean {c.mean():10.1f}  median {c.median():10.1f}  p90 {c.quantile(0.9):10.1f}  max {c.max():10.1f}")
-print(f"ticks per batch (median tile) {(st[:, 3] / st[:, 5].clamp(min=1)).median():.0f}")
+print(f"ticks per batch / step (median tile) {((st[:, 3] if dgr.get_option('VTGS_BWD_IMPL') != 3 else st[:, 1] + st[:, 2] + st[:, 3] + st[:, 6]) / st[:, 5].clamp(min=1)).median():.0f}")

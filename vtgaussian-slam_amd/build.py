@@ -37,6 +37,30 @@ def build(force: bool = False, verbose: bool = False, out: str = OUT, extra=()) 
     return out
 
 
+TORCH_EXT_SRC = os.path.join(HERE, "csrc", "vtgs_torch.cpp")
+TORCH_EXT_OUT = os.path.join(HERE, "lib", "vtgs_torch.so")
+
+
+def build_torch_ext(force: bool = False, verbose: bool = False) -> str:
+    """The C++ autograd node of the operator (csrc/vtgs_torch.cpp: host plumbing, no device code) as an in-tree Python
+    extension module, linked against libvtgs.so next to it.  g++ through torch.utils.cpp_extension (ninja)."""
+    hdr = os.path.join(HERE, "..", "include", "vtgs.h")
+    if (not force and os.path.exists(TORCH_EXT_OUT)
+            and os.path.getmtime(TORCH_EXT_OUT) >= max(os.path.getmtime(TORCH_EXT_SRC), os.path.getmtime(hdr))):   # (libvtgs.so is
+        # bound at load time through the C ABI: a kernel rebuild does not stale the node)
+        return TORCH_EXT_OUT
+    from torch.utils import cpp_extension
+    lib_dir = os.path.dirname(OUT)
+    build_dir = os.path.join(lib_dir, "build_vtgs_torch")
+    os.makedirs(build_dir, exist_ok=True)
+    cpp_extension.load(name="vtgs_torch", sources=[TORCH_EXT_SRC], extra_cflags=["-O2", "-std=c++17"],
+                       extra_ldflags=["-L" + lib_dir, "-lvtgs", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + lib_dir],
+                       build_directory=build_dir, verbose=verbose, is_python_module=False)
+    import shutil
+    shutil.copy2(os.path.join(build_dir, "vtgs_torch.so"), TORCH_EXT_OUT)
+    return TORCH_EXT_OUT
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if a != "--force"]
     out = OUT
@@ -44,3 +68,5 @@ if __name__ == "__main__":
         out = os.path.abspath(args[args.index("--out") + 1])
         del args[args.index("--out"):args.index("--out") + 2]
     print(build(force="--force" in sys.argv, verbose=True, out=out, extra=args))
+    if out == OUT:
+        print(build_torch_ext(force="--force" in sys.argv, verbose=True))

@@ -877,9 +877,13 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   __shared__ float4 lds_xch_all[WAVES][PXL ? 1 : 128];
   __shared__ __attribute__((aligned(16))) float lds_uw[WAVES][2][kImgFloats];
   __shared__ __attribute__((aligned(16))) float lds_phi[4 * kPhiQuarter];
-  // dual render: the contraction's dL/dcolor operands live in LDS ([wave][second set?][quarter][column][16 + 4]), not in 32 VGPRs
-  __shared__ __attribute__((aligned(16))) float lds_g_all[DUAL ? WAVES : 1][DUAL ? 2 * 16 * kImgRow : 4];
-  if (ctr->overflow) return;                                  // uniform over the grid
+  // the contraction's dL/dcolor operands live in LDS ([wave][second set?][quarter][column][16 + 4]), not in 16 / 32 VGPRs:
+  // round 3 -- the registers hold the NEXT chunk's geometry records instead (the gathers were 12 % of the wavefront's life)
+  __shared__ __attribute__((aligned(16))) float lds_g_all[WAVES][(DUAL ? 2 : 1) * 16 * kImgRow];
+  // Everything the wavefront needs before its first batch is requested up front -- flag, list length, image values, first
+  // list entries -- and the flag is looked at afterwards: the prologue was four dependent round trips (15 % of the
+  // wavefront's life, profiles/r3_stamps.md)
+  const uint32_t overflow_flag = ctr->overflow;
   // Phi table for the contraction's B operands: [pixel quarter][column 0..7][pixel 0..15 (+4 pad)], columns 6,7 = 0
   for (int i = (int)threadIdx.x; i < 4 * kPhiQuarter; i += 64 * WAVES) {
     const int pqt = i / kPhiQuarter, c = (i - pqt * kPhiQuarter) / kImgRow, kk = i - pqt * kPhiQuarter - c * kImgRow;
@@ -890,18 +894,20 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     v = (c == 3) ? PX * PX : v; v = (c == 4) ? PX * PY : v; v = (c == 5) ? PY * PY : v;
     lds_phi[i] = (kk < 16) ? v : 0.f;
   }
-  __syncthreads();                                            // before any per-wavefront exit
   const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
   const int gx8 = (cs.W + kSubTile - 1) / kSubTile, gy8 = (cs.H + kSubTile - 1) / kSubTile;
-  const TileCoord tc = tile_coord<WAVES>(cs, nblk, gx16, gx8, gy8);
-  if (!tc.tile_ok) return;
+  TileCoord tc = tile_coord<WAVES>(cs, nblk, gx16, gx8, gy8);
+  const bool tile_ok = tc.tile_ok;                              // wave-uniform
+  if (!tile_ok) { tc.tile = 0; tc.inside = false; }              // (its speculative loads below read tile 0's bin)
   const int l = lane_id();
   const int wv = (WAVES == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float4* lds_xch = lds_xch_all[wv];
   float* __restrict__ Us = lds_uw[wv][0];
   float* __restrict__ Ws = lds_uw[wv][1];
-  const uint32_t s = (uint32_t)tc.tile * tile_cap, e = s + min(tile_cnt[tc.tile], tile_cap);
-  if (s == e) return;
+  const uint32_t s = (uint32_t)tc.tile * tile_cap;
+  const uint32_t list_len = min(tile_cnt[tc.tile], tile_cap);
+  // first list entries (a bin holds at least 64 slots: reading past a short list stays inside the workspace; masked later)
+  uint32_t gid_first = sorted_gid[s + (uint32_t)lane_id()], inst_first = sorted_inst[s + (uint32_t)lane_id()];
   const size_t P = (size_t)cs.W * cs.H;
   const int j = l & 15, q = l >> 4;
   const int tx0 = tc.px - (l & 7), ty0 = tc.py - (l >> 3);
@@ -957,21 +963,19 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   // Contraction roles: l = cj + 4 sg + 16 pq -- column cj of every group, splat group sg, pixel quarter pq.
   // A operand: row (l & 3) of block (sg, pq) = splat 4 sg + (l & 3) = image row (l & 15); B operand: column cj.
   const int cj = l & 3, pq = q;
-  float Bg[DUAL ? 1 : 16];                                    // dL/dcolor channel cj at the quarter's 16 pixels (cj = 3: 0)
-  float* lds_g = lds_g_all[DUAL ? wv : 0];                    // dual: row (pq, cj) of set a at [(4 pq + cj) * kImgRow], set b 320 floats on
+  // dL/dcolor as the contraction's B operand: row (pq, channel) of set a at [(4 pq + channel) * kImgRow], 16 pixels + pad,
+  // channel 3 = 0; dual: set b 320 floats on.  Written from the lanes' OWN pixel gradients (lane L = pixel L = pixel
+  // (L & 15) of quarter L >> 4): no second trip to the image.
+  float* lds_g = lds_g_all[wv];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int p = 16 * pq + t;
-    const int qx = tx0 + (p & 7), qy = ty0 + (p >> 3);
-    const bool ok = cj < 3 && qx < cs.W && qy < cs.H;
-    const size_t pix = (size_t)cj * P + (size_t)qy * cs.W + qx;
-    if constexpr (DUAL) {                                     // (the four splat groups write the same values)
-      lds_g[(4 * pq + cj) * kImgRow + t] = ok ? grad_color[pix] : 0.f;
-      lds_g[16 * kImgRow + (4 * pq + cj) * kImgRow + t] = ok ? grad_color_b[pix] : 0.f;
-    } else {
-      Bg[t] = ok ? grad_color[pix] : 0.f;
-    }
+  for (int c = 0; c < 4; ++c) {
+    lds_g[(4 * pq + c) * kImgRow + j] = (c < 3) ? st.gown[c < 3 ? c : 0] : 0.f;
+    if constexpr (DUAL) lds_g[16 * kImgRow + (4 * pq + c) * kImgRow + j] = (c < 3) ? st.gown[3 + (c < 3 ? c : 0)] : 0.f;
   }
+  __syncthreads();                                            // the Phi table (and, per wavefront, the g image); before any exit
+  if (overflow_flag) return;                                  // uniform over the grid: the forward did not complete
+  if (!tile_ok || list_len == 0u) return;
+  const uint32_t e = s + list_len;
   const float4* __restrict__ Ga4 = reinterpret_cast<const float4*>(lds_g + (4 * pq + cj) * kImgRow);
   const float4* __restrict__ Gb4 = reinterpret_cast<const float4*>(lds_g + 16 * kImgRow + (4 * pq + cj) * kImgRow);
   const float4* Ua4 = reinterpret_cast<const float4*>(Us + pq * kImgQuarter + (l & 15) * kImgRow);   // alias Us / Ws: no restrict
@@ -990,12 +994,23 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
 #ifdef VTGS_Q_STAMPS
   st_loop0 = __builtin_amdgcn_s_memtime();
 #endif
-#if VTGS_BWD_PREFETCH
-  // the list entries of the NEXT chunk are requested while this one is composited: one of the two dependent trips to
-  // L2 / Infinity Cache per chunk leaves the wavefront's critical path (a lane past the end reads entry 0 of its own bin)
+  // Software pipeline of the gather, two deep as in composite_forward_q: while chunk c is composited, the list entries of
+  // chunk c + 2 and the geometry records + colours of chunk c + 1 are in flight (a lane past the end reads entry 0 of its bin).
   auto entry = [&](const uint32_t* __restrict__ list, uint32_t b) { const uint32_t p = b + (uint32_t)l; return list[p < e ? p : s]; };
-  uint32_t gid_nxt = entry(sorted_gid, s), inst_nxt = entry(sorted_inst, s);
-#endif
+  uint32_t gid_cur = gid_first, inst_cur = inst_first;
+  uint32_t gid_nxt = entry(sorted_gid, s + 64u), inst_nxt = entry(sorted_inst, s + 64u);
+  float4 g0n, g1n;
+  float cn[DUAL ? 6 : 3];
+  auto fetch = [&](uint32_t gid) {
+    const float4* gp = reinterpret_cast<const float4*>(geom + gid);
+    g0n = gp[0]; g1n = gp[1];
+    cn[0] = colors[3 * gid]; cn[1] = colors[3 * gid + 1]; cn[2] = colors[3 * gid + 2];
+    if constexpr (DUAL) { cn[3] = colors_b[3 * gid]; cn[4] = colors_b[3 * gid + 1]; cn[5] = colors_b[3 * gid + 2]; }
+  };
+  // (dual render: 14 more registers in flight across the batches push the kernel into scratch -- there the records are
+  // requested at the top of their own chunk, as in round 2; the entries still come one chunk ahead)
+  constexpr bool kRecordsAhead = !DUAL;
+  if constexpr (kRecordsAhead) fetch(gid_cur);
   for (; base < e; base += 64u) {
     const bool alive = PXL ? !ps.done : (st.Tb[0].x > 0.f || st.Tb[0].y > 0.f || st.Tb[1].x > 0.f || st.Tb[1].y > 0.f);
     if (__ballot(alive) == 0ull) break;
@@ -1003,14 +1018,20 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
 #ifdef VTGS_Q_STAMPS
     const unsigned long long sg0 = __builtin_amdgcn_s_memtime();
 #endif
-#if VTGS_BWD_PREFETCH
-    const MxSplat m = mx_gather_gid<DUAL>(gid_nxt, geom, colors, l < n, cx, cy, colors_b);
-    const uint32_t my_inst = (l < n) ? inst_nxt : 0u;
-    gid_nxt = entry(sorted_gid, base + 64u); inst_nxt = entry(sorted_inst, base + 64u);
-#else
-    const MxSplat m = mx_gather<DUAL>(sorted_gid, geom, colors, base + (uint32_t)l, l < n, cx, cy, colors_b);
-    const uint32_t my_inst = (l < n) ? sorted_inst[base + (uint32_t)l] : 0u;
-#endif
+    if constexpr (!kRecordsAhead) fetch(gid_cur);
+    MxSplat m;                                                  // this chunk's splats, from the records requested one chunk ago
+    m.K[0] = -1e30f; m.K[1] = m.K[2] = m.K[3] = m.K[4] = m.K[5] = 0.f;
+    m.pay = make_float4(0.f, 0.f, 0.f, 0.f); m.pay2 = make_float2(0.f, 0.f); m.hot = false;
+    if (l < n) {
+      tile_coefficients(g0n, g1n, cx, cy, m.K);
+      m.hot = g1n.y > kClampGuard;
+      m.pay = make_float4(cn[0], cn[1], cn[2], DUAL ? cn[DUAL ? 3 : 0] : g1n.z);
+      if constexpr (DUAL) m.pay2 = make_float2(cn[4], cn[5]);
+    }
+    const uint32_t my_inst = (l < n) ? inst_cur : 0u;
+    gid_cur = gid_nxt; inst_cur = inst_nxt;
+    gid_nxt = entry(sorted_gid, base + 128u); inst_nxt = entry(sorted_inst, base + 128u);
+    if constexpr (kRecordsAhead) fetch(gid_cur);                 // next chunk's records: in flight during this chunk's batches
     const bool hot = __ballot(m.hot) != 0ull;                 // wave-uniform: some splat of the chunk may hit the 0.99 clamp
 #ifdef VTGS_Q_STAMPS
     asm volatile("" :: "v"(m.K[0]), "v"(m.pay.x));
@@ -1047,13 +1068,15 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
         const float uav[4] = {ua.x, ua.y, ua.z, ua.w}, wav[4] = {wa.x, wa.y, wa.z, wa.w};
         const float bav[4] = {ba.x, ba.y, ba.z, ba.w}, bbv[4] = {bb.x, bb.y, bb.z, bb.w};
         float gav[4], gbv[4];
-        if constexpr (DUAL) {
-          const float4 ga = Ga4[t4], gb = Gb4[t4];
+        {
+          const float4 ga = Ga4[t4];
           gav[0] = ga.x; gav[1] = ga.y; gav[2] = ga.z; gav[3] = ga.w;
+        }
+        if constexpr (DUAL) {
+          const float4 gb = Gb4[t4];
           gbv[0] = gb.x; gbv[1] = gb.y; gbv[2] = gb.z; gbv[3] = gb.w;
         } else {
-#pragma unroll
-          for (int e4 = 0; e4 < 4; ++e4) { gav[e4] = Bg[4 * t4 + e4]; gbv[e4] = 0.f; }
+          gbv[0] = gbv[1] = gbv[2] = gbv[3] = 0.f;
         }
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
@@ -1064,7 +1087,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
         }
       }
 #if VTGS_PX_GROUP2
-      __builtin_amdgcn_sched_group_barrier(0x100, DUAL ? 24 : 16, 1);   // the image / Phi reads first ...
+      __builtin_amdgcn_sched_group_barrier(0x100, DUAL ? 24 : 20, 1);   // the image / Phi / g reads first ...
       __builtin_amdgcn_sched_group_barrier(0x008, DUAL ? 64 : 48, 1);   // ... then the contraction MFMAs back to back
 #endif
       // lane (cj, sg, rho = l >> 4) ends up with the totals of splat 4 sg + rho

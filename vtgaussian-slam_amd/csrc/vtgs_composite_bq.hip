@@ -10,20 +10,19 @@
 //     entry its quadrant pops in a step: it gathers that splat's geometry record and colour itself (requested one step
 //     ahead), so the exponent and g.c matrix instructions (v_mfma_f32_4x4x1, cbsz = 2: A from lanes 4g..4g+3 of the
 //     lane's own 16-lane group) read their operands from registers -- no coefficient table in LDS;
-//   * the sweeps run per GROUP of four splats (front to back: alpha, w = alpha T, T, P; anchor A = (CB - P) / T with one
-//     reciprocal per group; back to front: u' = G T (g.c - A), A += alpha (g.c - A)): 16 instead of 64 live per-pair
-//     registers, and a pixel that ends redoes four splats with the exact stop rule, not sixteen;
+//   * the sweeps are those of px_backward_batch (front to back: alpha, w = alpha T, T, P; one anchor A = (CB - P) / T per
+//     step; back to front: u' = G T (g.c - A), A += alpha (g.c - A));
 //   * the pixel contraction per quadrant: [16 splats x 16 px] x [16 px x 9] on v_mfma_f32_4x4x1 -- the quadrant's four
-//     blocks are its four splat groups -- through ONE 4 KB LDS image per wavefront (XOR-swizzled rows, no padding) that
-//     u' and w use one after the other: w is written while the u' products run;
+//     blocks are its four splat groups, so there is no cross-lane sum afterwards -- through ONE 4 KB LDS image per
+//     wavefront (XOR-swizzled rows, no padding) that w and u' use one after the other: the front sweep writes w, the colour
+//     products read it, the back sweep overwrites it with u' (LDS operations of a wavefront execute in order);
 //   * a splat's sums arrive from up to four quadrants in different steps: they are added into a per-wavefront LDS table
 //     (ds_add_f32, 9 floats per ring slot) and leave as ONE 40-byte record per (splat, tile) instance -- the format
 //     gather_splat_grads reads -- when the chunk retires: when all four queues have popped its last entry, the same
 //     invariant that frees the chunk's ring slots.  LDS float adds of one instruction are applied in a fixed lane order
 //     and the step sequence of a tile is a function of its list alone, so gradients stay bitwise reproducible run to run.
 //
-// Semantics: SURVEY.md Appendix A4 as restated in vtgs_composite.hip (same recurrences as px_backward_batch, anchored per
-// group of four instead of per sixteen).
+// Semantics: SURVEY.md Appendix A4 as restated in vtgs_composite.hip (the recurrences of px_backward_batch).
 #include "vtgs_internal.h"
 #include "vtgs_composite_common.h"
 
@@ -68,68 +67,70 @@ __device__ __forceinline__ f32x4 bq_gdotc(const float (&col)[3], const float (&g
 
 struct BqPixel { float T, P, CB; bool done; };   // T frozen once the pixel has ended (as in the forward)
 
-// One group of four splats for the lane's pixel.  uo / wo: u' = alpha_unclamped dL/dalpha and w = alpha T of the four pairs.
-template <int G, bool CLAMP>
-__device__ __forceinline__ void bq_group(BqPixel& px, const float (&K)[6], const float (&col)[3], const float (&Phi)[6],
-                                         const float (&gown)[3], float (&uo)[4], float (&wo)[4]) {
-  const f32x4 d = bq_exponents<G>(K, Phi);
-  const f32x4 gc = bq_gdotc<G>(col, gown);
-  float a[4], gT[4];
-  float Pn = px.P, Tn = px.done ? 0.f : px.T;
+// image [quadrant][splat row 0..15][16 px], rows XOR-swizzled in 4-float granules: pixel granule g of row k sits at
+// granule g ^ (k >> 2), which makes the column-wise ds_write_b32 and the row-wise ds_read_b128 conflict-free without padding
+__device__ __forceinline__ int img_read_off(int q, int row, int t4) { return q * 256 + row * 16 + 4 * (t4 ^ (row >> 2)); }
+
+// The sweeps of one step for the lane's pixel x the 16 splats its quadrant popped: the recurrences of px_backward_batch
+// (vtgs_composite.hip).  Front to back: alpha_k, w_k = alpha_k T_k -> image row k, T, P.  `wbase[g]` = the lane's image
+// offset for splat group g (rows 4g..4g+3 are 16 floats apart).  Returns with a[], gT[], the anchor in A.
+template <bool CLAMP, bool EXACT_FIRST>
+__device__ __forceinline__ void bq_front(BqPixel& px, bool& exact, const f32x4 (&d)[4], const f32x4 (&gcv)[4], float* __restrict__ img,
+                                         const int (&wbase)[4], float (&a)[16], float (&gT)[16], float& A) {
+  float Pn = px.P;
+  bool swept = false;
+  const bool was_done = px.done;
+  if constexpr (!EXACT_FIRST) {
+    float Tn = px.done ? 0.f : px.T;                             // optimistic: no stop test
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {                                // front to back, optimistic: no stop test
-    const float Gp = __builtin_amdgcn_exp2f(d[r]);
-    if constexpr (CLAMP) {
-      const float al = fminf(kAlphaMax, Gp);
-      const bool valid = al >= kAlphaMin;
-      a[r] = valid ? al : 0.f;
-      gT[r] = valid ? Gp * Tn : 0.f;                           // the 0.99 clamp passes the gradient through
-      wo[r] = a[r] * Tn;
-    } else {                                                   // no splat of this step can reach the clamp
-      a[r] = (Gp >= kAlphaMin) ? Gp : 0.f;
-      wo[r] = a[r] * Tn;
-      gT[r] = wo[r];
+    for (int k = 0; k < 16; ++k) {
+      const float Gp = __builtin_amdgcn_exp2f(d[k >> 2][k & 3]);
+      float w;
+      if constexpr (CLAMP) {
+        const float al = fminf(kAlphaMax, Gp);
+        const bool valid = al >= kAlphaMin;
+        a[k] = valid ? al : 0.f;
+        gT[k] = valid ? Gp * Tn : 0.f;                           // the 0.99 clamp passes the gradient through
+        w = a[k] * Tn;
+      } else {                                                   // no splat of this step can reach the clamp
+        a[k] = (Gp >= kAlphaMin) ? Gp : 0.f;
+        w = a[k] * Tn;
+        gT[k] = w;
+      }
+      img[wbase[k >> 2] + 16 * (k & 3)] = w;
+      Pn = fmaf(gcv[k >> 2][k & 3], w, Pn);
+      Tn = Tn - w;
     }
-    Pn = fmaf(gc[r], wo[r], Pn);
-    Tn = Tn - wo[r];
+    __builtin_amdgcn_sched_group_barrier(0x008, 36, 0);          // exponent + g.c MFMAs back to back, then the sweep
+    __builtin_amdgcn_sched_group_barrier(0x302, 400, 0);
+    if (__ballot(!px.done && Tn < kTStop) == 0ull) { px.T = px.done ? px.T : Tn; swept = true; }
+    else Pn = px.P;
   }
-  if (__ballot(!px.done && Tn < kTStop) == 0ull) {             // nobody ends inside this group (wave-uniform)
-    px.T = px.done ? px.T : Tn;
-  } else {
-    // exact: the first splat with T (1 - alpha) < 1e-4 ends the pixel BEFORE it is added; from there on alpha = G T = 0
-    Pn = px.P;
+  if (!swept) {
+    // exact: the first splat with T (1 - alpha) < 1e-4 ends the pixel BEFORE it is added; from there on alpha = G T = w = 0
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float Gp = __builtin_amdgcn_exp2f(d[r]);
+    for (int k = 0; k < 16; ++k) {
+      const float Gp = __builtin_amdgcn_exp2f(d[k >> 2][k & 3]);
       const float al = CLAMP ? fminf(kAlphaMax, Gp) : Gp;
       const float av = (al >= kAlphaMin) ? al : 0.f;
       const float wk = av * px.T;
       const float tn = px.T - wk;
-      const bool stop = tn < kTStop;                           // a live pixel has T >= 1e-4: alpha = 0 cannot trigger it
+      const bool stop = tn < kTStop;                             // a live pixel has T >= 1e-4: alpha = 0 cannot trigger it
       const bool live = !px.done && !stop;
-      a[r] = live ? av : 0.f;
-      gT[r] = live ? ((al >= kAlphaMin) ? Gp * px.T : 0.f) : 0.f;
-      wo[r] = live ? wk : 0.f;
-      Pn = fmaf(gc[r], wo[r], Pn);
+      a[k] = live ? av : 0.f;
+      gT[k] = live ? ((al >= kAlphaMin) ? Gp * px.T : 0.f) : 0.f;
+      const float w = live ? wk : 0.f;
+      img[wbase[k >> 2] + 16 * (k & 3)] = w;
+      Pn = fmaf(gcv[k >> 2][k & 3], w, Pn);
       px.T = live ? tn : px.T;
       px.done = px.done || stop;
     }
+    exact = __builtin_popcountll(__ballot(px.done && !was_done)) >= kExactFirstEndings;   // as in the forward
   }
-  // anchor: colour behind the group (behind the ending splat for an ended pixel) per unit of transmittance there; T > 0
-  float A = (px.CB - Pn) * __builtin_amdgcn_rcpf(px.T);
+  // anchor: colour behind the step (behind the ending splat for an ended pixel) per unit of transmittance there; T > 0
+  A = (px.CB - Pn) * __builtin_amdgcn_rcpf(px.T);
   px.P = Pn;
-#pragma unroll
-  for (int r = 3; r >= 0; --r) {                               // back to front
-    const float t = gc[r] - A;
-    uo[r] = gT[r] * t;
-    A = fmaf(a[r], t, A);
-  }
 }
-
-// image [quadrant][splat row 0..15][16 px], rows XOR-swizzled in 4-float granules: pixel granule g of row k sits at
-// granule g ^ (k >> 2), which makes the column-wise ds_write_b32 and the row-wise ds_read_b128 conflict-free without padding
-__device__ __forceinline__ int img_write_off(int q, int k, int i) { return q * 256 + k * 16 + 4 * ((i >> 2) ^ (k >> 2)) + (i & 3); }
-__device__ __forceinline__ int img_read_off(int q, int row, int t4) { return q * 256 + row * 16 + 4 * (t4 ^ (row >> 2)); }
 
 constexpr int kPhiRow = 20;                    // Phi table row: 16 pixels + 4 pad (bank spread of the b128 row reads)
 
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
   __shared__ uint32_t lds_gid[4][kBqRing + 1], lds_inst[4][kBqRing + 1];
   __shared__ uint8_t lds_q[4][4][kBqRing];
   __shared__ __attribute__((aligned(16))) float lds_phi[4 * 8 * kPhiRow];     // [quadrant][column 0..7][16 px + 4 pad]
+  __shared__ __attribute__((aligned(16))) float lds_g[4][4 * 4 * kPhiRow];   // per wavefront: dL/dcolor [quadrant][channel][16 px + 4 pad]
   // Everything this wavefront needs from memory before its first step is requested HERE, in one go -- the flags, its list
   // length, its pixels' image values, the first list entries -- and only then are the flags looked at: the prologue was four
   // dependent round trips to L2 / HBM (flag, length, images, list) and 15 % of the wavefront's life
@@ -182,13 +184,6 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
     Tf = final_T[pix];
   }
   const int cj = l & 3, row = l & 15;
-  float Bg[16];                                                 // dL/dcolor channel cj at the quadrant's 16 pixels (cj = 3: 0)
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int qx = tx0 + 4 * (q & 1) + (t & 3), qy = ty0 + 4 * (q >> 1) + (t >> 2);
-    const bool ok = tile_ok && cj < 3 && qx < cs.W && qy < cs.H;
-    Bg[t] = ok ? grad_color[(size_t)cj * P + (size_t)qy * cs.W + qx] : 0.f;
-  }
   // first list entries (a bin holds at least 64 slots: reading past a short list stays inside the bin; masked later)
   const bool have_mask_array = qmask != nullptr;
   uint32_t gid_n = sorted_gid[s + (uint32_t)l], inst_n = sorted_inst[s + (uint32_t)l];
@@ -208,6 +203,11 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
   float* __restrict__ acc = lds_acc[wv];
   uint32_t* __restrict__ tgid = lds_gid[wv];
   uint32_t* __restrict__ tinst = lds_inst[wv];
+  // dL/dcolor as the B operand of the colour contraction: [quadrant][channel 0..2, 3 = 0][16 px + 4 pad], from the lanes' own
+  // pixel gradients (no second trip to the image)
+  float* __restrict__ gimg = lds_g[wv];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) gimg[(4 * q + c) * kPhiRow + i] = (c < 3) ? gown[c < 3 ? c : 0] : 0.f;
   // ring state: accumulators start at zero (and are zeroed again when a chunk retires); dummy slot included
   for (int k = l; k < (kBqRing + 1) * kAccRow; k += 64) acc[k] = 0.f;
   if (l == 0) { tgid[kBqDummy] = 0u; tinst[kBqDummy] = 0u; }
@@ -228,6 +228,12 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
   // (l & 15) = 4 sg + cj of the quadrant's image; B operand: column cj (chain a: Phi 0..3, chain b: Phi 4, 5, chain w: dL/dcolor).
   const float4* __restrict__ PhiA4 = reinterpret_cast<const float4*>(lds_phi + (8 * q + cj) * kPhiRow);
   const float4* __restrict__ PhiB4 = reinterpret_cast<const float4*>(lds_phi + (8 * q + 4 + cj) * kPhiRow);
+  const float4* __restrict__ G4 = reinterpret_cast<const float4*>(gimg + (4 * q + cj) * kPhiRow);
+  // the lane's image offsets for the four splat groups: row k = 4 g + r at wbase[g] + 16 r (swizzle: granule ^ (k >> 2) = ^ g)
+  int wbase[4];
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) wbase[gq] = q * 256 + 64 * gq + 4 * ((i >> 2) ^ gq) + (i & 3);
+  bool px_exact = false;
   const uint32_t tile_bits = (uint32_t)tile;
   const bool have_masks = have_mask_array && masks_valid != 0u;               // uniform
 
@@ -238,9 +244,17 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
   auto lpos = [&](uint32_t b) { const uint32_t p = b + (uint32_t)l; return p < e ? p : s; };
 
   // the step in flight: cur = popped and gathered, to be computed; nxt = popped, gathers in flight
+#ifdef VTGS_Q_STAMPS
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+  unsigned long long st_app = 0ull, st_pop = 0ull, st_sweep = 0ull, st_contr = 0ull, st_acc = 0ull, st_prom = 0ull, st_ret = 0ull;
+#define BQ_STAMP(var) { asm volatile("" ::: "memory"); const unsigned long long now__ = __builtin_amdgcn_s_memtime(); var += now__ - tlast; tlast = now__; }
+  unsigned long long tlast = st0;
+#else
+#define BQ_STAMP(var)
+#endif
   bool have_cur = false;
   float curK[6] = {-1e30f, 0.f, 0.f, 0.f, 0.f, 0.f}, curC[3] = {0.f, 0.f, 0.f};
-  int cur_slot = kBqDummy, cur_d0 = 0;
+  int cur_slot = kBqDummy, cur_d0 = 0, cur_d1 = 0, cur_d2 = 0;   // entries of the current step by chunk in flight (oldest first)
   bool cur_hot = false;
 
   for (;;) {
@@ -280,6 +294,7 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
       else if (inflight == 1) { c1 += add_v; n1 = len; }
       else { c2 += add_v; n2 = len; }
       base += 64u; wslot = (wslot == (uint32_t)(kBqRing - 64)) ? 0u : wslot + 64u; ++inflight;
+      BQ_STAMP(st_app)
       continue;
     }
     // ---- pop the NEXT step (min(16, count) entries from every queue) and request its splats: lane (q, j) owns entry j ----
@@ -293,73 +308,94 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
     const float4 ng0 = ngp[0], ng1 = ngp[1];
     const float nc0 = colors[3 * ngid], nc1 = colors[3 * ngid + 1], nc2 = colors[3 * ngid + 2];
     head_v = bq_wrap(head_v + avail);
-    int nxt_d0;
+    int nxt_d0, nxt_d1, nxt_d2;
     {
       int t = avail;
       nxt_d0 = min(t, c0); c0 -= nxt_d0; t -= nxt_d0;
-      const int d1 = min(t, c1); c1 -= d1; t -= d1;
-      c2 -= t;
+      nxt_d1 = min(t, c1); c1 -= nxt_d1; t -= nxt_d1;
+      nxt_d2 = t; c2 -= t;
     }
     const bool have_nxt = __ballot(nxt_valid) != 0ull;
+    BQ_STAMP(st_pop)
 
     if (have_cur) {
-      // ---- compute the current step: four groups of four splats per quadrant ----------------------------------------------
+      // ---- compute the current step: the lane's pixel x the 16 splats of its quadrant ---------------------------------------
       ++nsteps;
-      float w[16];
       const bool hot = __ballot(cur_hot) != 0ull;               // wave-uniform: some splat of this step may hit the 0.99 clamp
-#define VTGS_BQ_GROUP(G)                                                                         \
-      {                                                                                           \
-        float uo[4];                                                                              \
-        if (hot) bq_group<G, true>(px, curK, curC, Phi, gown, uo, *(float(*)[4])(w + 4 * G));     \
-        else bq_group<G, false>(px, curK, curC, Phi, gown, uo, *(float(*)[4])(w + 4 * G));        \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) img[img_write_off(q, 4 * G + r, i)] = uo[r]; \
-      }
-      VTGS_BQ_GROUP(0) VTGS_BQ_GROUP(1) VTGS_BQ_GROUP(2) VTGS_BQ_GROUP(3)
-#undef VTGS_BQ_GROUP
-      // ---- pixel contraction per quadrant: u' x (Phi 0..3 | Phi 4, 5), then w x dL/dcolor --------------------------------
-      f32x4 Pa = {0.f, 0.f, 0.f, 0.f}, Pb = {0.f, 0.f, 0.f, 0.f}, Pw = {0.f, 0.f, 0.f, 0.f};
-      float4 ua[4], pa4[4], pb4[4];
+      const f32x4 d[4] = {bq_exponents<0>(curK, Phi), bq_exponents<1>(curK, Phi), bq_exponents<2>(curK, Phi), bq_exponents<3>(curK, Phi)};
+      const f32x4 gcv[4] = {bq_gdotc<0>(curC, gown), bq_gdotc<1>(curC, gown), bq_gdotc<2>(curC, gown), bq_gdotc<3>(curC, gown)};
+      float a[16], gT[16], A;
+      if (px_exact) bq_front<true, true>(px, px_exact, d, gcv, img, wbase, a, gT, A);     // (one exact-first body: the clamped form is always valid)
+      else if (hot) bq_front<true, false>(px, px_exact, d, gcv, img, wbase, a, gT, A);
+      else bq_front<false, false>(px, px_exact, d, gcv, img, wbase, a, gT, A);
+      BQ_STAMP(st_sweep)
+      // ---- colour sums: w x dL/dcolor over the quadrant's 16 pixels (the image holds w now) ---------------------------------
+      f32x4 Pw = {0.f, 0.f, 0.f, 0.f};
+      {
+        float4 wa[4], ga[4];
 #pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) {
-        ua[t4] = *reinterpret_cast<const float4*>(img + img_read_off(q, row, t4));
-        pa4[t4] = PhiA4[t4]; pb4[t4] = PhiB4[t4];
-      }
-      // (LDS operations of one wavefront execute in order: the w stores below cannot overtake the u' row reads above)
+        for (int t4 = 0; t4 < 4; ++t4) {
+          wa[t4] = *reinterpret_cast<const float4*>(img + img_read_off(q, row, t4));
+          ga[t4] = G4[t4];
+        }
 #pragma unroll
-      for (int k = 0; k < 16; ++k) img[img_write_off(q, k, i)] = w[k];
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const float wav[4] = {wa[t4].x, wa[t4].y, wa[t4].z, wa[t4].w}, gav[4] = {ga[t4].x, ga[t4].y, ga[t4].z, ga[t4].w};
 #pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) {
-        const float uav[4] = {ua[t4].x, ua[t4].y, ua[t4].z, ua[t4].w};
-        const float bav[4] = {pa4[t4].x, pa4[t4].y, pa4[t4].z, pa4[t4].w}, bbv[4] = {pb4[t4].x, pb4[t4].y, pb4[t4].z, pb4[t4].w};
-#pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {
-          Pa = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bav[e4], Pa, 0, 0, 0);
-          Pb = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bbv[e4], Pb, 0, 0, 0);
+          for (int e4 = 0; e4 < 4; ++e4) Pw = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], gav[e4], Pw, 0, 0, 0);
         }
       }
+      // ---- back to front: u'_k = G_k T_k (g.c_k - A), A <- A + alpha_k (g.c_k - A); u' takes the image over from w -----------
+      // (LDS operations of one wavefront execute in order: these stores cannot overtake the row reads above)
 #pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) {
-        const float4 wa = *reinterpret_cast<const float4*>(img + img_read_off(q, row, t4));
-        const float wav[4] = {wa.x, wa.y, wa.z, wa.w};
-#pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) Pw = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], Bg[4 * t4 + e4], Pw, 0, 0, 0);
+      for (int k = 15; k >= 0; --k) {
+        const float t = gcv[k >> 2][k & 3] - A;
+        img[wbase[k >> 2] + 16 * (k & 3)] = gT[k] * t;
+        A = fmaf(a[k], t, A);
       }
+      f32x4 Pa = {0.f, 0.f, 0.f, 0.f}, Pb = {0.f, 0.f, 0.f, 0.f};
+      {
+        float4 ua[4], pa4[4], pb4[4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          ua[t4] = *reinterpret_cast<const float4*>(img + img_read_off(q, row, t4));
+          pa4[t4] = PhiA4[t4]; pb4[t4] = PhiB4[t4];
+        }
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const float uav[4] = {ua[t4].x, ua[t4].y, ua[t4].z, ua[t4].w};
+          const float bav[4] = {pa4[t4].x, pa4[t4].y, pa4[t4].z, pa4[t4].w}, bbv[4] = {pb4[t4].x, pb4[t4].y, pb4[t4].z, pb4[t4].w};
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            Pa = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bav[e4], Pa, 0, 0, 0);
+            Pb = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bbv[e4], Pb, 0, 0, 0);
+          }
+        }
+      }
+#ifdef VTGS_Q_STAMPS
+      asm volatile("" :: "v"(Pa[0]), "v"(Pb[0]), "v"(Pw[0]));
+#endif
+      BQ_STAMP(st_contr)
       // ---- add the quadrant's partial sums to the splats' ring accumulators: lane (q, sg, cj) holds rows 4 sg + 0..3 -----
       {
         const int s0 = quad_bcast<0>(cur_slot), s1 = quad_bcast<1>(cur_slot), s2 = quad_bcast<2>(cur_slot), s3 = quad_bcast<3>(cur_slot);
         const int sl4[4] = {s0, s1, s2, s3};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float* a = acc + sl4[r] * kAccRow;
-          __hip_atomic_fetch_add(a + cj, Pa[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (cj < 2) __hip_atomic_fetch_add(a + 4 + cj, Pb[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (cj < 3) __hip_atomic_fetch_add(a + 6 + cj, Pw[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          float* ar = acc + sl4[r] * kAccRow;
+          __hip_atomic_fetch_add(ar + cj, Pa[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (cj < 2) __hip_atomic_fetch_add(ar + 4 + cj, Pb[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (cj < 3) __hip_atomic_fetch_add(ar + 6 + cj, Pw[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
+#ifdef VTGS_Q_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      BQ_STAMP(st_acc)
     }
     // ---- the popped step becomes the current one ----------------------------------------------------------------------------
     have_cur = have_nxt;
-    cur_slot = nxt_slot; cur_d0 = nxt_d0;
+    cur_slot = nxt_slot; cur_d0 = nxt_d0; cur_d1 = nxt_d1; cur_d2 = nxt_d2;
     cur_hot = nxt_valid && ng1.y > kClampGuard;
     {
       float K[6];
@@ -369,6 +405,10 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
       for (int m = 1; m < 6; ++m) curK[m] = nxt_valid ? K[m] : 0.f;
       curC[0] = nxt_valid ? nc0 : 0.f; curC[1] = nxt_valid ? nc1 : 0.f; curC[2] = nxt_valid ? nc2 : 0.f;
     }
+#ifdef VTGS_Q_STAMPS
+    asm volatile("" :: "v"(curK[0]), "v"(curC[0]));
+#endif
+    BQ_STAMP(st_prom)
     // ---- retire: the oldest chunk has left all four queues AND the step still to be computed holds none of its entries ---
     while (inflight > 0 && __ballot(c0 > 0) == 0ull && __ballot(have_cur && cur_d0 > 0) == 0ull) {
       const int slot = (int)rslot + l;
@@ -383,9 +423,11 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
         p[3] = make_float2(v[6], v[7]); p[4] = make_float2(v[8], __uint_as_float(tile_bits));
       }
       c0 = c1; c1 = c2; c2 = 0; n0 = n1; n1 = n2; n2 = 0;
+      cur_d0 = cur_d1; cur_d1 = cur_d2; cur_d2 = 0;              // what the step in flight holds of the NEW oldest chunk
       rslot = (rslot == (uint32_t)(kBqRing - 64)) ? 0u : rslot + 64u; --inflight;
     }
-    if (inflight == 0 && base >= e) break;                      // the list is exhausted and every chunk has retired
+    BQ_STAMP(st_ret)
+    if (inflight == 0 && base >= e && !have_cur) break;         // the list is exhausted, every chunk has retired, nothing in flight
   }
   // every pixel ended before the end of the list (or the loop ran out): chunks still in flight leave with what they have
   // gathered so far, entries never appended contributed nothing
@@ -408,6 +450,14 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
       p[4] = make_float2(0.f, __uint_as_float(tile_bits));
     }
   }
+#ifdef VTGS_Q_STAMPS
+  if (step_counters && l == 0) {
+    uint32_t* o = step_counters + 64 + 8 * tile;
+    const unsigned long long se = __builtin_amdgcn_s_memtime();
+    o[0] = (uint32_t)st_app; o[1] = (uint32_t)st_pop; o[2] = (uint32_t)st_sweep; o[3] = (uint32_t)st_contr;
+    o[4] = (uint32_t)(se - st0); o[5] = nsteps; o[6] = (uint32_t)st_acc; o[7] = (uint32_t)st_prom | ((uint32_t)(st_ret >> 4) << 20);
+  }
+#endif
   if (step_counters && l == 0) atomicAdd(&step_counters[blockIdx.x & 63u], nsteps);   // measurement only (VTGS_COUNT_STEPS)
 }
 

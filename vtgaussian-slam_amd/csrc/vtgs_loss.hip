@@ -184,6 +184,8 @@ __global__ __launch_bounds__(256) void ssim_backward_kernel(const float* __restr
 // mode 0 (tracking): mask = gt_depth > 0 & finite depth & finite uncertainty & silhouette > sil_thres;
 //                    partial[b] = {sum_mask |gt_im - im| (3 channels), sum_mask |gt_depth - depth|, count}
 // mode 1 (mapping):  mask = gt_depth > 0 & finite depth & finite uncertainty;   colour L1 over ALL pixels (it is a mean)
+// mode 2 (tracking with neither use_sil_for_loss nor ignore_outlier_depth_loss, src/vtgaussian_slam.py:601-602): the depth
+//                    term as in mode 0, the colour SUM over all pixels
 // Gradient images hold d(sum)/d(im) and d(sum)/d(depth_sil[0]) (channels 1, 2 of depth_sil only enter detached masks).
 __global__ __launch_bounds__(256) void masked_l1_kernel(const float* __restrict__ im, const float* __restrict__ ds,
                                                         const float* __restrict__ gt_im, const float* __restrict__ gt_depth,
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void masked_l1_kernel(const float* __restrict_
     const float depth = ds[i], sil = ds[P + i], unc = ds[2 * (size_t)P + i] - depth * depth;
     const float gd = gt_depth[i];
     bool m = gd > 0.f && depth == depth && unc == unc;
-    if (mode == 0) m = m && sil > sil_thres;
+    if (mode != 1) m = m && sil > sil_thres;
     if (extra_mask) m = m && extra_mask[i] != 0.f;           // visibility / far-depth / outlier masks of the other datasets
     const bool mc = (mode == 0) ? m : true;
     float d = gd - depth;
@@ -298,8 +300,8 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     const float cnt = red[0][2] + red[1][2] + red[2][2] + red[3][2];
     const float ssim = (red[0][3] + red[1][3] + red[2][3] + red[3][3]) / numel_im;
     // the two weighted terms the reference's get_loss reports beside their sum (weighted_losses['im'], ['depth'])
-    const float t_im = (mode == 0) ? w_im * s_im : w_im * (l1_coef * s_im / numel_im + 0.2f * (1.f - ssim));
-    const float t_d = (mode == 0) ? w_depth * s_d : w_depth * s_d / cnt;                   // tracking: masked SUMS, mapping: means
+    const float t_im = (mode != 1) ? w_im * s_im : w_im * (l1_coef * s_im / numel_im + 0.2f * (1.f - ssim));
+    const float t_d = (mode != 1) ? w_depth * s_d : w_depth * s_d / cnt;                   // tracking: masked SUMS, mapping: means
     out[0] = t_im + t_d; out[1] = cnt; out[2] = s_im; out[3] = s_d; out[4] = ssim; out[5] = t_im; out[6] = t_d; out[7] = 0.f;
   }
 }
@@ -313,22 +315,23 @@ __global__ __launch_bounds__(256) void loss_backward_kernel(const float* __restr
                                                             float* __restrict__ g_im, float* __restrict__ g_ds,
                                                             const float* __restrict__ extra_mask = nullptr) {
   const float up = upstream[0];
-  const float cd = (mode == 0) ? up * w_depth : up * w_depth / fwd_out[1];
+  const float cd = (mode != 1) ? up * w_depth : up * w_depth / fwd_out[1];
   const float ci = up * w_im;
   for (int i = (int)(blockIdx.x * 256u + threadIdx.x); i < P; i += (int)(gridDim.x * 256u)) {
     const float depth = ds[i], sil = ds[P + i], unc = ds[2 * (size_t)P + i] - depth * depth;
     const float gd = gt_depth[i];
     bool m = gd > 0.f && depth == depth && unc == unc;
-    if (mode == 0) m = m && sil > sil_thres;
+    if (mode != 1) m = m && sil > sil_thres;
     if (extra_mask) m = m && extra_mask[i] != 0.f;
+    const bool mc = (mode == 0) ? m : true;                  // mode 2: the colour sum runs over all pixels
     const float d = gd - depth;
     g_ds[i] = m ? (d > 0.f ? -cd : (d < 0.f ? cd : 0.f)) : 0.f;
     g_ds[P + i] = 0.f; g_ds[2 * (size_t)P + i] = 0.f;
-    if (mode == 0) {
+    if (mode != 1) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float e = gt_im[(size_t)c * P + i] - im[(size_t)c * P + i];
-        g_im[(size_t)c * P + i] = m ? (e > 0.f ? -ci : (e < 0.f ? ci : 0.f)) : 0.f;
+        g_im[(size_t)c * P + i] = mc ? (e > 0.f ? -ci : (e < 0.f ? ci : 0.f)) : 0.f;
       }
     }
   }
@@ -348,7 +351,7 @@ uint32_t vtgs_masked_l1_partial_rows(int32_t pixels) {
 
 int vtgs_masked_l1(const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth, int32_t pixels,
                    float sil_thres, int32_t mode, float* partial_sums, float* g_im, float* g_depth_sil, void* stream) {
-  if (!im || !depth_sil || !gt_im || !gt_depth || !partial_sums || !g_im || !g_depth_sil || pixels <= 0 || (mode != 0 && mode != 1))
+  if (!im || !depth_sil || !gt_im || !gt_depth || !partial_sums || !g_im || !g_depth_sil || pixels <= 0 || (mode < 0 || mode > 2))
     return VTGS_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(masked_l1_kernel, dim3(vtgs_masked_l1_partial_rows(pixels)), dim3(256), 0, (hipStream_t)stream, im,
                      depth_sil, gt_im, gt_depth, pixels, sil_thres, mode, partial_sums, g_im, g_depth_sil);
@@ -427,7 +430,7 @@ int vtgs_slam_loss_forward(int32_t mode, const float* im, const float* depth_sil
                            int32_t height, int32_t width, float sil_thres, float w_im, float w_depth, float* scratch,
                            float* ssim_grad_maps, float* out5, const float* extra_mask, const float* color_weight,
                            void* stream) {
-  if ((mode != 0 && mode != 1) || !im || !depth_sil || !gt_im || !gt_depth || !scratch || !out5 || height <= 0 || width <= 0)
+  if ((mode < 0 || mode > 2) || !im || !depth_sil || !gt_im || !gt_depth || !scratch || !out5 || height <= 0 || width <= 0)
     return VTGS_ERR_INVALID_ARGUMENT;
   const int32_t P = height * width;
   const uint32_t l1_rows = vtgs_masked_l1_partial_rows(P);
@@ -451,7 +454,7 @@ int vtgs_slam_loss_backward(int32_t mode, const float* im, const float* depth_si
                             int32_t height, int32_t width, float sil_thres, float w_im, float w_depth,
                             const float* ssim_grad_maps, const float* fwd_out5, const float* upstream, float* g_im,
                             float* g_depth_sil, const float* extra_mask, const float* color_weight, void* stream) {
-  if ((mode != 0 && mode != 1) || !im || !depth_sil || !gt_im || !gt_depth || !fwd_out5 || !upstream || !g_im || !g_depth_sil ||
+  if ((mode < 0 || mode > 2) || !im || !depth_sil || !gt_im || !gt_depth || !fwd_out5 || !upstream || !g_im || !g_depth_sil ||
       height <= 0 || width <= 0 || (mode == 1 && !ssim_grad_maps))
     return VTGS_ERR_INVALID_ARGUMENT;
   const int32_t P = height * width;

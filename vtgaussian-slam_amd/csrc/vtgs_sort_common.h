@@ -45,7 +45,7 @@ __device__ __forceinline__ void in_lane_cleaners(unsigned long long (&k)[E], uin
 }
 
 #ifndef VTGS_SORT_DPP
-#define VTGS_SORT_DPP 1
+#define VTGS_SORT_DPP 0
 #endif
 
 __device__ __forceinline__ unsigned long long lane_fetch64(unsigned long long x, int byte_addr) {   // x of lane byte_addr / 4
@@ -55,10 +55,12 @@ __device__ __forceinline__ unsigned long long lane_fetch64(unsigned long long x,
 }
 
 // x of lane (lane ^ MASK) for the masks the network uses, without the LDS crossbar: DPP row operations inside a 16-lane row,
-// v_permlane16_swap / v_permlane32_swap across rows (semantics: tests/micro/permlane_swap.hip).  When the sort runs at the top
-// of composite_forward_q, at 4 wavefronts per SIMD, it is bound by the latency of its 21 dependent cross-lane stages, not by
-// instruction issue: a ds_bpermute round trip per stage and key cost 19 k of the wavefront's 62 k cycles
-// (profiles/r3_forward_stamps.md); a DPP move has the latency of a vector instruction.
+// v_permlane16_swap / v_permlane32_swap across rows (semantics: tests/micro/permlane_swap.hip).  OFF by default
+// (VTGS_SORT_DPP = 0): measured inside composite_forward_q on one box it is SLOWER than ds_bpermute (133.4 / 131.5 us against
+// 127.3 / 126.2, gpurun_out/r3/timing_e.txt).  The network takes 19 k of the wavefront's 62 k cycles (profiles/r3_stamps.md),
+// but not because a crossbar round trip is slow: the sorting wavefront competes for vector issue with three wavefronts that
+// are compositing, and a ds_bpermute is work for the otherwise idle LDS unit while DPP moves (plus the wait states they need
+// behind the compare-exchange that produced their source) are more vector instructions.  Kept for the record and for A/B.
 template <int MASK>
 __device__ __forceinline__ uint32_t lane_xor32(uint32_t x, int lane) {
   constexpr int kQuad1 = 0xB1, kQuad2 = 0x4E, kQuad3 = 0x1B, kRowMirror = 0x140, kHalfMirror = 0x141, kRor8 = 0x128;

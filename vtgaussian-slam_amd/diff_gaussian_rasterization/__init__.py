@@ -14,6 +14,7 @@ Put the directory that contains this package (`vtgaussian-slam_amd/`) on PYTHONP
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import os
 import threading
@@ -23,7 +24,7 @@ from typing import NamedTuple, Optional, Tuple
 import torch
 import torch.nn as nn
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_forward_info"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_forward_info", "settle_pending"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("VTGS_LIBRARY", os.path.join(_HERE, "..", "lib", "libvtgs.so"))
@@ -101,6 +102,29 @@ def _load_library() -> ctypes.CDLL:
 _lib = _load_library()
 
 
+def _load_torch_ext():
+    """The operator's C++ autograd node (csrc/vtgs_torch.cpp -> lib/vtgs_torch.so, built by build.py): host plumbing only -- the
+    same C-ABI calls, without the interpreter in the backward.  Absent or stale (ABI mismatch) or VTGS_TORCH_EXT=0: the Python
+    autograd.Function below does the same job."""
+    if os.environ.get("VTGS_TORCH_EXT", "1") == "0":
+        return None
+    path = os.path.join(os.path.dirname(os.path.abspath(_LIB_PATH)), "vtgs_torch.so")
+    if not os.path.exists(path) or "VTGS_LIBRARY" in os.environ:      # (an experiment library is driven through ctypes only)
+        return None
+    import importlib.machinery
+    import importlib.util
+    try:
+        loader = importlib.machinery.ExtensionFileLoader("vtgs_torch", path)
+        mod = importlib.util.module_from_spec(importlib.util.spec_from_loader("vtgs_torch", loader))
+        loader.exec_module(mod)
+        return mod if int(mod.abi_version()) == ABI_VERSION else None
+    except (ImportError, OSError):
+        return None
+
+
+_ext = _load_torch_ext()
+
+
 def _check(status: int, what: str) -> None:
     if status != VTGS_OK:
         msg = _lib.vtgs_strerror(status).decode()
@@ -138,7 +162,9 @@ _FORWARD_MODE = os.environ.get("VTGS_FORWARD_MODE", "auto")
 
 
 def last_forward_info() -> dict:
-    """Statistics of the most recent forward on this process (instances, 16x16 tile count R, ...)."""
+    """Statistics of the most recent forward on this process (instances, 16x16 tile count R, ...); reads the records of
+    run-ahead forwards that are still outstanding first."""
+    settle_pending()
     return dict(_last_info)
 
 
@@ -212,6 +238,7 @@ class _Camera:
                              self.bg.data_ptr(), self.view.data_ptr(), self.proj.data_ptr())
         self.H, self.W = int(settings.image_height), int(settings.image_width)
         self.band = (b, e)
+        self.bytes = torch.frombuffer(bytearray(bytes(self.c)), dtype=torch.uint8)     # the record, for the C++ node
 
 
 _camera_cache: dict = {}
@@ -277,6 +304,7 @@ class _SlotPool:
         self.info = [_VtgsForwardInfo.from_address(a) for a in self.ptr]
         self.owner = [None] * self.SLOTS           # the _ForwardState whose record is still unread
         self.next = 0
+        self.pending = collections.deque()         # run-ahead forwards whose record has not been read, oldest first
 
     def take(self, fs):
         i = self.next
@@ -298,6 +326,28 @@ def _slot_pool(device, stream) -> "_SlotPool":
     if pool is None:
         pool = _slot_pools[key] = _SlotPool()
     return pool
+
+
+def _drain(pool: "_SlotPool", keep: int = 1) -> None:
+    """Read the records of run-ahead forwards that have landed; wait for the oldest ones while more than `keep` are
+    outstanding (the host may run ahead of the device by about one iteration, not more).  Called at the start of a forward:
+    with the C++ autograd node nothing on the host runs after the backward's launches."""
+    while pool.pending:
+        fs = pool.pending[0]
+        if fs.pending is not None:
+            if not pool.info[fs.pending[1]].complete and len(pool.pending) <= keep:
+                break
+            _settle(fs)
+        pool.pending.popleft()
+
+
+def settle_pending() -> None:
+    """Read the result records of ALL run-ahead forwards still outstanding (waiting for the device where needed) -- an
+    overflow among them raises here.  The loops do not need to call this (every forward does it for its predecessors);
+    it is for code that wants the verdict of the last iteration NOW, e.g. before reading its loss on the host."""
+    with _slot_lock:
+        for pool in list(_slot_pools.values()):
+            _drain(pool, keep=0)
 
 
 def _settle(fs) -> None:
@@ -423,6 +473,7 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
 
     with _slot_lock:
         pool = _slot_pool(device, stream)
+        _drain(pool)
         slot = pool.take(fs)
         capacity, tile_cap = _choose_capacities(key, n)
         run_ahead = want_async and _FORWARD_MODE == "auto" and _async_ok.get(key) == (capacity, tile_cap)
@@ -436,6 +487,7 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
                 _check(launch(workspace, nbytes, capacity, tile_cap, pool.ptr[slot], VTGS_FORWARD_ASYNC), "vtgs_forward")
                 fs.workspace, fs.capacity, fs.tile_cap, fs._instances = workspace, capacity, tile_cap, None
                 fs.pending = (pool, slot, device)
+                pool.pending.append(fs)
                 return color, radii, depth, fs
             for _attempt in range(6):
                 nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
@@ -455,6 +507,55 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
         _caps_in_use.setdefault(key, (capacity, tile_cap))
         _record_info(key, n, W, H, capacity, info)
         fs.workspace, fs.capacity, fs.tile_cap, fs._instances = workspace, capacity, tile_cap, int(info.instances)
+    return color, radii, depth, fs
+
+
+def _forward_ext(cam: _Camera, means3D, means2D, colors, opacities, scales, rotations):
+    """The forward through the C++ autograd node (csrc/vtgs_torch.cpp): the policy of _run_forward -- capacities, checked or
+    run-ahead mode, the pinned result record, the retry after an overflow -- with the per-call work and the whole backward
+    on the C++ side.  Returns (color, radii, depth, _ForwardState)."""
+    device = means3D.device
+    n = means3D.shape[0]
+    stream = _stream_ptr(device)
+    key = (device.index, n, cam.W, cam.H, cam.band)
+    fs = _ForwardState()
+    fs.cam, fs.n, fs.image_state, fs.key, fs.pending = cam, n, None, key, None
+    want_async = torch.is_grad_enabled() and (means3D.requires_grad or colors.requires_grad or opacities.requires_grad
+                                              or scales.requires_grad or rotations.requires_grad or means2D.requires_grad)
+    with _slot_lock:
+        pool = _slot_pool(device, stream)
+        _drain(pool)
+        slot = pool.take(fs)
+        capacity, tile_cap = _choose_capacities(key, n)
+        run_ahead = want_async and _FORWARD_MODE == "auto" and _async_ok.get(key) == (capacity, tile_cap)
+        info = pool.info[slot]
+        for _attempt in range(6):
+            info.complete = 0
+            color, radii, depth, workspace, status = _ext.rasterize(
+                means3D, means2D, colors, opacities, scales, rotations, cam.bytes, cam.bg, cam.view, cam.proj, capacity, tile_cap,
+                pool.ptr[slot], VTGS_FORWARD_ASYNC if run_ahead else VTGS_FORWARD_CHECKED, stream)
+            if run_ahead:
+                break
+            if int(status) == VTGS_ERR_INSTANCE_OVERFLOW:     # the record says what is needed: grow whichever was short
+                if info.overflow & 1:
+                    capacity = int(info.instances_needed * 1.5) + 4096
+                if info.overflow & 2:
+                    tile_cap = _tile_capacity_for(info.max_tile_list)
+                _caps_in_use[key] = (capacity, tile_cap)
+                continue
+            break
+        else:
+            raise RuntimeError("vtgs_forward: instance capacity kept overflowing")
+        fs.workspace, fs.capacity, fs.tile_cap = workspace, capacity, tile_cap
+        if run_ahead:
+            fs._instances = None
+            fs.pending = (pool, slot, device)
+            pool.pending.append(fs)
+        else:
+            pool.owner[slot] = None
+            _caps_in_use.setdefault(key, (capacity, tile_cap))
+            _record_info(key, n, cam.W, cam.H, capacity, info)
+            fs._instances = int(info.instances)
     return color, radii, depth, fs
 
 
@@ -662,6 +763,12 @@ class GaussianRasterizer(nn.Module):
         if not means3D.is_cuda:
             raise RuntimeError("GaussianRasterizer needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
         cam = _camera_for(self.raster_settings, means3D.device, self._rule, self._tile_rows)
+        if _ext is not None:
+            if means2D is None:
+                means2D = torch.zeros_like(means3D)
+            color, radii, depth, fs = _forward_ext(cam, means3D, means2D, colors_precomp, opacities, scales, rotations)
+            self._last_state = fs
+            return color, radii, depth
         color, radii, depth, fs = _RasterizeGaussians.apply(means3D, means2D, None, colors_precomp, opacities, scales,
                                                             rotations, None, cam, None)
         self._last_state = fs

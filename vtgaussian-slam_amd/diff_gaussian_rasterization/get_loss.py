@@ -12,23 +12,60 @@ composite (`fused.render_frame`), the masks of every dataset branch (`losses.vis
 Same arguments, same return value (`loss, variables, weighted_losses[, presence_sil_mask_mse_ls, sil_thres_ls]`), same
 bookkeeping of `variables['seen']` / `['max_2D_radius']` and of the two threshold lists.
 
-Differences, all outside what the shipped configurations use:
-  * `variables['means2D']` is not set: the dual backward sums the geometry gradients of both renders, so there is no
-    colour-render-only screen-space gradient (utils/slam_external.py:100-103 reads it only when
-    `use_gaussian_splatting_densification` is on; every config has it off);
-  * `use_l1=False` and tracking with neither `use_sil_for_loss` nor `ignore_outlier_depth_loss` (the unmasked colour sum,
-    :601-602) raise NotImplementedError; `visualize_tracking_loss` is ignored (plots);
+Every branch of the reference is covered: `use_l1=False` (no depth term, :591-596), tracking with neither
+`use_sil_for_loss` nor `ignore_outlier_depth_loss` (the colour sum over all pixels, :601-602), all dataset masks.
+Differences:
+  * `variables['means2D']` (:460-462: the screen-space positions of the COLOUR render, whose `.grad` feeds
+    `accumulate_mean2d_gradient`, utils/slam_external.py:100-103, when `use_gaussian_splatting_densification` is on --
+    every shipped config has it off).  The dual backward sums the geometry gradients of both renders, so by default
+    `variables['means2D']` is a placeholder whose `.grad` raises with this explanation instead of handing a stale tensor or
+    a KeyError to the densification code.  `get_loss.SCREEN_SPACE_GRADIENT = True` (module attribute, or the environment
+    variable VTGS_SCREEN_SPACE_GRADIENT=1) selects the two-render route -- `transform_to_frame` + the plain operator for the
+    colour render with `means2D.retain_grad()`, the depth / silhouette render over the same bins -- and sets the real tensor;
+  * `visualize_tracking_loss` is ignored (plots);
   * the entries of `weighted_losses` other than 'loss' are detached (the loops only log them).
-HIP only: no CPU path.
+Unsupported argument combinations are rejected BEFORE `params` / `variables` are touched.  HIP only: no CPU path.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
+from . import GaussianRasterizer
 from . import losses as _l
 from .fused import render_frame
 
-__all__ = ["get_loss"]
+__all__ = ["get_loss", "SCREEN_SPACE_GRADIENT"]
+
+SCREEN_SPACE_GRADIENT = os.environ.get("VTGS_SCREEN_SPACE_GRADIENT", "0") == "1"
+
+
+class _NoScreenSpaceGradient:
+    """Placeholder for variables['means2D'] on the fused route: reading `.grad` explains what to switch on."""
+
+    @property
+    def grad(self):
+        raise RuntimeError(
+            "variables['means2D'].grad: the fused get_loss composites both renders in one pass and has no colour-render-only "
+            "screen-space gradient (src/vtgaussian_slam.py:460-462). Densification from that gradient "
+            "(use_gaussian_splatting_densification) needs `diff_gaussian_rasterization.get_loss.SCREEN_SPACE_GRADIENT = True` "
+            "(or VTGS_SCREEN_SPACE_GRADIENT=1), which renders the two images separately.")
+
+
+def _render_separately(params, iter_time_idx, cam, w2c, gaussians_grad, camera_grad):
+    """The reference's own chain (:431-468) on the plain operator: the colour render keeps `means2D` in the graph."""
+    import slam_callers as sc                      # device-agnostic restatement of utils/slam_helpers.py (pinned by golden vectors)
+    tg = sc.transform_to_frame(params, iter_time_idx, gaussians_grad=gaussians_grad, camera_grad=camera_grad)
+    rv = sc.transformed_params2rendervar(params, tg)
+    dv = sc.transformed_params2depthplussilhouette(params, w2c, tg)
+    if rv["means2D"].requires_grad:
+        rv["means2D"].retain_grad()
+    rast = GaussianRasterizer(raster_settings=cam)
+    im, radius, _ = rast(**rv)
+    depth_sil, _ = rast.render_shared(dv["colors_precomp"], like=(rv["means3D"], dv["means2D"], rv["opacities"], rv["scales"],
+                                                                  rv["rotations"]))
+    return im, depth_sil, radius, rv["means2D"]
 
 
 def _cuda_f32(v):
@@ -45,14 +82,19 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
              presence_sil_mask_mse_ls=None, sil_thres_ls=None, far_depth_filter_thres=None, vis_mask_thres=0.05,
              curr_w2c=None, overlap_w2c=None, overlap_gtdepth=None, overlap_last_w2c=None, overlap_last_gtdepth=None,
              overlap_mid_w2c=None, overlap_mid_gtdepth=None):
-    # :416-426 -- everything on the device, float32, contiguous (a no-op for tensors that already are)
+    # argument combinations this function cannot serve are rejected before anything is converted in place
+    if tracking and use_sil_for_loss and dataset_name not in ("replica", "tum", "scannet", "scannetpp"):
+        raise ValueError(f"get_loss: no presence mask is defined for dataset_name={dataset_name!r} "
+                         "(src/vtgaussian_slam.py:470-514 knows replica, tum, scannet, scannetpp)")
+    if tracking and overlap_w2c is not None and dataset_name not in ("replica", "tum", "scannet", "scannetpp"):
+        raise ValueError(f"get_loss: visibility mask undefined for dataset_name={dataset_name!r}")
+    # :416-426 -- everything on the device, float32, contiguous (a no-op for tensors that already are).  A tensor that has to
+    # be converted is REPLACED in the caller's dict, as in the reference (whose Parameters already live on the device).
     for k, v in params.items():
         params[k] = _cuda_f32(v)
     for k, v in variables.items():
-        variables[k] = _cuda_f32(v)
-    if not use_l1:
-        raise NotImplementedError("use_l1=False leaves the depth term out (src/vtgaussian_slam.py:591-596); no shipped "
-                                  "configuration does that")
+        if k != "means2D":
+            variables[k] = _cuda_f32(v)
     # :428-449 -- who gets a gradient
     if tracking:
         gaussians_grad, camera_grad = False, True
@@ -61,7 +103,13 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
     else:
         gaussians_grad, camera_grad = True, False
     # :451-468 -- both renders
-    im, depth_sil, radius = render_frame(params, iter_time_idx, curr_data["cam"], curr_data["w2c"], gaussians_grad, camera_grad)
+    if SCREEN_SPACE_GRADIENT:
+        im, depth_sil, radius, means2D = _render_separately(params, iter_time_idx, curr_data["cam"], curr_data["w2c"],
+                                                            gaussians_grad, camera_grad)
+        variables["means2D"] = means2D                 # gradient only accumulated from the colour render (:462)
+    else:
+        im, depth_sil, radius = render_frame(params, iter_time_idx, curr_data["cam"], curr_data["w2c"], gaussians_grad, camera_grad)
+        variables["means2D"] = _NoScreenSpaceGradient()
     gt_im, gt_depth = curr_data["im"], curr_data["depth"]
     depth = depth_sil[0:1].detach()
 
@@ -77,9 +125,6 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
                 thr = sil_thres_ls[-1]
     elif dataset_name in ("tum", "scannet", "scannetpp"):
         thr = sil_thres
-    if tracking and use_sil_for_loss and thr is None:
-        raise ValueError(f"get_loss: no presence mask is defined for dataset_name={dataset_name!r} "
-                         "(src/vtgaussian_slam.py:470-514 knows replica, tum, scannet, scannetpp)")
 
     # :523-588 -- detached masks beyond gt_depth > 0 & finite (those two live in the loss node)
     masks = []
@@ -92,7 +137,7 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
             overlaps = [(overlap_w2c, overlap_gtdepth), (overlap_mid_w2c, overlap_mid_gtdepth),
                         (overlap_last_w2c, overlap_last_gtdepth)]
         else:
-            raise ValueError(f"get_loss: visibility mask undefined for dataset_name={dataset_name!r}")
+            overlaps = []
         masks.append(_l.visibility_mask(gt_depth, curr_data["intrinsics"], curr_w2c, overlaps, vis_mask_thres)[None])
     if tracking and far_depth_filter_thres is not None and dataset_name not in ("replica", "scannetpp"):
         masks.append(_l.far_depth_mask(gt_depth, far_depth_filter_thres))
@@ -101,17 +146,18 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
         extra = m if extra is None else (extra & m)
 
     # :590-611 -- the loss
-    w_im, w_depth = float(loss_weights["im"]), float(loss_weights["depth"])
+    w_im = float(loss_weights["im"])
+    w_depth = float(loss_weights["depth"]) if use_l1 else 0.0   # use_l1 = False: no depth term at all (:591-596)
     if tracking:
-        if not (use_sil_for_loss or ignore_outlier_depth_loss):
-            raise NotImplementedError("tracking with neither use_sil_for_loss nor ignore_outlier_depth_loss sums the colour "
-                                      "error over ALL pixels (src/vtgaussian_slam.py:601-602); no shipped configuration does that")
         loss, terms = _l.tracking_loss(im, depth_sil, gt_im, gt_depth, thr if use_sil_for_loss else float("-inf"),
-                                       w_im=w_im, w_depth=w_depth, extra_mask=extra, return_terms=True)
+                                       w_im=w_im, w_depth=w_depth, extra_mask=extra, return_terms=True,
+                                       colour_over_all_pixels=not (use_sil_for_loss or ignore_outlier_depth_loss))
     else:
         loss, terms = _l.mapping_loss(im, depth_sil, gt_im, gt_depth, w_im=w_im, w_depth=w_depth, extra_mask=extra,
                                       additional_mask=additional_mask, return_terms=True)
-    weighted_losses = {"im": terms[5], "depth": terms[6]}      # formed by the loss kernel: no element-wise launches here
+    weighted_losses = {"im": terms[5]}                          # formed by the loss kernel: no element-wise launches here
+    if use_l1:
+        weighted_losses["depth"] = terms[6]
 
     # :681-689 -- bookkeeping
     # max_2D_radius[seen] = max(radius[seen], max_2D_radius[seen]) without the boolean-mask gathers (each of them waits for

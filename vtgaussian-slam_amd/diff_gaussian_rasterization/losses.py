@@ -97,7 +97,7 @@ _lib.vtgs_slam_loss_backward.argtypes = [_I32, _P, _P, _P, _P, _I32, _I32, ctype
 
 class _SlamLoss(torch.autograd.Function):
     """The whole Replica branch of get_loss as one node: 2-3 launches for the value, 1-2 for both gradient images (the
-    upstream gradient is read on the device).  mode 0 = tracking, 1 = mapping."""
+    upstream gradient is read on the device).  mode 0 = tracking, 1 = mapping, 2 = tracking with the unmasked colour sum."""
 
     @staticmethod
     def forward(ctx, im, depth_sil, gt_im, gt_depth, mode: int, sil_thres: float, w_im: float, w_depth: float,
@@ -149,14 +149,16 @@ class _SlamLoss(torch.autograd.Function):
 
 
 def tracking_loss(im, depth_sil, gt_im, gt_depth, sil_thres: float, w_im: float = 0.5, w_depth: float = 0.025,
-                  extra_mask=None, return_terms: bool = False):
+                  extra_mask=None, return_terms: bool = False, colour_over_all_pixels: bool = False):
     """Tracking loss of get_loss (src/vtgaussian_slam.py:519-605): w_im * masked L1 SUM of colour + w_depth * masked L1
     SUM of depth over gt_depth > 0 & finite & silhouette > sil_thres [& extra_mask].  `extra_mask` [H,W] / [1,H,W]
     (bool or float, detached) carries the masks of the TUM / ScanNet / ScanNet++ branches -- build it with
     `visibility_mask`, `far_depth_mask`, `outlier_depth_mask` below and AND them together.
     return_terms: also the detached device vector {loss, mask count, colour sum, depth sum, -, w_im * colour term,
-    w_depth * depth term, 0}."""
-    loss, terms = _SlamLoss.apply(im, depth_sil, gt_im, gt_depth, 0, sil_thres, w_im, w_depth, extra_mask, None)
+    w_depth * depth term, 0}.  colour_over_all_pixels: the branch with neither use_sil_for_loss nor
+    ignore_outlier_depth_loss (:601-602) -- the colour sum ignores the mask; w_depth = 0: use_l1 = False (:591-596)."""
+    loss, terms = _SlamLoss.apply(im, depth_sil, gt_im, gt_depth, 2 if colour_over_all_pixels else 0, sil_thres, w_im, w_depth,
+                                  extra_mask, None)
     return (loss, terms) if return_terms else loss
 
 
