@@ -50,6 +50,11 @@ def parse_args(argv=None):
     ap.add_argument("--get-loss", action="store_true", help="drive both loops through diff_gaussian_rasterization.get_loss."
                                                             "get_loss, the function with the reference's own signature "
                                                             "(implies --fused): what a one-import swap in the driver gives")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one iteration of each phase (get_loss + backward: ~25 launches) into a hipGraph "
+                         "(torch.cuda.graph) and replay it; the optimiser step stays eager (its bias corrections are host "
+                         "scalars).  Opt-in: the reference's loops would need these few lines around their get_loss call "
+                         "(needs --get-loss)")
     ap.add_argument("--global-submaps", type=int, default=0,
                     help="K > 0: every mapping iteration makes the reference's SECOND get_loss call as well, over the global "
                          "set = K fixed submaps (+) the current one (src/vtgaussian_slam.py:2545-2556, 944-977): (K+1) N "
@@ -59,6 +64,8 @@ def parse_args(argv=None):
         args.fused = True
     if args.global_submaps and not args.get_loss:
         ap.error("--global-submaps needs --get-loss")
+    if args.graph and not args.get_loss:
+        ap.error("--graph needs --get-loss")
     return args
 
 
@@ -66,6 +73,13 @@ def run(args) -> dict:
     """One run of the loop; returns the JSON record (bench.py embeds a short run of it as its `slam` block)."""
     assert torch.cuda.is_available(), "bench_slam.py needs an MI355X"
     dev = torch.device("cuda", 0)
+    if args.graph:
+        # Everything -- the eager iterations too -- runs on ONE side stream: a graph cannot be captured on the default stream,
+        # and the AccumulateGrad nodes of the parameters remember the stream they were created under (a node created by an
+        # eager iteration on the default stream and still referenced would drag a cross-stream sync into the capture).
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(side)
 
     import diff_gaussian_rasterization as dgr
     import slam_callers as sc
@@ -169,6 +183,22 @@ def run(args) -> dict:
     def curr_data(t):                             # what the driver hands to get_loss for frame t (tracking_curr_data / iter_data of the driver)
         return {"cam": settings, "im": gts[t][0], "depth": gts[t][1], "id": t, "w2c": first_w2c}
 
+    def capture(fn):
+        """fn() -> loss (forward + loss of one iteration).  Two eager warm-up iterations on the capture stream (they move no
+        parameter), then the capture of forward + backward; returns (graph, static loss tensor)."""
+        for _ in range(2):
+            for v in params.values():
+                v.grad = None
+            fn().backward()
+        for v in params.values():
+            v.grad = None
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=torch.cuda.current_stream()):
+            loss = fn()
+            loss.backward()
+        return g, loss
+
     def pose_error(t):
         with torch.no_grad():
             dt = (params["cam_trans"][0, :, t] - gt_trans[0, :, t]).norm().item() * 100          # cm
@@ -200,7 +230,22 @@ def run(args) -> dict:
         torch.cuda.synchronize(); t0 = time.perf_counter()
         sil_thres, best = 0.99, (float("inf"), None, None)
         mse_ls, thr_ls = [], []
+        graph = None
         for it in range(args.tracking_iters):
+            if args.graph and it >= 1:
+                if graph is None:                  # iteration 0 (the threshold sweep reads the device) ran eagerly; capture 1..
+                    def track_fn(it=it):
+                        return mirror_get_loss(params, curr_data(t), variables, t, {"im": 0.5, "depth": 0.025}, True, 0.99, True,
+                                               False, tracking=True, plot_dir=None, visualize_tracking_loss=False,
+                                               tracking_iteration=it, dataset_name="replica",
+                                               presence_sil_mask_mse_ls=mse_ls, sil_thres_ls=thr_ls)[0]
+                    loss = _losses = None          # (no reference to an earlier iteration's autograd graph survives)
+                    graph, loss = capture(track_fn)
+                graph.replay()
+                if it % 10 == 9 and loss.item() < best[0]:
+                    best = (loss.item(), params["cam_unnorm_rots"][..., t].clone(), params["cam_trans"][..., t].clone())
+                opt.step()                         # eager: one launch; the replay overwrites the gradients, no zero_grad
+                continue
             if args.get_loss:                      # the call of src/vtgaussian_slam.py:1803-1806, argument for argument
                 loss, variables, _losses, mse_ls, thr_ls = mirror_get_loss(
                     params, curr_data(t), variables, t, {"im": 0.5, "depth": 0.025}, True, 0.99, True, False, tracking=True,
@@ -218,12 +263,34 @@ def run(args) -> dict:
                     if lv.item() < best[0]:
                         best = (lv.item(), params["cam_unnorm_rots"][..., t].clone(), params["cam_trans"][..., t].clone())
             opt.step(); opt.zero_grad(set_to_none=True)
+        if graph is not None:
+            torch.cuda.synchronize()
+            dgr.check_captured()
+            del graph
+            dgr.forget_captured()
+            opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize(); track_ms.append((time.perf_counter() - t0) * 1e3 / args.tracking_iters)
         errs_after.append(pose_error(t))
         # ---- mapping
         opt = make_adam([{"params": [v], "name": k, "lr": map_lrs[k]} for k, v in params.items()], lr=0.0, eps=1e-15)
         torch.cuda.synchronize(); t0 = time.perf_counter()
+        graph = None
         for it in range(args.mapping_iters):
+            if args.graph:
+                if graph is None:
+                    def map_fn():
+                        loss = mirror_get_loss(params, curr_data(t), variables, t, {"im": 1.0, "depth": 1.0}, False, 0.99, True,
+                                               False, mapping=True, dataset_name="replica")[0]
+                        if fixed:
+                            loss = loss + mirror_get_loss(concat_global(), curr_data(t), variables_global, t,
+                                                          {"im": 1.0, "depth": 1.0}, False, 0.99, True, False, mapping=True,
+                                                          dataset_name="replica")[0]
+                        return loss
+                    loss = _losses = None
+                    graph, loss = capture(map_fn)
+                graph.replay()
+                opt.step()
+                continue
             if args.get_loss:                      # (the mapping loops call it the same way, without the threshold lists)
                 loss, variables, _losses = mirror_get_loss(params, curr_data(t), variables, t, {"im": 1.0, "depth": 1.0}, False,
                                                            0.99, True, False, mapping=True, dataset_name="replica")
@@ -237,6 +304,12 @@ def run(args) -> dict:
                 loss = map_loss(im, depth_sil, gt_im, gt_depth)
             loss.backward()
             opt.step(); opt.zero_grad(set_to_none=True)
+        if graph is not None:
+            torch.cuda.synchronize()
+            dgr.check_captured()
+            del graph
+            dgr.forget_captured()
+            opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize(); map_ms.append((time.perf_counter() - t0) * 1e3 / args.mapping_iters)
         if os.environ.get("VTGS_SLAM_VERBOSE"):
             print(f"[bench_slam] frame {t}: tracking {track_ms[-1]:.3f} ms/it, mapping {map_ms[-1]:.3f} ms/it, "
@@ -250,7 +323,7 @@ def run(args) -> dict:
         "config": {"workload": f"view-tied submap N={N}, {W}x{H}; {args.tracking_iters} tracking + {args.mapping_iters} "
                                f"mapping iterations per frame, 2 renders fwd+bwd per iteration (configs/replica/room0.py)",
                    "frames": args.frames, "shared_geometry": bool(args.shared_geometry or args.fused), "fused_callers": bool(args.fused),
-                   "through_get_loss_mirror": bool(args.get_loss),
+                   "through_get_loss_mirror": bool(args.get_loss), "iteration_replayed_from_a_hipgraph": bool(args.graph),
                    "mapping_get_loss_calls_per_iteration": 2 if fixed else 1,
                    "gaussians_in_global_set": N * (1 + len(fixed)) if fixed else None},
         "tracking_ms_per_iter": round(sum(track_ms) / len(track_ms), 3),

@@ -997,7 +997,13 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   // Software pipeline of the gather, two deep as in composite_forward_q: while chunk c is composited, the list entries of
   // chunk c + 2 and the geometry records + colours of chunk c + 1 are in flight (a lane past the end reads entry 0 of its bin).
   auto entry = [&](const uint32_t* __restrict__ list, uint32_t b) { const uint32_t p = b + (uint32_t)l; return list[p < e ? p : s]; };
-  uint32_t gid_cur = gid_first, inst_cur = inst_first;
+  // the speculative first read went past the end of a short list, into slots nobody wrote: those lanes take entry 0 instead
+  // (every id that is gathered through must be a written one -- an unwritten slot holds whatever the memory held before)
+  const bool first_in = (uint32_t)l < list_len;
+  const uint32_t gid0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gid_first);    // lane 0 (all lanes active here): entry 0
+  const uint32_t inst0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)inst_first);
+  uint32_t gid_cur = first_in ? gid_first : gid0;
+  uint32_t inst_cur = first_in ? inst_first : inst0;
   uint32_t gid_nxt = entry(sorted_gid, s + 64u), inst_nxt = entry(sorted_inst, s + 64u);
   float4 g0n, g1n;
   float cn[DUAL ? 6 : 3];

@@ -215,6 +215,16 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
   if (overflow) return;                                         // uniform over the grid: the forward did not complete
   if (!tile_ok || list_len == 0u) return;
   const uint32_t e = s + list_len;
+  // the speculative first read went past the end of a short list, into slots nobody wrote: those lanes take entry 0 instead
+  // (every id that is gathered through must be a written one)
+  {
+    const uint32_t gid0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gid_n);      // lane 0 (all lanes active here): entry 0
+    const uint32_t inst0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)inst_n);
+    const bool first_in = (uint32_t)l < list_len;
+    gid_n = first_in ? gid_n : gid0;
+    inst_n = first_in ? inst_n : inst0;
+    mask_n = first_in ? mask_n : 0u;
+  }
   const float cx = (float)tx0 + 3.5f, cy = (float)ty0 + 3.5f;
   const float X = (float)lx - 3.5f, Y = (float)ly - 3.5f;
   const float Phi[6] = {1.f, X, Y, X * X, X * Y, Y * Y};

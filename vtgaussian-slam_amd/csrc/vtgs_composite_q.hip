@@ -44,6 +44,7 @@ namespace vtgs {
 constexpr int kQChunks = VTGS_Q_CHUNKS;                 // 64-entry chunks of the tile's list in flight at once
 constexpr int kQRing = 64 * kQChunks;       // table / queue ring: 192 slots
 constexpr int kQDummy = kQRing;             // table slot 192: a splat that reaches nothing (popped past the end of a queue)
+constexpr int kSortedIdsInLds = 416;        // sorted ids the wavefront keeps in LDS for its own chunks (4 workgroups per CU: 40 KB each)
 
 struct QuadCoord { int tile, px, py, q, i; bool tile_ok, inside; };
 
@@ -213,11 +214,14 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     uint32_t* sorted_inst, FinalizeArgs fin, uint8_t* __restrict__ qmask, uint32_t* __restrict__ step_counters) {
   // per wavefront: the table of the ring's entries (+ one dummy slot) and the four queues of table slots.  Queue bytes are
   // stored twice, 128 apart, so a pop reads [head & 127, head & 127 + 16) without wrapping.
-  __shared__ float4 lds_ka[4][kQRing + 1];                      // K0..K3
-  __shared__ float2 lds_kb[4][kQRing + 1];                      // K4, K5
-  __shared__ float4 lds_pa[4][kQRing + 1];                      // c0 c1 c2 depth   (dual: c0 c1 c2 c3)
+  // The three tables of a wavefront are carved from one block: the counting sort of the tile's list (vtgs_sort_common.h)
+  // uses the same bytes as staging before the first chunk is appended.
+  constexpr int kTabFloats = (kQRing + 1) * 10 + 2;             // ka 4 + pa 4 + kb 2 floats per slot, 16-byte multiples
+  static_assert(kTabFloats * 4 >= kCountSortMax * 8 + 256 * 4, "the sort's staging must fit into the table block");
+  __shared__ __attribute__((aligned(16))) float lds_tab[4][kTabFloats];
   __shared__ float4 lds_pb[DUAL ? 4 : 1][DUAL ? kQRing + 1 : 1];//                   (dual: c4 c5 0 0)
-  __shared__ uint8_t lds_q[4][4][2 * kQRing];
+  __shared__ uint8_t lds_q[4][4][kQRing];
+  __shared__ uint32_t lds_sgid[4][kSortedIdsInLds];             // the wavefront's own copy of the first sorted Gaussian ids
 #ifdef VTGS_Q_STAMPS
   const unsigned long long st0 = __builtin_amdgcn_s_memtime();
   unsigned long long st1 = st0, st2 = st0, st_app = 0ull, st_step = 0ull;
@@ -244,10 +248,11 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
   if (!qc.tile_ok) return;
   const int l = lane_id();
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  float4* ka = lds_ka[wv];
-  float2* kb = lds_kb[wv];
-  float4* pa = lds_pa[wv];
+  float4* ka = reinterpret_cast<float4*>(lds_tab[wv]);                                   // K0..K3
+  float4* pa = reinterpret_cast<float4*>(lds_tab[wv] + 4 * (kQRing + 1));                // c0 c1 c2 depth   (dual: c0 c1 c2 c3)
+  float2* kb = reinterpret_cast<float2*>(lds_tab[wv] + 8 * (kQRing + 1));                // K4, K5
   float4* pb = lds_pb[DUAL ? wv : 0];
+  uint32_t* sgid = lds_sgid[wv];
   const int q = qc.q, i = qc.i;
   const uint8_t* myq = lds_q[wv][q];
   const int lx = 4 * (q & 1) + (i & 3), ly = 4 * (q >> 1) + (i >> 2);
@@ -258,11 +263,24 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
   // sort_mode != 0 (the host picks it when no bin can hold more than 1024 entries): the wavefront sorts its own tile's list
   // here -- 1 = payload packed into the key, 2 = key + value -- instead of a sort kernel before this one: one launch less,
   // and the list's trip through memory overlaps with the other wavefronts' compositing.  The sorted list still goes to
-  // global memory (the backward and a second render read it) and is re-read below after the fence.
+  // global memory (the backward and a second render read it); the wavefront itself reads its first kSortedIdsInLds ids from
+  // the LDS copy the counting sort leaves behind (round 3), the rest -- or everything after the bitonic network -- from memory.
+  bool ids_in_lds = false;                                      // wave-uniform: the first kSortedIdsInLds sorted ids are in sgid
   if (sort_mode) {
     const uint32_t L = e - s;
     const size_t sz = (size_t)s;
-    if (L == 1u) {
+    bool counted = false;
+    if (L > 1u && L <= (uint32_t)kCountSortMax) {                // the common case: bucket pass + in-bucket ranks, ids kept in LDS
+      unsigned long long* stage = reinterpret_cast<unsigned long long*>(lds_tab[wv]);
+      uint32_t* cnt = reinterpret_cast<uint32_t*>(lds_tab[wv]) + 2 * kCountSortMax;
+      if (L <= 64u) counted = wave_count_sort<1>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, stage, cnt, sgid, kSortedIdsInLds);
+      else if (L <= 128u) counted = wave_count_sort<2>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, stage, cnt, sgid, kSortedIdsInLds);
+      else if (L <= 256u) counted = wave_count_sort<4>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, stage, cnt, sgid, kSortedIdsInLds);
+      else counted = wave_count_sort<8>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, stage, cnt, sgid, kSortedIdsInLds);
+      ids_in_lds = counted;
+    }
+    if (counted) {
+    } else if (L == 1u) {
       if (l == 0) { sorted_gid[s] = (uint32_t)bin_keys[s]; sorted_inst[s] = bin_vals[s]; }
     } else if (sort_mode == 1) {
       if (L <= 64u) { if (L) wave_sort_tile<1, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP); }
@@ -277,10 +295,12 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
       else if (L <= 512u) wave_sort_tile<8, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
       else wave_sort_tile<16, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
     }
-    // the wavefront's own stores before its own loads: program order within one wavefront, no cache maintenance (a
-    // device-scope fence here writes L2 back for every tile: 590 us instead of 90)
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0);
+    if (!(counted && L <= (uint32_t)kSortedIdsInLds)) {
+      // some of the list will be re-read from memory: the wavefront's own stores before its own loads -- program order within
+      // one wavefront, no cache maintenance (a device-scope fence here writes L2 back for every tile: 590 us instead of 90)
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_s_waitcnt(0);
+    }
   }
 #ifdef VTGS_Q_STAMPS
   st1 = __builtin_amdgcn_s_memtime();
@@ -291,7 +311,7 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
   pa[kQDummy] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (DUAL) pb[kQDummy] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int k = 0; k < (4 * 2 * kQRing) / 256; ++k)               // 4 queues x 2 x 192 bytes = 384 dwords per wavefront
+  for (int k = 0; k < (4 * kQRing) / 256; ++k)                   // 4 queues x 192 bytes = 192 dwords per wavefront
     reinterpret_cast<uint32_t*>(lds_q[wv][0])[64 * k + l] = 0u;
 
   float T = 1.f;
@@ -308,7 +328,11 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
   // record + colours of chunk c+1 are in flight (two dependent trips to L2 / Infinity Cache per chunk otherwise sit on the
   // wavefront's critical path: gather + compaction alone is 35 us of this kernel, profiles/r2_forward_ablation.md).
   // Loads are unconditional -- a lane past the end of the list reads entry 0 of its own bin -- and masked afterwards.
-  auto entry = [&](uint32_t b) { const uint32_t p = b + (uint32_t)l; return sorted_gid[p < e ? p : s]; };
+  auto entry = [&](uint32_t b) {
+    const uint32_t p = b + (uint32_t)l, pp = (p < e ? p : s) - s;
+    if (ids_in_lds && pp < (uint32_t)kSortedIdsInLds) return sgid[pp];          // (no trip to L2 for the wavefront's own list)
+    return sorted_gid[s + pp];
+  };
   uint32_t gid_cur = 0u, gid_nxt = 0u;
   float4 g0n = make_float4(0.f, 0.f, 0.f, 0.f), g1n = g0n;
   float c0n = 0.f, c1n = 0.f, c2n = 0.f, d0n = 0.f, d1n = 0.f, d2n = 0.f;
@@ -362,7 +386,6 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
           p -= (p >= kQRing) ? kQRing : 0;
           p -= (p >= kQRing) ? kQRing : 0;
           lds_q[wv][qq][p] = (uint8_t)slot;
-          lds_q[wv][qq][p + kQRing] = (uint8_t)slot;
         }
         const int add = (int)__builtin_popcountll(bal);
         add_v = (q == qq) ? add : add_v;
@@ -396,9 +419,10 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     const int avail = min(16, c0 + c1 + c2);
     const int hm = head_v;
     int sl[5];
-    sl[4] = (int)myq[hm + i];
+    auto qwrap = [](int x) { return x >= kQRing ? x - kQRing : x; };
+    sl[4] = (int)myq[qwrap(hm + i)];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sl[j] = (int)myq[hm + 4 * j + (i >> 2)];
+    for (int j = 0; j < 4; ++j) sl[j] = (int)myq[qwrap(hm + 4 * j + (i >> 2))];
     sl[4] = (i < avail) ? sl[4] : kQDummy;
 #pragma unroll
     for (int j = 0; j < 4; ++j) sl[j] = (4 * j + (i >> 2) < avail) ? sl[j] : kQDummy;

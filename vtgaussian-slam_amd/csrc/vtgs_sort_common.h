@@ -247,6 +247,104 @@ __device__ __forceinline__ void wave_sort_regs(unsigned long long (&k)[E], uint3
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Counting sort of one tile's bin by one wavefront (round 3).  Inside composite_forward_q the bitonic network above was the
+// largest single phase of a wavefront's life (31 %, profiles/r3_stamps.md): ~650 vector instructions + 168 crossbar
+// exchanges for a 225-entry list, issued in competition with three compositing wavefronts.  Depths of one 8x8 tile are a
+// narrow, smooth range, so a bucket pass does nearly all of the ordering:
+//   1. keys in registers (striped: element r * 64 + lane), min / max of their depth bits over the wavefront;
+//   2. bucket = floor((depth bits - min) * 256 / (range + 1)) -- monotone in the depth -- counted with one returning LDS
+//      atomic per key, which also hands the key its arrival index in the bucket;
+//   3. exclusive scan of the 256 counts (four per lane + a wavefront scan), longest bucket;
+//   4. keys to a staging array at bucket base + arrival index, then every key counts the keys of ITS bucket that are smaller
+//      (full 64-bit compare: depth bits, then Gaussian id -- the published stable order) and so learns its final position.
+// ~150 vector instructions and ~40 LDS operations instead of the network, no payload packing (any N), and the wavefront's
+// own copy of the sorted ids stays in LDS for its first chunks.  A bucket longer than kCountSortBucketMax (many exactly equal
+// depths) sends the tile to the network instead: same lists, bit for bit (tests/test_gpu_parity.py: sort tests).
+constexpr int kCountSortMax = 512;           // entries: 8 keys per lane
+constexpr int kCountSortBucketMax = 12;
+
+__device__ __forceinline__ uint32_t wave_min_u(uint32_t v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m, 64));
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, m, 64));
+  return v;
+}
+
+// stage: 64 E x 8 bytes, cnt: 256 x 4 bytes (LDS of this wavefront alone); lgid: the wavefront's LDS copy of the sorted ids,
+// first lgid_cap entries.  Returns false (nothing written) when a bucket is too long for step 4.
+template <int E>
+__device__ __forceinline__ bool wave_count_sort(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                uint32_t* __restrict__ sorted_gid, uint32_t* __restrict__ sorted_inst, size_t s,
+                                                uint32_t L, int lane, unsigned long long* __restrict__ stage,
+                                                uint32_t* __restrict__ cnt, uint32_t* __restrict__ lgid, uint32_t lgid_cap) {
+  unsigned long long k[E]; uint32_t v[E];
+  uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const uint32_t e = (uint32_t)r * 64u + (uint32_t)lane;
+    const bool in = e < L;
+    k[r] = in ? keys[s + e] : ~0ull;
+    v[r] = in ? vals[s + e] : 0u;
+    const uint32_t d = (uint32_t)(k[r] >> 32);
+    dmin = in ? min(dmin, d) : dmin;
+    dmax = in ? max(dmax, d) : dmax;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cnt[64 * j + lane] = 0u;
+  dmin = wave_min_u(dmin); dmax = wave_max_u(dmax);
+  const float scale = 256.0f / ((float)(dmax - dmin) + 1.0f);
+  uint32_t b[E], pib[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const bool in = (uint32_t)r * 64u + (uint32_t)lane < L;
+    b[r] = min(255u, (uint32_t)((float)((uint32_t)(k[r] >> 32) - dmin) * scale));
+    pib[r] = 0u;
+    if (in) pib[r] = atomicAdd(&cnt[b[r]], 1u);
+  }
+  // exclusive scan of the 256 counts: lane l owns buckets 4 l .. 4 l + 3
+  const uint4 c = reinterpret_cast<const uint4*>(cnt)[lane];
+  const uint32_t t1 = c.x + c.y, t2 = t1 + c.z, t3 = t2 + c.w;
+  const uint32_t excl = wave_incl_scan(t3) - t3;
+  const uint32_t longest = wave_max_u(max(max(c.x, c.y), max(c.z, c.w)));
+  if (longest > (uint32_t)kCountSortBucketMax) return false;                 // wave-uniform
+  reinterpret_cast<uint4*>(cnt)[lane] = make_uint4((excl << 16) | c.x, ((excl + c.x) << 16) | c.y, ((excl + t1) << 16) | c.z,
+                                                   ((excl + t2) << 16) | c.w);
+  uint32_t base[E], nb[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const bool in = (uint32_t)r * 64u + (uint32_t)lane < L;
+    const uint32_t pc = cnt[b[r]];
+    base[r] = pc >> 16; nb[r] = pc & 0xFFFFu;
+    if (in) stage[base[r] + pib[r]] = k[r];
+  }
+  uint32_t rank[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) rank[r] = 0u;
+  for (uint32_t j = 0; j < longest; ++j) {                                    // wave-uniform trip count, <= kCountSortBucketMax
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      const bool in = (uint32_t)r * 64u + (uint32_t)lane < L && j < nb[r];
+      const unsigned long long o = stage[in ? base[r] + j : 0u];
+      rank[r] += (in && o < k[r]) ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    if ((uint32_t)r * 64u + (uint32_t)lane < L) {
+      const uint32_t pos = base[r] + rank[r];
+      sorted_gid[s + pos] = (uint32_t)k[r];
+      sorted_inst[s + pos] = v[r];
+      if (pos < lgid_cap) lgid[pos] = (uint32_t)k[r];
+    }
+  }
+  return true;
+}
+
 // PACKED (Gaussian ids below 2^21, list positions below 2^11 -- the host decides): the low key word becomes
 // (gid << 11 | bin slot); the order (depth, gid) is unchanged, the instance id is fetched from its slot afterwards.
 constexpr uint32_t kSlotBits = 11u;            // (the host sends ids below 2^21 only: 21 + 11 bits)

@@ -238,7 +238,9 @@ class _Camera:
                              self.bg.data_ptr(), self.view.data_ptr(), self.proj.data_ptr())
         self.H, self.W = int(settings.image_height), int(settings.image_width)
         self.band = (b, e)
-        self.bytes = torch.frombuffer(bytearray(bytes(self.c)), dtype=torch.uint8)     # the record, for the C++ node
+        # the record, for the C++ node: an OWNING copy -- a frombuffer view would keep a Python object alive inside the autograd
+        # graph, to be released by an engine thread that does not hold the interpreter lock
+        self.bytes = torch.frombuffer(bytearray(bytes(self.c)), dtype=torch.uint8).clone()
 
 
 _camera_cache: dict = {}
@@ -278,10 +280,15 @@ def _require(t: torch.Tensor, name: str, shape_tail: int, n: int, device) -> tor
 class _ForwardState:
     """What a backward needs from its forward.  `pending`: the forward ran in the asynchronous mode and its result record has
     not been looked at yet (`_settle` does, after the backward has been enqueued)."""
-    __slots__ = ("cam", "n", "workspace", "capacity", "tile_cap", "_instances", "image_state", "key", "pending")
+    __slots__ = ("cam", "n", "workspace", "capacity", "tile_cap", "_instances", "image_state", "key", "pending", "captured")
+
+    def __init__(self):
+        self.pending = self.captured = self.image_state = self._instances = None
 
     @property
     def instances(self):
+        if self._instances is None and self.captured is not None:
+            return self.capacity                   # captured into a graph: the capacity bounds the instance ids
         if self._instances is None:                # asynchronous forward: the count arrives with the record
             _settle(self)
         return self._instances
@@ -295,16 +302,26 @@ class _SlotPool:
     """Pinned, device-mapped 64-byte result records, one per forward in flight.  A slot is handed out round-robin and stays
     with its forward until the record has been read (`_settle`); the pool is per (device, stream) and guarded by a lock, so
     forwards from several threads or streams never share a record."""
-    SLOTS = 64
+    SLOTS = 64                                     # handed out round-robin to eager forwards
+    GRAPH_SLOTS = 64                               # handed out once each to forwards captured into a hipGraph (they write their
+                                                   # record again on every replay, so the slot stays theirs)
 
     def __init__(self):
-        self.mem = torch.zeros((self.SLOTS * 64,), dtype=torch.uint8).pin_memory()
+        total = self.SLOTS + self.GRAPH_SLOTS
+        self.mem = torch.zeros((total * 64,), dtype=torch.uint8).pin_memory()
         base = self.mem.data_ptr()
-        self.ptr = [base + 64 * i for i in range(self.SLOTS)]
+        self.ptr = [base + 64 * i for i in range(total)]
         self.info = [_VtgsForwardInfo.from_address(a) for a in self.ptr]
         self.owner = [None] * self.SLOTS           # the _ForwardState whose record is still unread
         self.next = 0
+        self.next_graph = self.SLOTS
         self.pending = collections.deque()         # run-ahead forwards whose record has not been read, oldest first
+
+    def take_for_capture(self):
+        if self.next_graph >= self.SLOTS + self.GRAPH_SLOTS:
+            raise RuntimeError("too many forwards captured into graphs on this stream (64 result records)")
+        self.next_graph += 1
+        return self.next_graph - 1
 
     def take(self, fs):
         i = self.next
@@ -341,6 +358,37 @@ def _drain(pool: "_SlotPool", keep: int = 1) -> None:
         pool.pending.popleft()
 
 
+_captured_states: list = []       # forwards captured into graphs since the last forget_captured()
+
+
+def forget_captured() -> None:
+    """Call when the graphs captured so far have been dropped."""
+    del _captured_states[:]
+
+
+def check_captured(fs=None) -> None:
+    """After a replay of a graph that holds the forward `fs` (default: every forward captured since forget_captured()) has
+    FINISHED on the device: raise if that forward overflowed its workspace in the replay (its images and gradients are then
+    invalid; capture again after an eager iteration has grown the capacities)."""
+    if fs is None:
+        for f in list(_captured_states):
+            check_captured(f)
+        return
+    if fs.captured is None:
+        return
+    pool, slot = fs.captured
+    info = pool.info[slot]
+    if info.complete and info.overflow:
+        key = fs.key
+        cap = int(info.instances_needed * 1.5) + 4096 if info.overflow & 1 else fs.capacity
+        tcap = _tile_capacity_for(info.max_tile_list) if info.overflow & 2 else fs.tile_cap
+        _caps_in_use[key] = (cap, tcap)
+        _async_ok[key] = None
+        raise RuntimeError("a forward replayed from a captured graph overflowed its workspace (instances "
+                           f"{int(info.instances_needed)} of {fs.capacity}, longest tile list {int(info.max_tile_list)} of "
+                           f"{fs.tile_cap}): the iteration's results are invalid; capture again")
+
+
 def settle_pending() -> None:
     """Read the result records of ALL run-ahead forwards still outstanding (waiting for the device where needed) -- an
     overflow among them raises here.  The loops do not need to call this (every forward does it for its predecessors);
@@ -356,7 +404,7 @@ def _settle(fs) -> None:
     the caller already holds is invalid: raise, after growing the capacities so that the next forward fits."""
     pend = fs.pending
     if pend is None:
-        return
+        return                                     # (checked forward, already read, or captured into a graph)
     fs.pending = None
     pool, i, device = pend
     info = pool.info[i]
@@ -471,6 +519,26 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
                                       depth.data_ptr(), radii.data_ptr(), workspace.data_ptr(), nbytes, capacity, tile_cap,
                                       slot_ptr, flags, stream)
 
+    fs.captured = None
+    if torch.cuda.is_current_stream_capturing():
+        # Stream capture (torch.cuda.graph): nothing executes now, so nothing may be waited for.  The forward is enqueued in the
+        # asynchronous mode with the capacities the eager warm-up iterations settled on and a result record of its own, which
+        # every replay rewrites; `check_captured(state)` reads it after a replay.
+        with _slot_lock:
+            pool = _slot_pools.get((device.index, int(stream)))
+            if pool is None or key not in _caps_in_use:
+                raise RuntimeError("capturing a forward of a shape that has not run eagerly on this stream: run warm-up "
+                                   "iterations under torch.cuda.stream(capture_stream) first")
+            capacity, tile_cap = _caps_in_use[key]
+            slot = pool.take_for_capture()
+        nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
+        pool.info[slot].complete = 0
+        with _device_guard(device):
+            _check(launch(workspace, nbytes, capacity, tile_cap, pool.ptr[slot], VTGS_FORWARD_ASYNC), "vtgs_forward")
+        fs.workspace, fs.capacity, fs.tile_cap, fs._instances = workspace, capacity, tile_cap, None
+        fs.captured = (pool, slot)
+        _captured_states.append(fs)
+        return color, radii, depth, fs
     with _slot_lock:
         pool = _slot_pool(device, stream)
         _drain(pool)
@@ -581,7 +649,7 @@ def _device_guard(device):
 def _scratch_instances(fs: _ForwardState) -> int:
     """Instance records the backward needs room for: the forward's count, or -- while the record of an asynchronous forward
     has not been read -- its instance capacity (an upper bound; the block comes from the caching allocator either way)."""
-    return fs._instances if fs._instances is not None else fs.capacity
+    return fs._instances if fs._instances is not None else fs.capacity   # (captured forwards: always the capacity)
 
 
 def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotations, out_color, grad_color):
@@ -763,7 +831,7 @@ class GaussianRasterizer(nn.Module):
         if not means3D.is_cuda:
             raise RuntimeError("GaussianRasterizer needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
         cam = _camera_for(self.raster_settings, means3D.device, self._rule, self._tile_rows)
-        if _ext is not None:
+        if _ext is not None and not torch.cuda.is_current_stream_capturing():
             if means2D is None:
                 means2D = torch.zeros_like(means3D)
             color, radii, depth, fs = _forward_ext(cam, means3D, means2D, colors_precomp, opacities, scales, rotations)
