@@ -798,13 +798,12 @@ class GaussianRasterizer(nn.Module):
 
     def __init__(self, raster_settings, radius_rule: Optional[str] = None, tile_rows: Optional[Tuple[int, int]] = None):
         super().__init__()
-        self.raster_settings = raster_settings
         rule = radius_rule or os.environ.get("VTGS_RADIUS_RULE", "3sigma")
         if rule not in _RADIUS_RULES:
             raise ValueError(f"radius_rule must be one of {sorted(_RADIUS_RULES)}")
-        self._rule = _RADIUS_RULES[rule]
-        self._tile_rows = tile_rows
-        self._last_state: Optional[_ForwardState] = None
+        # plain attributes, written past nn.Module.__setattr__ (its Parameter / Module bookkeeping costs ~2 us per attribute,
+        # and the reference builds one rasterizer per render)
+        self.__dict__.update(raster_settings=raster_settings, _rule=_RADIUS_RULES[rule], _tile_rows=tile_rows, _last_state=None)
 
     def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
         with torch.no_grad():
@@ -835,7 +834,7 @@ class GaussianRasterizer(nn.Module):
             if means2D is None:
                 means2D = torch.zeros_like(means3D)
             color, radii, depth, fs = _forward_ext(cam, means3D, means2D, colors_precomp, opacities, scales, rotations)
-            self._last_state = fs
+            self.__dict__["_last_state"] = fs
             return color, radii, depth
         color, radii, depth, fs = _RasterizeGaussians.apply(means3D, means2D, None, colors_precomp, opacities, scales,
                                                             rotations, None, cam, None)
