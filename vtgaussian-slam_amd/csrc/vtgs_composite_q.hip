@@ -342,64 +342,94 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     c0n = colors[3 * gid]; c1n = colors[3 * gid + 1]; c2n = colors[3 * gid + 2];
     if (DUAL) { d0n = colors_b[3 * gid]; d1n = colors_b[3 * gid + 1]; d2n = colors_b[3 * gid + 2]; }
   };
-  if (s < e) {
-    gid_cur = entry(s);
-    gid_nxt = entry(s + 64u);
-    fetch(gid_cur);
+  // ---- append one 64-entry chunk whose records have arrived: table, wavefront-ballot compaction into the four queues -------
+  // (a macro, not a lambda: called from four places, the closure kept the ring counters in scratch memory)
+#define VTGS_Q_APPEND(G0, G1, FC0, FC1, FC2, FD0, FD1, FD2)                                                              \
+  {                                                                                                                      \
+    const float4 g0 = (G0), g1 = (G1);                                                                                   \
+    const uint32_t pos = base + (uint32_t)l;                                                                             \
+    const bool in = pos < e;                                                                                             \
+    const int slot = (int)wslot + l;                                                                                     \
+    {                                                                                                                    \
+      float K[6];                                                                                                        \
+      tile_coefficients(g0, g1, cx, cy, K);                                                                              \
+      ka[slot] = make_float4(K[0], K[1], K[2], K[3]);                                                                    \
+      kb[slot] = make_float2(K[4], K[5]);                                                                                \
+      pa[slot] = make_float4((FC0), (FC1), (FC2), DUAL ? (FD0) : g1.z);                                                  \
+      if (DUAL) pb[slot] = make_float4((FD1), (FD2), 0.f, 0.f);                                                          \
+    }                                                                                                                    \
+    const bool hot = __ballot(in && g1.y > kClampGuard) != 0ull;                                                         \
+    const uint32_t mask = in ? quadrant_mask(g0, g1, g0.x - cx, g0.y - cy) : 0u;                                         \
+    if (qmask && in) qmask[pos] = (uint8_t)mask;          /* kept for the backward (composite_backward_q) */             \
+    const int tail_v = head_v + c0 + c1 + c2;                                                                            \
+    int add_v = 0;                                                                                                       \
+    _Pragma("unroll") for (int qq = 0; qq < 4; ++qq) {                                                                   \
+      const bool in_q = (mask >> qq) & 1u;                                                                               \
+      const unsigned long long bal = __ballot(in_q);                                                                     \
+      const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u)); \
+      const int tail = __builtin_amdgcn_readlane(tail_v, 16 * qq);                                                       \
+      if (in_q) {                                                                                                        \
+        int p = tail + rank;                              /* tail < 2 kQRing, rank < 64 */                               \
+        p -= (p >= kQRing) ? kQRing : 0;                                                                                 \
+        p -= (p >= kQRing) ? kQRing : 0;                                                                                 \
+        lds_q[wv][qq][p] = (uint8_t)slot;                                                                                \
+      }                                                                                                                  \
+      const int add = (int)__builtin_popcountll(bal);                                                                    \
+      add_v = (q == qq) ? add : add_v;                                                                                   \
+    }                                                                                                                    \
+    if (inflight == 0) { c0 += add_v; hot0 = hot; }                                                                      \
+    else if (inflight == 1) { c1 += add_v; hot1 = hot; }                                                                 \
+    else { c2 += add_v; hot2 = hot; }                                                                                    \
+    base += 64u; wslot = (wslot == (uint32_t)(kQRing - 64)) ? 0u : wslot + 64u; ++inflight;                              \
+  }
+  static_assert(kQChunks == 3, "the prologue below requests exactly the ring's three chunks");
+  if (s < e && __ballot(!done) != 0ull) {
+    // The ring starts empty and takes up to three chunks at once: their records are requested TOGETHER (one round trip to L2 /
+    // Infinity Cache instead of three back to back -- ~8 % of the wavefront's life, profiles/r3_stamps.md), then appended.
+    const uint32_t gidB = entry(s + 64u), gidC = entry(s + 128u);
+    gid_cur = entry(s + 192u);
+    gid_nxt = entry(s + 256u);
+#define VTGS_Q_FETCH(tag, gid_expr)                                                                        \
+    const uint32_t gid_##tag = (gid_expr);                                                                  \
+    const float4* gp_##tag = reinterpret_cast<const float4*>(geom + gid_##tag);                             \
+    const float4 g0_##tag = gp_##tag[0], g1_##tag = gp_##tag[1];                                            \
+    const float c0_##tag = colors[3 * gid_##tag], c1_##tag = colors[3 * gid_##tag + 1], c2_##tag = colors[3 * gid_##tag + 2]; \
+    const float d0_##tag = DUAL ? colors_b[3 * gid_##tag] : 0.f, d1_##tag = DUAL ? colors_b[3 * gid_##tag + 1] : 0.f,         \
+                d2_##tag = DUAL ? colors_b[3 * gid_##tag + 2] : 0.f;
+    VTGS_Q_FETCH(a, entry(s))
+    VTGS_Q_FETCH(b, gidB)
+    VTGS_Q_FETCH(c, gidC)
+#undef VTGS_Q_FETCH
+#ifdef VTGS_Q_STAMPS
+    const unsigned long long sa = __builtin_amdgcn_s_memtime();
+#endif
+    VTGS_Q_APPEND(g0_a, g1_a, c0_a, c1_a, c2_a, d0_a, d1_a, d2_a)
+#ifdef VTGS_Q_STAMPS
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    { const unsigned long long sb = __builtin_amdgcn_s_memtime(); st_app += sb - sa; st2 = sb; }
+#endif
+    if (base < e) VTGS_Q_APPEND(g0_b, g1_b, c0_b, c1_b, c2_b, d0_b, d1_b, d2_b)
+    if (base < e) VTGS_Q_APPEND(g0_c, g1_c, c0_c, c1_c, c2_c, d0_c, d1_c, d2_c)
+    fetch(gid_cur);                                                // the fourth chunk's records: in flight during the first steps
   }
 
   for (;;) {
     if (inflight < kQChunks && base < e) {
-      // ---- append the next 64-entry chunk: gather, table, wavefront-ballot compaction into the four queues ----------
+      // ---- append the next 64-entry chunk (its records were requested one append ago) ------------------------------------------
       if (__ballot(!done) == 0ull) break;
 #ifdef VTGS_Q_STAMPS
       const unsigned long long sa = __builtin_amdgcn_s_memtime();
 #endif
-      const uint32_t pos = base + (uint32_t)l;
-      const bool in = pos < e;
-      const float4 g0 = g0n, g1 = g1n;                             // this chunk's data, requested one chunk ago
-      const int slot = (int)wslot + l;
-      {
-        float K[6];
-        tile_coefficients(g0, g1, cx, cy, K);
-        ka[slot] = make_float4(K[0], K[1], K[2], K[3]);
-        kb[slot] = make_float2(K[4], K[5]);
-        pa[slot] = make_float4(c0n, c1n, c2n, DUAL ? d0n : g1.z);
-        if (DUAL) pb[slot] = make_float4(d1n, d2n, 0.f, 0.f);
-      }
+      VTGS_Q_APPEND(g0n, g1n, c0n, c1n, c2n, d0n, d1n, d2n)
       gid_cur = gid_nxt;
-      gid_nxt = entry(base + 128u);
+      gid_nxt = entry(base + 64u);
       fetch(gid_cur);                                               // next chunk's data: in flight during this chunk's steps
-      const bool hot = __ballot(in && g1.y > kClampGuard) != 0ull;
-      const uint32_t mask = in ? quadrant_mask(g0, g1, g0.x - cx, g0.y - cy) : 0u;
-      if (qmask && in) qmask[pos] = (uint8_t)mask;                  // kept for the backward (composite_backward_q)
-      const int tail_v = head_v + c0 + c1 + c2;
-      int add_v = 0;
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        const bool in_q = (mask >> qq) & 1u;
-        const unsigned long long bal = __ballot(in_q);
-        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        const int tail = __builtin_amdgcn_readlane(tail_v, 16 * qq);
-        if (in_q) {
-          int p = tail + rank;                                     // tail < 2 kQRing, rank < 64
-          p -= (p >= kQRing) ? kQRing : 0;
-          p -= (p >= kQRing) ? kQRing : 0;
-          lds_q[wv][qq][p] = (uint8_t)slot;
-        }
-        const int add = (int)__builtin_popcountll(bal);
-        add_v = (q == qq) ? add : add_v;
-      }
-      if (inflight == 0) { c0 += add_v; hot0 = hot; }
-      else if (inflight == 1) { c1 += add_v; hot1 = hot; }
-      else { c2 += add_v; hot2 = hot; }
-      base += 64u; wslot = (wslot == (uint32_t)(kQRing - 64)) ? 0u : wslot + 64u; ++inflight;
 #ifdef VTGS_Q_STAMPS
       __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): the table / queue writes have landed
-      { const unsigned long long sb = __builtin_amdgcn_s_memtime(); st_app += sb - sa; if (base == s + 64u) st2 = sb; }
+      { const unsigned long long sb = __builtin_amdgcn_s_memtime(); st_app += sb - sa; }
 #endif
 #if defined(VTGS_Q_ABL) && VTGS_Q_ABL == 1                                 // ablation: gather + compaction only, no steps
-      asm volatile("" :: "v"(c0), "v"(mask));
+      asm volatile("" :: "v"(c0));
       head_v += c0 + c1 + c2; head_v -= (head_v >= kQRing) ? kQRing : 0; c0 = c1 = c2 = 0; inflight = 0;
 #endif
       continue;
