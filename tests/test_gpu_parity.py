@@ -617,6 +617,47 @@ def test_forward_runs_ahead_of_its_record_and_settles_after_the_backward(gpu_dev
         dgr._FORWARD_MODE = os.environ.get("VTGS_FORWARD_MODE", "auto")
 
 
+def test_run_ahead_forward_follows_a_growing_scene(gpu_device):
+    """A map whose splats grow by 1 % per iteration (300 iterations: ~20 x the scales, two orders of magnitude more instances
+    and longer tile lists): the capacity policy re-sizes the workspace whenever a need comes within 10 % of a capacity, the
+    forward of that iteration is checked and the following ones run ahead again -- no overflow is ever met in the run-ahead
+    mode (that takes a > 25 % jump from one iteration to the next), and the last frame equals a checked render of the same
+    parameters bit for bit."""
+    import diff_gaussian_rasterization as dgr
+    from parity_util import to_settings
+    dev = gpu_device
+    scene, cam = go.view_tied_scene(20000, 160, 96, seed=13)
+    st = to_settings(cam, dev)
+    g = torch.Generator().manual_seed(3)
+    grad_color = (torch.rand(3, 96, 160, generator=g) * 2 - 1).to(dev)
+    dgr._capacity_hint.clear(); dgr._caps_in_use.clear(); dgr._tile_cap_hint.clear(); dgr._async_ok.clear()
+    leaves = {k: v.to(dev).requires_grad_(True) for k, v in scene.items()}
+    ran_ahead = 0
+    try:
+        dgr._FORWARD_MODE = "auto"
+        for it in range(300):
+            for t in leaves.values():
+                t.grad = None
+            with torch.no_grad():
+                leaves["scales"].mul_(1.01)
+            rast = dgr.GaussianRasterizer(raster_settings=st)
+            c, r, d = rast(**leaves)
+            ran_ahead += rast._last_state.pending is not None
+            c.backward(grad_color)
+        dgr.settle_pending()
+        grads = {k: leaves[k].grad.clone() for k in GRAD_KEYS}
+        assert ran_ahead > 200, ran_ahead                          # most iterations did not wait for their record
+        info = dgr.last_forward_info()
+        dgr._FORWARD_MODE = "checked"
+        ref = run_hip({k: v.detach().cpu() for k, v in leaves.items()}, cam, dev, grad_color.cpu())
+        assert torch.equal(c.detach().cpu(), ref[0]) and torch.equal(d.detach().cpu(), ref[2])
+        for k in GRAD_KEYS:
+            assert torch.equal(grads[k].cpu(), ref[3][k]), k
+        assert info["instances"] > 30 * 20000
+    finally:
+        dgr._FORWARD_MODE = os.environ.get("VTGS_FORWARD_MODE", "auto")
+
+
 def test_forward_backward_replayed_from_a_graph(gpu_device):
     """An iteration captured with torch.cuda.graph (hipGraph) and replayed: under capture the forward is enqueued in the
     asynchronous mode with the capacities of the eager warm-up and a result record of its own (nothing may be waited for
