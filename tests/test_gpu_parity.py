@@ -567,7 +567,8 @@ def _quadrant_scenes():
 
 
 def test_forward_runs_ahead_of_its_record_and_settles_after_the_backward(gpu_device):
-    """a grad-mode forward whose predecessor of the same shape left >= 20 % headroom in both capacities
+    """a grad-mode forward in a STEADY loop -- the last three forwards of its shape needed the same (within
+    10 %) and left >= 20 % headroom in both capacities --
     returns without waiting for its result record (the host can enqueue the loss and the backward while the device is
     still busy); the record is read once the backward has been enqueued.  Same bits as the checked mode.  A no-grad
     forward is always checked.  An overflow in the run-ahead mode cannot be repaired -- the caller holds the image --
@@ -579,7 +580,7 @@ def test_forward_runs_ahead_of_its_record_and_settles_after_the_backward(gpu_dev
     st = to_settings(cam, dev)
     g = torch.Generator().manual_seed(3)
     grad_color = (torch.rand(3, 96, 160, generator=g) * 2 - 1).to(dev)
-    dgr._capacity_hint.clear(); dgr._caps_in_use.clear(); dgr._tile_cap_hint.clear(); dgr._async_ok.clear()
+    dgr._capacity_hint.clear(); dgr._caps_in_use.clear(); dgr._tile_cap_hint.clear(); dgr._async_ok.clear(); dgr._need_hist.clear()
 
     def step(sc, mode):
         dgr._FORWARD_MODE = mode
@@ -595,7 +596,9 @@ def test_forward_runs_ahead_of_its_record_and_settles_after_the_backward(gpu_dev
     try:
         p0, *_ = step(scene, "auto")                 # first forward of the shape: capacities unknown -> checked
         p1, c1, d1, g1 = step(scene, "auto")         # capacities re-chosen from the observed need -> checked once more
-        p2, c2, d2, g2 = step(scene, "auto")         # same capacities, < 80 % used -> runs ahead
+        p1b, *_ = step(scene, "auto")                # three forwards with the same need make the loop "steady" ...
+        p2, c2, d2, g2 = step(scene, "auto")         # ... same capacities, < 80 % used -> runs ahead
+        assert not p1 and not p1b
         p3, c3, d3, g3 = step(scene, "checked")
         assert (p0, p3) == (False, False) and p2, (p0, p1, p2, p3)
         assert torch.equal(c2, c3) and torch.equal(d2, d3)
@@ -618,11 +621,11 @@ def test_forward_runs_ahead_of_its_record_and_settles_after_the_backward(gpu_dev
 
 
 def test_run_ahead_forward_follows_a_growing_scene(gpu_device):
-    """A map whose splats grow by 1 % per iteration (300 iterations: ~20 x the scales, two orders of magnitude more instances
-    and longer tile lists): the capacity policy re-sizes the workspace whenever a need comes within 10 % of a capacity, the
-    forward of that iteration is checked and the following ones run ahead again -- no overflow is ever met in the run-ahead
-    mode (that takes a > 25 % jump from one iteration to the next), and the last frame equals a checked render of the same
-    parameters bit for bit."""
+    """A map whose splats grow by 0.4 % per iteration (300 iterations: 3.3 x the scales, several times the instances and much
+    longer tile lists): forwards run ahead while the need stays below 80 % of both capacities, are checked between 80 % and
+    the point (91 %) where the capacity policy re-sizes the workspace, and run ahead again after it -- no overflow is ever
+    met in the run-ahead mode (that takes a > 25 % jump from one iteration to the next), and the last frame equals a
+    checked render of the same parameters bit for bit."""
     import diff_gaussian_rasterization as dgr
     from parity_util import to_settings
     dev = gpu_device
@@ -630,7 +633,7 @@ def test_run_ahead_forward_follows_a_growing_scene(gpu_device):
     st = to_settings(cam, dev)
     g = torch.Generator().manual_seed(3)
     grad_color = (torch.rand(3, 96, 160, generator=g) * 2 - 1).to(dev)
-    dgr._capacity_hint.clear(); dgr._caps_in_use.clear(); dgr._tile_cap_hint.clear(); dgr._async_ok.clear()
+    dgr._capacity_hint.clear(); dgr._caps_in_use.clear(); dgr._tile_cap_hint.clear(); dgr._async_ok.clear(); dgr._need_hist.clear()
     leaves = {k: v.to(dev).requires_grad_(True) for k, v in scene.items()}
     ran_ahead = 0
     try:
@@ -639,21 +642,21 @@ def test_run_ahead_forward_follows_a_growing_scene(gpu_device):
             for t in leaves.values():
                 t.grad = None
             with torch.no_grad():
-                leaves["scales"].mul_(1.01)
+                leaves["scales"].mul_(1.004)
             rast = dgr.GaussianRasterizer(raster_settings=st)
             c, r, d = rast(**leaves)
             ran_ahead += rast._last_state.pending is not None
             c.backward(grad_color)
         dgr.settle_pending()
         grads = {k: leaves[k].grad.clone() for k in GRAD_KEYS}
-        assert ran_ahead > 200, ran_ahead                          # most iterations did not wait for their record
+        assert ran_ahead > 100, ran_ahead                          # a good part of the iterations did not wait for their record
         info = dgr.last_forward_info()
         dgr._FORWARD_MODE = "checked"
         ref = run_hip({k: v.detach().cpu() for k, v in leaves.items()}, cam, dev, grad_color.cpu())
         assert torch.equal(c.detach().cpu(), ref[0]) and torch.equal(d.detach().cpu(), ref[2])
         for k in GRAD_KEYS:
             assert torch.equal(grads[k].cpu(), ref[3][k]), k
-        assert info["instances"] > 30 * 20000
+        assert info["instances"] > 3 * 2.5 * 20000                 # (the scene started at ~2.5 instances per Gaussian)
     finally:
         dgr._FORWARD_MODE = os.environ.get("VTGS_FORWARD_MODE", "auto")
 

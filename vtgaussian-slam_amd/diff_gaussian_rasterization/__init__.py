@@ -154,6 +154,7 @@ _capacity_hint = {}          # (device index, N, W, H, band) -> instances seen l
 _tile_cap_hint = {}          # same key -> longest per-tile list seen last time
 _caps_in_use = {}            # same key -> (instance capacity, tile capacity) of the previous forward
 _async_ok = {}               # same key -> the (capacities) of which the last forward of this shape used < 80 %, else None
+_need_hist = {}              # same key -> (instances, longest tile list) of the last three forwards
 _last_info = {}
 # "auto" (default): a forward in grad mode returns without waiting for its result record when the previous forward of the
 # same shape left >= 20 % headroom in both capacities; the record is read after the backward has been enqueued.  "checked":
@@ -463,8 +464,14 @@ def _record_info(key, n, W, H, capacity, info):
     _capacity_hint[key] = max(int(info.instances_needed), 1)
     _tile_cap_hint[key] = max(int(info.max_tile_list), 1)
     cap, tcap = _caps_in_use.get(key, (0, 0))                  # the capacities this forward ran with
+    # Run-ahead is for STEADY loops (tracking, mapping on one frame): the last three forwards of this shape must have needed
+    # about the same (within 10 % of each other) and at most 80 % of both capacities.  A loop that alternates between views
+    # with very different instance counts under one shape (mapping over random keyframes) therefore stays in the checked mode.
+    hist = _need_hist.setdefault(key, collections.deque(maxlen=3))
+    hist.append((int(info.instances_needed), int(info.max_tile_list)))
+    steady = len(hist) == 3 and all(max(h[j] for h in hist) <= 1.1 * max(1, min(h[j] for h in hist)) for j in (0, 1))
     roomy = bool(cap and tcap and info.instances_needed <= 0.8 * cap and info.max_tile_list <= 0.8 * tcap)
-    _async_ok[key] = (cap, tcap) if roomy else None            # ... are the only ones the next forward may run ahead with
+    _async_ok[key] = (cap, tcap) if (roomy and steady) else None   # ... are the only ones the next forward may run ahead with
     _last_info.update(instances=int(info.instances), tiles16_touched=int(info.tiles16_touched),
                       visible=int(info.visible), max_tile_list=int(info.max_tile_list), n=n, width=W, height=H,
                       capacity=int(capacity))
