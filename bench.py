@@ -62,7 +62,7 @@ def self_launch(args) -> int:
     return proc.returncode if line is not None or proc.returncode else 1
 
 
-def kernel_algorithmic_bytes(n, p, r16):
+def kernel_algorithmic_bytes(n, p, r16, grad_bytes=68):
     """B_alg = 180 N + 28 P + 52 R per fwd+bwd call, split over the kernels that own each term
     (DESIGN.md section 3).  R = 16x16 tiles touched, counted by the op."""
     return {
@@ -71,7 +71,7 @@ def kernel_algorithmic_bytes(n, p, r16):
         "sort_tiles": 24 * r16,                          # sort read + sort write
         "composite_forward": 12 * n + 4 * r16 + 16 * p,  # colours read + id read + colour/depth out
         "composite_backward": 12 * n + 4 * r16 + 12 * p, # colours re-read + id read + grad_color in
-        "gather_splat_grads": 44 * n + 68 * n,           # params re-read + six gradients written
+        "gather_splat_grads": 44 * n + grad_bytes * n,   # params re-read + the gradients asked for (68 B: all six)
     }
 
 
@@ -89,6 +89,15 @@ def main():
                                                              "('' = skip the parity block)")
     ap.add_argument("--slam-frames", type=int, default=3, help="frames of the tracking+mapping loop in the `slam` block "
                                                                "(BASELINE.json metric 2; 0 = skip)")
+    ap.add_argument("--mode", default=None, choices=["rasterize", "tracking", "mapping"],
+                    help="which gradients a step asks for.  rasterize (default on 1 GPU, SURVEY 8d metric 1): all six inputs.  "
+                         "tracking (default on N > 1 GPUs, SURVEY 8e): the Gaussians are detached as in the reference's tracking "
+                         "loop (src/vtgaussian_slam.py:428-449) -- means3D + the screen-space term, 24 B per Gaussian written "
+                         "instead of 68 -- then the 7-float pose reduction and its all-reduce.  mapping: colours, opacities, "
+                         "scales (the trainable set of the mapping loop), one flat all-reduce of 28 B per Gaussian")
+    ap.add_argument("--band", default=None, metavar="R/W",
+                    help="rehearsal on one GPU: run rank R's band of a W-rank tile-row partition in this process, without "
+                         "collectives (per-rank kernel times and the replicated share; tools/band_rehearsal.sh)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank path with all ranks on one GPU)")
     args = ap.parse_args()
@@ -121,13 +130,23 @@ def main():
     P = W * H
     scene, cam = go.view_tied_scene(N, W, H, seed=0)
     settings = to_settings(cam, dev)
-    leaves = {k: v.to(dev).requires_grad_(True) for k, v in scene.items()}
+    mode = args.mode or ("rasterize" if world == 1 and not args.band else "tracking")
+    wanted = {"rasterize": set(scene), "tracking": {"means3D", "means2D"},
+              "mapping": {"means2D", "colors_precomp", "opacities", "scales"}}[mode]
+    leaves = {k: v.to(dev).requires_grad_(k in wanted) for k, v in scene.items()}
+    grad_bytes = sum(4 * scene[k][0].numel() for k in wanted)          # written per Gaussian by gather_splat_grads
     g = torch.Generator().manual_seed(1)
     grad_color = (torch.rand(3, H, W, generator=g) * 2 - 1).to(dev)
 
-    from diff_gaussian_rasterization.partition import band_for_rank, pose7_reduce
+    from diff_gaussian_rasterization.partition import all_reduce_sum, band_for_rank, pose7_reduce
     gy16 = (H + 15) // 16
     tile_rows = band_for_rank(H, world, rank) if world > 1 else None
+    emulated = None
+    if args.band:
+        assert world == 1, "--band is a single-process rehearsal"
+        emulated = tuple(int(x) for x in args.band.split("/"))
+        tile_rows = band_for_rank(H, emulated[1], emulated[0])
+        args.slam_frames, args.audit_rows, args.no_cpu_baseline = 0, "", True
     rast = dgr.GaussianRasterizer(raster_settings=settings, tile_rows=tile_rows)
 
     def step():
@@ -135,10 +154,17 @@ def main():
             t.grad = None
         color, radii, depth = rast(**leaves)
         color.backward(grad_color)
-        if dist is not None:
+        if mode == "tracking":
             # tracking: dL/dpose is a 7-float reduction of dL/dmeans3D; all-reduce it
             pose = pose7_reduce(leaves["means3D"], leaves["means3D"].grad)       # 7 floats, two launches
-            dist.all_reduce(pose)
+            if dist is not None:
+                all_reduce_sum(pose)
+        elif mode == "mapping" and dist is not None:
+            flat = torch.cat([leaves[k].grad.reshape(-1) for k in ("colors_precomp", "opacities", "scales")])
+            all_reduce_sum(flat)                                                 # 28 B per Gaussian, one collective
+        elif dist is not None:
+            pose = pose7_reduce(leaves["means3D"], leaves["means3D"].grad)
+            all_reduce_sum(pose)
         return color
 
     def fence():
@@ -176,12 +202,12 @@ def main():
     dgr.profile_enable(False)
     kern = {k: {"avg_us": v[0] / v[1] * 1e3, "launches": v[1]} for k, v in prof.items()}
     # rank 0's share: all N Gaussians are projected on every rank, pixels and tile instances only for its band
-    if world == 1:
+    if tile_rows is None:
         p_rank, r_rank = P, r16
     else:
         y0, y1 = tile_rows[0] * 16, min(tile_rows[1] * 16, H)
         p_rank, r_rank = W * (y1 - y0), int(r16 * (tile_rows[1] - tile_rows[0]) / gy16)
-    alg = kernel_algorithmic_bytes(N, p_rank, r_rank)
+    alg = kernel_algorithmic_bytes(N, p_rank, r_rank, grad_bytes)
     for fused in ("sort_tiles", "finalize_forward"):    # done inside the forward composite (no launch of their own)
         if kern and fused not in kern:
             alg["composite_forward"] += alg.pop(fused)
@@ -190,11 +216,11 @@ def main():
         dom = max(kern, key=lambda k: kern[k]["avg_us"])
         if alg is not None:
             achieved = alg[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
-            call_bytes = 180 * N + 28 * p_rank + 52 * r_rank
+            call_bytes = (112 + grad_bytes) * N + 28 * p_rank + 52 * r_rank
             traffic = None           # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-                if world == 1 and (N, W, H) == (1_000_000, 1200, 680) and dom in pmc:
+                if tile_rows is None and mode == "rasterize" and (N, W, H) == (1_000_000, 1200, 680) and dom in pmc:
                     traffic = pmc[dom]["traffic_bytes"]
             except (OSError, ValueError, KeyError):
                 pass
@@ -203,7 +229,7 @@ def main():
                         "kernel_avg_us": round(kern[dom]["avg_us"], 2), "algorithmic_bytes": alg[dom],
                         "call_algorithmic_bytes": call_bytes,
                         "call_frac": round(call_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                        "scope": "whole frame" if world == 1 else f"rank 0 band (tile rows {tile_rows[0]}..{tile_rows[1]})",
+                        "scope": "whole frame" if tile_rows is None else f"one band (tile rows {tile_rows[0]}..{tile_rows[1]})",
                         "note": "the composites are bound by fp32 issue (VALU + f32 MFMA share the lanes), see roofline.valu"}
 
     # secondary (VALU) bound, SURVEY.md 8(d): E = 256 x (16x16 tile instances) pixel x Gaussian evaluations of the published
@@ -318,16 +344,21 @@ def main():
 
     # ---- slam block (BASELINE.json metric 2): a short run of bench_slam.py's loop through the get_loss mirror ---------------
     slam = None
-    if rank == 0 and world == 1 and args.slam_frames > 0 and (N, W, H) == (1_000_000, 1200, 680):
+    if args.slam_frames > 0 and (N, W, H) == (1_000_000, 1200, 680):     # (every rank takes part in the N-rank loop)
         import bench_slam
-        print(f"[bench] slam block: {args.slam_frames} frames of the tracking+mapping loop ...", file=sys.stderr, flush=True)
+        if rank == 0:
+            print(f"[bench] slam block: {args.slam_frames} frames of the tracking+mapping loop ...", file=sys.stderr, flush=True)
         del leaves, rast
         torch.cuda.empty_cache()
-        rec = bench_slam.run(bench_slam.parse_args(["--frames", str(args.slam_frames), "--get-loss"]))
+        # 1 GPU: through the get_loss mirror (the reference's own call); N GPUs: the same fused operators with the band forms
+        # of the losses and the collectives of SURVEY 8e (bench_slam.py --fused under torch.distributed)
+        route = ["--get-loss"] if world == 1 else ["--fused", "--backend", args.backend]
+        rec = bench_slam.run(bench_slam.parse_args(["--frames", str(args.slam_frames)] + route))
         slam = {"metric": "SLAM frames/s, tracking+mapping loop", "value": rec["value"], "unit": "frames/s",
                 "frames": args.slam_frames, "tracking_ms_per_iter": rec["tracking_ms_per_iter"],
                 "mapping_ms_per_iter": rec["mapping_ms_per_iter"], "workload": rec["config"]["workload"],
-                "pose_error_after_tracking_cm_deg": rec["pose_error_after_tracking_cm_deg"],
+                "pose_error_after_tracking_cm_deg": rec["pose_error_after_tracking_cm_deg"], "n_gpus": world,
+                "partition": rec["config"]["partition"],
                 "note": "synthetic Replica-room0-like sequence, one submap, one get_loss per mapping iteration (upper bound of "
                         "the reference's per-frame work; `bench_slam.py --global-submaps 2` adds its second call over the "
                         "global set, profiles/r3_slam_loop.jsonl)"}
@@ -338,13 +369,28 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"view-tied synthetic scene (SURVEY 8d), N={N} isotropic Gaussians, {W}x{H}, "
-                                   f"3-channel render, grads to all six inputs",
+                                   f"3-channel render, " + {"rasterize": "grads to all six inputs",
+                                                             "tracking": "tracking step: grads to means3D + means2D (Gaussians "
+                                                                         "detached), 7-float pose reduction",
+                                                             "mapping": "mapping step: grads to colours, opacities, scales, "
+                                                                        "means2D"}[mode],
+                       "mode": mode,
                        "gaussians": N, "width": W, "height": H, "instances_8x8": info["instances"],
                        "tiles16_touched_R": r16, "max_tile_list": info["max_tile_list"],
-                       "partition": "none" if world == 1 else f"tile-row bands x{world} + all-reduce(7 floats)"},
+                       "partition": "none" if tile_rows is None else f"tile-row bands x{emulated[1] if emulated else world} + " +
+                                    ("all-reduce(28 B per Gaussian)" if mode == "mapping" else "all-reduce(7 floats)")},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "slam": slam,
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["avg_us"])},
         }
+        if tile_rows is not None and kern:
+            # what every rank of the partition does over ALL Gaussians (projection, per-Gaussian gradient gather) beside what
+            # it does for its band only (the two composites): SURVEY 8e "replicated work"
+            rep = sum(v["avg_us"] for k, v in kern.items() if not k.startswith("composite_"))
+            tot = sum(v["avg_us"] for v in kern.values())
+            out["band"] = {"rank": emulated[0] if emulated else rank, "world": emulated[1] if emulated else world,
+                           "tile_rows": list(tile_rows), "kernel_us_total": round(tot, 2),
+                           "replicated_kernel_us": round(rep, 2), "replicated_frac": round(rep / tot, 4),
+                           "emulated_in_one_process": bool(emulated)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -59,6 +59,9 @@ def parse_args(argv=None):
                     help="K > 0: every mapping iteration makes the reference's SECOND get_loss call as well, over the global "
                          "set = K fixed submaps (+) the current one (src/vtgaussian_slam.py:2545-2556, 944-977): (K+1) N "
                          "Gaussians rendered, gradients to the current submap only (needs --get-loss)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N ranks (started by torch.distributed.run): 'nccl' = RCCL, one GPU per rank; 'gloo' = rehearsal of the "
+                         "N-rank code path with every rank on GPU 0 and the collectives staged through the host")
     args = ap.parse_args(argv)
     if args.get_loss:
         args.fused = True
@@ -72,7 +75,23 @@ def parse_args(argv=None):
 def run(args) -> dict:
     """One run of the loop; returns the JSON record (bench.py embeds a short run of it as its `slam` block)."""
     assert torch.cuda.is_available(), "bench_slam.py needs an MI355X"
-    dev = torch.device("cuda", 0)
+    # N ranks = the tile-row partition (SURVEY.md 8e): every rank holds all Gaussians, renders one band of 16-pixel tile rows,
+    # owns the loss terms of its rows; per iteration ONE small all-reduce in tracking (7 pose-gradient floats), and in
+    # mapping the SSIM halo rows, 8 loss sums and the trainable per-Gaussian gradients (20 B each).  Adam runs replicated.
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    backend = getattr(args, "backend", "nccl")
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if (world > 1 and backend == "nccl") else 0)
+    torch.cuda.set_device(dev)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    if world > 1 and (args.get_loss or args.graph or not args.fused):
+        raise SystemExit("bench_slam.py: the N-rank loop runs on the fused route (--fused, without --get-loss / --graph)")
     if args.graph:
         # Everything -- the eager iterations too -- runs on ONE side stream: a graph cannot be captured on the default stream,
         # and the AccumulateGrad nodes of the parameters remember the stream they were created under (a node created by an
@@ -87,6 +106,8 @@ def run(args) -> dict:
     from parity_util import to_settings
 
     N, W, H, T = args.n, args.width, args.height, args.frames + 1
+    from diff_gaussian_rasterization import partition as pt
+    band = pt.band_for_rank(H, world, rank) if world > 1 else None
     scene, cam = go.view_tied_scene(N, W, H, seed=0)
     settings = to_settings(cam, dev)
     first_w2c = torch.eye(4, device=dev)
@@ -111,14 +132,18 @@ def run(args) -> dict:
         map_loss = lambda im, ds, gi, gd: fl.mapping_loss(im, ds, gi, gd)
         import functools
         pick_threshold, make_adam = fl.best_silhouette_threshold, functools.partial(FusedAdam, skip_frozen=True)
+        if world > 1:                                 # the same terms, summed over the bands
+            track_loss = lambda im, ds, gi, gd, thr: pt.band_tracking_loss(im, ds, gi, gd, band, thr)
+            map_loss = lambda im, ds, gi, gd: pt.band_mapping_loss(im, ds, gi, gd, band, rank, world)
+            pick_threshold = lambda im, sil, gi, gd: pt.band_silhouette_threshold(im, sil, gi, gd, band, world)
     else:                                             # exactly the reference's PyTorch formulation
         track_loss = lambda im, ds, gi, gd, thr: sc.tracking_loss(im, ds, gi, gd, thr)
         map_loss = lambda im, ds, gi, gd: sc.mapping_loss(im, ds, gi, gd)
         pick_threshold, make_adam = sc.best_silhouette_threshold, torch.optim.Adam
 
-    def render_pair(params, t_idx, gaussians_grad, camera_grad):
+    def render_pair(params, t_idx, gaussians_grad, camera_grad, tile_rows=None):
         if args.fused:
-            return render_frame(params, t_idx, settings, first_w2c, gaussians_grad, camera_grad)
+            return render_frame(params, t_idx, settings, first_w2c, gaussians_grad, camera_grad, tile_rows=tile_rows)
         tg = sc.transform_to_frame(params, t_idx, gaussians_grad=gaussians_grad, camera_grad=camera_grad)
         rv = sc.transformed_params2rendervar(params, tg)
         dv = sc.transformed_params2depthplussilhouette(params, first_w2c, tg)
@@ -210,9 +235,9 @@ def run(args) -> dict:
     # of each phase on a throw-away copy of the parameters
     warm = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
     for _ in range(3):
-        im, depth_sil, _ = render_pair(warm, 1, gaussians_grad=False, camera_grad=True)
+        im, depth_sil, _ = render_pair(warm, 1, gaussians_grad=False, camera_grad=True, tile_rows=band)
         track_loss(im, depth_sil, gts[1][0], gts[1][1], 0.99).backward()
-        im, depth_sil, _ = render_pair(warm, 1, gaussians_grad=True, camera_grad=False)
+        im, depth_sil, _ = render_pair(warm, 1, gaussians_grad=True, camera_grad=False, tile_rows=band)
         map_loss(im, depth_sil, gts[1][0], gts[1][1]).backward()
     del warm
 
@@ -252,14 +277,22 @@ def run(args) -> dict:
                     plot_dir=None, visualize_tracking_loss=False, tracking_iteration=it, dataset_name="replica",
                     presence_sil_mask_mse_ls=mse_ls, sil_thres_ls=thr_ls)
             else:
-                im, depth_sil, _ = render_pair(params, t, gaussians_grad=False, camera_grad=True)
+                im, depth_sil, _ = render_pair(params, t, gaussians_grad=False, camera_grad=True, tile_rows=band)
                 if it == 0:
                     sil_thres = pick_threshold(im, depth_sil[1], gt_im, gt_depth)
                 loss = track_loss(im, depth_sil, gt_im, gt_depth, sil_thres)
             loss.backward()
+            if world > 1:                          # the pose gradient of the frame = the sum over the bands (7 floats)
+                pose_grad = torch.cat([params["cam_unnorm_rots"].grad.reshape(-1), params["cam_trans"].grad.reshape(-1)])
+                pt.all_reduce_sum(pose_grad)
+                nq = params["cam_unnorm_rots"].grad.numel()
+                params["cam_unnorm_rots"].grad.copy_(pose_grad[:nq].view_as(params["cam_unnorm_rots"].grad))
+                params["cam_trans"].grad.copy_(pose_grad[nq:].view_as(params["cam_trans"].grad))
             with torch.no_grad():
                 lv = loss.detach()
                 if it % 10 == 9 or it == 0:       # the reference keeps the best pose; checking it costs a host sync
+                    if world > 1:
+                        lv = pt.all_reduce_sum(lv.clone().reshape(1))
                     if lv.item() < best[0]:
                         best = (lv.item(), params["cam_unnorm_rots"][..., t].clone(), params["cam_trans"][..., t].clone())
             opt.step(); opt.zero_grad(set_to_none=True)
@@ -300,9 +333,11 @@ def run(args) -> dict:
                         mapping=True, dataset_name="replica")
                     loss = loss + loss_global
             else:
-                im, depth_sil, _ = render_pair(params, t, gaussians_grad=True, camera_grad=False)
+                im, depth_sil, _ = render_pair(params, t, gaussians_grad=True, camera_grad=False, tile_rows=band)
                 loss = map_loss(im, depth_sil, gt_im, gt_depth)
             loss.backward()
+            if world > 1:                          # trainable per-Gaussian gradients: one flat all-reduce, 20 B per Gaussian
+                pt.allreduce_param_grads(params)
             opt.step(); opt.zero_grad(set_to_none=True)
         if graph is not None:
             torch.cuda.synchronize()
@@ -316,16 +351,25 @@ def run(args) -> dict:
                   f"instances {dgr.last_forward_info().get('instances')}, longest tile list {dgr.last_forward_info().get('max_tile_list')}", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     total = time.perf_counter() - t_all
+    if world > 1:                                  # the slowest rank's clock
+        tmax = torch.tensor([total, sum(track_ms) / len(track_ms), sum(map_ms) / len(map_ms)], dtype=torch.float64)
+        if backend == "nccl":
+            tmax = tmax.to(dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        total = float(tmax[0])
+        track_ms, map_ms = [float(tmax[1])], [float(tmax[2])]
     out = {
         "metric": "SLAM frames/s, tracking+mapping loop (synthetic Replica-room0-like sequence)",
-        "value": round(args.frames / total, 3), "unit": "frames/s", "n_gpus": 1, "higher_is_better": True,
+        "value": round(args.frames / total, 3), "unit": "frames/s", "n_gpus": world, "higher_is_better": True,
         "data": "synthetic", "dtype": "f32",
         "config": {"workload": f"view-tied submap N={N}, {W}x{H}; {args.tracking_iters} tracking + {args.mapping_iters} "
                                f"mapping iterations per frame, 2 renders fwd+bwd per iteration (configs/replica/room0.py)",
                    "frames": args.frames, "shared_geometry": bool(args.shared_geometry or args.fused), "fused_callers": bool(args.fused),
                    "through_get_loss_mirror": bool(args.get_loss), "iteration_replayed_from_a_hipgraph": bool(args.graph),
                    "mapping_get_loss_calls_per_iteration": 2 if fixed else 1,
-                   "gaussians_in_global_set": N * (1 + len(fixed)) if fixed else None},
+                   "gaussians_in_global_set": N * (1 + len(fixed)) if fixed else None,
+                   "partition": "none" if world == 1 else f"tile-row bands x{world} ({backend}): all-reduce of the pose gradient "
+                                                          "(tracking); SSIM halo rows + 8 loss sums + 20 B/Gaussian (mapping)"},
         "tracking_ms_per_iter": round(sum(track_ms) / len(track_ms), 3),
         "mapping_ms_per_iter": round(sum(map_ms) / len(map_ms), 3),
         "pose_error_before_tracking_cm_deg": [[round(a, 3), round(b, 4)] for a, b in errs_before],
@@ -339,7 +383,9 @@ def run(args) -> dict:
 
 
 def main():
-    print(json.dumps(run(parse_args())))
+    out = run(parse_args())
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":

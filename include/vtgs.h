@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VTGS_ABI_VERSION 11
+#define VTGS_ABI_VERSION 12
 
 typedef enum VtgsStatus {
   VTGS_OK = 0,
@@ -150,7 +150,10 @@ int vtgs_forward_shared(const VtgsCamera* cam, int32_t n, const float* colors,
  *   In band mode (tile_row_begin/end) the gradients are this band's partial sums; pixels outside the
  *   band are written as zero by the forward and ignored by the backward.
  *   g_means2D[N,3] holds the NDC-scaled screen-space gradient in [:, :2] (what means2D.grad shows at
- *   utils/slam_external.py:100-103), zeros in [:, 2].                                                */
+ *   utils/slam_external.py:100-103), zeros in [:, 2].
+ *   Any of the six outputs may be NULL (not all): that gradient is then not stored -- the tracking loop
+ *   detaches the Gaussians (src/vtgaussian_slam.py:428-449) and needs 24 of the 68 bytes per Gaussian.
+ *   The same holds for the seven outputs of vtgs_backward_dual.                                       */
 int vtgs_backward(const VtgsCamera* cam, int32_t n,
                   const float* means3D, const float* colors, const float* opacities,
                   const float* scales, const float* rotations,
@@ -292,6 +295,39 @@ int vtgs_slam_loss_backward(int32_t mode, const float* im, const float* depth_si
                             int32_t height, int32_t width, float sil_thres, float w_im, float w_depth,
                             const float* ssim_grad_maps, const float* fwd_out8, const float* upstream, float* g_im,
                             float* g_depth_sil, const float* extra_mask, const float* color_weight, void* stream);
+
+/* ---- The same loss for ONE BAND of the tile-row partition ------------------------------------------------
+ * A rank of the partition renders pixel rows [row_begin, row_end) and owns the loss terms of those rows.  Every term of
+ * get_loss is a sum over pixels except two: the mapping depth term is a masked MEAN (src/vtgaussian_slam.py:592-597:
+ * the band's sum over the count of ALL bands) and the SSIM window is 11x11 (utils/slam_external.py:78-87: rows
+ * [row_begin - 5, row_end + 5) of `im` must hold what the neighbouring ranks rendered; the caller exchanges them).
+ *   vtgs_slam_loss_band_sums   sums8 = {sum |gt_im - im| (weighted), sum |gt_depth - depth|, mask count, sum of the SSIM
+ *                              map over the band's rows, 0 x 4}: additive over the bands -- the caller all-reduces them.
+ *                              scratch / ssim_grad_maps as vtgs_slam_loss_forward (full-frame sizes; only band rows used).
+ *   vtgs_slam_loss_band_share  out8 as vtgs_slam_loss_forward for this band's SHARE of the loss: the shares of all bands
+ *                              sum to the full-frame loss (first_band carries the constant 0.2 w_im of 0.2 (1 - SSIM));
+ *                              out8[1] is the count over all bands, out8[4] the full-frame mean SSIM.
+ *   vtgs_slam_loss_band_backward  upstream[0] * d share / d im, d depth_sil.  Writes g_depth_sil rows [row_begin, row_end)
+ *                              and g_im rows [row_begin, row_end) (mapping: [row_begin - 5, row_end + 5) clipped to the
+ *                              image -- the part outside the band is the neighbours' renders' gradient, to be sent back);
+ *                              every other row is left untouched (hand in zero-filled images).
+ * The summation order inside a band differs from the full-frame call: values agree to float32 rounding.
+ * vtgs_silhouette_sweep_band: vtgs_silhouette_sweep over pixels [pixel_begin, pixel_end) (rows x width of the band).   */
+int vtgs_slam_loss_band_sums(int32_t mode, const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth,
+                             int32_t height, int32_t width, int32_t row_begin, int32_t row_end, float sil_thres,
+                             float* scratch, float* ssim_grad_maps, float* sums8, const float* extra_mask,
+                             const float* color_weight, void* stream);
+int vtgs_slam_loss_band_share(int32_t mode, const float* own_sums8, const float* all_sums8, int32_t height, int32_t width,
+                              float w_im, float w_depth, int32_t has_color_weight, int32_t first_band, float* out8,
+                              void* stream);
+int vtgs_slam_loss_band_backward(int32_t mode, const float* im, const float* depth_sil, const float* gt_im,
+                                 const float* gt_depth, int32_t height, int32_t width, int32_t row_begin, int32_t row_end,
+                                 float sil_thres, float w_im, float w_depth, const float* ssim_grad_maps,
+                                 const float* share_out8, const float* upstream, float* g_im, float* g_depth_sil,
+                                 const float* extra_mask, const float* color_weight, void* stream);
+int vtgs_silhouette_sweep_band(const float* im, const float* silhouette, const float* gt_im, const float* gt_depth,
+                               int32_t pixels, int32_t pixel_begin, int32_t pixel_end, const float* thresholds,
+                               int32_t n_thresholds, float* partial_sums, void* stream);
 
 /* ---- Adam over the parameter groups ------------------------------------------------------------------
  * Replaces torch.optim.Adam as the reference configures it (src/vtgaussian_slam.py:180-187: one group per tensor with its

@@ -162,3 +162,43 @@ def test_two_rank_mapping_loss_and_gradients_match_full_frame(tmp_path, outlier)
     for k, v in p.items():
         ref = v.grad
         assert (got[k] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-9, k
+
+
+# ---- tracking mode: additive masked sums, the threshold pick of iteration 0, the pose gradient as a 7-float sum ---------------
+def _tracking_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from diff_gaussian_rasterization import partition as pt
+    scene, cam, gt_im, gt_depth, params, render, sc = _mapping_problem()
+    H = cam.image_height
+    p = params()
+    band = band_for_rank(H, world, rank)
+    im, ds = render(p, band)
+    cands = (0.5, 0.8, 0.9, 0.95, 0.99)
+    thr = pt.band_silhouette_threshold(im.detach(), ds.detach()[1], gt_im, gt_depth, band, world, cands)
+    share = pt.band_tracking_loss(im, ds, gt_im, gt_depth, band, thr, w_im=0.5, w_depth=1.0)
+    share.backward()
+    pt.allreduce_param_grads(p)
+    total = pt.all_reduce_sum(share.detach().clone().reshape(1))
+    if rank == 0:
+        torch.save({"loss": total, "thr": thr, **{k: v.grad for k, v in p.items()}}, out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_tracking_loss_threshold_and_gradients_match_full_frame(tmp_path):
+    out = str(tmp_path / "t0.pt")
+    mp.spawn(_tracking_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    scene, cam, gt_im, gt_depth, params, render, sc = _mapping_problem()
+    p = params()
+    im, ds = render(p, None)
+    cands = (0.5, 0.8, 0.9, 0.95, 0.99)
+    thr = sc.best_silhouette_threshold(im.detach(), ds.detach()[1], gt_im, gt_depth, cands)
+    assert got["thr"] == thr
+    loss = sc.tracking_loss(im, ds, gt_im, gt_depth, thr, w_im=0.5, w_depth=1.0)
+    loss.backward()
+    assert abs(got["loss"].item() - loss.item()) <= 2e-6 * abs(loss.item())
+    for k, v in p.items():
+        ref = v.grad
+        assert (got[k] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-9, k

@@ -436,7 +436,9 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
     return VTGS_ERR_INVALID_ARGUMENT;
   if (n > 0 && (!means3D || !colors || !opacities || !scales || !rotations || (dual && !colors_b)))
     return VTGS_ERR_INVALID_ARGUMENT;
-  if (n > 0 && !frame && (!g_means3D || !g_means2D || !g_colors || !g_opacities || !g_scales || !g_rotations || (dual && !g_colors_b)))
+  // any output may be NULL (a gradient nobody asked for -- the tracking loop detaches the Gaussians,
+  // src/vtgaussian_slam.py:428-449 -- is then neither stored nor its array allocated), but not all of them
+  if (n > 0 && !frame && !g_means3D && !g_means2D && !g_colors && !g_opacities && !g_scales && !g_rotations && !(dual && g_colors_b))
     return VTGS_ERR_INVALID_ARGUMENT;
   if (n > 0 && frame) {                                      // the gradients leave through the frame epilogue instead
     const FrameEpilogue& f = *frame;

@@ -1176,11 +1176,14 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
         }
       } else {
         for (int i = 0; i < 3; ++i) {
-          g_means3D[3 * gid + i] = 0.f; g_means2D[3 * gid + i] = 0.f; g_colors[3 * gid + i] = 0.f; g_scales[3 * gid + i] = 0.f;
-          if constexpr (DUAL) g_colors_b[3 * gid + i] = 0.f;
+          if (g_means3D) g_means3D[3 * gid + i] = 0.f;
+          if (g_means2D) g_means2D[3 * gid + i] = 0.f;
+          if (g_colors) g_colors[3 * gid + i] = 0.f;
+          if (g_scales) g_scales[3 * gid + i] = 0.f;
+          if constexpr (DUAL) { if (g_colors_b) g_colors_b[3 * gid + i] = 0.f; }
         }
-        g_opacities[gid] = 0.f;
-        reinterpret_cast<float4*>(g_rotations)[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g_opacities) g_opacities[gid] = 0.f;
+        if (g_rotations) reinterpret_cast<float4*>(g_rotations)[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
     if constexpr (FRAME) {
@@ -1341,15 +1344,15 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     return;
   }
   if (!live) return;
-  for (int i = 0; i < 3; ++i) {
-    g_means3D[3 * gid + i] = g.mean3D[i];
-    g_means2D[3 * gid + i] = g.mean2D[i];
-    g_colors[3 * gid + i] = g.color[i];
-    g_scales[3 * gid + i] = g.scale[i];
-  }
-  g_opacities[gid] = g.opacity;
-  reinterpret_cast<float4*>(g_rotations)[gid] = make_float4(g.rot[0], g.rot[1], g.rot[2], g.rot[3]);
-  if constexpr (DUAL) { g_colors_b[3 * gid] = cb0; g_colors_b[3 * gid + 1] = cb1; g_colors_b[3 * gid + 2] = cb2; }
+  // an output nobody asked for is NULL (wave-uniform tests): 68 bytes per Gaussian when all six are wanted, 24 in a
+  // tracking iteration of the unfused loops (means3D + the screen-space term)
+  if (g_means3D) { for (int i = 0; i < 3; ++i) g_means3D[3 * gid + i] = g.mean3D[i]; }
+  if (g_means2D) { for (int i = 0; i < 3; ++i) g_means2D[3 * gid + i] = g.mean2D[i]; }
+  if (g_colors) { for (int i = 0; i < 3; ++i) g_colors[3 * gid + i] = g.color[i]; }
+  if (g_scales) { for (int i = 0; i < 3; ++i) g_scales[3 * gid + i] = g.scale[i]; }
+  if (g_opacities) g_opacities[gid] = g.opacity;
+  if (g_rotations) reinterpret_cast<float4*>(g_rotations)[gid] = make_float4(g.rot[0], g.rot[1], g.rot[2], g.rot[3]);
+  if constexpr (DUAL) { if (g_colors_b) { g_colors_b[3 * gid] = cb0; g_colors_b[3 * gid + 1] = cb1; g_colors_b[3 * gid + 2] = cb2; } }
 }
 template __global__ void gather_splat_grads<false>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*, FrameEpilogue);
 template __global__ void gather_splat_grads<true>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*, FrameEpilogue);

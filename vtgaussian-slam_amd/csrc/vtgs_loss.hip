@@ -26,7 +26,11 @@ __device__ __forceinline__ void gauss11(float (&w)[11]) {
 
 __global__ __launch_bounds__(256) void ssim_forward_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
                                                            int C, int H, int W, int tiles_x, int tiles_y,
-                                                           float* __restrict__ partial, float* __restrict__ gmaps) {
+                                                           float* __restrict__ partial, float* __restrict__ gmaps,
+                                                           int ty0 = 0, int rb = 0, int re = 1 << 30) {
+  // band form (tile-row multi-GPU partition): tiles_y tile rows starting at ty0 are launched and only the SSIM pixels of
+  // rows [rb, re) are summed / get derivative maps; the staged context rows around them are read as they are (the caller
+  // has put the neighbours' rows there).  Whole image: ty0 = 0, rb = 0, re >= H.
   __shared__ float px[kSP * kSP], py[kSP * kSP];
   __shared__ float hz[5][kSP * kST];
   __shared__ float red[4];
@@ -35,7 +39,7 @@ __global__ __launch_bounds__(256) void ssim_forward_kernel(const float* __restri
   const int t = (int)threadIdx.x;
   const int b = (int)blockIdx.x;
   const int c = b / (tiles_x * tiles_y), tb = b - c * tiles_x * tiles_y;
-  const int ty = tb / tiles_x, tx = tb - ty * tiles_x;
+  const int ty = ty0 + tb / tiles_x, tx = tb - (tb / tiles_x) * tiles_x;
   const int x0 = tx * kST - kSR, y0 = ty * kST - kSR;
   const size_t plane = (size_t)c * H * W;
   for (int i = t; i < kSP * kSP; i += 256) {
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void ssim_forward_kernel(const float* __restri
         m1 = fmaf(w[k], h[0][o + k], m1); m2 = fmaf(w[k], h[1][o + k], m2);
         xx = fmaf(w[k], h[2][o + k], xx); yy = fmaf(w[k], h[3][o + k], yy); xy = fmaf(w[k], h[4][o + k], xy);
       }
-      if (gy < H && gx < W) {
+      if (gy < H && gx < W && gy >= rb && gy < re) {
         const float s11 = xx - m1 * m1, s22 = yy - m2 * m2, s12 = xy - m1 * m2;
         const float a1 = 2.f * m1 * m2 + c1, a2 = 2.f * s12 + c2, b1 = m1 * m1 + m2 * m2 + c1, b2 = s11 + s22 + c2;
         const float ib = 1.f / (b1 * b2);
@@ -115,7 +119,10 @@ __global__ __launch_bounds__(256) void ssim_backward_kernel(const float* __restr
                                                             const float* __restrict__ gmaps, const float* __restrict__ upstream,
                                                             int C, int H, int W, int tiles_x, int tiles_y,
                                                             float* __restrict__ g_img1, float ssim_coef, float l1_coef,
-                                                            const float* __restrict__ l1_weight = nullptr) {
+                                                            const float* __restrict__ l1_weight = nullptr,
+                                                            int ty0 = 0, int rb = 0, int re = 1 << 30) {
+  // band form: the derivative maps exist on rows [rb, re) only (anything else counts as zero); the gradient is written on
+  // rows [rb - 5, re + 5) -- the blur carries it into the neighbours' rows -- and the L1 term belongs to rows [rb, re).
   __shared__ float pm[3][kSP * kSP];
   __shared__ float hz[3][kSP * kST];
   float w[11];
@@ -123,13 +130,13 @@ __global__ __launch_bounds__(256) void ssim_backward_kernel(const float* __restr
   const int t = (int)threadIdx.x;
   const int b = (int)blockIdx.x;
   const int c = b / (tiles_x * tiles_y), tb = b - c * tiles_x * tiles_y;
-  const int ty = tb / tiles_x, tx = tb - ty * tiles_x;
+  const int ty = ty0 + tb / tiles_x, tx = tb - (tb / tiles_x) * tiles_x;
   const int x0 = tx * kST - kSR, y0 = ty * kST - kSR;
   const size_t plane = (size_t)c * H * W, P3 = (size_t)C * H * W;
   for (int i = t; i < kSP * kSP; i += 256) {
     const int r = i / kSP, q = i - r * kSP;
     const int gy = y0 + r, gx = x0 + q;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;          // the adjoint of a zero-padded blur is the same blur
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W && gy >= rb && gy < re;   // the adjoint of a zero-padded blur is the same blur
     const size_t o = plane + (size_t)gy * W + gx;
     pm[0][i] = in ? gmaps[o] : 0.f; pm[1][i] = in ? gmaps[P3 + o] : 0.f; pm[2][i] = in ? gmaps[2 * P3 + o] : 0.f;
   }
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256) void ssim_backward_kernel(const float* __restr
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       const int gy = ty * kST + r0 + o, gx = tx * kST + q;
-      if (gy >= H || gx >= W) continue;
+      if (gy >= H || gx >= W || gy < rb - kSR || gy >= re + kSR) continue;
       float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int k = 0; k < 11; ++k) {
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256) void ssim_backward_kernel(const float* __restr
       }
       const size_t o2 = plane + (size_t)gy * W + gx;
       const float x = img1[o2], y = img2[o2];
-      const float lw = l1_weight ? l1s * l1_weight[o2] : l1s;
+      const float lw = (gy >= rb && gy < re) ? (l1_weight ? l1s * l1_weight[o2] : l1s) : 0.f;
       g_img1[o2] = scale * (s0 + 2.f * x * s1 + y * s2) + ((x > y) ? lw : (x < y) ? -lw : 0.f);
     }
   }
@@ -192,10 +199,13 @@ __global__ __launch_bounds__(256) void masked_l1_kernel(const float* __restrict_
                                                         int P, float sil_thres, int mode, float* __restrict__ partial,
                                                         float* __restrict__ g_im, float* __restrict__ g_ds,
                                                         const float* __restrict__ extra_mask = nullptr,
-                                                        const float* __restrict__ color_weight = nullptr) {
+                                                        const float* __restrict__ color_weight = nullptr,
+                                                        int p0 = 0, int p1 = -1) {
+  // [p0, p1): the pixels this call sums (a band of rows of the tile-row partition); P stays the plane stride
   __shared__ float red[4][3];
   float s_im = 0.f, s_d = 0.f, cnt = 0.f;
-  for (int i = (int)(blockIdx.x * 256u + threadIdx.x); i < P; i += (int)(gridDim.x * 256u)) {
+  if (p1 < 0) p1 = P;
+  for (int i = p0 + (int)(blockIdx.x * 256u + threadIdx.x); i < p1; i += (int)(gridDim.x * 256u)) {
     const float depth = ds[i], sil = ds[P + i], unc = ds[2 * (size_t)P + i] - depth * depth;
     const float gd = gt_depth[i];
     bool m = gd > 0.f && depth == depth && unc == unc;
@@ -229,12 +239,14 @@ struct SweepThresholds { float c[8]; int n; };
 
 __global__ __launch_bounds__(256) void silhouette_sweep_kernel(const float* __restrict__ im, const float* __restrict__ sil,
                                                                const float* __restrict__ gt_im, const float* __restrict__ gt_depth,
-                                                               int P, SweepThresholds th, float* __restrict__ partial) {
+                                                               int P, SweepThresholds th, float* __restrict__ partial,
+                                                               int p0 = 0, int p1 = -1) {
   __shared__ float red[4][16];
   float sum[8], cnt[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { sum[k] = 0.f; cnt[k] = 0.f; }
-  for (int i = (int)(blockIdx.x * 256u + threadIdx.x); i < P; i += (int)(gridDim.x * 256u)) {
+  if (p1 < 0) p1 = P;
+  for (int i = p0 + (int)(blockIdx.x * 256u + threadIdx.x); i < p1; i += (int)(gridDim.x * 256u)) {
     const float e0 = gt_im[i] - im[i], e1 = gt_im[(size_t)P + i] - im[(size_t)P + i],
                 e2 = gt_im[2 * (size_t)P + i] - im[2 * (size_t)P + i];
     const float sq = e0 * e0 + e1 * e1 + e2 * e2;
@@ -287,7 +299,8 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamLaunch a) {
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ l1_partial, uint32_t l1_rows,
                                                             const float* __restrict__ ssim_partial, uint32_t ssim_rows,
                                                             int mode, float w_im, float w_depth, float numel_im,
-                                                            float* __restrict__ out, float l1_coef = 0.8f) {
+                                                            float* __restrict__ out, float l1_coef = 0.8f,
+                                                            int raw = 0) {
   __shared__ float red[4][4];
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   for (uint32_t r = threadIdx.x; r < l1_rows; r += 256u) { a0 += l1_partial[3 * r]; a1 += l1_partial[3 * r + 1]; a2 += l1_partial[3 * r + 2]; }
@@ -298,6 +311,11 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
   if (threadIdx.x == 0) {
     const float s_im = red[0][0] + red[1][0] + red[2][0] + red[3][0], s_d = red[0][1] + red[1][1] + red[2][1] + red[3][1];
     const float cnt = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+    if (raw) {                                                // a band's additive sums (vtgs_slam_loss_band_sums)
+      out[0] = s_im; out[1] = s_d; out[2] = cnt; out[3] = red[0][3] + red[1][3] + red[2][3] + red[3][3];
+      out[4] = 0.f; out[5] = 0.f; out[6] = 0.f; out[7] = 0.f;
+      return;
+    }
     const float ssim = (red[0][3] + red[1][3] + red[2][3] + red[3][3]) / numel_im;
     // the two weighted terms the reference's get_loss reports beside their sum (weighted_losses['im'], ['depth'])
     const float t_im = (mode != 1) ? w_im * s_im : w_im * (l1_coef * s_im / numel_im + 0.2f * (1.f - ssim));
@@ -313,11 +331,13 @@ __global__ __launch_bounds__(256) void loss_backward_kernel(const float* __restr
                                                             int P, float sil_thres, int mode, float w_im, float w_depth,
                                                             const float* __restrict__ upstream, const float* __restrict__ fwd_out,
                                                             float* __restrict__ g_im, float* __restrict__ g_ds,
-                                                            const float* __restrict__ extra_mask = nullptr) {
+                                                            const float* __restrict__ extra_mask = nullptr,
+                                                            int p0 = 0, int p1 = -1) {
+  if (p1 < 0) p1 = P;
   const float up = upstream[0];
   const float cd = (mode != 1) ? up * w_depth : up * w_depth / fwd_out[1];
   const float ci = up * w_im;
-  for (int i = (int)(blockIdx.x * 256u + threadIdx.x); i < P; i += (int)(gridDim.x * 256u)) {
+  for (int i = p0 + (int)(blockIdx.x * 256u + threadIdx.x); i < p1; i += (int)(gridDim.x * 256u)) {
     const float depth = ds[i], sil = ds[P + i], unc = ds[2 * (size_t)P + i] - depth * depth;
     const float gd = gt_depth[i];
     bool m = gd > 0.f && depth == depth && unc == unc;
@@ -335,6 +355,18 @@ __global__ __launch_bounds__(256) void loss_backward_kernel(const float* __restr
       }
     }
   }
+}
+
+// One band's share of the loss from its own sums and the sums over all bands ({sum_im, sum_depth, count, sum SSIM}): the
+// shares of all bands add up to the full-frame loss of loss_finalize_kernel.  Only the mapping depth term is not additive
+// (a masked MEAN: the band's sum over the GLOBAL count); the "1" of (1 - SSIM) goes to the first band.
+__global__ void band_share_kernel(const float* __restrict__ own, const float* __restrict__ all, int mode, float w_im,
+                                  float w_depth, float numel_im, float l1_coef, int first, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float s_im = own[0], s_d = own[1], cnt = all[2];
+  const float t_im = (mode != 1) ? w_im * s_im : w_im * (l1_coef * s_im / numel_im + 0.2f * ((first ? 1.f : 0.f) - own[3] / numel_im));
+  const float t_d = (mode != 1) ? w_depth * s_d : w_depth * s_d / cnt;
+  out[0] = t_im + t_d; out[1] = cnt; out[2] = s_im; out[3] = s_d; out[4] = all[3] / numel_im; out[5] = t_im; out[6] = t_d; out[7] = 0.f;
 }
 
 }  // namespace vtgs
@@ -467,6 +499,82 @@ int vtgs_slam_loss_backward(int32_t mode, const float* im, const float* depth_si
                        height, width, tx, ty, g_im, -0.2f * w_im, (color_weight ? 1.0f : 0.8f) * w_im / (float)((size_t)3 * P),
                        color_weight);
   }
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+// ---- one band of the tile-row partition: additive sums, the band's share, its gradient images -----------
+static bool band_ok(int32_t height, int32_t width, int32_t rb, int32_t re) {
+  return height > 0 && width > 0 && rb >= 0 && re > rb && re <= height;
+}
+
+int vtgs_slam_loss_band_sums(int32_t mode, const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth,
+                             int32_t height, int32_t width, int32_t row_begin, int32_t row_end, float sil_thres,
+                             float* scratch, float* ssim_grad_maps, float* sums8, const float* extra_mask,
+                             const float* color_weight, void* stream) {
+  if ((mode < 0 || mode > 2) || !im || !depth_sil || !gt_im || !gt_depth || !scratch || !sums8 ||
+      !band_ok(height, width, row_begin, row_end))
+    return VTGS_ERR_INVALID_ARGUMENT;
+  const int32_t P = height * width, p0 = row_begin * width, p1 = row_end * width;
+  const uint32_t l1_rows = vtgs_masked_l1_partial_rows(p1 - p0);
+  float* ssim_partial = scratch + (size_t)vtgs_masked_l1_partial_rows(P) * 3;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(masked_l1_kernel, dim3(l1_rows), dim3(256), 0, st, im, depth_sil, gt_im, gt_depth, P, sil_thres, mode,
+                     scratch, (float*)nullptr, (float*)nullptr, extra_mask, mode == 1 ? color_weight : (const float*)nullptr,
+                     p0, p1);
+  uint32_t ssim_rows = 0;
+  if (mode == 1) {
+    const int tx = (width + kST - 1) / kST, ty0 = row_begin / kST, ty = (row_end - 1) / kST - ty0 + 1;
+    ssim_rows = (uint32_t)(3 * tx * ty);
+    hipLaunchKernelGGL(ssim_forward_kernel, dim3(ssim_rows), dim3(256), 0, st, im, gt_im, 3, height, width, tx, ty,
+                       ssim_partial, ssim_grad_maps, ty0, row_begin, row_end);
+  }
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, l1_rows, ssim_partial, ssim_rows, mode, 0.f,
+                     0.f, (float)((size_t)3 * P), sums8, 0.8f, 1);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+int vtgs_slam_loss_band_share(int32_t mode, const float* own_sums8, const float* all_sums8, int32_t height, int32_t width,
+                              float w_im, float w_depth, int32_t has_color_weight, int32_t first_band, float* out8,
+                              void* stream) {
+  if ((mode < 0 || mode > 2) || !own_sums8 || !all_sums8 || !out8 || height <= 0 || width <= 0) return VTGS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(band_share_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, own_sums8, all_sums8, mode, w_im, w_depth,
+                     (float)((size_t)3 * height * width), (mode == 1 && has_color_weight) ? 1.0f : 0.8f, first_band, out8);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+int vtgs_slam_loss_band_backward(int32_t mode, const float* im, const float* depth_sil, const float* gt_im,
+                                 const float* gt_depth, int32_t height, int32_t width, int32_t row_begin, int32_t row_end,
+                                 float sil_thres, float w_im, float w_depth, const float* ssim_grad_maps,
+                                 const float* share_out8, const float* upstream, float* g_im, float* g_depth_sil,
+                                 const float* extra_mask, const float* color_weight, void* stream) {
+  if ((mode < 0 || mode > 2) || !im || !depth_sil || !gt_im || !gt_depth || !share_out8 || !upstream || !g_im || !g_depth_sil ||
+      !band_ok(height, width, row_begin, row_end) || (mode == 1 && !ssim_grad_maps))
+    return VTGS_ERR_INVALID_ARGUMENT;
+  const int32_t P = height * width, p0 = row_begin * width, p1 = row_end * width;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(loss_backward_kernel, dim3(vtgs_masked_l1_partial_rows(p1 - p0)), dim3(256), 0, st, im, depth_sil, gt_im,
+                     gt_depth, P, sil_thres, mode, w_im, w_depth, upstream, share_out8, g_im, g_depth_sil, extra_mask, p0, p1);
+  if (mode == 1) {
+    const int lo = row_begin - kSR > 0 ? row_begin - kSR : 0, hi = row_end + kSR < height ? row_end + kSR : height;
+    const int tx = (width + kST - 1) / kST, ty0 = lo / kST, ty = (hi - 1) / kST - ty0 + 1;
+    hipLaunchKernelGGL(ssim_backward_kernel, dim3(3 * tx * ty), dim3(256), 0, st, im, gt_im, ssim_grad_maps, upstream, 3,
+                       height, width, tx, ty, g_im, -0.2f * w_im, (color_weight ? 1.0f : 0.8f) * w_im / (float)((size_t)3 * P),
+                       color_weight, ty0, row_begin, row_end);
+  }
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+int vtgs_silhouette_sweep_band(const float* im, const float* silhouette, const float* gt_im, const float* gt_depth,
+                               int32_t pixels, int32_t pixel_begin, int32_t pixel_end, const float* thresholds,
+                               int32_t n_thresholds, float* partial_sums, void* stream) {
+  if (!im || !silhouette || !gt_im || !gt_depth || !thresholds || !partial_sums || pixels <= 0 || n_thresholds <= 0 ||
+      n_thresholds > 8 || pixel_begin < 0 || pixel_end <= pixel_begin || pixel_end > pixels)
+    return VTGS_ERR_INVALID_ARGUMENT;
+  SweepThresholds th;
+  th.n = n_thresholds;
+  for (int k = 0; k < 8; ++k) th.c[k] = k < n_thresholds ? thresholds[k] : 0.f;
+  hipLaunchKernelGGL(silhouette_sweep_kernel, dim3(vtgs_masked_l1_partial_rows(pixel_end - pixel_begin)), dim3(256), 0,
+                     (hipStream_t)stream, im, silhouette, gt_im, gt_depth, pixels, th, partial_sums, pixel_begin, pixel_end);
   return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
 }
 

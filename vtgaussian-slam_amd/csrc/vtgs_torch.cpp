@@ -13,6 +13,7 @@
 // Built in-tree by __graft_entry__.build() / vtgaussian-slam_amd/build.py (torch.utils.cpp_extension, g++; no device code).
 #include <torch/extension.h>
 
+#include <algorithm>
 #include <cstring>
 
 #include "../../include/vtgs.h"
@@ -99,11 +100,25 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
                   tile_cap = ctx->saved_data["tile_cap"].toInt(), stream = ctx->saved_data["stream"].toInt();
     at::Tensor grad_color = grads[0].defined() ? grads[0].to(at::kFloat).contiguous() : at::zeros_like(color);
     const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
-    at::Tensor flat = at::empty({17 * n}, f32);                  // one allocation, six contiguous arrays
-    at::Tensor g_means3D = flat.narrow(0, 0, 3 * n).view({n, 3}), g_means2D = flat.narrow(0, 3 * n, 3 * n).view({n, 3}),
-               g_colors = flat.narrow(0, 6 * n, 3 * n).view({n, 3}), g_opac = flat.narrow(0, 9 * n, n).view({n, 1}),
-               g_scales = flat.narrow(0, 10 * n, 3 * n).view({n, 3}), g_rot = flat.narrow(0, 13 * n, 4 * n).view({n, 4});
-    if (n > 0) {
+    // one allocation for the gradients somebody asked for (68 bytes per Gaussian when all six are; a tracking iteration of
+    // the unfused loops, src/vtgaussian_slam.py:428-449, detaches the Gaussians and needs 24): the others are neither
+    // allocated nor stored by the kernel
+    static const int64_t kWidth[6] = {3, 3, 3, 1, 3, 4};       // means3D, means2D, colours, opacities, scales, rotations
+    int64_t total = 0;
+    bool want[6];
+    for (int i = 0; i < 6; ++i) { want[i] = ctx->needs_input_grad(i); total += want[i] ? kWidth[i] : 0; }
+    at::Tensor flat = at::empty({std::max<int64_t>(total, 1) * n}, f32);
+    at::Tensor g[6];
+    float* gp[6];
+    int64_t off = 0;
+    for (int i = 0; i < 6; ++i) {
+      gp[i] = nullptr;
+      if (!want[i]) continue;
+      g[i] = flat.narrow(0, off * n, kWidth[i] * n).view({n, kWidth[i]});
+      gp[i] = g[i].data_ptr<float>();
+      off += kWidth[i];
+    }
+    if (n > 0 && total > 0) {
       // the record of a run-ahead forward may not have been read yet: its instance CAPACITY bounds the instance ids
       const VtgsForwardInfo* info = reinterpret_cast<const VtgsForwardInfo*>(ctx->saved_data["slot_ptr"].toInt());
       const uint64_t instances = (info && info->complete && !info->overflow) ? info->instances : (uint64_t)capacity;
@@ -113,13 +128,11 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
                                    scales.data_ptr<float>(), rot.data_ptr<float>(), color.data_ptr<float>(),
                                    grad_color.data_ptr<float>(), workspace.data_ptr(), (size_t)workspace.numel(),
                                    (uint64_t)capacity, (uint32_t)tile_cap, nullptr, scratch.data_ptr(), sbytes,
-                                   g_means3D.data_ptr<float>(), g_means2D.data_ptr<float>(), g_colors.data_ptr<float>(),
-                                   g_opac.data_ptr<float>(), g_scales.data_ptr<float>(), g_rot.data_ptr<float>(),
-                                   reinterpret_cast<void*>(stream));
+                                   gp[0], gp[1], gp[2], gp[3], gp[4], gp[5], reinterpret_cast<void*>(stream));
       TORCH_CHECK(st == VTGS_OK, "vtgs_backward failed: ", vtgs_strerror(st), " (", vtgs_last_hip_error(), ")");
     }
     at::Tensor none;
-    return {g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot, none, none, none, none, none, none, none, none, none};
+    return {g[0], g[1], g[2], g[3], g[4], g[5], none, none, none, none, none, none, none, none, none};
   }
 };
 

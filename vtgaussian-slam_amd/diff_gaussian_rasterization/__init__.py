@@ -52,7 +52,7 @@ class _VtgsProfileEntry(ctypes.Structure):
 
 
 VTGS_OK, VTGS_ERR_INSTANCE_OVERFLOW = 0, 3
-ABI_VERSION = 11
+ABI_VERSION = 12
 VTGS_FORWARD_SYNC, VTGS_FORWARD_ASYNC, VTGS_FORWARD_CHECKED = 0, 1, 2
 _P, _U64, _I32, _SZ = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
 
@@ -659,13 +659,21 @@ def _scratch_instances(fs: _ForwardState) -> int:
     return fs._instances if fs._instances is not None else fs.capacity   # (captured forwards: always the capacity)
 
 
-def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotations, out_color, grad_color):
+def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotations, out_color, grad_color,
+                  want=(True, True, True, True, True, True)):
+    """want: which of (means3D, means2D, colours, opacities, scales, rotations) need a gradient; the others come back as
+    None and are neither allocated nor stored by the kernel (68 bytes per Gaussian when all six are wanted)."""
     device = means3D.device
     n = fs.n
-    flat = torch.empty((17 * n,), dtype=torch.float32, device=device)             # one allocation, six contiguous arrays
-    g_means3D, g_means2D, g_colors = flat[:3 * n].view(n, 3), flat[3 * n:6 * n].view(n, 3), flat[6 * n:9 * n].view(n, 3)
-    g_opac, g_scales, g_rot = flat[9 * n:10 * n].view(n, 1), flat[10 * n:13 * n].view(n, 3), flat[13 * n:].view(n, 4)
-    if n == 0:
+    widths = (3, 3, 3, 1, 3, 4)
+    total = sum(w for w, k in zip(widths, want) if k)
+    flat = torch.empty((max(total, 1) * n,), dtype=torch.float32, device=device)    # one allocation, contiguous arrays
+    outs, off = [], 0
+    for w, k in zip(widths, want):
+        outs.append(flat[off * n:(off + w) * n].view(n, w) if k else None)
+        off += w if k else 0
+    g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot = outs
+    if n == 0 or total == 0:
         return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
     sbytes = _lib.vtgs_backward_scratch_bytes(n, _scratch_instances(fs))
     scratch = torch.empty((sbytes,), dtype=torch.uint8, device=device)
@@ -674,8 +682,8 @@ def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotatio
         st = _lib.vtgs_backward(ctypes.byref(fs.cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
                                 scales.data_ptr(), rotations.data_ptr(), out_color.data_ptr(), grad_color.data_ptr(),
                                 fs.workspace.data_ptr(), fs.workspace.numel(), fs.capacity, fs.tile_cap, state_ptr,
-                                scratch.data_ptr(), sbytes, g_means3D.data_ptr(), g_means2D.data_ptr(), g_colors.data_ptr(),
-                                g_opac.data_ptr(), g_scales.data_ptr(), g_rot.data_ptr(), _stream_ptr(device))
+                                scratch.data_ptr(), sbytes, *[None if t is None else t.data_ptr() for t in outs],
+                                _stream_ptr(device))
     _check(st, "vtgs_backward")
     _settle(fs)                                    # asynchronous forward: its record is read now, behind the backward's launches
     return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
@@ -783,8 +791,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         if grad_color is None:
             grad_color = torch.zeros_like(color)
         grad_color = grad_color.to(torch.float32).contiguous()
+        need = ctx.needs_input_grad
         g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot = _run_backward(
-            ctx.fs, means3D, colors, opac, scales_c, rot, color, grad_color)
+            ctx.fs, means3D, colors, opac, scales_c, rot, color, grad_color,
+            want=(need[0], need[1], need[3], need[4], need[5], need[6]))
         return g_means3D, g_means2D, None, g_colors, g_opac, g_scales, g_rot, None, None, None
 
 

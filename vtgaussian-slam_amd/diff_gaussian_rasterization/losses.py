@@ -172,6 +172,102 @@ def mapping_loss(im, depth_sil, gt_im, gt_depth, w_im: float = 1.0, w_depth: flo
     return (loss, terms) if return_terms else loss
 
 
+# ---- one band of the tile-row partition: the same loss, summed over the ranks ---------------------------
+_lib.vtgs_slam_loss_band_sums.restype = ctypes.c_int
+_lib.vtgs_slam_loss_band_sums.argtypes = [_I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, ctypes.c_float, _P, _P, _P, _P, _P, _P]
+_lib.vtgs_slam_loss_band_share.restype = ctypes.c_int
+_lib.vtgs_slam_loss_band_share.argtypes = [_I32, _P, _P, _I32, _I32, ctypes.c_float, ctypes.c_float, _I32, _I32, _P, _P]
+_lib.vtgs_slam_loss_band_backward.restype = ctypes.c_int
+_lib.vtgs_slam_loss_band_backward.argtypes = [_I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, ctypes.c_float, ctypes.c_float,
+                                              ctypes.c_float, _P, _P, _P, _P, _P, _P, _P, _P]
+
+
+class _BandLoss(torch.autograd.Function):
+    """A band's share of the get_loss value (see include/vtgs.h, "ONE BAND"): value 3-4 launches + the caller's reduction
+    of eight floats, gradient images 1-2 launches."""
+
+    @staticmethod
+    def forward(ctx, im, depth_sil, gt_im, gt_depth, rows, mode: int, sil_thres: float, w_im: float, w_depth: float,
+                extra_mask, color_weight, reduce, first_band: bool):
+        if not im.is_cuda:
+            raise RuntimeError("the fused losses need tensors on a HIP device (torch 'cuda'); no CPU path exists")
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        a, d, ga, gd = f32(im), f32(depth_sil), f32(gt_im), f32(gt_depth)
+        if a.shape[-3] != 3 or d.shape[-3] != 3:
+            raise ValueError("im and depth_sil must be [3,H,W]")
+        H, W = a.shape[-2], a.shape[-1]
+        r0, r1 = int(rows[0]), int(rows[1])
+        if not 0 <= r0 < r1 <= H:
+            raise ValueError(f"rows {rows} outside an image of {H} rows")
+        em = None if extra_mask is None else extra_mask.detach().to(device=a.device, dtype=torch.float32).reshape(-1).contiguous()
+        cw = None if color_weight is None else color_weight.detach().to(device=a.device, dtype=torch.float32).expand(3, H, W).contiguous()
+        if em is not None and em.numel() != H * W:
+            raise ValueError("extra_mask must have H*W elements (the full frame)")
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        st = _stream_ptr(a.device)
+        scratch = torch.empty(int(_lib.vtgs_loss_scratch_floats(H, W)), dtype=torch.float32, device=a.device)
+        gmaps = torch.empty((3, 3, H, W), dtype=torch.float32, device=a.device) if (mode == 1 and need) else None
+        own = torch.empty(8, dtype=torch.float32, device=a.device)
+        _check(_lib.vtgs_slam_loss_band_sums(mode, a.data_ptr(), d.data_ptr(), ga.data_ptr(), gd.data_ptr(), H, W, r0, r1,
+                                             float(sil_thres), scratch.data_ptr(), None if gmaps is None else gmaps.data_ptr(),
+                                             own.data_ptr(), None if em is None else em.data_ptr(),
+                                             None if cw is None else cw.data_ptr(), st), "vtgs_slam_loss_band_sums")
+        if reduce is None:
+            total = own
+        else:
+            total = own.clone()
+            got = reduce(total)                 # in place (dist.all_reduce) or returning the reduced tensor
+            total = total if got is None else got
+        out = torch.empty(8, dtype=torch.float32, device=a.device)
+        _check(_lib.vtgs_slam_loss_band_share(mode, own.data_ptr(), total.data_ptr(), H, W, float(w_im), float(w_depth),
+                                              0 if cw is None else 1, 1 if first_band else 0, out.data_ptr(), st),
+               "vtgs_slam_loss_band_share")
+        ctx.em, ctx.cw = em, cw
+        ctx.save_for_backward(a, d, ga, gd, out, gmaps if gmaps is not None else out)
+        ctx.cfg = (mode, float(sil_thres), float(w_im), float(w_depth), need, gmaps is not None, r0, r1)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(out, total)
+        return out[0], out, total
+
+    @staticmethod
+    def backward(ctx, g, _g_terms=None, _g_total=None):
+        mode, sil_thres, w_im, w_depth, need, has_maps, r0, r1 = ctx.cfg
+        if g is None or not need:
+            return (None,) * 13
+        a, d, ga, gd, out, gmaps = ctx.saved_tensors
+        H, W = a.shape[-2], a.shape[-1]
+        up = g.detach().to(torch.float32).reshape(1).contiguous()
+        g_im, g_ds = torch.zeros_like(a), torch.zeros_like(d)      # rows outside the band (+ SSIM halo) stay zero
+        _check(_lib.vtgs_slam_loss_band_backward(mode, a.data_ptr(), d.data_ptr(), ga.data_ptr(), gd.data_ptr(), H, W, r0, r1,
+                                                 sil_thres, w_im, w_depth, gmaps.data_ptr() if has_maps else None,
+                                                 out.data_ptr(), up.data_ptr(), g_im.data_ptr(), g_ds.data_ptr(),
+                                                 None if ctx.em is None else ctx.em.data_ptr(),
+                                                 None if ctx.cw is None else ctx.cw.data_ptr(), _stream_ptr(a.device)),
+               "vtgs_slam_loss_band_backward")
+        return (g_im, g_ds) + (None,) * 11
+
+
+def band_loss(im, depth_sil, gt_im, gt_depth, rows, mode: str = "mapping", sil_thres: float = 0.0, w_im: float = 1.0,
+              w_depth: float = 1.0, extra_mask=None, additional_mask=None, reduce=None, first_band: bool = True,
+              colour_over_all_pixels: bool = False, return_terms: bool = False):
+    """This band's share of `tracking_loss` / `mapping_loss` (mode "tracking" / "mapping") over pixel rows
+    rows = (begin, end) of full-frame [3,H,W] images: the shares of all bands sum to the full-frame loss, the gradients of
+    the shares are the full-frame gradients restricted to what this band's terms touch.  `reduce(t)`: sums the 8-float
+    device tensor `t` over the ranks, in place or returning the result (`torch.distributed.all_reduce`); None = a single
+    band.  Mapping needs rows [begin-5, end+5) of `im` filled with the neighbours' renders (partition.halo_exchange) and
+    `first_band=True` on exactly one rank.  return_terms: (share, the 8-float record of the share, the reduced sums
+    {colour sum, depth sum, mask count, SSIM sum})."""
+    if mode == "tracking":
+        m, cw = (2 if colour_over_all_pixels else 0), None
+    elif mode == "mapping":
+        m, cw = 1, (None if additional_mask is None else 10.0 * additional_mask.to(torch.float32) + 0.8)
+    else:
+        raise ValueError("mode is 'tracking' or 'mapping'")
+    loss, terms, total = _BandLoss.apply(im, depth_sil, gt_im, gt_depth, rows, m, sil_thres, w_im, w_depth, extra_mask, cw,
+                                         reduce, first_band)
+    return (loss, terms, total) if return_terms else loss
+
+
 # ---- detached masks of the TUM / ScanNet / ScanNet++ branches (device-side torch ops: plumbing, no gradients) ----------
 def outlier_depth_mask(gt_depth, depth):
     """src/vtgaussian_slam.py:525-528 (ignore_outlier_depth_loss): |gt - depth| (0 where gt <= 0) below 50 x its median,
@@ -216,11 +312,14 @@ def visibility_mask(gt_depth, intrinsics, curr_w2c, overlaps, vis_mask_thres: fl
 
 _lib.vtgs_silhouette_sweep.restype = ctypes.c_int
 _lib.vtgs_silhouette_sweep.argtypes = [_P, _P, _P, _P, _I32, ctypes.POINTER(ctypes.c_float), _I32, _P, _P]
+_lib.vtgs_silhouette_sweep_band.restype = ctypes.c_int
+_lib.vtgs_silhouette_sweep_band.argtypes = [_P, _P, _P, _P, _I32, _I32, _I32, ctypes.POINTER(ctypes.c_float), _I32, _P, _P]
 
 
-def silhouette_sweep(im, silhouette, gt_im, gt_depth, candidates):
+def silhouette_sweep(im, silhouette, gt_im, gt_depth, candidates, rows=None):
     """Per candidate c: (sum over channels of (gt_im - im)^2, pixel count) over silhouette > c & gt_depth > 0, as a
-    [K,2] float64 tensor on the device (one kernel; src/vtgaussian_slam.py:476-496)."""
+    [K,2] float64 tensor on the device (one kernel; src/vtgaussian_slam.py:476-496).  rows = (begin, end): only those
+    pixel rows (a band of the tile-row partition; the sums of all bands add up to the full-frame ones)."""
     if not im.is_cuda:
         raise RuntimeError("the fused losses need tensors on a HIP device (torch 'cuda'); no CPU path exists")
     f32 = lambda t: t.detach().to(torch.float32).contiguous()
@@ -228,12 +327,15 @@ def silhouette_sweep(im, silhouette, gt_im, gt_depth, candidates):
     K = len(candidates)
     if not 1 <= K <= 8:
         raise ValueError("1..8 candidate thresholds")
-    P = a.shape[-1] * a.shape[-2]
-    rows = int(_lib.vtgs_masked_l1_partial_rows(P))
-    partial = torch.empty((rows, K, 2), dtype=torch.float32, device=a.device)
+    W = a.shape[-1]
+    P = W * a.shape[-2]
+    p0, p1 = (0, P) if rows is None else (int(rows[0]) * W, int(rows[1]) * W)
+    if not 0 <= p0 < p1 <= P:
+        raise ValueError(f"rows {rows} outside the image")
+    partial = torch.empty((int(_lib.vtgs_masked_l1_partial_rows(p1 - p0)), K, 2), dtype=torch.float32, device=a.device)
     th = (ctypes.c_float * K)(*[float(c) for c in candidates])
-    _check(_lib.vtgs_silhouette_sweep(a.data_ptr(), s.data_ptr(), ga.data_ptr(), gd.data_ptr(), P, th, K, partial.data_ptr(),
-                                      _stream_ptr(a.device)), "vtgs_silhouette_sweep")
+    _check(_lib.vtgs_silhouette_sweep_band(a.data_ptr(), s.data_ptr(), ga.data_ptr(), gd.data_ptr(), P, p0, p1, th, K,
+                                           partial.data_ptr(), _stream_ptr(a.device)), "vtgs_silhouette_sweep_band")
     return partial.sum(0, dtype=torch.float64)
 
 

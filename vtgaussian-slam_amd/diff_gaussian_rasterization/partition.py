@@ -29,6 +29,25 @@ def pixel_rows(band: Tuple[int, int], image_height: int) -> Tuple[int, int]:
     return band[0] * 16, min(band[1] * 16, int(image_height))
 
 
+def _host_staged(group=None) -> bool:
+    """gloo moves host memory: device tensors go through a CPU copy (the rehearsal of the N-rank path on one GPU box and the
+    CPU tests); RCCL (backend "nccl") takes device tensors as they are."""
+    import torch.distributed as dist
+    return dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum(t, group=None):
+    """In-place sum over the ranks of a (small) tensor on any device, with either backend."""
+    import torch.distributed as dist
+    if t.is_cuda and _host_staged(group):
+        c = t.cpu()
+        dist.all_reduce(c, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
 
 def pose7_reduce(points, g_points):
     """{sum g, sum p x g, sum g_z} of camera-frame points and their gradients as ONE 7-float device tensor (two launches):
@@ -76,7 +95,7 @@ def allreduce_param_grads(params, keys=("rgb_colors", "logit_opacities", "log_sc
     ref = params[keys[0]]
     parts = [(params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])).reshape(-1) for k in keys]
     flat = torch.cat(parts).to(ref.device)
-    dist.all_reduce(flat, group=group)
+    all_reduce_sum(flat, group)
     o = 0
     for k, p in zip(keys, parts):
         n = p.numel()
@@ -92,6 +111,21 @@ def allreduce_param_grads(params, keys=("rgb_colors", "logit_opacities", "log_sc
 def _halo_autograd():
     import torch
     import torch.distributed as dist
+
+    def _exchange(ops, recv_up, recv_down, group):
+        """Runs the batched sends / receives; with gloo and device tensors the payload goes through host copies."""
+        if not ops:
+            return recv_up, recv_down
+        staged = any(o.tensor.is_cuda for o in ops) and _host_staged(group)
+        if staged:
+            host = {id(o.tensor): o.tensor.cpu() for o in ops}
+            ops = [dist.P2POp(o.op, host[id(o.tensor)], o.peer, group) for o in ops]
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        if staged:
+            recv_up = None if recv_up is None else host[id(recv_up)].to(recv_up.device)
+            recv_down = None if recv_down is None else host[id(recv_down)].to(recv_down.device)
+        return recv_up, recv_down
 
     class HaloExchange(torch.autograd.Function):
         """img [C,H,W] holds this rank's pixel rows [y0, y1) (anything elsewhere is ignored).  Returns a copy whose rows
@@ -113,9 +147,7 @@ def _halo_autograd():
                 send = img[:, max(y1 - halo, y0):y1].contiguous()
                 recv_down = torch.empty_like(img[:, y1:hi1])
                 ops += [dist.P2POp(dist.isend, send, down, group), dist.P2POp(dist.irecv, recv_down, down, group)]
-            if ops:
-                for r in dist.batch_isend_irecv(ops):
-                    r.wait()
+            recv_up, recv_down = _exchange(ops, recv_up, recv_down, group)
             if recv_up is not None:
                 out[:, lo0:y0] = recv_up
             if recv_down is not None:
@@ -139,9 +171,7 @@ def _halo_autograd():
                 send = g[:, y1:hi1].contiguous()
                 recv_down = torch.empty_like(g[:, max(y1 - halo, y0):y1])
                 ops += [dist.P2POp(dist.isend, send, down, group), dist.P2POp(dist.irecv, recv_down, down, group)]
-            if ops:
-                for r in dist.batch_isend_irecv(ops):
-                    r.wait()
+            recv_up, recv_down = _exchange(ops, recv_up, recv_down, group)
             if recv_up is not None:
                 gi[:, y0:min(y0 + halo, y1)] += recv_up
             if recv_down is not None:
@@ -163,7 +193,10 @@ def global_median(local_values, group=None):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    dev = local_values.device
     v = local_values.detach().reshape(-1)
+    if v.is_cuda and _host_staged(group):
+        return global_median(v.cpu(), group).to(dev)
     counts = [torch.zeros(1, dtype=torch.long, device=v.device) for _ in range(world)]
     dist.all_gather(counts, torch.tensor([v.numel()], dtype=torch.long, device=v.device), group=group)
     m = int(max(int(c) for c in counts))
@@ -186,6 +219,21 @@ def band_mapping_loss(im, depth_sil, gt_im, gt_depth, band: Tuple[int, int], ran
     H, W = im.shape[-2], im.shape[-1]
     y0, y1 = pixel_rows(band, H)
     rows = slice(y0, y1)
+    if im.is_cuda:
+        # the HIP route: the band forms of the loss kernels (vtgs_slam_loss_band_*): SSIM over the band's rows with the
+        # neighbours' rows as context, masked sums, ONE 8-float all-reduce (global mask count), gradient images in 2 launches
+        from . import losses as _l
+        full = halo_exchange(im, band, H, rank, world, SSIM_HALO, group) if world > 1 else im
+        extra = None
+        if ignore_outlier_depth_loss:
+            gd, d = gt_depth[:, rows], depth_sil[0:1, rows].detach()
+            err = torch.abs(gd - d) * (gd > 0)
+            med = global_median(err, group) if world > 1 else err.median()
+            extra = torch.zeros((H, W), dtype=torch.float32, device=im.device)
+            extra[rows] = ((err < 50 * med) & (gd > 0))[0].to(torch.float32)
+        red = (lambda t: all_reduce_sum(t, group)) if world > 1 else None
+        return _l.band_loss(full, depth_sil, gt_im, gt_depth, (y0, y1), "mapping", w_im=w_im, w_depth=w_depth,
+                            extra_mask=extra, reduce=red, first_band=(rank == 0))
     depth = depth_sil[0:1, rows]
     unc = (depth_sil[2:3, rows] - depth ** 2).detach()
     gd = gt_depth[:, rows]
@@ -196,7 +244,7 @@ def band_mapping_loss(im, depth_sil, gt_im, gt_depth, band: Tuple[int, int], ran
         mask = gd > 0
     mask = (mask & ~torch.isnan(depth) & ~torch.isnan(unc)).detach()
     stats = torch.stack([mask.sum().to(torch.float32)])
-    dist.all_reduce(stats, group=group)                       # global mask count: the depth term is a MEAN over the frame
+    all_reduce_sum(stats, group)                       # global mask count: the depth term is a MEAN over the frame
     l_depth = torch.abs(gd - depth)[mask].sum() / stats[0]
     numel = float(3 * H * W)
     l1 = torch.abs(im[:, rows] - gt_im[:, rows]).sum() / numel
@@ -215,3 +263,58 @@ def band_mapping_loss(im, depth_sil, gt_im, gt_depth, band: Tuple[int, int], ran
     ssim_share = smap[0, :, y0 - c0:y1 - c0].sum() / numel
     const = 0.2 if rank == 0 else 0.0                          # the "1" of (1 - SSIM) belongs to one rank
     return w_im * (0.8 * l1 + const - 0.2 * ssim_share) + w_depth * l_depth
+
+
+def band_tracking_loss(im, depth_sil, gt_im, gt_depth, band: Tuple[int, int], sil_thres: float, w_im: float = 0.5,
+                       w_depth: float = 0.025, extra_mask=None, colour_over_all_pixels: bool = False):
+    """This rank's share of the tracking loss of get_loss (src/vtgaussian_slam.py:519-605): masked SUMS, so the shares of
+    all ranks add up to the full-frame loss without any exchange; the pose gradient is all-reduced afterwards (7 floats).
+    extra_mask: full-frame [H,W] / [1,H,W] (the TUM / ScanNet masks), only the band's rows are read."""
+    import torch
+    H = im.shape[-2]
+    y0, y1 = pixel_rows(band, H)
+    if im.is_cuda:
+        from . import losses as _l
+        return _l.band_loss(im, depth_sil, gt_im, gt_depth, (y0, y1), "tracking", sil_thres=sil_thres, w_im=w_im,
+                            w_depth=w_depth, extra_mask=extra_mask, colour_over_all_pixels=colour_over_all_pixels)
+    rows = slice(y0, y1)
+    depth, sil = depth_sil[0:1, rows], depth_sil[1:2, rows]
+    unc = (depth_sil[2:3, rows] - depth ** 2).detach()
+    gd = gt_depth[:, rows]
+    mask = (gd > 0) & ~torch.isnan(depth) & ~torch.isnan(unc) & (sil > sil_thres)
+    if extra_mask is not None:
+        mask = mask & extra_mask.reshape(1, H, -1)[:, rows].bool()
+    mask = mask.detach()
+    l_depth = torch.abs(gd - depth)[mask].sum()
+    diff = torch.abs(gt_im[:, rows] - im[:, rows])
+    l_im = diff.sum() if colour_over_all_pixels else diff[mask.expand_as(diff)].sum()
+    return w_im * l_im + w_depth * l_depth
+
+
+def band_silhouette_threshold(im, silhouette, gt_im, gt_depth, band: Tuple[int, int], world: int,
+                              candidates=(0.990, 0.993, 0.995, 0.997, 0.999), group=None):
+    """The threshold pick of tracking iteration 0 (src/vtgaussian_slam.py:472-510) over a partitioned frame: every rank
+    sums its band's squared error and pixel count per candidate (one kernel), ONE all-reduce of 2 x K floats, the same
+    arg-min on every rank."""
+    import torch
+    H = im.shape[-2]
+    y0, y1 = pixel_rows(band, H)
+    if im.is_cuda:
+        from . import losses as _l
+        sums = _l.silhouette_sweep(im, silhouette, gt_im, gt_depth, candidates, rows=(y0, y1))
+    else:
+        rows = slice(y0, y1)
+        sq = ((gt_im[:, rows] - im[:, rows]) ** 2).sum(0).to(torch.float64)
+        valid = gt_depth[0, rows] > 0
+        sums = torch.stack([torch.stack([sq[valid & (silhouette[rows] > c)].sum(),
+                                         (valid & (silhouette[rows] > c)).sum().to(torch.float64)]) for c in candidates])
+    if world > 1:
+        all_reduce_sum(sums, group)
+    sums = sums.cpu()
+    best, best_mse = candidates[0], float("inf")
+    for k, c in enumerate(candidates):
+        cnt = float(sums[k, 1])
+        mse = float(sums[k, 0]) / (3.0 * cnt) if cnt > 0 else float("inf")
+        if mse < best_mse:
+            best, best_mse = c, mse
+    return best
