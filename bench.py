@@ -206,7 +206,7 @@ def main():
         p_rank, r_rank = P, r16
     else:
         y0, y1 = tile_rows[0] * 16, min(tile_rows[1] * 16, H)
-        p_rank, r_rank = W * (y1 - y0), int(r16 * (tile_rows[1] - tile_rows[0]) / gy16)
+        p_rank, r_rank = W * (y1 - y0), r16             # (the op counts the tiles of what this band looked at)
     alg = kernel_algorithmic_bytes(N, p_rank, r_rank, grad_bytes)
     for fused in ("sort_tiles", "finalize_forward"):    # done inside the forward composite (no launch of their own)
         if kern and fused not in kern:

@@ -77,7 +77,28 @@ typedef struct VtgsForwardInfo {
   uint32_t overflow;         /* bit 0: instance_capacity too small; bit 1: tile_capacity too small.      */
                              /* Non-zero: the outputs are invalid                                        */
   uint32_t complete;         /* 1 once the record has been written (async mode: poll / wait on it)   */
+  uint64_t bin_slots_needed; /* bin slots in total if every bin were sized to its own list (planned bins,   */
+                             /* below): compare with tiles x tile_capacity to see what uniform bins waste   */
 } VtgsForwardInfo;
+
+/* ---- Planned bins ------------------------------------------------------------------------------------------------
+ * By default every 8x8 tile owns a bin of `tile_capacity` slots (21 bytes each): one pass, no scan -- but ONE dense
+ * tile (a pile of Gaussians along one ray) sizes every bin.  With planned bins the bins follow a PLAN: a persistent,
+ * caller-owned device array of vtgs_bin_plan_entries(width, height) offsets (bin t = [plan[t], plan[t+1])), which every
+ * forward rewrites from its own list lengths (half again as much + 16 per bin) for the NEXT forward of that view -- the
+ * hints a SLAM loop needs live on the device, per tile.  A forward whose lists outgrow the plan it was given reports
+ * overflow bit 1 as usual; the plan has then already been rewritten from the exact lengths, so the caller repeats the
+ * call (with a workspace of at least info.bin_slots_needed slots) and it fits.
+ *   vtgs_bin_plan_uniform   fills a plan with uniform bins (the first forward of a view).
+ *   vtgs_forward_planned / vtgs_forward_dual_planned   = vtgs_forward / vtgs_forward_dual with a plan.  Pass
+ *     tile_capacity = VTGS_TILE_CAPACITY_PLANNED | c  HERE AND TO EVERY CALL THAT TAKES THE WORKSPACE (backward, shared
+ *     render, workspace_bytes, debug_layout): the workspace then holds tiles x c slots in total, plan[tiles] must not
+ *     exceed that, and the forward keeps its own copy of the plan in the workspace for its backward.
+ * Planned bins cost one more dependent load per tile in every kernel that walks a list and always take the separate
+ * sort kernel: they are for skewed scenes, the default stays uniform.                                                  */
+#define VTGS_TILE_CAPACITY_PLANNED 0x80000000u
+uint32_t vtgs_bin_plan_entries(int32_t width, int32_t height);
+int vtgs_bin_plan_uniform(int32_t width, int32_t height, uint32_t slots_per_bin, uint32_t* bin_plan, void* stream);
 
 /* vtgs_forward flags */
 #define VTGS_FORWARD_SYNC  0u   /* wait for the forward, fill `info`, return VTGS_ERR_INSTANCE_OVERFLOW on overflow  */
@@ -121,7 +142,9 @@ size_t vtgs_backward_scratch_bytes(int32_t n, uint64_t instances);
 /* Forward.  Replaces `_C.rasterize_gaussians` for the colors_precomp + scales/rotations signature
  * the reference uses (shs / cov3D_precomp are rejected in the Python layer).
  *   means3D[N,3] opacities[N,1] colors[N,3] scales[N,3] rotations[N,4](w,x,y,z)
- *   out_color[3,H,W] out_depth[1,H,W] out_radii[N] (0 = culled)
+ *   out_color[3,H,W] out_depth[1,H,W] out_radii[N] (0 = culled; in band mode also 0 for a Gaussian that cannot
+ *   meet the band's rows -- it is skipped before it is projected -- so the radii of a partitioned frame are the
+ *   element-wise MAXIMUM over the ranks, and info.visible / tiles16_touched count what this band looked at)
  * `info`: host record (may be NULL with VTGS_FORWARD_SYNC); `flags`: VTGS_FORWARD_*.                    */
 int vtgs_forward(const VtgsCamera* cam, int32_t n,
                  const float* means3D, const float* colors, const float* opacities,
@@ -176,6 +199,15 @@ int vtgs_forward_dual(const VtgsCamera* cam, int32_t n, const float* means3D, co
                       float* out_color_b, int32_t* out_radii, void* workspace, size_t workspace_bytes,
                       uint64_t instance_capacity, uint32_t tile_capacity, VtgsForwardInfo* info, uint32_t flags,
                       void* stream);
+int vtgs_forward_planned(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* opacities,
+                         const float* scales, const float* rotations, float* out_color, float* out_depth, int32_t* out_radii,
+                         void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
+                         uint32_t* bin_plan, VtgsForwardInfo* info, uint32_t flags, void* stream);
+int vtgs_forward_dual_planned(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors_a,
+                              const float* colors_b, const float* opacities, const float* scales, const float* rotations,
+                              float* out_color_a, float* out_color_b, int32_t* out_radii, void* workspace,
+                              size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity, uint32_t* bin_plan,
+                              VtgsForwardInfo* info, uint32_t flags, void* stream);
 int vtgs_backward_dual(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors_a, const float* colors_b,
                        const float* opacities, const float* scales, const float* rotations, const float* out_color_a,
                        const float* out_color_b, const float* grad_color_a, const float* grad_color_b,
@@ -380,9 +412,11 @@ int vtgs_profile_collect(VtgsProfileEntry* out, int32_t max_entries, int32_t* n_
  * tiles8 (count, not an offset).  8x8 tiles are numbered row-major over ceil(W/8) x ceil(H/8); tile t owns
  * entries [t * tile_capacity, t * tile_capacity + count[t]).  out[8] = quadrant masks (tiles8 x tile_capacity x u8, bit q =
  * the entry's alpha >= 1/255 box reaches 4x4 quadrant q of its tile; written by the default forward), out[9] = 64 x u32
- * partial sums of the forward's queue steps (only with option VTGS_COUNT_STEPS = 1).                       */
+ * partial sums of the forward's queue steps (only with option VTGS_COUNT_STEPS = 1).  out[10] = the forward's copy of the
+ * bin plan ((tiles8 + 1) x u32; planned bins only: tile t then owns [plan[t], plan[t] + count[t]) instead), out[11] =
+ * bin slots in total (a count).                                                                              */
 int vtgs_debug_layout(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity, uint32_t tile_capacity,
-                      uint64_t out[10]);
+                      uint64_t out[12]);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,13 @@ void hostsim_backward(int W, int H, float tanfovx, float tanfovy, float mod, int
   }
 }
 
+// out[n] = 1 where a call over tile rows [row_b, row_e) may skip the Gaussian before projecting it (conservative y-cull)
+void hostsim_outside_rows(int W, int H, float tanfovx, float tanfovy, float mod, int rule, const float* V, const float* PV,
+                          int n, const float* means, const float* scales, int row_b, int row_e, uint8_t* out) {
+  const CamParams cam = make_cam(W, H, tanfovx, tanfovy, mod, rule, V, PV);
+  for (int i = 0; i < n; ++i) out[i] = outside_tile_rows(cam, means + 3 * i, scales + 3 * i, row_b, row_e) ? 1 : 0;
+}
+
 // min of the quadratic form over a rectangle (tile culling predicate)
 float hostsim_min_quadratic(float A, float B, float C, float u, float v, float px0, float py0, float px1, float py1) {
   return min_quadratic_over_rect(A, B, C, u, v, px0, py0, px1, py1);

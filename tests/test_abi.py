@@ -54,7 +54,7 @@ def test_version_strings_and_sizes(lib):
 def test_invalid_arguments_are_rejected_before_any_device_work(lib):
     assert lib.vtgs_forward(None, 0, *([None] * 9), ctypes.c_size_t(0), ctypes.c_uint64(1), 64, None, 0, None) == 1
     assert lib.vtgs_mark_visible(None, 0, None, None, None) == 1
-    out = (ctypes.c_uint64 * 10)()
+    out = (ctypes.c_uint64 * 12)()
     lib.vtgs_debug_layout.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
     assert lib.vtgs_debug_layout(5, 33, 17, 64, 32, out) == 0
     assert out[7] == 5 * 3 and out[3] == 256            # ceil(33/8) x ceil(17/8) tiles; tile_cnt right after counters
@@ -132,3 +132,21 @@ def test_header_is_plain_c99_and_links(tmp_path):
                     "-L", lib_dir, "-lvtgs", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert out[0] == "12"
+
+
+def test_planned_bins_entry_points_check_their_arguments(lib):
+    """Planned bins (include/vtgs.h): the plan has one offset per 8x8 tile + 1; the PLANNED bit of tile_capacity does not
+    change the workspace size; a planned forward without a plan (or a plan without the bit) is refused before any device work."""
+    PLANNED = 0x80000000
+    lib.vtgs_bin_plan_entries.restype = ctypes.c_uint32
+    assert lib.vtgs_bin_plan_entries(33, 17) == 5 * 3 + 1 and lib.vtgs_bin_plan_entries(0, 17) == 0
+    assert lib.vtgs_bin_plan_uniform(33, 17, 64, None, None) == 1
+    lib.vtgs_workspace_bytes.restype = ctypes.c_size_t
+    lib.vtgs_workspace_bytes.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_uint64, ctypes.c_uint32]
+    assert lib.vtgs_workspace_bytes(1000, 640, 480, 8000, 256) == lib.vtgs_workspace_bytes(1000, 640, 480, 8000, PLANNED | 256)
+    assert lib.vtgs_workspace_bytes(1000, 640, 480, 8000, PLANNED) == 0
+    out = (ctypes.c_uint64 * 12)()
+    lib.vtgs_debug_layout.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
+    assert lib.vtgs_debug_layout(5, 33, 17, 64, PLANNED | 32, out) == 0 and out[11] == 15 * 32 and out[10] > out[8]
+    args = [None, 0] + [None] * 9 + [ctypes.c_size_t(0), ctypes.c_uint64(1)]
+    assert lib.vtgs_forward_planned(*args, ctypes.c_uint32(PLANNED | 64), None, None, 0, None) == 1

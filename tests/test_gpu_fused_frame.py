@@ -87,6 +87,43 @@ def test_fused_render_frame_equals_unfused_chain(gpu_device, gaussians_grad, cam
         assert err <= 2e-3 * scale + 1e-7, (k, err, scale)
 
 
+@pytest.mark.parametrize("gaussians_grad,camera_grad", [(False, True), (True, True)])
+def test_render_frame_takes_anisotropic_maps(gpu_device, gaussians_grad, camera_grad):
+    """log_scales [N,3] (utils/slam_helpers.py:376-383: the rotations are composed with the camera's): render_frame -- and
+    with it the get_loss mirror -- serves them through the reference's own element-wise chain on the HIP operator; against
+    two independent renders of the same chain."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization.fused import render_frame
+    dev = gpu_device
+    params, cam = _params(dev, 9000, 160, 120, seed=7)
+    g = torch.Generator().manual_seed(17)
+    n = params["means3D"].shape[0]
+    params["log_scales"] = torch.nn.Parameter((params["log_scales"].detach().cpu() + 0.4 * torch.randn(n, 3, generator=g)).to(dev))
+    params["unnorm_rotations"] = torch.nn.Parameter(torch.randn(n, 4, generator=g).to(dev))
+    st = to_settings(cam, dev)
+    w2c = torch.eye(4, device=dev)
+    g1 = (torch.rand(3, 120, 160, generator=g) * 2 - 1).to(dev)
+    g2 = (torch.rand(3, 120, 160, generator=g) * 2 - 1).to(dev)
+    tg = sc.transform_to_frame(params, 1, gaussians_grad, camera_grad)
+    assert not torch.equal(tg["unnorm_rotations"], params["unnorm_rotations"])          # the quat_mult branch
+    im0, r0, _ = dgr.GaussianRasterizer(raster_settings=st)(**sc.transformed_params2rendervar(params, tg))
+    ds0, _, _ = dgr.GaussianRasterizer(raster_settings=st)(**sc.transformed_params2depthplussilhouette(params, w2c, tg))
+    ((im0 * g1).sum() + (ds0 * g2).sum()).backward()
+    ref = {k: (None if v.grad is None else v.grad.clone()) for k, v in params.items()}
+    for v in params.values():
+        v.grad = None
+    im1, ds1, r1 = render_frame(params, 1, st, w2c, gaussians_grad, camera_grad)
+    ((im1 * g1).sum() + (ds1 * g2).sum()).backward()
+    assert torch.equal(r0, r1) and torch.equal(im0, im1) and torch.equal(ds0, ds1)     # same kernels, second render over the first's bins
+    for k, v in params.items():
+        if ref[k] is None:
+            assert v.grad is None or float(v.grad.abs().max()) == 0, k
+            continue
+        scale = ref[k].abs().max().item()
+        assert (ref[k] - v.grad).abs().max().item() <= 1e-4 * scale + 1e-7, k
+    assert ref["cam_unnorm_rots"].abs().max().item() > 0
+
+
 @pytest.mark.parametrize("shape,n,opacity_boost", [((160, 120), 12000, 0.0), ((333, 201), 60000, 0.0), ((96, 64), 40000, 6.0)])
 def test_dual_composite_equals_two_renders(gpu_device, monkeypatch, shape, n, opacity_boost):
     """vtgs_forward_dual / vtgs_backward_dual (one six-channel pass) against vtgs_forward + vtgs_forward_shared + two
@@ -186,11 +223,12 @@ def test_render_frame_bands_add_up_to_the_full_frame(gpu_device):
         y0, y1 = pixel_rows(band, H)
         assert float(im[:, :y0].abs().max() if y0 else 0) == 0 and float(im[:, y1:].abs().max() if y1 < H else 0) == 0
         assert torch.equal(im[:, y0:y1], im_f[:, y0:y1]) and torch.equal(ds[:, y0:y1], ds_f[:, y0:y1])
-        assert torch.equal(r, r_f)                                   # every rank projects every Gaussian: radii complete
+        assert bool(((r == 0) | (r == r_f)).all())                   # band-local radii: complete as the maximum over the ranks
+        r_max = r.clone() if band == all_bands(H, 3)[0] else torch.maximum(r_max, r)
         im_s += im; ds_s += ds
         for k in keys:
             g_s[k] += gb[k]
-    assert torch.equal(im_s, im_f) and torch.equal(ds_s, ds_f)
+    assert torch.equal(im_s, im_f) and torch.equal(ds_s, ds_f) and torch.equal(r_max, r_f)
     for k in keys:
         scale = g_f[k].abs().max().item()
         assert (g_s[k] - g_f[k]).abs().max().item() <= 2e-5 * scale + 1e-9, (k, (g_s[k] - g_f[k]).abs().max().item(), scale)

@@ -126,3 +126,31 @@ def test_min_quadratic_over_rect_is_a_lower_bound(hostsim):
         dx, dy = u - xs, v - ys
         dense = (0.5 * (a * dx * dx + c * dy * dy) + b * dx * dy).min()
         assert q >= dense - 0.05 * abs(dense) - 1e-2
+
+
+@pytest.mark.parametrize("aniso,seed,rule", [(False, 11, "3sigma"), (True, 12, "3sigma"), (True, 13, "opacity")])
+def test_row_cull_of_the_tile_row_partition_is_conservative(hostsim, aniso, seed, rule):
+    """outside_tile_rows (the early exit of project_and_bin on a rank of the tile-row partition) may only skip a Gaussian
+    whose tile rectangle misses the band's rows -- and it should skip nearly all of those."""
+    sc, cam = go.random_scene(6000, 200, 136, seed=seed, anisotropic=aniso, w2c=_random_w2c(seed))
+    n = sc["means3D"].shape[0]
+    args, keep = _cam_args(cam, {"3sigma": 0, "opacity": 1}[rule])
+    arr = {k: v.numpy().astype(np.float32).copy() for k, v in sc.items()}
+    arr["scales"][:50] *= 30.0                                   # a few splats that span many rows
+    proj = np.zeros((n, 12), dtype=np.float32)
+    hostsim.hostsim_project(*args, ctypes.c_int(n), _fp(arr["means3D"]), _fp(arr["scales"]), _fp(arr["rotations"]),
+                            _fp(arr["opacities"]), _fp(proj))
+    vis, y0, y1 = proj[:, 11] > 0, proj[:, 8], proj[:, 10]
+    gy16 = (cam.image_height + 15) // 16
+    skipped_total = missed_total = 0
+    for b, e in ((0, 2), (2, 5), (5, gy16), (3, 4), (0, gy16)):
+        out = np.zeros(n, dtype=np.uint8)
+        hostsim.hostsim_outside_rows(*args, ctypes.c_int(n), _fp(arr["means3D"]), _fp(arr["scales"]), ctypes.c_int(b),
+                                     ctypes.c_int(e), _fp(out))
+        touches = vis & (y0 < e) & (y1 > b)
+        assert not (touches & (out > 0)).any(), f"rows {b}..{e}: a Gaussian of the band was skipped"
+        skipped_total += int((out > 0).sum())
+        missed_total += int((vis & ~touches & (out == 0)).sum())     # visible, beside the band, still projected
+        if (b, e) == (0, gy16):
+            assert (out[vis] == 0).all()
+    assert skipped_total > 3 * missed_total, (skipped_total, missed_total)   # the bound is loose by design, not useless

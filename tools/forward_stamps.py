@@ -21,7 +21,7 @@ with torch.no_grad():
         rast(**leaves)
 torch.cuda.synchronize()
 fs = rast._last_state
-out = (ctypes.c_uint64 * 10)()
+out = (ctypes.c_uint64 * 12)()
 dgr._lib.vtgs_debug_layout(fs.n, fs.cam.W, fs.cam.H, fs.capacity, fs.tile_cap, out)
 tiles = int(out[7])
 st = fs.workspace[int(out[9]) + 256: int(out[9]) + 256 + 32 * tiles].view(torch.int32).reshape(tiles, 8).cpu().double()

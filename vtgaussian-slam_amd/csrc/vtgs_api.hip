@@ -14,10 +14,10 @@ __global__ void project_and_bin(CamScalars, const float*, const float*, int, con
                                 const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*,
                                 Counters*, BlockStats*, unsigned long long, uint32_t);
 __global__ void finalize_forward(const uint32_t*, uint32_t, Counters*, unsigned long long, uint32_t, const BlockStats*,
-                                 uint32_t, VtgsForwardInfo*);
+                                 uint32_t, VtgsForwardInfo*, const uint32_t*, uint32_t*);
 template <bool WIDE>
 __global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t,
-                           const Counters*, int);
+                           const Counters*, int, const uint32_t*, uint32_t);
 __global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                   const GeomRec*, const float*, float*, float*, float*, const Counters*);
 template <int WAVES, bool DUAL>
@@ -47,6 +47,10 @@ __global__ void gather_splat_grads(CamScalars, const float*, const float*, int, 
                                    const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*,
                                    float*, const Counters*, float*, FrameEpilogue);
 __global__ void mark_visible_kernel(const float*, int, const float*, uint8_t*);
+__global__ void uniform_plan_kernel(uint32_t* plan, uint32_t entries, uint32_t slots_per_bin) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < entries) plan[i] = i * slots_per_bin;
+}
 }  // namespace vtgs
 
 using namespace vtgs;
@@ -109,6 +113,7 @@ static CamScalars scalars_of(const VtgsCamera* cam, int row8_begin, int row8_end
   cs.tanfovx = cam->tanfovx; cs.tanfovy = cam->tanfovy; cs.mod = cam->scale_modifier;
   cs.radius_rule = cam->radius_rule;
   cs.row8_begin = row8_begin; cs.row8_end = row8_end;
+  cs.bin_plan = nullptr; cs.bin_limit = 0u;                  // planned bins: set by the caller once the workspace layout is known
   return cs;
 }
 
@@ -131,7 +136,7 @@ const char* vtgs_strerror(int status) {
 const char* vtgs_last_hip_error(void) { return g_hip_err; }
 
 size_t vtgs_workspace_bytes(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity, uint32_t tile_capacity) {
-  if (n < 0 || width <= 0 || height <= 0 || tile_capacity == 0) return 0;
+  if (n < 0 || width <= 0 || height <= 0 || (tile_capacity & ~VTGS_TILE_CAPACITY_PLANNED) == 0) return 0;
   return make_layout(n, width, height, instance_capacity, tile_capacity).total;
 }
 
@@ -243,9 +248,10 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
                         const float* opacities, const float* scales, const float* rotations, float* out_color,
                         float* out_depth, float* out_color_b, int32_t* out_radii, void* workspace, size_t workspace_bytes,
                         uint64_t instance_capacity, uint32_t tile_capacity, VtgsForwardInfo* info, uint32_t flags,
-                        void* stream, bool dual) {
+                        void* stream, bool dual, uint32_t* bin_plan = nullptr) {
   if (!cam_ok(cam) || n < 0 || !out_color || (dual ? !out_color_b : !out_depth) || !workspace || instance_capacity == 0 ||
-      instance_capacity > 0xFFFFFFFFull || tile_capacity == 0)
+      instance_capacity > 0xFFFFFFFFull || (tile_capacity & ~VTGS_TILE_CAPACITY_PLANNED) == 0 ||
+      ((tile_capacity & VTGS_TILE_CAPACITY_PLANNED) != 0) != (bin_plan != nullptr))
     return VTGS_ERR_INVALID_ARGUMENT;
   if (n > 0 && (!means3D || !colors || (dual && !colors_b) || !opacities || !scales || !rotations || !out_radii))
     return VTGS_ERR_INVALID_ARGUMENT;
@@ -256,8 +262,15 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   if ((uint64_t)L.tiles8 * L.tile_cap >= (1ull << 32)) return VTGS_ERR_INVALID_ARGUMENT;   // bin offsets are 32-bit in the composites
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
-  const CamScalars cs = scalars_of(cam, r8b, r8e);
+  CamScalars cs = scalars_of(cam, r8b, r8e);
   Counters* ctr = (Counters*)(ws + L.counters);
+  if (L.planned) {
+    // this forward (and its backward) bins into a COPY of the caller's plan: the persistent one is rewritten for the next
+    // forward by finalize_forward.  A plan that does not fit the workspace (its total is on the device) makes every bin
+    // look empty-capacity to nobody: finalize_forward flags it (plan[tiles] > slots) like any other overflow.
+    VTGS_HIP(hipMemcpyAsync(ws + L.plan, bin_plan, ((size_t)L.tiles8 + 1) * 4, hipMemcpyDeviceToDevice, st));
+    cs.bin_plan = (const uint32_t*)(ws + L.plan); cs.bin_limit = L.tiles8 * L.tile_cap;
+  }
 
   // counters + per-tile list lengths in one fill (adjacent in the layout, padded to 256 B)
   VTGS_HIP(hipMemsetAsync(ws + L.counters, 0, 256 + align256(((size_t)L.tiles8 + 1) * 4), st));
@@ -319,29 +332,30 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   // The quadrant-queue forward sorts its own tile's list when no bin can hold more than the 1024 entries one wavefront
   // takes (VTGS_SORT_FUSED, default 1), and its first workgroup does finalize_forward's job: nothing is launched between
   // the binning and the composite.
-  const bool fused_sort = option(OPT_FWD_IMPL) == 3 && option(OPT_SORT_FUSED) == 1 && L.tile_cap <= 1024u;
+  const bool fused_sort = option(OPT_FWD_IMPL) == 3 && option(OPT_SORT_FUSED) == 1 && L.tile_cap <= 1024u && !L.planned;
   FinalizeArgs fin;
   fin.tile_cnt = (const uint32_t*)(ws + L.tile_cnt); fin.tiles = L.tiles8; fin.ctr = ctr;
   fin.capacity = (unsigned long long)instance_capacity; fin.tile_cap = L.tile_cap;
   fin.block_stats = (const BlockStats*)(ws + L.block_stats); fin.nblocks = (uint32_t)((n + 1023) / 1024);
   fin.host_record = host_record;
+  fin.plan = cs.bin_plan; fin.plan_next = L.planned ? bin_plan : nullptr;
   if (!fused_sort) {
     ProfScope ps__("finalize_forward", st);
     hipLaunchKernelGGL(finalize_forward, dim3(1), dim3(1024), 0, st, fin.tile_cnt, fin.tiles, ctr, fin.capacity, fin.tile_cap,
-                       fin.block_stats, fin.nblocks, host_record);
+                       fin.block_stats, fin.nblocks, host_record, fin.plan, fin.plan_next);
   }
   VTGS_HIP(hipGetLastError());
   if (!fused_sort) {
     ProfScope ps__("sort_tiles", st);
     // lists cannot be longer than the bin capacity: the wide (32 keys per lane) form is only worth its registers beyond 1024
-    if (packed && L.tile_cap > 1024u)
+    if (packed && (L.tile_cap > 1024u || L.planned))
       hipLaunchKernelGGL(sort_tiles<true>, dim3((band_tiles + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
                          (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
-                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed);
+                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed, cs.bin_plan, cs.bin_limit);
     else
       hipLaunchKernelGGL(sort_tiles<false>, dim3((band_tiles + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
                          (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
-                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed);
+                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed, cs.bin_plan, cs.bin_limit);
   }
   VTGS_HIP(hipGetLastError());
   int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st,
@@ -349,7 +363,7 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
                                     fused_sort ? (packed ? 1 : 2) : 0, fin, true);
   if (rc != VTGS_OK) return rc;
   // result record: assembled on the device by finalize_forward at byte 64 of the counters block
-  static_assert(sizeof(VtgsForwardInfo) == 40, "VtgsForwardInfo layout is mirrored in Counters");
+  static_assert(sizeof(VtgsForwardInfo) == 48, "VtgsForwardInfo layout is mirrored in Counters");
   const char* image = (const char*)ctr + offsetof(Counters, info_instances);
   if (flags & VTGS_FORWARD_ASYNC) {
     if (!info) return VTGS_ERR_INVALID_ARGUMENT;
@@ -404,18 +418,53 @@ int vtgs_forward_dual(const VtgsCamera* cam, int32_t n, const float* means3D, co
                       out_radii, workspace, workspace_bytes, instance_capacity, tile_capacity, info, flags, stream, true);
 }
 
+int vtgs_forward_planned(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* opacities,
+                         const float* scales, const float* rotations, float* out_color, float* out_depth, int32_t* out_radii,
+                         void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
+                         uint32_t* bin_plan, VtgsForwardInfo* info, uint32_t flags, void* stream) {
+  return forward_impl(cam, n, means3D, colors, nullptr, opacities, scales, rotations, out_color, out_depth, nullptr,
+                      out_radii, workspace, workspace_bytes, instance_capacity, tile_capacity, info, flags, stream, false,
+                      bin_plan);
+}
+
+int vtgs_forward_dual_planned(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors_a,
+                              const float* colors_b, const float* opacities, const float* scales, const float* rotations,
+                              float* out_color_a, float* out_color_b, int32_t* out_radii, void* workspace,
+                              size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity, uint32_t* bin_plan,
+                              VtgsForwardInfo* info, uint32_t flags, void* stream) {
+  return forward_impl(cam, n, means3D, colors_a, colors_b, opacities, scales, rotations, out_color_a, nullptr, out_color_b,
+                      out_radii, workspace, workspace_bytes, instance_capacity, tile_capacity, info, flags, stream, true,
+                      bin_plan);
+}
+
+uint32_t vtgs_bin_plan_entries(int32_t width, int32_t height) {
+  if (width <= 0 || height <= 0) return 0;
+  return (uint32_t)((width + kSubTile - 1) / kSubTile) * (uint32_t)((height + kSubTile - 1) / kSubTile) + 1u;
+}
+
+int vtgs_bin_plan_uniform(int32_t width, int32_t height, uint32_t slots_per_bin, uint32_t* bin_plan, void* stream) {
+  const uint32_t entries = vtgs_bin_plan_entries(width, height);
+  if (!entries || !bin_plan || slots_per_bin == 0 || (uint64_t)(entries - 1) * slots_per_bin >= (1ull << 31))
+    return VTGS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(uniform_plan_kernel, dim3((entries + 255) / 256), dim3(256), 0, (hipStream_t)stream, bin_plan, entries,
+                     slots_per_bin);
+  VTGS_HIP(hipGetLastError());
+  return VTGS_OK;
+}
+
 int vtgs_forward_shared(const VtgsCamera* cam, int32_t n, const float* colors, float* out_color, float* out_depth,
                         const void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
                         float* image_state, void* stream) {
   if (!cam_ok(cam) || n < 0 || !colors || !out_color || !out_depth || !workspace || !image_state ||
-      instance_capacity == 0 || instance_capacity > 0xFFFFFFFFull || tile_capacity == 0)
+      instance_capacity == 0 || instance_capacity > 0xFFFFFFFFull || (tile_capacity & ~VTGS_TILE_CAPACITY_PLANNED) == 0)
     return VTGS_ERR_INVALID_ARGUMENT;
   int r8b, r8e, rows16, row16_0;
   if (!band_of(cam, &r8b, &r8e, &rows16, &row16_0)) return VTGS_ERR_INVALID_ARGUMENT;
   const WsLayout L = make_layout(n, cam->image_width, cam->image_height, instance_capacity, tile_capacity);
   if (workspace_bytes < L.total) return VTGS_ERR_WORKSPACE_TOO_SMALL;
   hipStream_t st = (hipStream_t)stream;
-  const CamScalars cs = scalars_of(cam, r8b, r8e);
+  CamScalars cs = scalars_of(cam, r8b, r8e);
+  if (L.planned) { cs.bin_plan = (const uint32_t*)((const char*)workspace + L.plan); cs.bin_limit = L.tiles8 * L.tile_cap; }
   if (rows16 * kBinTile < cam->image_height || cam->tile_row_begin != 0) {
     const size_t P = (size_t)cam->image_width * cam->image_height;
     VTGS_HIP(hipMemsetAsync(out_color, 0, 3 * P * sizeof(float), st));
@@ -432,7 +481,7 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
                          float* g_colors, float* g_colors_b, float* g_opacities, float* g_scales, float* g_rotations,
                          void* stream, bool dual, const FrameEpilogue* frame = nullptr) {
   if (!cam_ok(cam) || n < 0 || !out_color || !grad_color || !workspace || !scratch || instance_capacity == 0 ||
-      instance_capacity > 0xFFFFFFFFull || tile_capacity == 0 || (dual && (!out_color_b || !grad_color_b)) || (frame && !dual))
+      instance_capacity > 0xFFFFFFFFull || (tile_capacity & ~VTGS_TILE_CAPACITY_PLANNED) == 0 || (dual && (!out_color_b || !grad_color_b)) || (frame && !dual))
     return VTGS_ERR_INVALID_ARGUMENT;
   if (n > 0 && (!means3D || !colors || !opacities || !scales || !rotations || (dual && !colors_b)))
     return VTGS_ERR_INVALID_ARGUMENT;
@@ -455,7 +504,8 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
   if (scratch_bytes < (dual ? kGradRecDual : kGradRec) * sizeof(float)) return VTGS_ERR_INVALID_ARGUMENT;
   hipStream_t st = (hipStream_t)stream;
   const char* ws = (const char*)workspace;
-  const CamScalars cs = scalars_of(cam, r8b, r8e);
+  CamScalars cs = scalars_of(cam, r8b, r8e);
+  if (L.planned) { cs.bin_plan = (const uint32_t*)(ws + L.plan); cs.bin_limit = L.tiles8 * L.tile_cap; }
   const float* state = image_state ? image_state : (const float*)(ws + L.final_T);
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   const uint32_t nblk16 = (uint32_t)(gx16 * rows16);
@@ -593,11 +643,12 @@ int vtgs_profile_collect(VtgsProfileEntry* out, int32_t max_entries, int32_t* n_
 }
 
 int vtgs_debug_layout(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity, uint32_t tile_capacity,
-                      uint64_t out[10]) {
-  if (n < 0 || width <= 0 || height <= 0 || !out || tile_capacity == 0) return VTGS_ERR_INVALID_ARGUMENT;
+                      uint64_t out[12]) {
+  if (n < 0 || width <= 0 || height <= 0 || !out || (tile_capacity & ~VTGS_TILE_CAPACITY_PLANNED) == 0) return VTGS_ERR_INVALID_ARGUMENT;
   const WsLayout L = make_layout(n, width, height, instance_capacity, tile_capacity);
   out[0] = L.counters; out[1] = L.geom; out[2] = L.gaux; out[3] = L.tile_cnt; out[4] = L.sorted_gid;
   out[5] = L.sorted_inst; out[6] = L.final_T; out[7] = L.tiles8; out[8] = L.qmask; out[9] = L.dbg;
+  out[10] = L.plan; out[11] = (uint64_t)L.tiles8 * L.tile_cap;
   return VTGS_OK;
 }
 

@@ -154,11 +154,27 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
   if (valid) {
     const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
     const float sc[3] = {scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
-    const float4 q4 = reinterpret_cast<const float4*>(rotations)[gid];
-    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-    op = opacities[gid];
-    vis = project_splat(cam, mean, sc, q, op, sp, aux);
+    // a rank of the tile-row partition skips what cannot meet its rows before the rotation / opacity loads and the covariance
+    // algebra (7/8 of the Gaussians at 8 ranks; view-tied maps are stored in raster order, so whole wavefronts leave here).
+    // Such a Gaussian reports radius 0 on this rank: radii are complete as the MAXIMUM over the ranks.
+    const bool banded = cam.row8_begin > 0 || cam.row8_end < cam.gy8;          // wave-uniform
+    if (!(banded && outside_tile_rows(cam, mean, sc, cam.row8_begin / 2, (cam.row8_end + 1) / 2))) {
+      const float4 q4 = reinterpret_cast<const float4*>(rotations)[gid];
+      const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+      op = opacities[gid];
+      vis = project_splat(cam, mean, sc, q, op, sp, aux);
+    }
     radii[gid] = vis ? sp.radius : 0;
+  }
+  if (cam.row8_begin > 0 || cam.row8_end < cam.gy8) {           // (kernel-uniform) a rank of the tile-row partition:
+    // view-tied maps are stored in raster order, so most WORKGROUPS hold nothing that meets the band -- those leave here,
+    // after one trip to memory, instead of walking the reservation chain (three barriers, the instance-range atomic, the
+    // per-tile reservations) with nothing to reserve
+    if (__syncthreads_or(vis ? 1 : 0) == 0) {
+      if (valid) gaux[gid] = GaussAux{0u, 0u};
+      if (threadIdx.x == 0) { BlockStats bs; bs.visible = 0; bs.pad = 0; bs.r16 = 0; block_stats[blockIdx.x] = bs; }
+      return;
+    }
   }
   // alpha = o*G >= 1/255 somewhere  <=>  q <= ln(255 o); slack keeps the test conservative
   float tau = -1.f;
@@ -249,8 +265,9 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
         const int tile = tty * cam.gx8 + ttx;
         const uint32_t slot = atomicAdd(&lds_tile[tile - tile0], 1u);
         const unsigned long long id = (unsigned long long)inst_base + ord;
-        if (id < capacity && slot < tile_cap) {                  // an overflowing bin / id is dropped and flagged later
-          const size_t pos = (size_t)tile * tile_cap + slot;
+        const BinRange br = bin_range(cs, (uint32_t)tile, tile_cap);
+        if (id < capacity && slot < br.cap) {                    // an overflowing bin / id is dropped and flagged later
+          const size_t pos = (size_t)br.s + slot;
           keys[pos] = key;
           vals[pos] = (uint32_t)id;
         }
@@ -265,8 +282,9 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     const uint32_t slot = reserve_resolve(r);
     if (r.act) {
       const unsigned long long id = (unsigned long long)inst_base + ord;
-      if (id < capacity && slot < tile_cap) {                  // an overflowing bin / id is dropped and flagged later
-        const size_t pos = (size_t)r.tile * tile_cap + slot;
+      const BinRange br = bin_range(cs, (uint32_t)r.tile, tile_cap);
+      if (id < capacity && slot < br.cap) {                    // an overflowing bin / id is dropped and flagged later
+        const size_t pos = (size_t)br.s + slot;
         keys[pos] = key;
         vals[pos] = (uint32_t)id;
       }
@@ -338,8 +356,9 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
         const uint32_t slot = atomicAdd(&tile_cnt[tile], 1u);
         const uint32_t rank = (uint32_t)__builtin_popcountll(hb & ((1ull << l) - 1ull));
         const unsigned long long id = (unsigned long long)base + done + rank;            // raster order of the walk
-        if (id < capacity && slot < tile_cap) {
-          const size_t pos = (size_t)tile * tile_cap + slot;
+        const BinRange br = bin_range(cs, (uint32_t)tile, tile_cap);
+        if (id < capacity && slot < br.cap) {
+          const size_t pos = (size_t)br.s + slot;
           keys[pos] = key_src;
           vals[pos] = (uint32_t)id;
         }
@@ -366,8 +385,9 @@ template __global__ void project_and_bin<true>(CamScalars, const float*, const f
 __global__ __launch_bounds__(1024) void finalize_forward(const uint32_t* __restrict__ tile_cnt, uint32_t tiles,
                                                          Counters* __restrict__ ctr, unsigned long long capacity,
                                                          uint32_t tile_cap, const BlockStats* __restrict__ block_stats,
-                                                         uint32_t nblocks, VtgsForwardInfo* host_record) {
-  finalize_block<1024>(tile_cnt, tiles, ctr, capacity, tile_cap, block_stats, nblocks, host_record);
+                                                         uint32_t nblocks, VtgsForwardInfo* host_record,
+                                                         const uint32_t* __restrict__ plan, uint32_t* __restrict__ plan_next) {
+  finalize_block<1024>(tile_cnt, tiles, ctr, capacity, tile_cap, block_stats, nblocks, host_record, plan, plan_next);
 }
 
 __device__ __forceinline__ void order_pair(unsigned long long* k, uint32_t* v, uint32_t i, uint32_t p) {
@@ -408,7 +428,8 @@ template <bool WIDE>
 __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ tile_cnt, unsigned long long* __restrict__ keys,
                                                   uint32_t* __restrict__ vals, uint32_t* __restrict__ sorted_gid,
                                                   uint32_t* __restrict__ sorted_inst, uint32_t tile_first, uint32_t tiles,
-                                                  uint32_t tile_cap, const Counters* __restrict__ ctr, int packed) {
+                                                  uint32_t tile_cap, const Counters* __restrict__ ctr, int packed,
+                                                  const uint32_t* __restrict__ plan, uint32_t bin_limit) {
   __shared__ unsigned long long sk[kSortLds];
   __shared__ uint32_t sv[kSortLds];
   if (ctr->overflow) return;                    // some bin slots were never written: nothing valid to sort
@@ -419,8 +440,9 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
   {
     const uint32_t tile = tile_first + 4u * b + (uint32_t)wv;
     if (4u * b + (uint32_t)wv < tiles) {
-      const size_t s = (size_t)tile * tile_cap;
-      const uint32_t L = min(tile_cnt[tile], tile_cap);
+      const BinRange br = bin_range(plan, bin_limit, tile, tile_cap);
+      const size_t s = (size_t)br.s;
+      const uint32_t L = min(tile_cnt[tile], br.cap);
       if (L == 1u) {
         if (lane == 0) { sorted_gid[s] = (uint32_t)keys[s]; sorted_inst[s] = vals[s]; }
       } else if (packed) {
@@ -444,8 +466,9 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
   for (uint32_t q = 0; q < 4u; ++q) {
     const uint32_t tile = tile_first + 4u * b + q;
     if (4u * b + q >= tiles) break;
-    const size_t s = (size_t)tile * tile_cap;
-    const uint32_t L = min(tile_cnt[tile], tile_cap);
+    const BinRange br = bin_range(plan, bin_limit, tile, tile_cap);
+    const size_t s = (size_t)br.s;
+    const uint32_t L = min(tile_cnt[tile], br.cap);
     if (L <= (uint32_t)((WIDE && packed) ? kWaveSortMaxPacked : kWaveSortMax)) continue;
     uint32_t n2 = 1;
     while (n2 < L) n2 <<= 1;
@@ -462,7 +485,7 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
   }
 }
 
-template __global__ void sort_tiles<false>(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, const Counters*, int);
-template __global__ void sort_tiles<true>(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, const Counters*, int);
+template __global__ void sort_tiles<false>(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, const Counters*, int, const uint32_t*, uint32_t);
+template __global__ void sort_tiles<true>(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, const Counters*, int, const uint32_t*, uint32_t);
 
 }  // namespace vtgs

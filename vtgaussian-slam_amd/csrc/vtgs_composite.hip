@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void composite_forward(
   if (!tc.tile_ok) return;                       // wave-uniform
   const int l = lane_id();
   const float pxf = (float)tc.px, pyf = (float)tc.py;
-  const uint32_t s = (uint32_t)tc.tile * tile_cap, e = s + min(tile_cnt[tc.tile], tile_cap);
+  const BinRange br = bin_range(cs, (uint32_t)tc.tile, tile_cap);
+  const uint32_t s = br.s, e = s + min(tile_cnt[tc.tile], br.cap);
 
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
   bool done = !tc.inside;
@@ -246,7 +247,8 @@ __global__ __launch_bounds__(64 * WAVES, DUAL ? 3 : 4) void composite_forward_mx
   const float cx = (float)tx0 + 3.5f, cy = (float)ty0 + 3.5f;
   const float X = (float)(l & 7) - 3.5f, Y = (float)(l >> 3) - 3.5f;
   const float Phi[6] = {1.f, X, Y, X * X, X * Y, Y * Y};
-  const uint32_t s = (uint32_t)tc.tile * tile_cap, e = s + min(tile_cnt[tc.tile], tile_cap);
+  const BinRange br = bin_range(cs, (uint32_t)tc.tile, tile_cap);
+  const uint32_t s = br.s, e = s + min(tile_cnt[tc.tile], br.cap);
 
   MxFwdState<DUAL> st;
 #pragma unroll
@@ -407,7 +409,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_forward_px(
   const float cx = (float)tx0 + 3.5f, cy = (float)ty0 + 3.5f;
   const float X = (float)(l & 7) - 3.5f, Y = (float)(l >> 3) - 3.5f;
   const float Phi[6] = {1.f, X, Y, X * X, X * Y, Y * Y};
-  const uint32_t s = (uint32_t)tc.tile * tile_cap, e = s + min(tile_cnt[tc.tile], tile_cap);
+  const BinRange br = bin_range(cs, (uint32_t)tc.tile, tile_cap);
+  const uint32_t s = br.s, e = s + min(tile_cnt[tc.tile], br.cap);
 
   float T = 1.f, C[NC];
   bool done = !tc.inside, exact = false;
@@ -485,7 +488,8 @@ __global__ __launch_bounds__(256) void composite_backward(
   float* __restrict__ Us = lds[wv][0];
   float* __restrict__ Ws = lds[wv][1];
   const float pxf = (float)tc.px, pyf = (float)tc.py;
-  const uint32_t s = (uint32_t)tc.tile * tile_cap, e = s + min(tile_cnt[tc.tile], tile_cap);
+  const BinRange br = bin_range(cs, (uint32_t)tc.tile, tile_cap);
+  const uint32_t s = br.s, e = s + min(tile_cnt[tc.tile], br.cap);
   if (s == e) return;
   const size_t P = (size_t)cs.W * cs.H;
 
@@ -904,8 +908,9 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   float4* lds_xch = lds_xch_all[wv];
   float* __restrict__ Us = lds_uw[wv][0];
   float* __restrict__ Ws = lds_uw[wv][1];
-  const uint32_t s = (uint32_t)tc.tile * tile_cap;
-  const uint32_t list_len = min(tile_cnt[tc.tile], tile_cap);
+  const BinRange br = bin_range(cs, (uint32_t)tc.tile, tile_cap);
+  const uint32_t s = br.s;
+  const uint32_t list_len = min(tile_cnt[tc.tile], br.cap);
   // first list entries (a bin holds at least 64 slots: reading past a short list stays inside the workspace; masked later)
   uint32_t gid_first = sorted_gid[s + (uint32_t)lane_id()], inst_first = sorted_inst[s + (uint32_t)lane_id()];
   const size_t P = (size_t)cs.W * cs.H;

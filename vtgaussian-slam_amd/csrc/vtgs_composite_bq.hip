@@ -174,8 +174,9 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
   const bool inside = tile_ok && pxx < cs.W && pyy < cs.H;
   const size_t P = (size_t)cs.W * cs.H;
   const uint32_t overflow = ctr->overflow, masks_valid = ctr->qmask_valid;
-  const uint32_t s = (uint32_t)tile * tile_cap;
-  const uint32_t list_len = min(tile_cnt[tile], tile_cap);
+  const BinRange br = bin_range(cs, (uint32_t)tile, tile_cap);
+  const uint32_t s = br.s;
+  const uint32_t list_len = min(tile_cnt[tile], br.cap);
   float gown[3] = {0.f, 0.f, 0.f}, oc[3] = {0.f, 0.f, 0.f}, Tf = 0.f;
   if (inside) {
     const size_t pix = (size_t)pyy * cs.W + pxx;

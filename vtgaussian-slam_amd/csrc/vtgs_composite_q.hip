@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     // every wavefront decides for itself whether its bin is safe to read: slots below min(count, capacity) are all
     // written unless the INSTANCE capacity overflowed (then an entry may have been dropped after its slot was taken).
     if (blockIdx.x == 0u) finalize_block<256>(fin.tile_cnt, fin.tiles, fin.ctr, fin.capacity, fin.tile_cap, fin.block_stats,
-                                              fin.nblocks, fin.host_record);
+                                              fin.nblocks, fin.host_record, fin.plan, fin.plan_next);
     if ((unsigned long long)ctr->inst_total > fin.capacity) return;
   } else if (ctr->overflow) {
     return;                                                     // bins hold unwritten slots after an overflow
@@ -259,7 +259,8 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
   const float cx = (float)(qc.px - lx) + 3.5f, cy = (float)(qc.py - ly) + 3.5f;
   const float X = (float)lx - 3.5f, Y = (float)ly - 3.5f;
   const float Phi[6] = {1.f, X, Y, X * X, X * Y, Y * Y};
-  const uint32_t s = (uint32_t)qc.tile * tile_cap, e = s + min(tile_cnt[qc.tile], tile_cap);
+  const BinRange br = bin_range(cs, (uint32_t)qc.tile, tile_cap);
+  const uint32_t s = br.s, e = s + min(tile_cnt[qc.tile], br.cap);
   // sort_mode != 0 (the host picks it when no bin can hold more than 1024 entries): the wavefront sorts its own tile's list
   // here -- 1 = payload packed into the key, 2 = key + value -- instead of a sort kernel before this one: one launch less,
   // and the list's trip through memory overlaps with the other wavefronts' compositing.  The sorted list still goes to

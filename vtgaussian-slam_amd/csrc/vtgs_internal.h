@@ -35,6 +35,7 @@ struct Counters {
   // byte 64: image of the public VtgsForwardInfo, written by finalize_forward, copied to the host by vtgs_forward
   unsigned long long info_instances, info_needed, info_r16;
   uint32_t info_visible, info_max_list, info_overflow, info_complete;
+  unsigned long long info_slots;
 };
 static_assert(sizeof(Counters) <= 256, "counters block");
 
@@ -54,8 +55,9 @@ constexpr int kGradRec = 10;       // floats per instance gradient record: 6 mom
 constexpr int kGradRecDual = 14;   // dual render: 6 moments + 6 colour sums + tile id + one pad word (56-byte stride, float2 access)
 
 struct WsLayout {
-  size_t counters, geom, gaux, block_stats, tile_cnt, keys, vals, sorted_gid, sorted_inst, final_T, qmask, dbg, total;
-  uint32_t tiles8, tile_cap;
+  size_t counters, geom, gaux, block_stats, tile_cnt, keys, vals, sorted_gid, sorted_inst, final_T, qmask, dbg, plan, total;
+  uint32_t tiles8, tile_cap;      // tile_cap: slots per bin (uniform bins) or the average over the bins (planned bins)
+  bool planned;                   // VTGS_TILE_CAPACITY_PLANNED: bin t = [plan[t], plan[t+1]) instead of [t * tile_cap, (t+1) * tile_cap)
 };
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -65,6 +67,8 @@ inline WsLayout make_layout(int32_t n, int32_t w, int32_t h, uint64_t cap, uint3
   WsLayout L;
   const uint32_t gx8 = (uint32_t)(w + kSubTile - 1) / kSubTile, gy8 = (uint32_t)(h + kSubTile - 1) / kSubTile;
   L.tiles8 = gx8 * gy8;
+  L.planned = (tile_cap & VTGS_TILE_CAPACITY_PLANNED) != 0u;
+  tile_cap &= ~VTGS_TILE_CAPACITY_PLANNED;
   L.tile_cap = tile_cap;
   const size_t slots = (size_t)L.tiles8 * tile_cap;
   size_t o = 0;
@@ -84,6 +88,7 @@ inline WsLayout make_layout(int32_t n, int32_t w, int32_t h, uint64_t cap, uint3
 #else
   L.dbg = o;         o += 256;                           // 64 step counters (measurement only, VTGS_COUNT_STEPS)
 #endif
+  L.plan = o;        o += align256(((size_t)L.tiles8 + 1) * 4);   // planned bins: this forward's copy of the caller's plan
   L.total = o;
   return L;
 }
@@ -95,7 +100,25 @@ struct CamScalars {
   float tanfovx, tanfovy, mod;
   int radius_rule;
   int row8_begin, row8_end;
+  const uint32_t* bin_plan;       // planned bins: offsets [tiles8 + 1] (the workspace's copy); NULL = uniform bins of tile_cap slots
+  uint32_t bin_limit;             // ... and the slots the workspace holds: no bin reaches past it, whatever the plan says
 };
+
+// where tile t's bin lives: a wave-uniform branch on a kernel argument (uniform bins pay nothing for the planned form)
+struct BinRange { uint32_t s, cap; };
+#if defined(__HIPCC__)
+__device__ __forceinline__ BinRange bin_range(const uint32_t* __restrict__ plan, uint32_t limit, uint32_t tile, uint32_t tile_cap) {
+  BinRange r;
+  if (plan) {
+    const uint32_t a = min(plan[tile], limit), b = min(plan[tile + 1], limit);
+    r.s = a; r.cap = b > a ? b - a : 0u;                      // a plan that outgrew the workspace is flagged by finalize_forward
+  } else { r.s = tile * tile_cap; r.cap = tile_cap; }
+  return r;
+}
+__device__ __forceinline__ BinRange bin_range(const CamScalars& cs, uint32_t tile, uint32_t tile_cap) {
+  return bin_range(cs.bin_plan, cs.bin_limit, tile, tile_cap);
+}
+#endif
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ CamParams load_cam(const CamScalars& cs, const float* __restrict__ V,
@@ -157,40 +180,74 @@ __device__ __forceinline__ uint32_t xcd_swizzle(uint32_t bid, uint32_t nblk) {
 struct FinalizeArgs {
   const uint32_t* tile_cnt; uint32_t tiles; Counters* ctr; unsigned long long capacity; uint32_t tile_cap;
   const BlockStats* block_stats; uint32_t nblocks; VtgsForwardInfo* host_record;
+  const uint32_t* plan;      // planned bins: the plan this forward binned into (workspace copy), else NULL
+  uint32_t* plan_next;       // ... and the caller's persistent plan, rewritten from this forward's list lengths
 };
+
+// capacity the next plan gives a bin whose list is `cnt` long now: half again as much + 16, in multiples of 16
+__host__ __device__ inline uint32_t planned_bin_capacity(uint32_t cnt) { return (cnt + (cnt >> 1) + 31u) & ~15u; }
 template <int THREADS>
 __device__ __forceinline__ void finalize_block(const uint32_t* __restrict__ tile_cnt, uint32_t tiles, Counters* __restrict__ ctr,
                                                unsigned long long capacity, uint32_t tile_cap,
                                                const BlockStats* __restrict__ block_stats, uint32_t nblocks,
-                                               VtgsForwardInfo* host_record) {
+                                               VtgsForwardInfo* host_record, const uint32_t* __restrict__ plan = nullptr,
+                                               uint32_t* __restrict__ plan_next = nullptr) {
   constexpr int kW = THREADS / 64;
-  __shared__ uint32_t wmax[kW], svis[kW];
+  __shared__ uint32_t wmax[kW], svis[kW], sover[kW], swsum[kW];
   __shared__ unsigned long long sr16[kW];
   const uint32_t t = threadIdx.x;
-  uint32_t mx = 0;
-  for (uint32_t i = t; i < tiles; i += (uint32_t)THREADS) mx = max(mx, tile_cnt[i]);
+  uint32_t mx = 0, over = 0;
+  for (uint32_t i = t; i < tiles; i += (uint32_t)THREADS) {
+    const uint32_t c = tile_cnt[i];
+    mx = max(mx, c);
+    if (plan) {                                                  // planned bins: every bin against its own capacity
+      const uint32_t limit = tiles * tile_cap, a = min(plan[i], limit), b = min(plan[i + 1], limit);
+      over |= (c > (b > a ? b - a : 0u)) ? 1u : 0u;
+    }
+  }
   mx = (uint32_t)wave_max_i((int)mx);
+  over = (uint32_t)wave_max_i((int)over);
   uint32_t vis = 0; unsigned long long r16 = 0;
   for (uint32_t i = t; i < nblocks; i += (uint32_t)THREADS) { vis += block_stats[i].visible; r16 += block_stats[i].r16; }
   for (int m = 1; m < 64; m <<= 1) {
     vis += (uint32_t)__shfl_xor((int)vis, m, 64);
     r16 += (unsigned long long)__shfl_xor((long long)r16, m, 64);
   }
-  if ((t & 63u) == 0) { wmax[t >> 6] = mx; svis[t >> 6] = vis; sr16[t >> 6] = r16; }
+  // planned bins: the NEXT plan from this forward's list lengths (the caller's persistent buffer; this forward and its
+  // backward read the workspace copy).  Thread t owns a contiguous run of tiles: run sums, one scan over the threads, offsets.
+  uint32_t run_sum = 0;
+  const uint32_t per = (tiles + (uint32_t)THREADS - 1u) / (uint32_t)THREADS, lo = min(t * per, tiles), hi = min(lo + per, tiles);
+  for (uint32_t i = lo; i < hi; ++i) run_sum += planned_bin_capacity(tile_cnt[i]);   // (always: the record reports the total)
+  const uint32_t incl = wave_incl_scan(run_sum);
+  if ((t & 63u) == 0) { wmax[t >> 6] = mx; svis[t >> 6] = vis; sr16[t >> 6] = r16; sover[t >> 6] = over; }
+  if ((t & 63u) == 63u) swsum[t >> 6] = incl;
   __syncthreads();
+  unsigned long long slots_next = 0;
+  uint32_t off = incl - run_sum;
+  for (int i = 0; i < kW; ++i) {
+    if (i < (int)(t >> 6)) off += swsum[i];
+    slots_next += swsum[i];
+  }
+  if (plan_next) {
+    for (uint32_t i = lo; i < hi; ++i) { plan_next[i] = off; off += planned_bin_capacity(tile_cnt[i]); }
+    if (t == (uint32_t)THREADS - 1u) plan_next[tiles] = (uint32_t)slots_next;      // (its run is the last one, possibly empty)
+  }
   if (t == 0) {
-    uint32_t m = 0, v = 0; unsigned long long r = 0;
-    for (int i = 0; i < kW; ++i) { m = max(m, wmax[i]); v += svis[i]; r += sr16[i]; }
+    uint32_t m = 0, v = 0, ov = 0; unsigned long long r = 0;
+    for (int i = 0; i < kW; ++i) { m = max(m, wmax[i]); v += svis[i]; r += sr16[i]; ov |= sover[i]; }
     const uint32_t total = ctr->inst_total;
-    const uint32_t ovf = (((unsigned long long)total > capacity) ? 1u : 0u) | ((m > tile_cap) ? 2u : 0u);
+    const bool bin_over = plan ? (ov != 0u) : (m > tile_cap);
+    const uint32_t ovf = (((unsigned long long)total > capacity) ? 1u : 0u) | (bin_over ? 2u : 0u);
+    const unsigned long long slots = slots_next;     // what bins sized to this forward's lists take in total (planned bins)
     ctr->overflow = ovf;
     ctr->info_instances = ovf ? 0ull : (unsigned long long)total;
     ctr->info_needed = total; ctr->info_r16 = r;
-    ctr->info_visible = v; ctr->info_max_list = m; ctr->info_overflow = ovf; ctr->info_complete = 1u;
+    ctr->info_visible = v; ctr->info_max_list = m; ctr->info_overflow = ovf; ctr->info_slots = slots; ctr->info_complete = 1u;
     if (host_record) {                         // the caller's pinned record, device-addressable
       host_record->instances = ovf ? 0ull : (unsigned long long)total;
       host_record->instances_needed = total; host_record->tiles16_touched = r;
       host_record->visible = v; host_record->max_tile_list = m; host_record->overflow = ovf;
+      host_record->bin_slots_needed = slots;
       __threadfence_system();
       host_record->complete = 1u;              // last: the host treats the record as landed once this is set
     }

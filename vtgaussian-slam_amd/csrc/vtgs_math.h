@@ -167,6 +167,45 @@ VTGS_HD bool project_splat(const CamParams& cam, const float mean[3], const floa
   return true;
 }
 
+// Tile-row partition: can this Gaussian be skipped by a call that renders 16-pixel tile rows [row_b, row_e)
+// only?  True only when project_splat would give it a tile rectangle that misses those rows (or cull it) -- decided from the
+// mean and the scales alone, before the rotation, the opacity and the covariance algebra are touched:
+//   lambda_max(Sigma2) <= smax(J)^2 smax(Rw)^2 lambda_max(Sigma3) + 0.3,   lambda_max(Sigma3) = (mod max scale)^2,
+//   smax(J)^2 = the larger eigenvalue of J J^T (2x2, J as in ewa_M with the clamped tx/tz, ty/tz),
+//   smax(Rw)^2 <= the largest absolute row sum of Rw^T Rw (exactly 1 for a rigid view matrix),
+// and the radius of either rule is at most ceil(3 sqrt(lam)), lam <= lambda_max + sqrt(0.1) (the floor inside the root).
+// Two pixels of slack cover ceil() and the float32 rounding of v on both sides; a NaN makes every comparison false: not skipped.
+VTGS_HD bool outside_tile_rows(const CamParams& cam, const float mean[3], const float scale[3], int row_b, int row_e) {
+  const float x = mean[0], y = mean[1], z = mean[2];
+  const float* V = cam.V;
+  const float tz = fmaf(V[2], x, fmaf(V[6], y, fmaf(V[10], z, V[14])));
+  if (!(tz > kNearCull)) return tz <= kNearCull;               // culled by the near plane on every rank (NaN: not decided here)
+  const float* P = cam.PV;
+  const float hy = fmaf(P[1], x, fmaf(P[5], y, fmaf(P[9], z, P[13])));
+  const float hw = fmaf(P[3], x, fmaf(P[7], y, fmaf(P[11], z, P[15])));
+  const float v = ((hy * (1.f / (hw + 1e-7f)) + 1.f) * (float)cam.H - 1.f) * 0.5f;
+  const float smax = cam.mod * fmaxf(fabsf(scale[0]), fmaxf(fabsf(scale[1]), fabsf(scale[2])));
+  float gram = 0.f;                                            // smax(Rw)^2 <= max_i sum_j |(Rw^T Rw)_ij|
+  for (int i = 0; i < 3; ++i) {
+    float row = 0.f;
+    for (int j = 0; j < 3; ++j) row += fabsf(V[4 * i] * V[4 * j] + V[4 * i + 1] * V[4 * j + 1] + V[4 * i + 2] * V[4 * j + 2]);
+    gram = fmaxf(gram, row);
+  }
+  const float tx = fmaf(V[0], x, fmaf(V[4], y, fmaf(V[8], z, V[12])));
+  const float ty = fmaf(V[1], x, fmaf(V[5], y, fmaf(V[9], z, V[13])));
+  const float iz = 1.f / tz;
+  const float rx = fminf(cam.limx, fmaxf(-cam.limx, tx * iz)), ry = fminf(cam.limy, fmaxf(-cam.limy, ty * iz));
+  const float ja = cam.fx * cam.fx * (1.f + rx * rx), jc = cam.fy * cam.fy * (1.f + ry * ry), jb = cam.fx * cam.fy * rx * ry;
+  const float hd = 0.5f * (ja - jc);
+  const float j2 = (0.5f * (ja + jc) + sqrtf(hd * hd + jb * jb)) * iz * iz;
+  const float lam = j2 * gram * smax * smax * 1.001f + kDilation + 0.32f;
+  const float r = 3.f * sqrtf(lam) + 2.f;                      // ceil() and one pixel of slack
+  const float it = 1.f / (float)kBinTile;
+  const bool above = (v + r + (float)(kBinTile - 1)) * it + kRectEps < (float)row_b + 1.f;   // => y1 = floor(.) <= row_b
+  const bool below = (v - r) * it >= (float)row_e;                                          // => y0 = floor(. + eps) >= row_e
+  return above || below;
+}
+
 // Smallest value of q(d) = 1/2 (A dx^2 + C dy^2) + B dx dy over the pixel-centre rectangle
 // [px0,px1] x [py0,py1] for a splat centred at (u,v).  A splat reaches a pixel only where
 // q <= ln(255 o), so a tile whose minimum exceeds that bound receives nothing from it.

@@ -50,8 +50,8 @@ CamRecord camera_from(const at::Tensor& cam_bytes, const at::Tensor& bg, const a
 struct Rasterize : public torch::autograd::Function<Rasterize> {
   static variable_list forward(AutogradContext* ctx, at::Tensor means3D, at::Tensor means2D, at::Tensor colors, at::Tensor opac,
                                at::Tensor scales, at::Tensor rot, at::Tensor cam_bytes, at::Tensor bg, at::Tensor view,
-                               at::Tensor proj, int64_t capacity, int64_t tile_cap, int64_t slot_ptr, int64_t flags,
-                               int64_t stream) {
+                               at::Tensor proj, int64_t capacity, int64_t tile_cap, int64_t bin_plan, int64_t slot_ptr,
+                               int64_t flags, int64_t stream) {
     const at::Device dev = means3D.device();
     TORCH_CHECK(dev.is_cuda(), "GaussianRasterizer needs tensors on a HIP device (torch 'cuda'); no CPU path exists");
     c10::DeviceGuard guard(dev);
@@ -69,10 +69,17 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     at::Tensor radii = at::empty({n}, f32.dtype(at::kInt));
     const size_t nbytes = vtgs_workspace_bytes((int32_t)n, (int32_t)W, (int32_t)H, (uint64_t)capacity, (uint32_t)tile_cap);
     at::Tensor workspace = at::empty({(int64_t)nbytes}, f32.dtype(at::kByte));
-    const int st = vtgs_forward(&cam.c, (int32_t)n, means3D.data_ptr<float>(), colors.data_ptr<float>(), opac.data_ptr<float>(),
-                                scales.data_ptr<float>(), rot.data_ptr<float>(), color.data_ptr<float>(), depth.data_ptr<float>(),
-                                radii.data_ptr<int32_t>(), workspace.data_ptr(), nbytes, (uint64_t)capacity, (uint32_t)tile_cap,
-                                reinterpret_cast<VtgsForwardInfo*>(slot_ptr), (uint32_t)flags, reinterpret_cast<void*>(stream));
+    // bin_plan != 0: planned bins (tile_cap carries VTGS_TILE_CAPACITY_PLANNED; the backward needs nothing else)
+    const int st = bin_plan
+        ? vtgs_forward_planned(&cam.c, (int32_t)n, means3D.data_ptr<float>(), colors.data_ptr<float>(), opac.data_ptr<float>(),
+                               scales.data_ptr<float>(), rot.data_ptr<float>(), color.data_ptr<float>(), depth.data_ptr<float>(),
+                               radii.data_ptr<int32_t>(), workspace.data_ptr(), nbytes, (uint64_t)capacity, (uint32_t)tile_cap,
+                               reinterpret_cast<uint32_t*>(bin_plan), reinterpret_cast<VtgsForwardInfo*>(slot_ptr),
+                               (uint32_t)flags, reinterpret_cast<void*>(stream))
+        : vtgs_forward(&cam.c, (int32_t)n, means3D.data_ptr<float>(), colors.data_ptr<float>(), opac.data_ptr<float>(),
+                       scales.data_ptr<float>(), rot.data_ptr<float>(), color.data_ptr<float>(), depth.data_ptr<float>(),
+                       radii.data_ptr<int32_t>(), workspace.data_ptr(), nbytes, (uint64_t)capacity, (uint32_t)tile_cap,
+                       reinterpret_cast<VtgsForwardInfo*>(slot_ptr), (uint32_t)flags, reinterpret_cast<void*>(stream));
     TORCH_CHECK(st == VTGS_OK || st == VTGS_ERR_INSTANCE_OVERFLOW, "vtgs_forward failed: ", vtgs_strerror(st), " (",
                 vtgs_last_hip_error(), ")");
     ctx->save_for_backward({means3D, colors, opac, scales, rot, color, workspace, cam_bytes, bg, view, proj});
@@ -132,15 +139,16 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
       TORCH_CHECK(st == VTGS_OK, "vtgs_backward failed: ", vtgs_strerror(st), " (", vtgs_last_hip_error(), ")");
     }
     at::Tensor none;
-    return {g[0], g[1], g[2], g[3], g[4], g[5], none, none, none, none, none, none, none, none, none};
+    return {g[0], g[1], g[2], g[3], g[4], g[5], none, none, none, none, none, none, none, none, none, none};
   }
 };
 
 std::vector<at::Tensor> rasterize(at::Tensor means3D, at::Tensor means2D, at::Tensor colors, at::Tensor opac, at::Tensor scales,
                                   at::Tensor rot, at::Tensor cam_bytes, at::Tensor bg, at::Tensor view, at::Tensor proj,
-                                  int64_t capacity, int64_t tile_cap, int64_t slot_ptr, int64_t flags, int64_t stream) {
-  return Rasterize::apply(means3D, means2D, colors, opac, scales, rot, cam_bytes, bg, view, proj, capacity, tile_cap, slot_ptr,
-                          flags, stream);
+                                  int64_t capacity, int64_t tile_cap, int64_t bin_plan, int64_t slot_ptr, int64_t flags,
+                                  int64_t stream) {
+  return Rasterize::apply(means3D, means2D, colors, opac, scales, rot, cam_bytes, bg, view, proj, capacity, tile_cap, bin_plan,
+                          slot_ptr, flags, stream);
 }
 
 }  // namespace

@@ -77,6 +77,12 @@ _SIGNATURES = {
                            + [_P] * 8),
     "vtgs_backward_dual_frame": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32] + [_P] * 11 + [_SZ, _U64, ctypes.c_uint32, _P, _SZ,
                                                 ctypes.c_uint32] + [_P] * 12),
+    "vtgs_forward_planned": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _U64,
+                                            ctypes.c_uint32, _P, _P, ctypes.c_uint32, _P]),
+    "vtgs_forward_dual_planned": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ,
+                                                 _U64, ctypes.c_uint32, _P, _P, ctypes.c_uint32, _P]),
+    "vtgs_bin_plan_entries": (ctypes.c_uint32, [_I32, _I32]),
+    "vtgs_bin_plan_uniform": (ctypes.c_int, [_I32, _I32, ctypes.c_uint32, _P, _P]),
     "vtgs_mark_visible": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P]),
     "vtgs_debug_layout": (ctypes.c_int, [_I32, _I32, _I32, _U64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]),
     "vtgs_profile_enable": (ctypes.c_int, [ctypes.c_int]),
@@ -444,25 +450,102 @@ def _tile_capacity_for(max_list: int) -> int:
     return max(64, (int(max_list * 1.5) + 63) // 64 * 64)
 
 
+# ---- planned bins (include/vtgs.h): bins sized per tile by a plan the device rewrites after every forward ---------------------
+# Uniform bins are the default (one dependent load less per tile, the sort fused into the forward); a view whose longest list
+# would make uniform bins several times larger than what its lists need in total -- one pile of Gaussians along a ray sizes
+# every bin -- runs with planned bins instead.  VTGS_BINS = auto | uniform | planned.
+PLANNED = 0x80000000
+_BINS_MODE = os.environ.get("VTGS_BINS", "auto")
+if _BINS_MODE not in ("auto", "uniform", "planned"):
+    raise ImportError("VTGS_BINS must be auto, uniform or planned")
+_PLANNED_MIN_BYTES = 256 << 20          # auto: uniform bins below this size are never worth replacing
+_slots_hint = {}                        # key -> bin slots the last forward's lists needed in total (planned_bin_capacity each)
+_bin_plans = {}                         # key -> persistent device plan (int32 [tiles8 + 1]); rewritten by every planned forward
+
+
+def _tiles8(W: int, H: int) -> int:
+    return ((W + 7) // 8) * ((H + 7) // 8)
+
+
+def _wants_planned(key, uniform_tcap: int) -> bool:
+    if _BINS_MODE != "auto":
+        return _BINS_MODE == "planned"
+    tiles, need = _tiles8(key[2], key[3]), _slots_hint.get(key, 0)
+    return bool(need) and tiles * uniform_tcap > 4 * need and tiles * uniform_tcap * 21 > _PLANNED_MIN_BYTES
+
+
+def _planned_capacity(key, slots_needed: int) -> int:
+    """Average slots per bin (the workspace holds tiles x that) for a plan of `slots_needed` slots: a quarter of headroom."""
+    tiles = _tiles8(key[2], key[3])
+    return PLANNED | max(32, -(-int(slots_needed * 1.25 + 1024) // tiles))
+
+
+def _plan_for(key, device, tile_cap: int, workspace=None, fs_shape=None):
+    """The persistent plan of `key` (created on first use).  With the workspace of a forward that just overflowed: the plan
+    is rebuilt from that forward's exact list lengths, which the binning counted past its capacities."""
+    tiles = _tiles8(key[2], key[3])
+    plan = _bin_plans.get(key)
+    if plan is None or plan.device != device:
+        plan = _bin_plans[key] = torch.empty(tiles + 1, dtype=torch.int32, device=device)
+        _check(_lib.vtgs_bin_plan_uniform(key[2], key[3], tile_cap & ~PLANNED, plan.data_ptr(), _stream_ptr(device)),
+               "vtgs_bin_plan_uniform")
+    if workspace is not None:
+        n, capacity, old_tcap = fs_shape
+        out = (ctypes.c_uint64 * 12)()
+        _check(_lib.vtgs_debug_layout(n, key[2], key[3], capacity, old_tcap, out), "vtgs_debug_layout")
+        cnt = workspace[int(out[3]): int(out[3]) + 4 * tiles].view(torch.int32).to(torch.int64)
+        caps = (cnt + (cnt >> 1) + 31) & ~15                       # planned_bin_capacity of csrc/vtgs_internal.h
+        plan[0] = 0
+        plan[1:] = torch.cumsum(caps, 0).to(torch.int32)
+    return plan
+
+
 def _choose_capacities(key, n):
     """Capacities for the next forward.  They move with hysteresis -- only when the last observed need comes within
     10 % of the capacity in use, or falls below a quarter of it -- so consecutive forwards ask the caching allocator
-    for identically sized workspaces (it can then recycle the blocks instead of calling hipMalloc/hipFree)."""
+    for identically sized workspaces (it can then recycle the blocks instead of calling hipMalloc/hipFree).
+    The second value carries the PLANNED bit when the view runs with planned bins."""
     need_i, need_t = _capacity_hint.get(key, 0), _tile_cap_hint.get(key, 0)
     if not need_i:
-        return 8 * n + 65536, 512
+        return 8 * n + 65536, (PLANNED | 512) if _BINS_MODE == "planned" else 512
     cap, tcap = _caps_in_use.get(key, (0, 0))
     if need_i * 1.1 > cap or need_i * 4 < cap:
         cap = max(int(need_i * 1.5) + 4096, 4 * n + 4096)
-    if need_t * 1.1 > tcap or need_t * 4 < tcap:
+    if _wants_planned(key, _tile_capacity_for(need_t)):
+        tiles, need_s = _tiles8(key[2], key[3]), _slots_hint[key]
+        have = (tcap & ~PLANNED) * tiles if tcap & PLANNED else 0
+        if need_s * 1.1 > have or need_s * 4 < have:
+            tcap = _planned_capacity(key, need_s)
+    elif tcap & PLANNED or need_t * 1.1 > tcap or need_t * 4 < tcap:
         tcap = _tile_capacity_for(need_t)
     _caps_in_use[key] = (cap, tcap)
     return cap, tcap
 
 
+def _grow_after_overflow(key, n, device, info, capacity, tile_cap, workspace):
+    """The capacities for the next attempt after a forward that reported an overflow (its record says what was needed;
+    `workspace` is that forward's, with its exact list lengths)."""
+    used = (n, capacity, tile_cap)
+    if info.overflow & 1:
+        capacity = int(info.instances_needed * 1.5) + 4096
+    if info.overflow & 2:
+        _slots_hint[key] = int(info.bin_slots_needed)
+        uniform = _tile_capacity_for(info.max_tile_list)
+        if tile_cap & PLANNED:                                     # the forward has rewritten the plan from its exact lengths
+            tile_cap = _planned_capacity(key, int(info.bin_slots_needed))
+        elif _wants_planned(key, uniform):
+            tile_cap = _planned_capacity(key, int(info.bin_slots_needed))
+            _plan_for(key, device, tile_cap, workspace, used)
+        else:
+            tile_cap = uniform
+    _caps_in_use[key] = (capacity, tile_cap)
+    return capacity, tile_cap
+
+
 def _record_info(key, n, W, H, capacity, info):
     _capacity_hint[key] = max(int(info.instances_needed), 1)
     _tile_cap_hint[key] = max(int(info.max_tile_list), 1)
+    _slots_hint[key] = max(int(info.bin_slots_needed), 1)
     cap, tcap = _caps_in_use.get(key, (0, 0))                  # the capacities this forward ran with
     # Run-ahead is for STEADY loops (tracking, mapping on one frame): the last three forwards of this shape must have needed
     # about the same (within 10 % of each other) and at most 80 % of both capacities.  A loop that alternates between views
@@ -470,7 +553,11 @@ def _record_info(key, n, W, H, capacity, info):
     hist = _need_hist.setdefault(key, collections.deque(maxlen=3))
     hist.append((int(info.instances_needed), int(info.max_tile_list)))
     steady = len(hist) == 3 and all(max(h[j] for h in hist) <= 1.1 * max(1, min(h[j] for h in hist)) for j in (0, 1))
-    roomy = bool(cap and tcap and info.instances_needed <= 0.8 * cap and info.max_tile_list <= 0.8 * tcap)
+    if tcap & PLANNED:            # every bin already has half again its own list; the plan as a whole must fit the workspace
+        bins_roomy = info.bin_slots_needed <= 0.9 * (tcap & ~PLANNED) * _tiles8(W, H)
+    else:
+        bins_roomy = info.max_tile_list <= 0.8 * tcap
+    roomy = bool(cap and tcap and info.instances_needed <= 0.8 * cap and bins_roomy)
     _async_ok[key] = (cap, tcap) if (roomy and steady) else None   # ... are the only ones the next forward may run ahead with
     _last_info.update(instances=int(info.instances), tiles16_touched=int(info.tiles16_touched),
                       visible=int(info.visible), max_tile_list=int(info.max_tile_list), n=n, width=W, height=H,
@@ -516,6 +603,17 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
     fs.cam, fs.n, fs.image_state, fs.key, fs.pending = cam, n, None, key, None
 
     def launch(workspace, nbytes, capacity, tile_cap, slot_ptr, flags):
+        if tile_cap & PLANNED:
+            plan = _plan_for(key, device, tile_cap).data_ptr()
+            if colors_b is None:
+                return _lib.vtgs_forward_planned(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(),
+                                                 opacities.data_ptr(), scales.data_ptr(), rotations.data_ptr(), color.data_ptr(),
+                                                 depth.data_ptr(), radii.data_ptr(), workspace.data_ptr(), nbytes, capacity,
+                                                 tile_cap, plan, slot_ptr, flags, stream)
+            return _lib.vtgs_forward_dual_planned(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(),
+                                                  colors_b.data_ptr(), opacities.data_ptr(), scales.data_ptr(),
+                                                  rotations.data_ptr(), color.data_ptr(), depth.data_ptr(), radii.data_ptr(),
+                                                  workspace.data_ptr(), nbytes, capacity, tile_cap, plan, slot_ptr, flags, stream)
         if colors_b is None:
             return _lib.vtgs_forward(ctypes.byref(cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
                                      scales.data_ptr(), rotations.data_ptr(), color.data_ptr(), depth.data_ptr(),
@@ -568,11 +666,7 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
                 nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
                 st = launch(workspace, nbytes, capacity, tile_cap, pool.ptr[slot], VTGS_FORWARD_CHECKED)
                 if st == VTGS_ERR_INSTANCE_OVERFLOW:          # the record says what is needed: grow whichever was short
-                    if info.overflow & 1:
-                        capacity = int(info.instances_needed * 1.5) + 4096
-                    if info.overflow & 2:
-                        tile_cap = _tile_capacity_for(info.max_tile_list)
-                    _caps_in_use[key] = (capacity, tile_cap)
+                    capacity, tile_cap = _grow_after_overflow(key, n, device, info, capacity, tile_cap, workspace)
                     continue
                 _check(st, "vtgs_forward")
                 break
@@ -606,17 +700,14 @@ def _forward_ext(cam: _Camera, means3D, means2D, colors, opacities, scales, rota
         info = pool.info[slot]
         for _attempt in range(6):
             info.complete = 0
+            plan = _plan_for(key, device, tile_cap).data_ptr() if tile_cap & PLANNED else 0
             color, radii, depth, workspace, status = _ext.rasterize(
                 means3D, means2D, colors, opacities, scales, rotations, cam.bytes, cam.bg, cam.view, cam.proj, capacity, tile_cap,
-                pool.ptr[slot], VTGS_FORWARD_ASYNC if run_ahead else VTGS_FORWARD_CHECKED, stream)
+                plan, pool.ptr[slot], VTGS_FORWARD_ASYNC if run_ahead else VTGS_FORWARD_CHECKED, stream)
             if run_ahead:
                 break
             if int(status) == VTGS_ERR_INSTANCE_OVERFLOW:     # the record says what is needed: grow whichever was short
-                if info.overflow & 1:
-                    capacity = int(info.instances_needed * 1.5) + 4096
-                if info.overflow & 2:
-                    tile_cap = _tile_capacity_for(info.max_tile_list)
-                _caps_in_use[key] = (capacity, tile_cap)
+                capacity, tile_cap = _grow_after_overflow(key, n, device, info, capacity, tile_cap, workspace)
                 continue
             break
         else:
@@ -718,20 +809,22 @@ def debug_tile_lists(rasterizer: "GaussianRasterizer", with_qmask: bool = False)
     of `rasterizer`, copied to the CPU and compacted (tile t = sorted_gid[offsets[t]:offsets[t+1]]).  8x8 tiles, row-major.
     with_qmask: a fourth value, the quadrant masks [R] uint8 the quadrant-queue forward wrote for the same entries."""
     fs = rasterizer._last_state
-    out = (ctypes.c_uint64 * 10)()
+    out = (ctypes.c_uint64 * 12)()
     _check(_lib.vtgs_debug_layout(fs.n, fs.cam.W, fs.cam.H, fs.capacity, fs.tile_cap, out), "vtgs_debug_layout")
     ws = fs.workspace
-    tiles8, cap = int(out[7]), fs.tile_cap
+    tiles8, cap, slots = int(out[7]), fs.tile_cap & ~PLANNED, int(out[11])
     cnt = ws[int(out[3]): int(out[3]) + 4 * tiles8].view(torch.int32).cpu().long()
-    bins = ws[int(out[4]): int(out[4]) + 4 * tiles8 * cap].view(torch.int32).reshape(tiles8, cap).cpu().long()
-    keep = torch.arange(cap)[None, :] < cnt[:, None]
-    gid = bins[keep]
     offs = torch.zeros(tiles8 + 1, dtype=torch.long)
     offs[1:] = torch.cumsum(cnt, 0)
+    if fs.tile_cap & PLANNED:                      # bin t starts at plan[t] (the forward's own copy of the plan)
+        first = ws[int(out[10]): int(out[10]) + 4 * tiles8].view(torch.int32).cpu().long()
+    else:
+        first = torch.arange(tiles8) * cap
+    pos = torch.repeat_interleave(first - offs[:-1], cnt) + torch.arange(int(offs[-1]))      # slot of every list entry
+    gid = ws[int(out[4]): int(out[4]) + 4 * slots].view(torch.int32).cpu().long()[pos]
     geom = ws[int(out[1]): int(out[1]) + 32 * fs.n].view(torch.float32).reshape(fs.n, 8).cpu()
     if with_qmask:
-        qm = ws[int(out[8]): int(out[8]) + tiles8 * cap].reshape(tiles8, cap).cpu()
-        return offs, gid, geom, qm[keep]
+        return offs, gid, geom, ws[int(out[8]): int(out[8]) + slots].cpu()[pos]
     return offs, gid, geom
 
 
@@ -739,7 +832,7 @@ def debug_forward_steps(rasterizer: "GaussianRasterizer") -> int:
     """Test / measurement hook: queue steps taken by the quadrant-queue forward of the last forward of `rasterizer`, summed
     over its tiles (needs set_option("VTGS_COUNT_STEPS", 1) before that forward)."""
     fs = rasterizer._last_state
-    out = (ctypes.c_uint64 * 10)()
+    out = (ctypes.c_uint64 * 12)()
     _check(_lib.vtgs_debug_layout(fs.n, fs.cam.W, fs.cam.H, fs.capacity, fs.tile_cap, out), "vtgs_debug_layout")
     return int(fs.workspace[int(out[9]): int(out[9]) + 256].view(torch.int32).sum().item())
 

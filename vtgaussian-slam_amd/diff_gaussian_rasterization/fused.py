@@ -10,7 +10,8 @@ is equivalent to the reference's
     im, radii, _      = Renderer(cam)(**transformed_params2rendervar(params, tg))                       :127-160
     depth_sil, _, _   = Renderer(cam)(**transformed_params2depthplussilhouette(params, w2c, tg))        :255-287
 
-for isotropic maps (log_scales [N,1], every reference config), but runs the element-wise chain as one HIP kernel
+but -- for isotropic maps (log_scales [N,1], every reference config; anisotropic ones take the chain above on the HIP
+operator, `render_frame_unfused`) -- runs the element-wise chain as one HIP kernel
 each way (vtgs_prepare_frame / vtgs_prepare_frame_backward), projects / bins / sorts once and composites BOTH
 renders in one six-channel pass each way (vtgs_forward_dual / vtgs_backward_dual; VTGS_DUAL=0 selects the earlier
 vtgs_forward + vtgs_forward_shared + 2 x vtgs_backward route, kept as the cross-check) and reduces dL/dmeans to the 7
@@ -161,12 +162,17 @@ def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings
     depth_sil [3,H,W], radii [N] int32).  `tile_rows=(begin, end)`: this rank's band of 16-pixel tile rows (multi-GPU
     partition, `partition.band_for_rank`): pixels outside the band come back as zero and the gradients are the band's
     share -- the pose gradient of a rank is then 7 floats to all-reduce, with no dense per-Gaussian array behind it."""
-    if params["log_scales"].shape[1] != 1:
-        raise NotImplementedError("render_frame covers isotropic maps (log_scales [N,1]) -- what every reference config "
-                                  "uses; anisotropic maps go through transform_to_frame + GaussianRasterizer")
     dev = params["means3D"].device
     if dev.type != "cuda":
         raise RuntimeError("render_frame needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
+    if params["log_scales"].shape[1] != 1:
+        # anisotropic maps (log_scales [N,3]: no reference config, but transform_to_frame has the branch,
+        # utils/slam_helpers.py:376-383 -- the rotations are composed with the camera's): the pose transform and the
+        # render-variable builders run as the reference's own element-wise chain, both renders on the HIP operator with
+        # the second one over the first one's bins
+        im, depth_sil, radii, _ = render_frame_unfused(params, time_idx, raster_settings, first_frame_w2c, gaussians_grad,
+                                                       camera_grad, radius_rule, tile_rows)
+        return im, depth_sil, radii
     import os
     rule = _RADIUS_RULES[radius_rule or os.environ.get("VTGS_RADIUS_RULE", "3sigma")]
     cam = _Camera(raster_settings, dev, rule, tile_rows)
@@ -184,3 +190,23 @@ def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings
     return _RenderFrame.apply(g(params["means3D"]), params["rgb_colors"], g(params["unnorm_rotations"]),
                               params["logit_opacities"], params["log_scales"], q, t,
                               first_frame_w2c.to(dev), cam, flags)
+
+
+def render_frame_unfused(params, time_idx: int, raster_settings, first_frame_w2c, gaussians_grad: bool, camera_grad: bool,
+                         radius_rule: Optional[str] = None, tile_rows=None):
+    """The reference's own chain (src/vtgaussian_slam.py:431-468) on the plain operator: `transform_to_frame`, the two
+    render-variable builders, the colour render and the [z,1,z^2] render over the same bins.  Returns (im, depth_sil, radii,
+    means2D): the colour render keeps `means2D` in the graph (its .grad is the screen-space gradient of the COLOUR render
+    only, :460-462).  Any map, isotropic or not."""
+    import slam_callers as sc                      # device-agnostic restatement of utils/slam_helpers.py (pinned by golden vectors)
+    from . import GaussianRasterizer
+    tg = sc.transform_to_frame(params, time_idx, gaussians_grad=gaussians_grad, camera_grad=camera_grad)
+    rv = sc.transformed_params2rendervar(params, tg)
+    dv = sc.transformed_params2depthplussilhouette(params, first_frame_w2c, tg)
+    if rv["means2D"].requires_grad:
+        rv["means2D"].retain_grad()
+    rast = GaussianRasterizer(raster_settings=raster_settings, radius_rule=radius_rule, tile_rows=tile_rows)
+    im, radius, _ = rast(**rv)
+    depth_sil, _ = rast.render_shared(dv["colors_precomp"], like=(rv["means3D"], dv["means2D"], rv["opacities"], rv["scales"],
+                                                                  rv["rotations"]))
+    return im, depth_sil, radius, rv["means2D"]

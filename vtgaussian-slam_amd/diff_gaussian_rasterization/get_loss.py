@@ -32,9 +32,8 @@ import os
 
 import torch
 
-from . import GaussianRasterizer
 from . import losses as _l
-from .fused import render_frame
+from .fused import render_frame, render_frame_unfused
 
 __all__ = ["get_loss", "SCREEN_SPACE_GRADIENT"]
 
@@ -55,17 +54,7 @@ class _NoScreenSpaceGradient:
 
 def _render_separately(params, iter_time_idx, cam, w2c, gaussians_grad, camera_grad):
     """The reference's own chain (:431-468) on the plain operator: the colour render keeps `means2D` in the graph."""
-    import slam_callers as sc                      # device-agnostic restatement of utils/slam_helpers.py (pinned by golden vectors)
-    tg = sc.transform_to_frame(params, iter_time_idx, gaussians_grad=gaussians_grad, camera_grad=camera_grad)
-    rv = sc.transformed_params2rendervar(params, tg)
-    dv = sc.transformed_params2depthplussilhouette(params, w2c, tg)
-    if rv["means2D"].requires_grad:
-        rv["means2D"].retain_grad()
-    rast = GaussianRasterizer(raster_settings=cam)
-    im, radius, _ = rast(**rv)
-    depth_sil, _ = rast.render_shared(dv["colors_precomp"], like=(rv["means3D"], dv["means2D"], rv["opacities"], rv["scales"],
-                                                                  rv["rotations"]))
-    return im, depth_sil, radius, rv["means2D"]
+    return render_frame_unfused(params, iter_time_idx, cam, w2c, gaussians_grad, camera_grad)
 
 
 def _cuda_f32(v):

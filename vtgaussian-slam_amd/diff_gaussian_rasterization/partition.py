@@ -87,6 +87,20 @@ def pose7_reduce(points, g_points):
 SSIM_HALO = 5                      # rows a band needs from each neighbour: (11 - 1) / 2
 
 
+def allreduce_radii(radii, group=None):
+    """A rank of the partition skips the Gaussians that cannot meet its rows (radius 0 there): the radii of the frame --
+    variables['max_2D_radius'] / ['seen'] of the reference, src/vtgaussian_slam.py:681-689 -- are the element-wise maximum
+    over the ranks.  In place; returns `radii`."""
+    import torch.distributed as dist
+    if radii.is_cuda and _host_staged(group):
+        c = radii.cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.MAX, group=group)
+        radii.copy_(c)
+    else:
+        dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=group)
+    return radii
+
+
 def allreduce_param_grads(params, keys=("rgb_colors", "logit_opacities", "log_scales"), group=None):
     """Sum `.grad` of the listed parameters over the ranks with one flat all-reduce (20 B per Gaussian for the default
     keys).  Parameters without a gradient on this rank (no Gaussian of theirs met the band) count as zero."""
