@@ -125,13 +125,18 @@ def test_header_is_plain_c99_and_links(tmp_path):
     lib_dir = os.path.join(root, "vtgaussian-slam_amd", "lib")
     src = tmp_path / "abi.c"
     src.write_text('#include "vtgs.h"\n#include <stdio.h>\n'
-                   'int main(void) { printf("%u %s\\n", vtgs_abi_version(), vtgs_strerror(VTGS_ERR_INSTANCE_OVERFLOW)); '
+                   'int main(void) { printf("%u %u %u %u %s\\n", vtgs_abi_version(), (unsigned)sizeof(VtgsForwardInfo), '
+                   '(unsigned)sizeof(VtgsCamera), (unsigned)sizeof(VtgsProfileEntry), vtgs_strerror(VTGS_ERR_INSTANCE_OVERFLOW)); '
                    'return vtgs_get_option("VTGS_FWD_IMPL") < 0; }\n')
     exe = tmp_path / "abi"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src),
                     "-L", lib_dir, "-lvtgs", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert out[0] == "12"
+    # the ctypes mirrors of the package describe the same records as the header
+    import diff_gaussian_rasterization as dgr
+    assert [int(x) for x in out[1:4]] == [ctypes.sizeof(dgr._VtgsForwardInfo), ctypes.sizeof(dgr._VtgsCamera),
+                                          ctypes.sizeof(dgr._VtgsProfileEntry)]
 
 
 def test_planned_bins_entry_points_check_their_arguments(lib):

@@ -127,7 +127,11 @@ __device__ __forceinline__ BigWalk broadcast_walk(const TileWalk& w, const Splat
 // global slot range per touched tile -- all those device-scope atomics are in flight together, so their round trip
 // (microseconds: they execute at the memory side) is paid once per workgroup instead of once per step of the lock-step
 // walk -- and hands out the slots with LDS atomics.  Otherwise: run-aggregated, software-pipelined global atomics.
-template <bool LDSBINS>
+// MODE (kernel-uniform facts, compiled apart so that the common case -- whole frame, uniform bins -- keeps its scalar-register
+// budget: either feature alone cost that case 13 us of 54 through s_load re-materialisation, batch P of round 3):
+//   bit 0  a band of the tile-row partition (row cull before the projection, early exit of workgroups with nothing in the band)
+//   bit 1  planned bins (bin t = [plan[t], plan[t+1]), include/vtgs.h)
+template <bool LDSBINS, int MODE>
 __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
     const float* __restrict__ means3D, const float* __restrict__ opacities,
@@ -151,14 +155,25 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
   Splat sp{}; SplatAux aux;
   float op = 0.f;
   bool vis = false;
-  if (valid) {
+  constexpr bool banded = (MODE & 1) != 0;                      // a rank of the tile-row partition
+  constexpr bool planned = (MODE & 2) != 0;
+  if (valid && !banded) {
+    // whole frame: the four input streams are requested together (one trip to memory on the kernel's latency chain)
     const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
     const float sc[3] = {scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
-    // a rank of the tile-row partition skips what cannot meet its rows before the rotation / opacity loads and the covariance
-    // algebra (7/8 of the Gaussians at 8 ranks; view-tied maps are stored in raster order, so whole wavefronts leave here).
-    // Such a Gaussian reports radius 0 on this rank: radii are complete as the MAXIMUM over the ranks.
-    const bool banded = cam.row8_begin > 0 || cam.row8_end < cam.gy8;          // wave-uniform
-    if (!(banded && outside_tile_rows(cam, mean, sc, cam.row8_begin / 2, (cam.row8_end + 1) / 2))) {
+    const float4 q4 = reinterpret_cast<const float4*>(rotations)[gid];
+    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+    op = opacities[gid];
+    vis = project_splat(cam, mean, sc, q, op, sp, aux);
+    radii[gid] = vis ? sp.radius : 0;
+  }
+  if (valid && banded) {
+    // a band: a Gaussian that cannot meet the band's rows is dropped on its mean and scales alone (outside_tile_rows),
+    // before the rotation / opacity loads and the covariance algebra -- 7/8 of them at 8 ranks.  It reports radius 0 on this
+    // rank: radii are complete as the MAXIMUM over the ranks.  The survivors pay a second trip to memory.
+    const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
+    const float sc[3] = {scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
+    if (!outside_tile_rows(cam, mean, sc, cam.row8_begin / 2, (cam.row8_end + 1) / 2)) {
       const float4 q4 = reinterpret_cast<const float4*>(rotations)[gid];
       const float q[4] = {q4.x, q4.y, q4.z, q4.w};
       op = opacities[gid];
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     }
     radii[gid] = vis ? sp.radius : 0;
   }
-  if (cam.row8_begin > 0 || cam.row8_end < cam.gy8) {           // (kernel-uniform) a rank of the tile-row partition:
+  if (banded) {
     // view-tied maps are stored in raster order, so most WORKGROUPS hold nothing that meets the band -- those leave here,
     // after one trip to memory, instead of walking the reservation chain (three barriers, the instance-range atomic, the
     // per-tile reservations) with nothing to reserve
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
         const int tile = tty * cam.gx8 + ttx;
         const uint32_t slot = atomicAdd(&lds_tile[tile - tile0], 1u);
         const unsigned long long id = (unsigned long long)inst_base + ord;
-        const BinRange br = bin_range(cs, (uint32_t)tile, tile_cap);
+        const BinRange br = planned ? bin_range(cs, (uint32_t)tile, tile_cap) : BinRange{(uint32_t)tile * tile_cap, tile_cap};
         if (id < capacity && slot < br.cap) {                    // an overflowing bin / id is dropped and flagged later
           const size_t pos = (size_t)br.s + slot;
           keys[pos] = key;
@@ -282,7 +297,7 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     const uint32_t slot = reserve_resolve(r);
     if (r.act) {
       const unsigned long long id = (unsigned long long)inst_base + ord;
-      const BinRange br = bin_range(cs, (uint32_t)r.tile, tile_cap);
+      const BinRange br = planned ? bin_range(cs, (uint32_t)r.tile, tile_cap) : BinRange{(uint32_t)r.tile * tile_cap, tile_cap};
       if (id < capacity && slot < br.cap) {                    // an overflowing bin / id is dropped and flagged later
         const size_t pos = (size_t)br.s + slot;
         keys[pos] = key;
@@ -356,7 +371,7 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
         const uint32_t slot = atomicAdd(&tile_cnt[tile], 1u);
         const uint32_t rank = (uint32_t)__builtin_popcountll(hb & ((1ull << l) - 1ull));
         const unsigned long long id = (unsigned long long)base + done + rank;            // raster order of the walk
-        const BinRange br = bin_range(cs, (uint32_t)tile, tile_cap);
+        const BinRange br = planned ? bin_range(cs, (uint32_t)tile, tile_cap) : BinRange{(uint32_t)tile * tile_cap, tile_cap};
         if (id < capacity && slot < br.cap) {
           const size_t pos = (size_t)br.s + slot;
           keys[pos] = key_src;
@@ -376,8 +391,15 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
   }
 }
 
-template __global__ void project_and_bin<false>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin<true>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+
+template __global__ void project_and_bin<false, 0>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin<false, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin<false, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin<false, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin<true, 0>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin<true, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin<true, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin<true, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
 
 // One workgroup right after the binning: longest tile list, statistics, overflow flags and the image of the
 // host-visible VtgsForwardInfo (finalize_block, vtgs_internal.h; the quadrant-queue forward runs it in its first workgroup

@@ -193,13 +193,14 @@ __device__ __forceinline__ void finalize_block(const uint32_t* __restrict__ tile
                                                VtgsForwardInfo* host_record, const uint32_t* __restrict__ plan = nullptr,
                                                uint32_t* __restrict__ plan_next = nullptr) {
   constexpr int kW = THREADS / 64;
-  __shared__ uint32_t wmax[kW], svis[kW], sover[kW], swsum[kW];
+  __shared__ uint32_t wmax[kW], svis[kW], sover[kW], swsum[kW], sslots[kW];
   __shared__ unsigned long long sr16[kW];
   const uint32_t t = threadIdx.x;
-  uint32_t mx = 0, over = 0;
+  uint32_t mx = 0, over = 0, slots = 0;
   for (uint32_t i = t; i < tiles; i += (uint32_t)THREADS) {
     const uint32_t c = tile_cnt[i];
     mx = max(mx, c);
+    slots += planned_bin_capacity(c);                            // what bins sized to these lists take in total
     if (plan) {                                                  // planned bins: every bin against its own capacity
       const uint32_t limit = tiles * tile_cap, a = min(plan[i], limit), b = min(plan[i + 1], limit);
       over |= (c > (b > a ? b - a : 0u)) ? 1u : 0u;
@@ -212,25 +213,34 @@ __device__ __forceinline__ void finalize_block(const uint32_t* __restrict__ tile
   for (int m = 1; m < 64; m <<= 1) {
     vis += (uint32_t)__shfl_xor((int)vis, m, 64);
     r16 += (unsigned long long)__shfl_xor((long long)r16, m, 64);
+    slots += (uint32_t)__shfl_xor((int)slots, m, 64);
   }
   // planned bins: the NEXT plan from this forward's list lengths (the caller's persistent buffer; this forward and its
-  // backward read the workspace copy).  Thread t owns a contiguous run of tiles: run sums, one scan over the threads, offsets.
-  uint32_t run_sum = 0;
-  const uint32_t per = (tiles + (uint32_t)THREADS - 1u) / (uint32_t)THREADS, lo = min(t * per, tiles), hi = min(lo + per, tiles);
-  for (uint32_t i = lo; i < hi; ++i) run_sum += planned_bin_capacity(tile_cnt[i]);   // (always: the record reports the total)
-  const uint32_t incl = wave_incl_scan(run_sum);
-  if ((t & 63u) == 0) { wmax[t >> 6] = mx; svis[t >> 6] = vis; sr16[t >> 6] = r16; sover[t >> 6] = over; }
-  if ((t & 63u) == 63u) swsum[t >> 6] = incl;
+  // backward read the workspace copy).  Wavefront w owns a contiguous run of tiles, walked 64 at a time (coalesced) with a
+  // wavefront scan and a running carry; the runs' totals are scanned over the wavefronts in between.
+  const uint32_t wv = t >> 6, ln = t & 63u;
+  const uint32_t per = ((tiles + (uint32_t)kW - 1u) / (uint32_t)kW + 63u) & ~63u;        // tiles per wavefront, whole rows of 64
+  const uint32_t lo = min(wv * per, tiles), hi = min(lo + per, tiles);
+  uint32_t run_total = 0;
+  if (plan_next) {
+    for (uint32_t i = lo + ln; i < hi; i += 64u) run_total += planned_bin_capacity(tile_cnt[i]);
+    for (int m = 1; m < 64; m <<= 1) run_total += (uint32_t)__shfl_xor((int)run_total, m, 64);
+  }
+  if (ln == 0) { wmax[wv] = mx; svis[wv] = vis; sr16[wv] = r16; sover[wv] = over; swsum[wv] = run_total; sslots[wv] = slots; }
   __syncthreads();
   unsigned long long slots_next = 0;
-  uint32_t off = incl - run_sum;
-  for (int i = 0; i < kW; ++i) {
-    if (i < (int)(t >> 6)) off += swsum[i];
-    slots_next += swsum[i];
-  }
+  for (int i = 0; i < kW; ++i) slots_next += sslots[i];
   if (plan_next) {
-    for (uint32_t i = lo; i < hi; ++i) { plan_next[i] = off; off += planned_bin_capacity(tile_cnt[i]); }
-    if (t == (uint32_t)THREADS - 1u) plan_next[tiles] = (uint32_t)slots_next;      // (its run is the last one, possibly empty)
+    uint32_t carry = 0;
+    for (uint32_t i = 0; i < wv; ++i) carry += swsum[i];
+    for (uint32_t i0 = lo; i0 < hi; i0 += 64u) {                 // (wave-uniform bounds)
+      const uint32_t i = i0 + ln;
+      const uint32_t cap = i < hi ? planned_bin_capacity(tile_cnt[i]) : 0u;
+      const uint32_t incl = wave_incl_scan(cap);
+      if (i < hi) plan_next[i] = carry + incl - cap;
+      carry += (uint32_t)__shfl((int)incl, 63, 64);
+    }
+    if (t == 0) plan_next[tiles] = (uint32_t)slots_next;
   }
   if (t == 0) {
     uint32_t m = 0, v = 0, ov = 0; unsigned long long r = 0;

@@ -43,7 +43,7 @@ class _VtgsCamera(ctypes.Structure):
 class _VtgsForwardInfo(ctypes.Structure):
     _fields_ = [("instances", ctypes.c_uint64), ("instances_needed", ctypes.c_uint64),
                 ("tiles16_touched", ctypes.c_uint64), ("visible", ctypes.c_uint32), ("max_tile_list", ctypes.c_uint32),
-                ("overflow", ctypes.c_uint32), ("complete", ctypes.c_uint32)]
+                ("overflow", ctypes.c_uint32), ("complete", ctypes.c_uint32), ("bin_slots_needed", ctypes.c_uint64)]
 
 
 class _VtgsProfileEntry(ctypes.Structure):
@@ -458,7 +458,8 @@ PLANNED = 0x80000000
 _BINS_MODE = os.environ.get("VTGS_BINS", "auto")
 if _BINS_MODE not in ("auto", "uniform", "planned"):
     raise ImportError("VTGS_BINS must be auto, uniform or planned")
-_PLANNED_MIN_BYTES = 256 << 20          # auto: uniform bins below this size are never worth replacing
+_PLANNED_MIN_BYTES = 2 << 30            # auto: uniform bins below this size are never worth replacing (planned bins run the
+                                        # separate sort and one more load per tile: +10-25 % on the forward, batch Q of round 3)
 _slots_hint = {}                        # key -> bin slots the last forward's lists needed in total (planned_bin_capacity each)
 _bin_plans = {}                         # key -> persistent device plan (int32 [tiles8 + 1]); rewritten by every planned forward
 
