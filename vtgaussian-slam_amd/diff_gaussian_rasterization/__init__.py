@@ -461,7 +461,7 @@ if _BINS_MODE not in ("auto", "uniform", "planned"):
 _PLANNED_MIN_BYTES = 2 << 30            # auto: uniform bins below this size are never worth replacing (planned bins run the
                                         # separate sort and one more load per tile: +10-25 % on the forward, batch Q of round 3)
 _slots_hint = {}                        # key -> bin slots the last forward's lists needed in total (planned_bin_capacity each)
-_bin_plans = {}                         # key -> persistent device plan (int32 [tiles8 + 1]); rewritten by every planned forward
+_bin_plans = {}                         # (key, stream) -> persistent device plan (int32 [tiles8 + 1]); rewritten by every planned forward
 
 
 def _tiles8(W: int, H: int) -> int:
@@ -485,11 +485,12 @@ def _plan_for(key, device, tile_cap: int, workspace=None, fs_shape=None):
     """The persistent plan of `key` (created on first use).  With the workspace of a forward that just overflowed: the plan
     is rebuilt from that forward's exact list lengths, which the binning counted past its capacities."""
     tiles = _tiles8(key[2], key[3])
-    plan = _bin_plans.get(key)
-    if plan is None or plan.device != device:
-        plan = _bin_plans[key] = torch.empty(tiles + 1, dtype=torch.int32, device=device)
-        _check(_lib.vtgs_bin_plan_uniform(key[2], key[3], tile_cap & ~PLANNED, plan.data_ptr(), _stream_ptr(device)),
-               "vtgs_bin_plan_uniform")
+    stream = _stream_ptr(device)
+    pkey = (key, int(stream))                      # one plan per stream: a forward rewrites the plan it was given, in stream order
+    plan = _bin_plans.get(pkey)
+    if plan is None:
+        plan = _bin_plans[pkey] = torch.empty(tiles + 1, dtype=torch.int32, device=device)
+        _check(_lib.vtgs_bin_plan_uniform(key[2], key[3], tile_cap & ~PLANNED, plan.data_ptr(), stream), "vtgs_bin_plan_uniform")
     if workspace is not None:
         n, capacity, old_tcap = fs_shape
         out = (ctypes.c_uint64 * 12)()
