@@ -151,13 +151,60 @@ __device__ __forceinline__ float wave_sum(float v) {   // butterfly; every lane 
   for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
   return v;
 }
+// Integer reductions / scans over the wavefront through DPP row operations + four readlanes instead of six ds_bpermute round
+// trips each (a crossbar trip is ~100+ cycles of latency on a wavefront's critical path -- the counting sort of the forward
+// composite makes four such reductions per tile, the projection three per workgroup).  VTGS_WAVE_DPP=0: the shuffle forms.
+#ifndef VTGS_WAVE_DPP
+#define VTGS_WAVE_DPP 1
+#endif
+template <int CTRL>
+__device__ __forceinline__ int dpp_all(int v) {                 // a DPP control under which every lane has a valid source
+  return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {   // row shifts: a lane whose source is outside its row reads 0
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+// op over the 16 lanes of each row (every lane ends with its row's result): lane ^ 1, lane ^ 2, mirror within 8, mirror within 16
+#define VTGS_ROW_ALLREDUCE(v, OP)                 \
+  v = OP(v, dpp_all<0xB1>(v));                    \
+  v = OP(v, dpp_all<0x4E>(v));                    \
+  v = OP(v, dpp_all<0x141>(v));                   \
+  v = OP(v, dpp_all<0x140>(v))
 __device__ __forceinline__ int wave_max_i(int v) {
+#if VTGS_WAVE_DPP
+  VTGS_ROW_ALLREDUCE(v, max);
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+#else
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) v = max(v, __shfl_xor(v, m, 64));
   return v;
+#endif
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#if VTGS_WAVE_DPP
+  VTGS_ROW_ALLREDUCE(v, min);
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+#else
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = min(v, __shfl_xor(v, m, 64));
+  return v;
+#endif
 }
 // inclusive prefix sum over lanes
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+#if VTGS_WAVE_DPP
+  v += dpp_or_zero<0x111>(v);                                   // row_shr:1, 2, 4, 8: inclusive scan inside each row of 16
+  v += dpp_or_zero<0x112>(v);
+  v += dpp_or_zero<0x114>(v);
+  v += dpp_or_zero<0x118>(v);
+  const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
+                 r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+  const int l = lane_id();
+  return v + (l >= 16 ? r0 : 0u) + (l >= 32 ? r1 : 0u) + (l >= 48 ? r2 : 0u);
+#else
   const int l = lane_id();
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -165,6 +212,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     if (l >= d) v += t;
   }
   return v;
+#endif
 }
 
 // XCD-aware block remap (8 XCDs, blocks dealt round-robin): gives each XCD a contiguous chunk of

@@ -264,16 +264,9 @@ __device__ __forceinline__ void wave_sort_regs(unsigned long long (&k)[E], uint3
 constexpr int kCountSortMax = 512;           // entries: 8 keys per lane
 constexpr int kCountSortBucketMax = 12;
 
-__device__ __forceinline__ uint32_t wave_min_u(uint32_t v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m, 64));
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, m, 64));
-  return v;
-}
+// unsigned order through the signed reductions of vtgs_internal.h: flipping the top bit maps one order onto the other
+__device__ __forceinline__ uint32_t wave_min_u(uint32_t v) { return (uint32_t)wave_min_i((int)(v ^ 0x80000000u)) ^ 0x80000000u; }
+__device__ __forceinline__ uint32_t wave_max_u(uint32_t v) { return (uint32_t)wave_max_i((int)(v ^ 0x80000000u)) ^ 0x80000000u; }
 
 // stage: 64 E x 8 bytes, cnt: 256 x 4 bytes (LDS of this wavefront alone); lgid: the wavefront's LDS copy of the sorted ids,
 // first lgid_cap entries.  Returns false (nothing written) when a bucket is too long for step 4.
