@@ -94,8 +94,9 @@ typedef struct VtgsForwardInfo {
  *     tile_capacity = VTGS_TILE_CAPACITY_PLANNED | c  HERE AND TO EVERY CALL THAT TAKES THE WORKSPACE (backward, shared
  *     render, workspace_bytes, debug_layout): the workspace then holds tiles x c slots in total, plan[tiles] must not
  *     exceed that, and the forward keeps its own copy of the plan in the workspace for its backward.
- * Planned bins cost one more dependent load per tile in every kernel that walks a list and always take the separate
- * sort kernel: they are for skewed scenes, the default stays uniform.                                                  */
+ * Planned bins cost one more dependent load per tile in every kernel that walks a list, and a pass of the sort kernel for
+ * the lists beyond 1,024 entries ahead of the forward composite (which sorts the others itself, as with uniform bins):
+ * they are for skewed scenes, the default stays uniform.                                                              */
 #define VTGS_TILE_CAPACITY_PLANNED 0x80000000u
 uint32_t vtgs_bin_plan_entries(int32_t width, int32_t height);
 int vtgs_bin_plan_uniform(int32_t width, int32_t height, uint32_t slots_per_bin, uint32_t* bin_plan, void* stream);

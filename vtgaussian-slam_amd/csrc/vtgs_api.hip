@@ -17,7 +17,7 @@ __global__ void finalize_forward(const uint32_t*, uint32_t, Counters*, unsigned 
                                  uint32_t, VtgsForwardInfo*, const uint32_t*, uint32_t*);
 template <bool WIDE>
 __global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t,
-                           const Counters*, int, const uint32_t*, uint32_t);
+                           const Counters*, int, const uint32_t*, uint32_t, unsigned long long);
 __global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                   const GeomRec*, const float*, float*, float*, float*, const Counters*);
 template <int WAVES, bool DUAL>
@@ -342,7 +342,10 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   // The quadrant-queue forward sorts its own tile's list when no bin can hold more than the 1024 entries one wavefront
   // takes (VTGS_SORT_FUSED, default 1), and its first workgroup does finalize_forward's job: nothing is launched between
   // the binning and the composite.
-  const bool fused_sort = option(OPT_FWD_IMPL) == 3 && option(OPT_SORT_FUSED) == 1 && L.tile_cap <= 1024u && !L.planned;
+  // Planned bins: the host does not know the longest bin, so the lists beyond 1,024 entries (usually none, or the one dense
+  // tile the plan exists for) are sorted by a pass of sort_tiles ahead of the composite, which fuses the rest.
+  const bool fused_sort = option(OPT_FWD_IMPL) == 3 && option(OPT_SORT_FUSED) == 1 && (L.tile_cap <= 1024u || L.planned);
+  const bool long_pass = fused_sort && L.planned;
   FinalizeArgs fin;
   fin.tile_cnt = (const uint32_t*)(ws + L.tile_cnt); fin.tiles = L.tiles8; fin.ctr = ctr;
   fin.capacity = (unsigned long long)instance_capacity; fin.tile_cap = L.tile_cap;
@@ -355,17 +358,18 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
                        fin.block_stats, fin.nblocks, host_record, fin.plan, fin.plan_next);
   }
   VTGS_HIP(hipGetLastError());
-  if (!fused_sort) {
+  if (!fused_sort || long_pass) {
     ProfScope ps__("sort_tiles", st);
+    const unsigned long long long_only = long_pass ? (unsigned long long)instance_capacity : 0ull;
     // lists cannot be longer than the bin capacity: the wide (32 keys per lane) form is only worth its registers beyond 1024
     if (packed && (L.tile_cap > 1024u || L.planned))
       hipLaunchKernelGGL(sort_tiles<true>, dim3((band_tiles + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
                          (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
-                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed, cs.bin_plan, cs.bin_limit);
+                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed, cs.bin_plan, cs.bin_limit, long_only);
     else
       hipLaunchKernelGGL(sort_tiles<false>, dim3((band_tiles + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
                          (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
-                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed, cs.bin_plan, cs.bin_limit);
+                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed, cs.bin_plan, cs.bin_limit, long_only);
   }
   VTGS_HIP(hipGetLastError());
   int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st,

@@ -451,10 +451,16 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
                                                   uint32_t* __restrict__ vals, uint32_t* __restrict__ sorted_gid,
                                                   uint32_t* __restrict__ sorted_inst, uint32_t tile_first, uint32_t tiles,
                                                   uint32_t tile_cap, const Counters* __restrict__ ctr, int packed,
-                                                  const uint32_t* __restrict__ plan, uint32_t bin_limit) {
+                                                  const uint32_t* __restrict__ plan, uint32_t bin_limit,
+                                                  unsigned long long long_only_capacity) {
+  // long_only_capacity != 0 (planned bins with the sort fused into the forward composite): only the lists that one wavefront
+  // of the composite cannot sort (> 1,024 entries) are sorted here, ahead of it.  finalize has not run yet in that mode, so
+  // the kernel makes the composite's own safety test: nothing if the INSTANCE capacity overflowed (an entry may have been
+  // dropped after its slot was taken), and no list whose bin overflowed (the composite bails on those).
   __shared__ unsigned long long sk[kSortLds];
   __shared__ uint32_t sv[kSortLds];
-  if (ctr->overflow) return;                    // some bin slots were never written: nothing valid to sort
+  const bool long_only = long_only_capacity != 0ull;
+  if (long_only ? ((unsigned long long)ctr->inst_total > long_only_capacity) : (ctr->overflow != 0u)) return;
   const uint32_t nblk = (tiles + 3u) >> 2;
   const uint32_t b = xcd_swizzle(blockIdx.x, nblk);
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -464,7 +470,8 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
     if (4u * b + (uint32_t)wv < tiles) {
       const BinRange br = bin_range(plan, bin_limit, tile, tile_cap);
       const size_t s = (size_t)br.s;
-      const uint32_t L = min(tile_cnt[tile], br.cap);
+      const uint32_t cnt = tile_cnt[tile];
+      const uint32_t L = (long_only && (cnt > br.cap || cnt <= (uint32_t)kWaveSortMax)) ? 0u : min(cnt, br.cap);
       if (L == 1u) {
         if (lane == 0) { sorted_gid[s] = (uint32_t)keys[s]; sorted_inst[s] = vals[s]; }
       } else if (packed) {
@@ -490,7 +497,8 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
     if (4u * b + q >= tiles) break;
     const BinRange br = bin_range(plan, bin_limit, tile, tile_cap);
     const size_t s = (size_t)br.s;
-    const uint32_t L = min(tile_cnt[tile], br.cap);
+    const uint32_t cnt = tile_cnt[tile];
+    const uint32_t L = (long_only && cnt > br.cap) ? 0u : min(cnt, br.cap);
     if (L <= (uint32_t)((WIDE && packed) ? kWaveSortMaxPacked : kWaveSortMax)) continue;
     uint32_t n2 = 1;
     while (n2 < L) n2 <<= 1;
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
   }
 }
 
-template __global__ void sort_tiles<false>(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, const Counters*, int, const uint32_t*, uint32_t);
-template __global__ void sort_tiles<true>(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, const Counters*, int, const uint32_t*, uint32_t);
+template __global__ void sort_tiles<false>(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, const Counters*, int, const uint32_t*, uint32_t, unsigned long long);
+template __global__ void sort_tiles<true>(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, const Counters*, int, const uint32_t*, uint32_t, unsigned long long);
 
 }  // namespace vtgs

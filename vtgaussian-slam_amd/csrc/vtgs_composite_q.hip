@@ -288,13 +288,14 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
       else if (L <= 128u) wave_sort_tile<2, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
       else if (L <= 256u) wave_sort_tile<4, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
       else if (L <= 512u) wave_sort_tile<8, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
-      else wave_sort_tile<16, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
+      else if (L <= 1024u) wave_sort_tile<16, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
+      // (longer: planned bins -- sort_tiles' long-list pass has sorted it ahead of this kernel)
     } else {
       if (L <= 64u) { if (L) wave_sort_tile<1, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP); }
       else if (L <= 128u) wave_sort_tile<2, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
       else if (L <= 256u) wave_sort_tile<4, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
       else if (L <= 512u) wave_sort_tile<8, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
-      else wave_sort_tile<16, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
+      else if (L <= 1024u) wave_sort_tile<16, false>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
     }
     if (!(counted && L <= (uint32_t)kSortedIdsInLds)) {
       // some of the list will be re-read from memory: the wavefront's own stores before its own loads -- program order within
