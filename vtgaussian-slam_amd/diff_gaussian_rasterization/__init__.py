@@ -172,6 +172,9 @@ def last_forward_info() -> dict:
     """Statistics of the most recent forward on this process (instances, 16x16 tile count R, ...); reads the records of
     run-ahead forwards that are still outstanding first."""
     settle_pending()
+    if _last_raw is not None:
+        _last_info.update(zip(("instances", "tiles16_touched", "visible", "max_tile_list", "n", "width", "height", "capacity"),
+                              _last_raw))
     return dict(_last_info)
 
 
@@ -270,7 +273,12 @@ def _camera_for(settings, device, radius_rule: int, tile_rows) -> "_Camera":
     return cam
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)      # the handle without building a Stream object (~5 us less)
+
+
 def _stream_ptr(device) -> int:
+    if _raw_stream is not None:
+        return _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(device).cuda_stream
 
 
@@ -388,7 +396,10 @@ def check_captured(fs=None) -> None:
     if info.complete and info.overflow:
         key = fs.key
         cap = int(info.instances_needed * 1.5) + 4096 if info.overflow & 1 else fs.capacity
-        tcap = _tile_capacity_for(info.max_tile_list) if info.overflow & 2 else fs.tile_cap
+        tcap = fs.tile_cap
+        if info.overflow & 2:
+            tcap = _planned_capacity(key, int(info.bin_slots_needed)) if tcap & PLANNED else _tile_capacity_for(info.max_tile_list)
+        _slots_hint[key] = max(int(info.bin_slots_needed), 1)
         _caps_in_use[key] = (cap, tcap)
         _async_ok[key] = None
         raise RuntimeError("a forward replayed from a captured graph overflowed its workspace (instances "
@@ -431,7 +442,10 @@ def _settle(fs) -> None:
     key, n = fs.key, fs.n
     if info.overflow:
         cap = int(info.instances_needed * 1.5) + 4096 if info.overflow & 1 else fs.capacity
-        tcap = _tile_capacity_for(info.max_tile_list) if info.overflow & 2 else fs.tile_cap
+        tcap = fs.tile_cap
+        if info.overflow & 2:
+            tcap = _planned_capacity(key, int(info.bin_slots_needed)) if tcap & PLANNED else _tile_capacity_for(info.max_tile_list)
+        _slots_hint[key] = max(int(info.bin_slots_needed), 1)
         _caps_in_use[key] = (cap, tcap)
         _capacity_hint[key] = max(int(info.instances_needed), 1)
         _tile_cap_hint[key] = max(int(info.max_tile_list), 1)
@@ -545,25 +559,34 @@ def _grow_after_overflow(key, n, device, info, capacity, tile_cap, workspace):
 
 
 def _record_info(key, n, W, H, capacity, info):
-    _capacity_hint[key] = max(int(info.instances_needed), 1)
-    _tile_cap_hint[key] = max(int(info.max_tile_list), 1)
-    _slots_hint[key] = max(int(info.bin_slots_needed), 1)
+    # (once per forward, on the host's critical path of the host-bound shapes: plain ints, no generator expressions)
+    need_i, need_t, need_s = int(info.instances_needed), int(info.max_tile_list), int(info.bin_slots_needed)
+    _capacity_hint[key] = need_i or 1
+    _tile_cap_hint[key] = need_t or 1
+    _slots_hint[key] = need_s or 1
     cap, tcap = _caps_in_use.get(key, (0, 0))                  # the capacities this forward ran with
     # Run-ahead is for STEADY loops (tracking, mapping on one frame): the last three forwards of this shape must have needed
     # about the same (within 10 % of each other) and at most 80 % of both capacities.  A loop that alternates between views
     # with very different instance counts under one shape (mapping over random keyframes) therefore stays in the checked mode.
-    hist = _need_hist.setdefault(key, collections.deque(maxlen=3))
-    hist.append((int(info.instances_needed), int(info.max_tile_list)))
-    steady = len(hist) == 3 and all(max(h[j] for h in hist) <= 1.1 * max(1, min(h[j] for h in hist)) for j in (0, 1))
+    hist = _need_hist.get(key)
+    if hist is None:
+        hist = _need_hist[key] = collections.deque(maxlen=3)
+    hist.append((need_i, need_t))
+    steady = False
+    if len(hist) == 3:
+        (a0, b0), (a1, b1), (a2, b2) = hist
+        steady = (max(a0, a1, a2) <= 1.1 * max(1, min(a0, a1, a2))) and (max(b0, b1, b2) <= 1.1 * max(1, min(b0, b1, b2)))
     if tcap & PLANNED:            # every bin already has half again its own list; the plan as a whole must fit the workspace
-        bins_roomy = info.bin_slots_needed <= 0.9 * (tcap & ~PLANNED) * _tiles8(W, H)
+        bins_roomy = need_s <= 0.9 * (tcap & ~PLANNED) * _tiles8(W, H)
     else:
-        bins_roomy = info.max_tile_list <= 0.8 * tcap
-    roomy = bool(cap and tcap and info.instances_needed <= 0.8 * cap and bins_roomy)
+        bins_roomy = need_t <= 0.8 * tcap
+    roomy = bool(cap and tcap and need_i <= 0.8 * cap and bins_roomy)
     _async_ok[key] = (cap, tcap) if (roomy and steady) else None   # ... are the only ones the next forward may run ahead with
-    _last_info.update(instances=int(info.instances), tiles16_touched=int(info.tiles16_touched),
-                      visible=int(info.visible), max_tile_list=int(info.max_tile_list), n=n, width=W, height=H,
-                      capacity=int(capacity))
+    global _last_raw
+    _last_raw = (int(info.instances), int(info.tiles16_touched), int(info.visible), need_t, n, W, H, int(capacity))
+
+
+_last_raw = None
 
 
 _MAX_WORKSPACE_BYTES = int(os.environ.get("VTGS_MAX_WORKSPACE_GB", "96")) << 30
