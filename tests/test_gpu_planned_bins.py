@@ -97,3 +97,48 @@ def test_one_dense_tile_no_longer_sizes_every_bin(gpu_device, monkeypatch):
     assert not uni["planned"] and uni["ws_bytes"] > 20 * auto["ws_bytes"]
     _same(uni, auto)
     _same(uni, again)
+
+
+def test_fused_frame_and_shared_render_through_planned_bins(gpu_device, monkeypatch):
+    """The other consumers of the bins -- the dual render of `render_frame` with its frame-epilogue backward, and the second
+    render over the first one's bins (`render_shared`) -- read the forward's copy of the plan: identical to uniform bins."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization.fused import render_frame
+    dev = gpu_device
+    scene, cam = go.view_tied_scene(15000, 200, 136, seed=21)
+    n = scene["means3D"].shape[0]
+    g = torch.Generator().manual_seed(7)
+    base = {"means3D": scene["means3D"], "rgb_colors": scene["colors_precomp"], "unnorm_rotations": scene["rotations"],
+            "logit_opacities": torch.randn(n, 1, generator=g), "log_scales": torch.log(scene["scales"][:, :1]),
+            "cam_unnorm_rots": torch.tensor([1.0, 0.003, -0.002, 0.001]).reshape(1, 4, 1),
+            "cam_trans": torch.tensor([0.002, -0.001, 0.003]).reshape(1, 3, 1)}
+    st = to_settings(cam, dev)
+    w2c = torch.eye(4, device=dev)
+    g1 = (torch.rand(3, cam.image_height, cam.image_width, generator=g) * 2 - 1).to(dev)
+    g2 = (torch.rand(3, cam.image_height, cam.image_width, generator=g) * 2 - 1).to(dev)
+
+    def run(mode):
+        monkeypatch.setattr(dgr, "_BINS_MODE", mode)
+        p = {k: torch.nn.Parameter(v.clone().to(dev)) for k, v in base.items()}
+        im, ds, radii = render_frame(p, 0, st, w2c, True, True)
+        ((im * g1).sum() + (ds * g2).sum()).backward()
+        out = {"im": im.detach().clone(), "ds": ds.detach().clone(), "radii": radii.clone(),
+               **{"g_" + k: v.grad.clone() for k, v in p.items() if v.grad is not None}}
+        leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in scene.items()}
+        rast = dgr.GaussianRasterizer(raster_settings=st)
+        c, _, _ = rast(**leaves)
+        z = leaves["means3D"][:, 2:3]
+        c2, _ = rast.render_shared(torch.cat([z, torch.ones_like(z), z * z], 1).detach(),
+                                   like=tuple(leaves[k] for k in ("means3D", "means2D", "opacities", "scales", "rotations")))
+        ((c * g1).sum() + (c2 * g2).sum()).backward()
+        dgr.settle_pending()
+        out.update(c=c.detach().clone(), c2=c2.detach().clone(), planned=bool(rast._last_state.tile_cap & dgr.PLANNED),
+                   **{"s_" + k: v.grad.clone() for k, v in leaves.items() if v.grad is not None})
+        return out
+    uni = run("uniform")
+    for _ in range(2):
+        pl = run("planned")
+        assert pl["planned"] and not uni["planned"]
+        for k, v in uni.items():
+            if k != "planned":
+                assert torch.equal(v, pl[k]), k
