@@ -256,3 +256,41 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_iteration(gpu_device, tm
             assert scale > 0, (kind, k)
             err = (got[kind][k] - v).abs().max().item() / scale
             assert err <= 2e-4, f"{kind}: d loss / d {k} differs by {err:.2e} of its maximum"
+
+
+def _rccl_main(rank, world, port, out):
+    import torch.distributed as dist
+    from diff_gaussian_rasterization import partition as pt
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert not pt._host_staged()
+    t = torch.arange(8, dtype=torch.float32, device=dev)
+    pt.all_reduce_sum(t)
+    r = torch.tensor([0, 3, 0, 7], dtype=torch.int32, device=dev)
+    pt.allreduce_radii(r)
+    p = {k: torch.nn.Parameter(torch.ones(5, w, device=dev)) for k, w in (("rgb_colors", 3), ("logit_opacities", 1), ("log_scales", 1))}
+    for v in p.values():
+        v.grad = torch.full_like(v, 2.0)
+    nbytes = pt.allreduce_param_grads(p)
+    img = torch.rand(3, 32, 16, device=dev, requires_grad=True)
+    full = pt.halo_exchange(img, (0, 2), 32, rank, world)                    # one rank: no neighbour, a differentiable copy
+    full.sum().backward()
+    med = pt.global_median(torch.tensor([3.0, 1.0, 2.0, 9.0], device=dev))
+    torch.cuda.synchronize()
+    torch.save({"t": t.cpu(), "r": r.cpu(), "bytes": nbytes, "g": p["rgb_colors"].grad.cpu(), "halo_equal": bool(torch.equal(full, img)),
+                "halo_grad": img.grad.cpu(), "median": med.cpu()}, out)
+    dist.destroy_process_group()
+
+
+def test_collectives_of_the_partition_run_on_rccl(gpu_device, tmp_path):
+    """One rank, backend "nccl" (= RCCL): the collective helpers of the N-rank loop take device tensors as they are (no host
+    staging) and RCCL initialises on this box -- the N-GPU run itself is the driver's."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "rccl.pt")
+    mp.spawn(_rccl_main, args=(1, _free_port(), out), nprocs=1, join=True)
+    got = torch.load(out)
+    assert torch.equal(got["t"], torch.arange(8, dtype=torch.float32)) and got["r"].tolist() == [0, 3, 0, 7]
+    assert got["bytes"] == 20 * 5 and bool((got["g"] == 2).all()) and got["halo_equal"]
+    assert bool((got["halo_grad"] == 1).all()) and got["median"].item() == 2.0
