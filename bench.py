@@ -328,8 +328,28 @@ def main():
             gmax, gp999 = max(gmax, mx), max(gp999, p999)
             gl2 = max(gl2, ((r - h).norm() / (r.norm() + 1e-300)).item())
             gp999_all = max(gp999_all, grad_error(ref_g[k][clean].double(), leaves[k].grad.cpu()[clean].double())[1])
+        # The same statistics for the published algorithm itself in float32 (the CPU oracle, which evaluates every exponent
+        # directly from the pixel offset) against its float64 form: what single precision of the operator's own inputs --
+        # pixel centres carry 2^-24 x 1200 px -- leaves of these figures for ANY float32 implementation.
+        f32 = None
+        try:
+            c32, _, d32, g32, keep32, _, _ = oracle_rows(scene, cam, rows, gsel, dtype=torch.float32)
+            sel32 = clean_inner & keep32
+            f_p999 = f_max = 0.0
+            for k in GRAD_KEYS:
+                if k == "rotations" or ref_g[k].abs().max().item() == 0 or not bool(sel32.any()):
+                    continue
+                mx, p999 = grad_error(ref_g[k][sel32].double(), g32[k][sel32].double())
+                f_p999, f_max = max(f_p999, p999), max(f_max, mx)
+            img32 = max((((ref_c - c32.double()).abs().amax()) / ref_c.abs().amax()).item(),
+                        (((ref_d - d32.double()).abs().amax()) / ref_d.abs().amax()).item())
+            f32 = {"grad_p999": f_p999, "grad_max_rel": f_max, "img_max_rel": img32,
+                   "note": "float32 CPU oracle vs float64 CPU oracle, same rows, same Gaussians, same statistics"}
+        except Exception as e:                                   # (reporting only: never fail the bench line over it)
+            f32 = {"error": repr(e)}
         n_px = int(mask.sum()) * W
         parity = {"oracle": "float64, tile rows " + ",".join(map(str, rows)) + f" ({n_px} pixels, {int(keep.sum())} Gaussians)",
+                  "float32_oracle_vs_float64": f32,
                   "img_outliers_gt_1e-4": a_c["outliers"] + a_d["outliers"], "img_max_rel": max(a_c["max_rel"], a_d["max_rel"]),
                   "unexplained": len(a_c["unexplained"]) + len(a_d["unexplained"]),
                   "radii_differ": int(rdiff.sum()), "gaussians_beside_an_audited_pixel": int(taint_full.sum()),
