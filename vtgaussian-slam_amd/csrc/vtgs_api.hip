@@ -13,6 +13,10 @@ template <bool LDSBINS, int MODE>
 __global__ void project_and_bin(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
                                 const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*,
                                 Counters*, BlockStats*, unsigned long long, uint32_t);
+template <bool LDSBINS, int MODE>
+__global__ void project_and_bin_capped(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
+                                const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*,
+                                Counters*, BlockStats*, unsigned long long, uint32_t);
 __global__ void finalize_forward(const uint32_t*, uint32_t, Counters*, unsigned long long, uint32_t, const BlockStats*,
                                  uint32_t, VtgsForwardInfo*, const uint32_t*, uint32_t*);
 template <bool WIDE>
@@ -295,9 +299,9 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
       if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) { (void)hipGetLastError(); dev_id = -1; }
       if (dev_id < 0 || !raised[dev_id]) {
         if (hipFuncSetAttribute((const void*)project_and_bin<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
-            hipFuncSetAttribute((const void*)project_and_bin<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
-            hipFuncSetAttribute((const void*)project_and_bin<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
-            hipFuncSetAttribute((const void*)project_and_bin<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess) {
+            hipFuncSetAttribute((const void*)project_and_bin_capped<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
+            hipFuncSetAttribute((const void*)project_and_bin_capped<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
+            hipFuncSetAttribute((const void*)project_and_bin_capped<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess) {
           if (dev_id >= 0) raised[dev_id] = true;
         } else { (void)hipGetLastError(); lds_bins = false; }
       }
@@ -306,22 +310,30 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
       ProfScope ps__("project_and_bin", st);
       const int mode = ((r8b > 0 || r8e < (cam->image_height + kSubTile - 1) / kSubTile) ? 1 : 0) | (L.planned ? 2 : 0);
 #define VTGS_LAUNCH_PROJECT(LDS, MODE, SHMEM)                                                                          \
-      hipLaunchKernelGGL((project_and_bin<LDS, MODE>), dim3((n + 1023) / 1024), dim3(1024), SHMEM, st, cs,             \
+      hipLaunchKernelGGL((VTGS_PROJECT_KERNEL(LDS, MODE)), dim3((n + 1023) / 1024), dim3(1024), SHMEM, st, cs,             \
                          cam->viewmatrix, cam->projmatrix, n, means3D, opacities, scales, rotations, out_radii,         \
                          (GeomRec*)(ws + L.geom), (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt),              \
                          (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), ctr,                            \
                          (BlockStats*)(ws + L.block_stats), (unsigned long long)instance_capacity, L.tile_cap)
       if (lds_bins) {
+#define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin<LDS, MODE>
         if (mode == 0) VTGS_LAUNCH_PROJECT(true, 0, table_bytes);
+#undef VTGS_PROJECT_KERNEL
+#define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin_capped<LDS, MODE>
         else if (mode == 1) VTGS_LAUNCH_PROJECT(true, 1, table_bytes);
         else if (mode == 2) VTGS_LAUNCH_PROJECT(true, 2, table_bytes);
         else VTGS_LAUNCH_PROJECT(true, 3, table_bytes);
       } else {
+#undef VTGS_PROJECT_KERNEL
+#define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin<LDS, MODE>
         if (mode == 0) VTGS_LAUNCH_PROJECT(false, 0, 0);
+#undef VTGS_PROJECT_KERNEL
+#define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin_capped<LDS, MODE>
         else if (mode == 1) VTGS_LAUNCH_PROJECT(false, 1, 0);
         else if (mode == 2) VTGS_LAUNCH_PROJECT(false, 2, 0);
         else VTGS_LAUNCH_PROJECT(false, 3, 0);
       }
+#undef VTGS_PROJECT_KERNEL
 #undef VTGS_LAUNCH_PROJECT
     }
     VTGS_HIP(hipGetLastError());

@@ -132,7 +132,7 @@ __device__ __forceinline__ BigWalk broadcast_walk(const TileWalk& w, const Splat
 //   bit 0  a band of the tile-row partition (row cull before the projection, early exit of workgroups with nothing in the band)
 //   bit 1  planned bins (bin t = [plan[t], plan[t+1]), include/vtgs.h)
 template <bool LDSBINS, int MODE>
-__global__ __launch_bounds__(kProjBlock) void project_and_bin(
+__device__ __forceinline__ void project_and_bin_body(
     CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
     const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -392,14 +392,39 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
 }
 
 
+
+// The kernels proper.  MODE 0 (whole frame, uniform bins) compiles to 79 scalar registers by itself; the other modes need 82-90,
+// which costs the second workgroup per CU (13 us of 54 at the headline shape, profiles/r3_project_ab.txt): they are capped at
+// 80, a few scalars then live in vector-register lanes.  (The cap on MODE 0 would push it to 65 vector registers -- the same cliff
+// from the other side -- hence two definitions.)
+template <bool LDSBINS, int MODE>
+__global__ __launch_bounds__(kProjBlock) void project_and_bin(
+    CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
+    const float* __restrict__ means3D, const float* __restrict__ opacities,
+    const float* __restrict__ scales, const float* __restrict__ rotations,
+    int32_t* __restrict__ radii, GeomRec* __restrict__ geom, GaussAux* __restrict__ gaux,
+    uint32_t* __restrict__ tile_cnt, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
+    Counters* __restrict__ ctr, BlockStats* __restrict__ block_stats, unsigned long long capacity, uint32_t tile_cap) {
+  project_and_bin_body<LDSBINS, MODE>(cs, Vp, PVp, n, means3D, opacities, scales, rotations, radii, geom, gaux, tile_cnt, keys, vals, ctr, block_stats, capacity, tile_cap);
+}
+template <bool LDSBINS, int MODE>
+__global__ __launch_bounds__(kProjBlock) __attribute__((amdgpu_num_sgpr(80))) void project_and_bin_capped(
+    CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
+    const float* __restrict__ means3D, const float* __restrict__ opacities,
+    const float* __restrict__ scales, const float* __restrict__ rotations,
+    int32_t* __restrict__ radii, GeomRec* __restrict__ geom, GaussAux* __restrict__ gaux,
+    uint32_t* __restrict__ tile_cnt, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
+    Counters* __restrict__ ctr, BlockStats* __restrict__ block_stats, unsigned long long capacity, uint32_t tile_cap) {
+  project_and_bin_body<LDSBINS, MODE>(cs, Vp, PVp, n, means3D, opacities, scales, rotations, radii, geom, gaux, tile_cnt, keys, vals, ctr, block_stats, capacity, tile_cap);
+}
 template __global__ void project_and_bin<false, 0>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin<false, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin<false, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin<false, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
 template __global__ void project_and_bin<true, 0>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin<true, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin<true, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin<true, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<false, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<false, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<false, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<true, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<true, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<true, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
 
 // One workgroup right after the binning: longest tile list, statistics, overflow flags and the image of the
 // host-visible VtgsForwardInfo (finalize_block, vtgs_internal.h; the quadrant-queue forward runs it in its first workgroup

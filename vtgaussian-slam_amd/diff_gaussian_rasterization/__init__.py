@@ -473,7 +473,7 @@ _BINS_MODE = os.environ.get("VTGS_BINS", "auto")
 if _BINS_MODE not in ("auto", "uniform", "planned"):
     raise ImportError("VTGS_BINS must be auto, uniform or planned")
 _PLANNED_MIN_BYTES = 2 << 30            # auto: uniform bins below this size are never worth replacing (planned bins cost a step
-                                        # 5-7 % at the headline shape: gpurun_out/r3/timing_v.txt)
+                                        # 2 % at the headline shape: profiles/r3_planned_bins.txt)
 _slots_hint = {}                        # key -> bin slots the last forward's lists needed in total (planned_bin_capacity each)
 _bin_plans = {}                         # (key, stream) -> persistent device plan (int32 [tiles8 + 1]); rewritten by every planned forward
 
