@@ -879,6 +879,10 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
 #endif
   constexpr int REC = DUAL ? kGradRecDual : kGradRec;         // floats per (splat, tile) record
   __shared__ float4 lds_xch_all[WAVES][PXL ? 1 : 128];
+#ifdef VTGS_AB_BWD_PAD                                          // occupancy experiment: extra LDS so that fewer workgroups fit a CU
+  __shared__ float ab_pad[VTGS_AB_BWD_PAD];
+  if (cs.W < 0) { ab_pad[threadIdx.x] = 1.f; __syncthreads(); if (ab_pad[(threadIdx.x + 1) & 255] == 2.f) return; }
+#endif
   __shared__ __attribute__((aligned(16))) float lds_uw[WAVES][2][kImgFloats];
   __shared__ __attribute__((aligned(16))) float lds_phi[4 * kPhiQuarter];
   // the contraction's dL/dcolor operands live in LDS ([wave][second set?][quarter][column][16 + 4]), not in 16 / 32 VGPRs:
