@@ -222,6 +222,10 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
   __shared__ float4 lds_pb[DUAL ? 4 : 1][DUAL ? kQRing + 1 : 1];//                   (dual: c4 c5 0 0)
   __shared__ uint8_t lds_q[4][4][kQRing];
   __shared__ uint32_t lds_sgid[4][kSortedIdsInLds];             // the wavefront's own copy of the first sorted Gaussian ids
+#ifdef VTGS_AB_FWD_PAD                                          // occupancy experiment: extra LDS so that fewer workgroups fit a CU
+  __shared__ float ab_pad[VTGS_AB_FWD_PAD];
+  if (cs.W < 0) { ab_pad[threadIdx.x] = 1.f; __syncthreads(); if (ab_pad[(threadIdx.x + 1) & 255] == 2.f) return; }
+#endif
 #ifdef VTGS_Q_STAMPS
   const unsigned long long st0 = __builtin_amdgcn_s_memtime();
   unsigned long long st1 = st0, st2 = st0, st_app = 0ull, st_step = 0ull;
