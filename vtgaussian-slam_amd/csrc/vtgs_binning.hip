@@ -144,10 +144,6 @@ __device__ __forceinline__ void project_and_bin_body(
   const CamParams cam = load_cam(cs, Vp, PVp);
   const int tile0 = cam.row8_begin * cam.gx8;                    // first tile of the band (tile-row multi-GPU partition)
   const int tiles8 = (cam.row8_end - cam.row8_begin) * cam.gx8;
-  if constexpr (LDSBINS) {
-    for (int i = (int)threadIdx.x; i < tiles8; i += kProjBlock) lds_tile[i] = 0u;
-    __syncthreads();
-  }
   const int gid = (int)(blockIdx.x * (uint32_t)kProjBlock + threadIdx.x);
   const int l = lane_id();
   const bool valid = gid < n;
@@ -215,6 +211,12 @@ __device__ __forceinline__ void project_and_bin_body(
   const bool big = area_all > kBigArea;                        // left to the wavefront, at the end of the kernel
   const int area = big ? 0 : area_all;
 
+  // the per-tile table is cleared only now: the input loads above are in flight while it happens, and the workgroups of a
+  // band that left above never touch it
+  if constexpr (LDSBINS) {
+    for (int i = (int)threadIdx.x; i < tiles8; i += kProjBlock) lds_tile[i] = 0u;
+    __syncthreads();
+  }
   // pass 1: which candidate tiles does this splat really reach (remembered as a bitmask for the first 64)
   uint32_t cnt = 0;
   unsigned long long reach_mask = 0ull;
