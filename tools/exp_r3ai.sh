@@ -1,0 +1,15 @@
+#!/bin/bash
+# batch AI: workgroup counting sort for lists of 513..2048 entries in sort_tiles
+set -o pipefail
+R=$PWD; O=$R/gpurun_out/r3; mkdir -p $O
+fail() { echo "FAILED: $1"; exit 1; }
+timeout -k 10 900 python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py tests/test_gpu_planned_bins.py tests/test_gpu_abi_modes.py -q -m gpu > $O/pytest_ai1.log 2>&1 || { tail -40 $O/pytest_ai1.log | cut -c1-300; fail "tests"; }
+tail -2 $O/pytest_ai1.log
+: > $O/timing_ai.txt
+for rep in 1 2; do
+ABL_N=2000000 ABL_W=640 ABL_H=480 ABL_TAG=scannet_2M timeout -k 10 200 python tools/kernel_timing.py >> $O/timing_ai.txt 2>&1 || fail 2m
+ABL_N=2000000 ABL_W=640 ABL_H=480 ABL_BAND=1/4 ABL_TAG=scannet_2M_band1of4 timeout -k 10 200 python tools/kernel_timing.py >> $O/timing_ai.txt 2>&1 || fail 2mband
+done
+VTGS_SORT_FUSED=0 ABL_TAG=headline_sort_kernel timeout -k 10 200 python tools/kernel_timing.py >> $O/timing_ai.txt 2>&1 || fail headline
+ABL_N=1000000 ABL_W=640 ABL_H=480 ABL_TAG=1M_640x480 timeout -k 10 200 python tools/kernel_timing.py >> $O/timing_ai.txt 2>&1 || fail 1m640
+grep -v amdgpu.ids $O/timing_ai.txt

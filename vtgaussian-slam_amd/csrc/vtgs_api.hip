@@ -21,7 +21,9 @@ __global__ void finalize_forward(const uint32_t*, uint32_t, Counters*, unsigned 
                                  uint32_t, VtgsForwardInfo*, const uint32_t*, uint32_t*);
 template <bool WIDE>
 __global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t,
-                           const Counters*, int, const uint32_t*, uint32_t, unsigned long long);
+                           const Counters*, int, const uint32_t*, uint32_t, unsigned long long, int);
+__global__ void sort_long_lists(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t,
+                                const Counters*, const uint32_t*, uint32_t, unsigned long long);
 __global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                   const GeomRec*, const float*, float*, float*, float*, const Counters*);
 template <int WAVES, bool DUAL>
@@ -373,15 +375,22 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   if (!fused_sort || long_pass) {
     ProfScope ps__("sort_tiles", st);
     const unsigned long long long_only = long_pass ? (unsigned long long)instance_capacity : 0ull;
+    // lists of 513 (1,025 ahead of a fusing forward) .. 2,048 entries: one workgroup each, counting sort; then everything else
+    const int mid_done = (L.tile_cap > (long_pass ? 1024u : 512u) || L.planned) ? 1 : 0;
+    if (mid_done)
+      hipLaunchKernelGGL(sort_long_lists, dim3(band_tiles), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
+                         (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
+                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, cs.bin_plan,
+                         cs.bin_limit, long_only);
     // lists cannot be longer than the bin capacity: the wide (32 keys per lane) form is only worth its registers beyond 1024
-    if (packed && (L.tile_cap > 1024u || L.planned))
+    if (packed && (L.tile_cap > 1024u || L.planned) && !mid_done)   // (the wide register form: only without the long-list kernel)
       hipLaunchKernelGGL(sort_tiles<true>, dim3((band_tiles + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
                          (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
-                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed, cs.bin_plan, cs.bin_limit, long_only);
+                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed, cs.bin_plan, cs.bin_limit, long_only, mid_done);
     else
       hipLaunchKernelGGL(sort_tiles<false>, dim3((band_tiles + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
                          (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
-                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed, cs.bin_plan, cs.bin_limit, long_only);
+                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed, cs.bin_plan, cs.bin_limit, long_only, mid_done);
   }
   VTGS_HIP(hipGetLastError());
   int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st,

@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
                                                   uint32_t* __restrict__ sorted_inst, uint32_t tile_first, uint32_t tiles,
                                                   uint32_t tile_cap, const Counters* __restrict__ ctr, int packed,
                                                   const uint32_t* __restrict__ plan, uint32_t bin_limit,
-                                                  unsigned long long long_only_capacity) {
+                                                  unsigned long long long_only_capacity, int mid_done) {
   // long_only_capacity != 0 (planned bins with the sort fused into the forward composite): only the lists that one wavefront
   // of the composite cannot sort (> 1,024 entries) are sorted here, ahead of it.  finalize has not run yet in that mode, so
   // the kernel makes the composite's own safety test: nothing if the INSTANCE capacity overflowed (an entry may have been
@@ -498,7 +498,8 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
       const BinRange br = bin_range(plan, bin_limit, tile, tile_cap);
       const size_t s = (size_t)br.s;
       const uint32_t cnt = tile_cnt[tile];
-      const uint32_t L = (long_only && (cnt > br.cap || cnt <= (uint32_t)kWaveSortMax)) ? 0u : min(cnt, br.cap);
+      uint32_t L = (long_only && (cnt > br.cap || cnt <= (uint32_t)kWaveSortMax)) ? 0u : min(cnt, br.cap);
+      if (mid_done && L > (uint32_t)kCountSortMax && L <= (uint32_t)kBlockSortMax) L = 0u;   // sorted by sort_long_lists
       if (L == 1u) {
         if (lane == 0) { sorted_gid[s] = (uint32_t)keys[s]; sorted_inst[s] = vals[s]; }
       } else if (packed) {
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
     const size_t s = (size_t)br.s;
     const uint32_t cnt = tile_cnt[tile];
     const uint32_t L = (long_only && cnt > br.cap) ? 0u : min(cnt, br.cap);
-    if (L <= (uint32_t)((WIDE && packed) ? kWaveSortMaxPacked : kWaveSortMax)) continue;
+    if (L <= (uint32_t)((WIDE && packed) ? kWaveSortMaxPacked : kWaveSortMax) || (mid_done && L <= (uint32_t)kBlockSortMax)) continue;
     uint32_t n2 = 1;
     while (n2 < L) n2 <<= 1;
     __syncthreads();
@@ -542,7 +543,39 @@ __global__ __launch_bounds__(256) void sort_tiles(const uint32_t* __restrict__ t
   }
 }
 
-template __global__ void sort_tiles<false>(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, const Counters*, int, const uint32_t*, uint32_t, unsigned long long);
-template __global__ void sort_tiles<true>(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, const Counters*, int, const uint32_t*, uint32_t, unsigned long long);
+// Lists of 513 .. 2,048 entries (1,025 .. 2,048 ahead of a forward that sorts the rest itself), ONE list per workgroup: the
+// workgroup counting sort of vtgs_sort_common.h, or -- when it declines a list (a bucket of more than 12 near-equal depths) --
+// the LDS network.  sort_tiles (mid_done = 1) leaves those lists alone.  Dense maps (2 M Gaussians at 640x480, ~1,300 per
+// tile): the 32-keys-per-lane register network took 113 us for them, this takes profiles/r3_long_list_sort.txt.
+__global__ __launch_bounds__(256) void sort_long_lists(const uint32_t* __restrict__ tile_cnt, unsigned long long* __restrict__ keys,
+                                                       uint32_t* __restrict__ vals, uint32_t* __restrict__ sorted_gid,
+                                                       uint32_t* __restrict__ sorted_inst, uint32_t tile_first, uint32_t tiles,
+                                                       uint32_t tile_cap, const Counters* __restrict__ ctr,
+                                                       const uint32_t* __restrict__ plan, uint32_t bin_limit,
+                                                       unsigned long long long_only_capacity) {
+  __shared__ unsigned long long sk[kSortLds];
+  __shared__ uint32_t sv[kSortLds];
+  static_assert(kSortLds >= kBlockSortMax && kSortLds >= kBlockSortBuckets, "LDS staging of the workgroup counting sort");
+  const bool long_only = long_only_capacity != 0ull;
+  if (long_only ? ((unsigned long long)ctr->inst_total > long_only_capacity) : (ctr->overflow != 0u)) return;
+  const uint32_t tile = tile_first + xcd_swizzle(blockIdx.x, tiles);
+  const BinRange br = bin_range(plan, bin_limit, tile, tile_cap);
+  const uint32_t cnt = tile_cnt[tile];
+  if (cnt > br.cap) return;                                     // an overflowing bin: every consumer bails on the flag
+  const uint32_t L = cnt, lo = long_only ? (uint32_t)kWaveSortMax : (uint32_t)kCountSortMax;
+  if (L <= lo || L > (uint32_t)kBlockSortMax) return;           // workgroup-uniform
+  const size_t s = (size_t)br.s;
+  const uint32_t t = threadIdx.x;
+  if (block_count_sort(keys, vals, sorted_gid, sorted_inst, s, L, t, sk, sv)) return;
+  uint32_t n2 = 1;
+  while (n2 < L) n2 <<= 1;
+  for (uint32_t i = t; i < L; i += 256u) { sk[i] = keys[s + i]; sv[i] = vals[s + i]; }
+  __syncthreads();
+  sort_network(sk, sv, L, n2, t);
+  for (uint32_t i = t; i < L; i += 256u) { sorted_gid[s + i] = (uint32_t)sk[i]; sorted_inst[s + i] = sv[i]; }
+}
+
+template __global__ void sort_tiles<false>(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, const Counters*, int, const uint32_t*, uint32_t, unsigned long long, int);
+template __global__ void sort_tiles<true>(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, const Counters*, int, const uint32_t*, uint32_t, unsigned long long, int);
 
 }  // namespace vtgs

@@ -338,6 +338,83 @@ __device__ __forceinline__ bool wave_count_sort(const unsigned long long* __rest
   return true;
 }
 
+// The same counting sort by a whole 256-thread workgroup for ONE list of 513 .. 2048 entries (dense maps: 2 M Gaussians at
+// 640x480 average ~1,300 per tile): 1,024 buckets, eight keys per thread, stage / cnt in the workgroup's LDS (16 KB + 4 KB).
+// Replaces the 32-keys-per-lane register network for such lists (round 3: sort_tiles 113 -> see profiles/r3_long_list_sort.txt).
+// All 256 threads call it (barriers inside); returns false -- nothing written -- when a bucket is too long for the rank pass.
+constexpr int kBlockSortMax = 2048;
+constexpr int kBlockSortBuckets = 1024;
+__device__ __forceinline__ bool block_count_sort(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                 uint32_t* __restrict__ sorted_gid, uint32_t* __restrict__ sorted_inst, size_t s,
+                                                 uint32_t L, uint32_t t, unsigned long long* __restrict__ stage,
+                                                 uint32_t* __restrict__ cnt) {
+  constexpr int E = kBlockSortMax / 256;                         // 8 keys per thread: element r * 256 + t
+  __shared__ uint32_t red[8];
+  unsigned long long k[E];
+  uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const uint32_t e = (uint32_t)r * 256u + t;
+    const bool in = e < L;
+    k[r] = in ? keys[s + e] : ~0ull;
+    const uint32_t d = (uint32_t)(k[r] >> 32);
+    dmin = in ? min(dmin, d) : dmin;
+    dmax = in ? max(dmax, d) : dmax;
+  }
+#pragma unroll
+  for (int j = 0; j < kBlockSortBuckets / 256; ++j) cnt[256 * j + t] = 0u;
+  dmin = wave_min_u(dmin); dmax = wave_max_u(dmax);
+  if ((t & 63u) == 0u) { red[t >> 6] = dmin; red[4 + (t >> 6)] = dmax; }
+  __syncthreads();
+  dmin = min(min(red[0], red[1]), min(red[2], red[3]));
+  dmax = max(max(red[4], red[5]), max(red[6], red[7]));
+  const float scale = (float)kBlockSortBuckets / ((float)(dmax - dmin) + 1.0f);
+  uint32_t bp[E];                                               // bucket (10 bits) | arrival index in the bucket << 16
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const bool in = (uint32_t)r * 256u + t < L;
+    const uint32_t b = min((uint32_t)kBlockSortBuckets - 1u, (uint32_t)((float)((uint32_t)(k[r] >> 32) - dmin) * scale));
+    bp[r] = b;
+    if (in) bp[r] |= atomicAdd(&cnt[b], 1u) << 16;
+  }
+  __syncthreads();
+  // exclusive scan of the 1,024 counts: thread t owns buckets 4 t .. 4 t + 3
+  const uint4 c = reinterpret_cast<const uint4*>(cnt)[t];
+  const uint32_t t1 = c.x + c.y, t2 = t1 + c.z, t3 = t2 + c.w;
+  const uint32_t incl = wave_incl_scan(t3);
+  uint32_t longest = wave_max_u(max(max(c.x, c.y), max(c.z, c.w)));
+  __syncthreads();                                              // (red is read above by everybody before it is rewritten)
+  if ((t & 63u) == 63u) red[t >> 6] = incl;
+  if ((t & 63u) == 0u) red[4 + (t >> 6)] = longest;
+  __syncthreads();
+  uint32_t excl = incl - t3;
+  for (uint32_t w = 0; w < (t >> 6); ++w) excl += red[w];
+  longest = max(max(red[4], red[5]), max(red[6], red[7]));
+  if (longest > (uint32_t)kCountSortBucketMax) return false;    // workgroup-uniform
+  reinterpret_cast<uint4*>(cnt)[t] = make_uint4((excl << 16) | c.x, ((excl + c.x) << 16) | c.y, ((excl + t1) << 16) | c.z,
+                                                ((excl + t2) << 16) | c.w);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    if ((uint32_t)r * 256u + t < L) stage[(cnt[bp[r] & 0xFFFFu] >> 16) + (bp[r] >> 16)] = k[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const uint32_t e = (uint32_t)r * 256u + t;
+    if (e < L) {
+      const uint32_t pc = cnt[bp[r] & 0xFFFFu], base = pc >> 16, nb = pc & 0xFFFFu;
+      uint32_t rank = 0u;
+      for (uint32_t j = 0; j < nb; ++j) rank += (stage[base + j] < k[r]) ? 1u : 0u;
+      const uint32_t pos = base + rank;
+      sorted_gid[s + pos] = (uint32_t)k[r];
+      sorted_inst[s + pos] = vals[s + e];
+    }
+  }
+  __syncthreads();                                              // stage / cnt are the caller's to reuse
+  return true;
+}
+
 // PACKED (Gaussian ids below 2^21, list positions below 2^11 -- the host decides): the low key word becomes
 // (gid << 11 | bin slot); the order (depth, gid) is unchanged, the instance id is fetched from its slot afterwards.
 constexpr uint32_t kSlotBits = 11u;            // (the host sends ids below 2^21 only: 21 + 11 bits)
