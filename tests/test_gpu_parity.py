@@ -856,3 +856,34 @@ def test_quadrant_queue_backward_against_the_oracle(gpu_device, name):
     backward -- and is covered by the kernel-vs-kernel test above instead of a bound loosened for it.)"""
     _opt("VTGS_BWD_IMPL", 3)
     test_forward_backward_parity(gpu_device, name)
+
+
+@pytest.mark.parametrize("ties", [False, True])
+def test_long_list_counting_sort_equals_the_network(gpu_device, monkeypatch, ties):
+    """Dense maps: lists of 513 .. 2,048 entries go through the workgroup counting sort (sort_long_lists); with many exactly
+    equal depths a bucket overflows and the same kernel falls back to the LDS network.  Both orders are THE order -- strictly
+    increasing (depth bits, Gaussian id) -- and identical to what the network alone produces (VTGS_SORT_LONG_COUNTING=0)."""
+    import diff_gaussian_rasterization as dgr
+    from parity_util import to_settings
+    scene, cam = go.view_tied_scene(260_000, 160, 120, seed=29)          # 300 tiles of 8x8: ~1,000 - 1,800 entries each
+    if ties:
+        scene["means3D"][:, 2] = (scene["means3D"][:, 2] * 4).round() / 4   # a few distinct depths: every bucket overflows
+    dev = gpu_device
+    leaves = {k: v.to(dev) for k, v in scene.items()}
+    res = {}
+    for counting in (1, 0):
+        _opt("VTGS_SORT_LONG_COUNTING", counting)
+        rast = dgr.GaussianRasterizer(raster_settings=to_settings(cam, dev))
+        with torch.no_grad():
+            color, radii, depth = rast(**leaves)
+        offs, gid, geom = dgr.debug_tile_lists(rast)
+        res[counting] = (color.cpu(), depth.cpu(), offs, gid)
+        lens = offs[1:] - offs[:-1]
+        assert int(((lens > 512) & (lens <= 2048)).sum()) > 100, int(lens.max())      # the lists this test is about
+        zbits = geom[:, 6].view(torch.int32).long()
+        key = (zbits[gid] << 32) | gid
+        tile_of = torch.repeat_interleave(torch.arange(lens.numel()), lens)
+        assert bool(((key[1:] > key[:-1]) | (tile_of[1:] != tile_of[:-1])).all())
+    _opt("VTGS_SORT_LONG_COUNTING", 1)
+    for a, b in zip(res[1], res[0]):
+        assert torch.equal(a, b)

@@ -23,7 +23,7 @@ template <bool WIDE>
 __global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t,
                            const Counters*, int, const uint32_t*, uint32_t, unsigned long long, int);
 __global__ void sort_long_lists(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t,
-                                const Counters*, const uint32_t*, uint32_t, unsigned long long);
+                                const Counters*, const uint32_t*, uint32_t, unsigned long long, int);
 __global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                   const GeomRec*, const float*, float*, float*, float*, const Counters*);
 template <int WAVES, bool DUAL>
@@ -161,8 +161,8 @@ size_t vtgs_backward_dual_scratch_bytes(int32_t n, uint64_t instances) {
 // Implementation switches: defaults from the environment, read once; vtgs_set_option overrides them at run time.
 struct Option { const char* name; int dflt; int value; };
 static Option g_options[] = {{"VTGS_FWD_IMPL", 3, -1}, {"VTGS_BWD_IMPL", 2, -1}, {"VTGS_BIN_IMPL", 1, -1}, {"VTGS_SORT_PACKED", 1, -1},
-                             {"VTGS_SORT_FUSED", 1, -1}, {"VTGS_COUNT_STEPS", 0, -1}};
-enum { OPT_FWD_IMPL = 0, OPT_BWD_IMPL, OPT_BIN_IMPL, OPT_SORT_PACKED, OPT_SORT_FUSED, OPT_COUNT_STEPS, OPT_COUNT };
+                             {"VTGS_SORT_FUSED", 1, -1}, {"VTGS_COUNT_STEPS", 0, -1}, {"VTGS_SORT_LONG_COUNTING", 1, -1}};
+enum { OPT_FWD_IMPL = 0, OPT_BWD_IMPL, OPT_BIN_IMPL, OPT_SORT_PACKED, OPT_SORT_FUSED, OPT_COUNT_STEPS, OPT_SORT_LONG_COUNTING, OPT_COUNT };
 static std::once_flag g_options_once;
 static void options_init() {                                   // thread-safe: the first caller reads the environment
   std::call_once(g_options_once, [] {
@@ -381,7 +381,7 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
       hipLaunchKernelGGL(sort_long_lists, dim3(band_tiles), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
                          (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
                          (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, cs.bin_plan,
-                         cs.bin_limit, long_only);
+                         cs.bin_limit, long_only, option(OPT_SORT_LONG_COUNTING));
     // lists cannot be longer than the bin capacity: the wide (32 keys per lane) form is only worth its registers beyond 1024
     if (packed && (L.tile_cap > 1024u || L.planned) && !mid_done)   // (the wide register form: only without the long-list kernel)
       hipLaunchKernelGGL(sort_tiles<true>, dim3((band_tiles + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),

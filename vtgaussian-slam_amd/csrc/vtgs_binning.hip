@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) void sort_long_lists(const uint32_t* __restric
                                                        uint32_t* __restrict__ sorted_inst, uint32_t tile_first, uint32_t tiles,
                                                        uint32_t tile_cap, const Counters* __restrict__ ctr,
                                                        const uint32_t* __restrict__ plan, uint32_t bin_limit,
-                                                       unsigned long long long_only_capacity) {
+                                                       unsigned long long long_only_capacity, int counting) {
   __shared__ unsigned long long sk[kSortLds];
   __shared__ uint32_t sv[kSortLds];
   static_assert(kSortLds >= kBlockSortMax && kSortLds >= kBlockSortBuckets, "LDS staging of the workgroup counting sort");
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void sort_long_lists(const uint32_t* __restric
   if (L <= lo || L > (uint32_t)kBlockSortMax) return;           // workgroup-uniform
   const size_t s = (size_t)br.s;
   const uint32_t t = threadIdx.x;
-  if (block_count_sort(keys, vals, sorted_gid, sorted_inst, s, L, t, sk, sv)) return;
+  if (counting && block_count_sort(keys, vals, sorted_gid, sorted_inst, s, L, t, sk, sv)) return;   // (counting = 0: cross-check switch)
   uint32_t n2 = 1;
   while (n2 < L) n2 <<= 1;
   for (uint32_t i = t; i < L; i += 256u) { sk[i] = keys[s + i]; sv[i] = vals[s + i]; }

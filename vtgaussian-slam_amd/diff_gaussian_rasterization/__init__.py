@@ -191,7 +191,7 @@ def profile_collect() -> dict:
     return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches) for i in range(n.value)}
 
 
-_OPTION_NAMES = ("VTGS_FWD_IMPL", "VTGS_BWD_IMPL", "VTGS_BIN_IMPL", "VTGS_SORT_PACKED", "VTGS_SORT_FUSED", "VTGS_COUNT_STEPS")
+_OPTION_NAMES = ("VTGS_FWD_IMPL", "VTGS_BWD_IMPL", "VTGS_BIN_IMPL", "VTGS_SORT_PACKED", "VTGS_SORT_FUSED", "VTGS_COUNT_STEPS", "VTGS_SORT_LONG_COUNTING")
 
 
 def set_option(name: str, value: int) -> None:
