@@ -23,7 +23,7 @@ template <bool WIDE>
 __global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t,
                            const Counters*, int, const uint32_t*, uint32_t, unsigned long long, int);
 __global__ void sort_long_lists(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t,
-                                const Counters*, const uint32_t*, uint32_t, unsigned long long, int);
+                                const Counters*, const uint32_t*, uint32_t, unsigned long long, int, uint32_t);
 __global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                   const GeomRec*, const float*, float*, float*, float*, const Counters*);
 template <int WAVES, bool DUAL>
@@ -360,6 +360,10 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   // tile the plan exists for) are sorted by a pass of sort_tiles ahead of the composite, which fuses the rest.
   const bool fused_sort = option(OPT_FWD_IMPL) == 3 && option(OPT_SORT_FUSED) == 1 && (L.tile_cap <= 1024u || L.planned);
   const bool long_pass = fused_sort && L.planned;
+  // Uniform bins of 513 .. 1,024 slots under a fusing forward: its 16-keys-per-lane network for the lists beyond 512 entries
+  // is the slowest sort in the library; sort_long_lists takes them ahead of it (sort_mode bit 2 tells the forward).
+  // (from 768 slots: the package sizes bins at 1.5 x the longest list, so smaller bins hold no list beyond 512 entries)
+  const bool mid_pass = fused_sort && !L.planned && L.tile_cap >= 768u && option(OPT_SORT_LONG_COUNTING) == 1;
   FinalizeArgs fin;
   fin.tile_cnt = (const uint32_t*)(ws + L.tile_cnt); fin.tiles = L.tiles8; fin.ctr = ctr;
   fin.capacity = (unsigned long long)instance_capacity; fin.tile_cap = L.tile_cap;
@@ -372,6 +376,13 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
                        fin.block_stats, fin.nblocks, host_record, fin.plan, fin.plan_next);
   }
   VTGS_HIP(hipGetLastError());
+  if (mid_pass) {
+    ProfScope ps__("sort_tiles", st);
+    hipLaunchKernelGGL(sort_long_lists, dim3(band_tiles), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
+                       (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
+                       (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, cs.bin_plan,
+                       cs.bin_limit, (unsigned long long)instance_capacity, 1, 512u);
+  }
   if (!fused_sort || long_pass) {
     ProfScope ps__("sort_tiles", st);
     const unsigned long long long_only = long_pass ? (unsigned long long)instance_capacity : 0ull;
@@ -381,7 +392,7 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
       hipLaunchKernelGGL(sort_long_lists, dim3(band_tiles), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
                          (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
                          (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, cs.bin_plan,
-                         cs.bin_limit, long_only, option(OPT_SORT_LONG_COUNTING));
+                         cs.bin_limit, long_only, option(OPT_SORT_LONG_COUNTING), long_pass ? 1024u : 512u);
     // lists cannot be longer than the bin capacity: the wide (32 keys per lane) form is only worth its registers beyond 1024
     if (packed && (L.tile_cap > 1024u || L.planned) && !mid_done)   // (the wide register form: only without the long-list kernel)
       hipLaunchKernelGGL(sort_tiles<true>, dim3((band_tiles + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
@@ -395,7 +406,7 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   VTGS_HIP(hipGetLastError());
   int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st,
                                     dual ? colors_b : nullptr, dual ? out_color_b : nullptr,
-                                    fused_sort ? (packed ? 1 : 2) : 0, fin, true);
+                                    fused_sort ? ((packed ? 1 : 2) | (mid_pass ? 4 : 0)) : 0, fin, true);
   if (rc != VTGS_OK) return rc;
   // result record: assembled on the device by finalize_forward at byte 64 of the counters block
   static_assert(sizeof(VtgsForwardInfo) == 48, "VtgsForwardInfo layout is mirrored in Counters");

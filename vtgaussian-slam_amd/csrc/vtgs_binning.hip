@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) void sort_long_lists(const uint32_t* __restric
                                                        uint32_t* __restrict__ sorted_inst, uint32_t tile_first, uint32_t tiles,
                                                        uint32_t tile_cap, const Counters* __restrict__ ctr,
                                                        const uint32_t* __restrict__ plan, uint32_t bin_limit,
-                                                       unsigned long long long_only_capacity, int counting) {
+                                                       unsigned long long long_only_capacity, int counting, uint32_t lo) {
   __shared__ unsigned long long sk[kSortLds];
   __shared__ uint32_t sv[kSortLds];
   static_assert(kSortLds >= kBlockSortMax && kSortLds >= kBlockSortBuckets, "LDS staging of the workgroup counting sort");
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void sort_long_lists(const uint32_t* __restric
   const BinRange br = bin_range(plan, bin_limit, tile, tile_cap);
   const uint32_t cnt = tile_cnt[tile];
   if (cnt > br.cap) return;                                     // an overflowing bin: every consumer bails on the flag
-  const uint32_t L = cnt, lo = long_only ? (uint32_t)kWaveSortMax : (uint32_t)kCountSortMax;
+  const uint32_t L = cnt;                                       // lo: 512, or 1,024 ahead of a forward that sorts up to there itself
   if (L <= lo || L > (uint32_t)kBlockSortMax) return;           // workgroup-uniform
   const size_t s = (size_t)br.s;
   const uint32_t t = threadIdx.x;

@@ -275,7 +275,9 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     const uint32_t L = e - s;
     const size_t sz = (size_t)s;
     bool counted = false;
-    if (L > 1u && L <= (uint32_t)kCountSortMax) {                // the common case: bucket pass + in-bucket ranks, ids kept in LDS
+    const bool presorted = (sort_mode & 4) != 0 && L > (uint32_t)kCountSortMax;   // sort_long_lists has been here (lists > 512)
+    if (presorted) {
+    } else if (L > 1u && L <= (uint32_t)kCountSortMax) {                // the common case: bucket pass + in-bucket ranks, ids kept in LDS
       unsigned long long* stage = reinterpret_cast<unsigned long long*>(lds_tab[wv]);
       uint32_t* cnt = reinterpret_cast<uint32_t*>(lds_tab[wv]) + 2 * kCountSortMax;
       if (L <= 64u) counted = wave_count_sort<1>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, stage, cnt, sgid, kSortedIdsInLds);
@@ -284,10 +286,10 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
       else counted = wave_count_sort<8>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, stage, cnt, sgid, kSortedIdsInLds);
       ids_in_lds = counted;
     }
-    if (counted) {
+    if (counted || presorted) {
     } else if (L == 1u) {
       if (l == 0) { sorted_gid[s] = (uint32_t)bin_keys[s]; sorted_inst[s] = bin_vals[s]; }
-    } else if (sort_mode == 1) {
+    } else if ((sort_mode & 3) == 1) {
       if (L <= 64u) { if (L) wave_sort_tile<1, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP); }
       else if (L <= 128u) wave_sort_tile<2, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
       else if (L <= 256u) wave_sort_tile<4, true>(bin_keys, bin_vals, sorted_gid, sorted_inst, sz, L, l, VTGS_SORT_STAMP);
