@@ -387,12 +387,12 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
     ProfScope ps__("sort_tiles", st);
     const unsigned long long long_only = long_pass ? (unsigned long long)instance_capacity : 0ull;
     // lists of 513 (1,025 ahead of a fusing forward) .. 2,048 entries: one workgroup each, counting sort; then everything else
-    const int mid_done = (L.tile_cap > (long_pass ? 1024u : 512u) || L.planned) ? 1 : 0;
+    const int mid_done = (L.tile_cap > 512u || L.planned) ? 1 : 0;
     if (mid_done)
       hipLaunchKernelGGL(sort_long_lists, dim3(band_tiles), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
                          (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
                          (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, cs.bin_plan,
-                         cs.bin_limit, long_only, option(OPT_SORT_LONG_COUNTING), long_pass ? 1024u : 512u);
+                         cs.bin_limit, long_only, option(OPT_SORT_LONG_COUNTING), 512u);   // (ahead of a fusing forward too: sort_mode bit 2)
     // lists cannot be longer than the bin capacity: the wide (32 keys per lane) form is only worth its registers beyond 1024
     if (packed && (L.tile_cap > 1024u || L.planned) && !mid_done)   // (the wide register form: only without the long-list kernel)
       hipLaunchKernelGGL(sort_tiles<true>, dim3((band_tiles + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
@@ -406,7 +406,7 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   VTGS_HIP(hipGetLastError());
   int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st,
                                     dual ? colors_b : nullptr, dual ? out_color_b : nullptr,
-                                    fused_sort ? ((packed ? 1 : 2) | (mid_pass ? 4 : 0)) : 0, fin, true);
+                                    fused_sort ? ((packed ? 1 : 2) | ((mid_pass || long_pass) ? 4 : 0)) : 0, fin, true);
   if (rc != VTGS_OK) return rc;
   // result record: assembled on the device by finalize_forward at byte 64 of the counters block
   static_assert(sizeof(VtgsForwardInfo) == 48, "VtgsForwardInfo layout is mirrored in Counters");

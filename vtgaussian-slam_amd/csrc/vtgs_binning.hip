@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void sort_long_lists(const uint32_t* __restric
   const BinRange br = bin_range(plan, bin_limit, tile, tile_cap);
   const uint32_t cnt = tile_cnt[tile];
   if (cnt > br.cap) return;                                     // an overflowing bin: every consumer bails on the flag
-  const uint32_t L = cnt;                                       // lo: 512, or 1,024 ahead of a forward that sorts up to there itself
+  const uint32_t L = cnt;                                       // lo = 512: the lists the wavefront-level counting sort does not take
   if (L <= lo || L > (uint32_t)kBlockSortMax) return;           // workgroup-uniform
   const size_t s = (size_t)br.s;
   const uint32_t t = threadIdx.x;
