@@ -353,17 +353,17 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   const uint32_t gx8 = (uint32_t)((cam->image_width + kSubTile - 1) / kSubTile);
   const uint32_t band_first = (uint32_t)r8b * gx8, band_tiles = (uint32_t)(r8e - r8b) * gx8;
   const int packed = (n <= (1 << 21) && option(OPT_SORT_PACKED) == 1) ? 1 : 0;
-  // The quadrant-queue forward sorts its own tile's list when no bin can hold more than the 1024 entries one wavefront
-  // takes (VTGS_SORT_FUSED, default 1), and its first workgroup does finalize_forward's job: nothing is launched between
-  // the binning and the composite.
-  // Planned bins: the host does not know the longest bin, so the lists beyond 1,024 entries (usually none, or the one dense
-  // tile the plan exists for) are sorted by a pass of sort_tiles ahead of the composite, which fuses the rest.
-  const bool fused_sort = option(OPT_FWD_IMPL) == 3 && option(OPT_SORT_FUSED) == 1 && (L.tile_cap <= 1024u || L.planned);
-  const bool long_pass = fused_sort && L.planned;
-  // Uniform bins of 513 .. 1,024 slots under a fusing forward: its 16-keys-per-lane network for the lists beyond 512 entries
-  // is the slowest sort in the library; sort_long_lists takes them ahead of it (sort_mode bit 2 tells the forward).
-  // (from 768 slots: the package sizes bins at 1.5 x the longest list, so smaller bins hold no list beyond 512 entries)
-  const bool mid_pass = fused_sort && !L.planned && L.tile_cap >= 768u && option(OPT_SORT_LONG_COUNTING) == 1;
+  // Who sorts what.  With the quadrant-queue forward and VTGS_SORT_FUSED (the defaults) the forward sorts the lists of up to
+  // 512 entries itself (counting sort at the top of each wavefront; up to 1,024 with its network when nobody pre-sorted them)
+  // and its first workgroup does finalize_forward's job.  Ahead of it, only where such lists can exist:
+  //   pre512   sort_long_lists: lists of 513 .. 2,048 entries, one workgroup each (bins of >= 768 slots: the package sizes
+  //            bins at 1.5 x the longest list, so smaller bins hold no list beyond 512 entries; planned bins: always);
+  //   pre2048  a pass of sort_tiles over the lists beyond 2,048 entries (bins that large, or planned bins).
+  // Both make the forward's own safety test (finalize has not run yet): nothing if the instance capacity overflowed, no
+  // list whose bin overflowed.  Otherwise (other forwards, VTGS_SORT_FUSED = 0): finalize_forward, sort_long_lists, sort_tiles.
+  const bool fused_sort = option(OPT_FWD_IMPL) == 3 && option(OPT_SORT_FUSED) == 1;
+  const bool pre512 = L.planned || L.tile_cap >= 768u;
+  const bool pre2048 = L.planned || L.tile_cap > 2048u;
   FinalizeArgs fin;
   fin.tile_cnt = (const uint32_t*)(ws + L.tile_cnt); fin.tiles = L.tiles8; fin.ctr = ctr;
   fin.capacity = (unsigned long long)instance_capacity; fin.tile_cap = L.tile_cap;
@@ -376,37 +376,24 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
                        fin.block_stats, fin.nblocks, host_record, fin.plan, fin.plan_next);
   }
   VTGS_HIP(hipGetLastError());
-  if (mid_pass) {
+  const unsigned long long own_checks = fused_sort ? (unsigned long long)instance_capacity : 0ull;   // != 0: no overflow flag yet
+  if (pre512 || !fused_sort) {
     ProfScope ps__("sort_tiles", st);
-    hipLaunchKernelGGL(sort_long_lists, dim3(band_tiles), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
-                       (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
-                       (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, cs.bin_plan,
-                       cs.bin_limit, (unsigned long long)instance_capacity, 1, 512u);
-  }
-  if (!fused_sort || long_pass) {
-    ProfScope ps__("sort_tiles", st);
-    const unsigned long long long_only = long_pass ? (unsigned long long)instance_capacity : 0ull;
-    // lists of 513 (1,025 ahead of a fusing forward) .. 2,048 entries: one workgroup each, counting sort; then everything else
-    const int mid_done = (L.tile_cap > 512u || L.planned) ? 1 : 0;
-    if (mid_done)
+    if (pre512)
       hipLaunchKernelGGL(sort_long_lists, dim3(band_tiles), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
                          (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
                          (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, cs.bin_plan,
-                         cs.bin_limit, long_only, option(OPT_SORT_LONG_COUNTING), 512u);   // (ahead of a fusing forward too: sort_mode bit 2)
-    // lists cannot be longer than the bin capacity: the wide (32 keys per lane) form is only worth its registers beyond 1024
-    if (packed && (L.tile_cap > 1024u || L.planned) && !mid_done)   // (the wide register form: only without the long-list kernel)
-      hipLaunchKernelGGL(sort_tiles<true>, dim3((band_tiles + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
-                         (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
-                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed, cs.bin_plan, cs.bin_limit, long_only, mid_done);
-    else
+                         cs.bin_limit, own_checks, option(OPT_SORT_LONG_COUNTING), 512u);
+    if (!fused_sort || pre2048)
       hipLaunchKernelGGL(sort_tiles<false>, dim3((band_tiles + 3) / 4), dim3(256), 0, st, (const uint32_t*)(ws + L.tile_cnt),
                          (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_gid),
-                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed, cs.bin_plan, cs.bin_limit, long_only, mid_done);
+                         (uint32_t*)(ws + L.sorted_inst), band_first, band_tiles, L.tile_cap, (const Counters*)ctr, packed,
+                         cs.bin_plan, cs.bin_limit, own_checks, pre512 ? 1 : 0);
   }
   VTGS_HIP(hipGetLastError());
   int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st,
                                     dual ? colors_b : nullptr, dual ? out_color_b : nullptr,
-                                    fused_sort ? ((packed ? 1 : 2) | ((mid_pass || long_pass) ? 4 : 0)) : 0, fin, true);
+                                    fused_sort ? ((packed ? 1 : 2) | (pre512 ? 4 : 0)) : 0, fin, true);
   if (rc != VTGS_OK) return rc;
   // result record: assembled on the device by finalize_forward at byte 64 of the counters block
   static_assert(sizeof(VtgsForwardInfo) == 48, "VtgsForwardInfo layout is mirrored in Counters");
