@@ -119,8 +119,8 @@ uint32_t    vtgs_abi_version(void);
  * "VTGS_FWD_IMPL" / "VTGS_BWD_IMPL" (2 = lane-per-pixel matrix-core composites, the backward's default; 1 = pixel x
  * splat-quad form; 0 = scalar kernels), "VTGS_BIN_IMPL" (1 = LDS-binned slot
  * reservation where the tile table fits, 0 = global atomics), "VTGS_SORT_PACKED" (1 = payload in the key's low bits for
- * N <= 2^21), "VTGS_SORT_FUSED" (1 = the quadrant-queue forward sorts its own tile's list when tile_capacity <= 1024,
- * no sort launch), "VTGS_SORT_LONG_COUNTING" (1 = lists of 513 .. 2048 entries by the workgroup counting sort, 0 = by the
+ * N <= 2^21), "VTGS_SORT_FUSED" (1 = the quadrant-queue forward sorts its own tile's list -- lists beyond 512 entries are pre-sorted
+ * by a kernel ahead of it where bins of that size exist -- and does the finalize step; 0 = separate finalize and sort launches), "VTGS_SORT_LONG_COUNTING" (1 = lists of 513 .. 2048 entries by the workgroup counting sort, 0 = by the
  * LDS network: cross-check), "VTGS_COUNT_STEPS" (1 = the quadrant-queue forward counts its steps, see vtgs_debug_layout;
  * measurement only).  Defaults come from the environment variables of the same names, read ONCE at first use.
  * vtgs_set_option returns VTGS_ERR_INVALID_ARGUMENT for an unknown name; value < 0 restores the default.           */
