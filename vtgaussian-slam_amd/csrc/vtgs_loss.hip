@@ -34,6 +34,10 @@ __global__ __launch_bounds__(256) void ssim_forward_kernel(const float* __restri
   __shared__ float px[kSP * kSP], py[kSP * kSP];
   __shared__ float hz[5][kSP * kST];
   __shared__ float red[4];
+#ifdef VTGS_AB_SSIM_PAD                                         // occupancy experiment
+  __shared__ float ab_pad[VTGS_AB_SSIM_PAD];
+  if (C < 0) { ab_pad[threadIdx.x] = 1.f; __syncthreads(); if (ab_pad[(threadIdx.x + 1) & 255] == 2.f) return; }
+#endif
   float w[11];
   gauss11(w);
   const int t = (int)threadIdx.x;
