@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VTGS_ABI_VERSION 12
+#define VTGS_ABI_VERSION 13
 
 typedef enum VtgsStatus {
   VTGS_OK = 0,
@@ -42,7 +42,8 @@ typedef enum VtgsStatus {
   VTGS_ERR_INSTANCE_OVERFLOW = 3,  /* more (Gaussian,tile) instances than instance_capacity, or a    */
                                    /* tile list longer than tile_capacity; VtgsForwardInfo says how  */
                                    /* many (instances_needed, max_tile_list); re-allocate and call   */
-                                   /* again (outputs of the failed call are undefined)               */
+                                   /* again (the image of the failed call is the background colour,  */
+                                   /* its radii are valid, its lists are not)                         */
   VTGS_ERR_HIP = 4,                /* a HIP runtime call failed (see vtgs_last_hip_error)          */
   VTGS_ERR_STALE_WORKSPACE = 5     /* reserved                                                     */
 } VtgsStatus;
@@ -113,6 +114,12 @@ int vtgs_bin_plan_uniform(int32_t width, int32_t height, uint32_t slots_per_bin,
                                 /* returns VTGS_ERR_INSTANCE_OVERFLOW like the synchronous mode -- the caller always  */
                                 /* holds a valid image when the call returns VTGS_OK.  Falls back to a full wait when */
                                 /* `info` is not device-mapped.                                                       */
+#define VTGS_FORWARD_EXPECT_SHORT_LISTS 4u /* hint, OR-ed to one of the above: the caller expects no tile list beyond 512      */
+                                /* entries (its last forward of this view had none).  With bins of 768..1024 slots the  */
+                                /* pre-sort pass for long lists is then not launched; a list of 513..1024 entries that    */
+                                /* turns up anyway is sorted by the composite itself (slower, same result).  Ignored    */
+                                /* for larger and for planned bins.                                                      */
+#define VTGS_FORWARD_MODE_MASK 3u
 
 uint32_t    vtgs_abi_version(void);
 /* Implementation switches (tests and ablations): "VTGS_FWD_IMPL" (3 = per-quadrant splat queues, default) and

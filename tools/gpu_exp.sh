@@ -1,0 +1,56 @@
+#!/bin/bash
+# One parametrised experiment runner for the GPU box (replaces the per-experiment tools/exp_r*.sh scripts of rounds 2-3).
+#
+#   tools/gpu_exp.sh <tag> <step> [<step> ...]        (run on the GPU box: gpurun -- 'bash tools/gpu_exp.sh r4a tests bench')
+#
+# Each step writes gpurun_out/<round>/<step>_<tag>.log; the script stops at the first failing step (no GPU step is started
+# after a failed or timed-out one) and exits NON-ZERO when any log mentions a GPU memory access fault, an abort or a
+# segmentation fault -- an experiment script of round 3 exited 0 through such a fault.
+#
+# steps:   tests            the whole -m gpu suite, one process
+#          tests:<expr>     pytest -k <expr> of the -m gpu suite
+#          smoke            __graft_entry__.smoke()
+#          bench            python bench.py (default arguments)
+#          bench:<args>     python bench.py <args>   (commas for spaces: bench:--steps,50,--mode,tracking)
+#          timing           tools/kernel_timing.py at the headline shape (env ABL_* passes through)
+#          timing:<lib>     the same with VTGS_LIBRARY=vtgaussian-slam_amd/lib/<lib>   (A/B builds on the same box)
+#          stamps:<lib>     tools/forward_stamps.py with a -DVTGS_Q_STAMPS build
+#          slam:<args>      python bench_slam.py <args>
+#          py:<file>[:args] python <file> <args>
+#          profile          tools/profile_round.sh <tag>
+set -o pipefail
+TAG=$1; shift
+ROUND=${VTGS_ROUND:-r4}
+R=$PWD; O=$R/gpurun_out/$ROUND; mkdir -p $O
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+LIMIT=${VTGS_STEP_TIMEOUT:-900}
+fail=0
+run() {   # run <log> <command...>
+  local log=$1; shift
+  echo "== $* > $log"
+  timeout -k 10 $LIMIT "$@" > $log 2>&1
+  local rc=$?
+  if grep -q -E "Memory access fault|Fatal Python error|Segmentation fault|core dumped|HSA_STATUS_ERROR" $log; then
+    echo "GPU FAULT / ABORT in $log:"; grep -E "Memory access fault|Fatal Python error|Segmentation fault|core dumped|HSA_STATUS_ERROR" $log | head -5
+    fail=2; return 2
+  fi
+  if [ $rc -ne 0 ]; then echo "step failed (rc $rc): $*"; tail -25 $log | cut -c1-300; fail=1; return 1; fi
+  tail -${VTGS_TAIL:-3} $log | cut -c1-1500
+  return 0
+}
+for step in "$@"; do
+  name=${step%%:*}; arg=""; [ "$step" != "$name" ] && arg=${step#*:}
+  case $name in
+    tests)   if [ -n "$arg" ]; then run $O/tests_$TAG.log python -m pytest tests/ -x -q -m gpu -k "$arg"; else run $O/tests_$TAG.log python -m pytest tests/ -x -q -m gpu; fi ;;
+    smoke)   run $O/smoke_$TAG.log python -c "import __graft_entry__ as g; g.smoke()" ;;
+    bench)   run $O/bench_$TAG.log python bench.py ${arg//,/ } ;;
+    timing)  if [ -n "$arg" ]; then VTGS_LIBRARY=$R/vtgaussian-slam_amd/lib/$arg ABL_TAG=$arg run $O/timing_${TAG}_${arg%.so}.log python tools/kernel_timing.py; else ABL_TAG=shipped run $O/timing_$TAG.log python tools/kernel_timing.py; fi ;;
+    stamps)  VTGS_LIBRARY=$R/vtgaussian-slam_amd/lib/$arg VTGS_TAIL=40 run $O/stamps_${TAG}.log python tools/forward_stamps.py ;;
+    slam)    run $O/slam_$TAG.log python bench_slam.py ${arg//,/ } ;;
+    py)      f=${arg%%:*}; a=""; [ "$arg" != "$f" ] && a=${arg#*:}; VTGS_TAIL=${VTGS_TAIL:-30} run $O/py_${TAG}_$(basename $f .py).log python $f ${a//,/ } ;;
+    profile) run $O/profile_$TAG.log bash tools/profile_round.sh $TAG ;;
+    *) echo "unknown step $step"; exit 64 ;;
+  esac
+  [ $fail -ne 0 ] && break
+done
+exit $fail

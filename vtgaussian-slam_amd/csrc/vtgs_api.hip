@@ -362,7 +362,9 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   // Both make the forward's own safety test (finalize has not run yet): nothing if the instance capacity overflowed, no
   // list whose bin overflowed.  Otherwise (other forwards, VTGS_SORT_FUSED = 0): finalize_forward, sort_long_lists, sort_tiles.
   const bool fused_sort = option(OPT_FWD_IMPL) == 3 && option(OPT_SORT_FUSED) == 1;
-  const bool pre512 = L.planned || L.tile_cap >= 768u;
+  // (VTGS_FORWARD_EXPECT_SHORT_LISTS: bins of 768 .. 1,024 slots without the pre-sort pass -- the composite's own network
+  // takes a list of 513 .. 1,024 entries that turns up against the caller's expectation)
+  const bool pre512 = L.planned || L.tile_cap > 1024u || (L.tile_cap >= 768u && !(flags & VTGS_FORWARD_EXPECT_SHORT_LISTS));
   const bool pre2048 = L.planned || L.tile_cap > 2048u;
   FinalizeArgs fin;
   fin.tile_cnt = (const uint32_t*)(ws + L.tile_cnt); fin.tiles = L.tiles8; fin.ctr = ctr;

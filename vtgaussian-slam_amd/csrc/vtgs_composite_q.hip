@@ -234,6 +234,9 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
 #else
 #define VTGS_SORT_STAMP nullptr
 #endif
+  // bail (uniform over the grid): the forward cannot complete -- every tile is composited as EMPTY, so the caller's image is
+  // the background colour instead of whatever its memory held (a run-ahead caller looks at the result record later).
+  bool bail = false;
   if (sort_mode) {
     // Nothing ran between the binning and this kernel: the first workgroup does what finalize_forward does (longest list,
     // statistics, overflow flags, the host's record -- it is dispatched first, so the record still leaves early), and
@@ -241,9 +244,9 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     // written unless the INSTANCE capacity overflowed (then an entry may have been dropped after its slot was taken).
     if (blockIdx.x == 0u) finalize_block<256>(fin.tile_cnt, fin.tiles, fin.ctr, fin.capacity, fin.tile_cap, fin.block_stats,
                                               fin.nblocks, fin.host_record, fin.plan, fin.plan_next);
-    if ((unsigned long long)ctr->inst_total > fin.capacity) return;
-  } else if (ctr->overflow) {
-    return;                                                     // bins hold unwritten slots after an overflow
+    bail = (unsigned long long)ctr->inst_total > fin.capacity;
+  } else {
+    bail = ctr->overflow != 0u;                                 // bins hold unwritten slots after an overflow
   }
   if (qmask && blockIdx.x == 0u && threadIdx.x == 0u) fin.ctr->qmask_valid = 1u;
   const int gx16 = (cs.W + kBinTile - 1) / kBinTile;
@@ -264,7 +267,11 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
   const float X = (float)lx - 3.5f, Y = (float)ly - 3.5f;
   const float Phi[6] = {1.f, X, Y, X * X, X * Y, Y * Y};
   const BinRange br = bin_range(cs, (uint32_t)qc.tile, tile_cap);
-  const uint32_t s = br.s, e = s + min(tile_cnt[qc.tile], br.cap);
+  // A bin whose list outgrew it (the flag is raised by the first workgroup, possibly after this wavefront has started) is
+  // composited as empty too: nobody sorted it -- sort_long_lists and sort_tiles skip such a bin -- so beyond 512 slots its
+  // sorted list would be whatever the workspace held before (unchecked ids from unwritten memory).
+  const uint32_t cnt_raw = tile_cnt[qc.tile];
+  const uint32_t s = br.s, e = s + ((bail || cnt_raw > br.cap) ? 0u : cnt_raw);
   // sort_mode != 0 (the host picks it when no bin can hold more than 1024 entries): the wavefront sorts its own tile's list
   // here -- 1 = payload packed into the key, 2 = key + value -- instead of a sort kernel before this one: one launch less,
   // and the list's trip through memory overlaps with the other wavefronts' compositing.  The sorted list still goes to

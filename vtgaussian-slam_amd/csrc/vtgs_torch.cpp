@@ -14,6 +14,7 @@
 #include <torch/extension.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 #include "../../include/vtgs.h"
@@ -29,6 +30,11 @@ at::Tensor need(const at::Tensor& t, const char* name, int64_t tail, int64_t n, 
   TORCH_CHECK(t.numel() == n * tail, name, " must have ", n, "x", tail, " elements");
   return t.contiguous();
 }
+
+// tests only (diff_gaussian_rasterization.poison_workspaces): every workspace / scratch block starts as 0xFF bytes, the images
+// as NaN, so that a kernel that reads a slot nobody wrote -- which passes silently when the caching allocator hands back
+// clean memory -- shows up as a wrong result (the cause of the GPU fault of round 3).
+bool g_poison = false;
 
 struct CamRecord {            // VtgsCamera with the three device tensors it points at kept alive
   VtgsCamera c;
@@ -69,6 +75,7 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     at::Tensor radii = at::empty({n}, f32.dtype(at::kInt));
     const size_t nbytes = vtgs_workspace_bytes((int32_t)n, (int32_t)W, (int32_t)H, (uint64_t)capacity, (uint32_t)tile_cap);
     at::Tensor workspace = at::empty({(int64_t)nbytes}, f32.dtype(at::kByte));
+    if (g_poison) { workspace.fill_(0xFF); images.fill_(std::nanf("")); }
     // bin_plan != 0: planned bins (tile_cap carries VTGS_TILE_CAPACITY_PLANNED; the backward needs nothing else)
     const int st = bin_plan
         ? vtgs_forward_planned(&cam.c, (int32_t)n, means3D.data_ptr<float>(), colors.data_ptr<float>(), opac.data_ptr<float>(),
@@ -85,7 +92,6 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     ctx->save_for_backward({means3D, colors, opac, scales, rot, color, workspace, cam_bytes, bg, view, proj});
     ctx->saved_data["capacity"] = capacity;
     ctx->saved_data["tile_cap"] = tile_cap;
-    ctx->saved_data["slot_ptr"] = slot_ptr;
     ctx->saved_data["stream"] = stream;
     ctx->saved_data["n"] = n;
     ctx->set_materialize_grads(false);
@@ -126,11 +132,13 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
       off += kWidth[i];
     }
     if (n > 0 && total > 0) {
-      // the record of a run-ahead forward may not have been read yet: its instance CAPACITY bounds the instance ids
-      const VtgsForwardInfo* info = reinterpret_cast<const VtgsForwardInfo*>(ctx->saved_data["slot_ptr"].toInt());
-      const uint64_t instances = (info && info->complete && !info->overflow) ? info->instances : (uint64_t)capacity;
-      const size_t sbytes = vtgs_backward_scratch_bytes((int32_t)n, instances);
+      // The scratch is indexed by instance id, and the instance CAPACITY bounds the ids whatever the forward counted.  (Round 3
+      // sized it from the pinned result record behind slot_ptr; that slot is shared round-robin with later forwards, so a
+      // backward that runs 64 forwards after its own forward could read another forward's -- smaller -- count: ADVICE r3.
+      // Untouched tail pages of the block cost nothing.)
+      const size_t sbytes = vtgs_backward_scratch_bytes((int32_t)n, (uint64_t)capacity);
       at::Tensor scratch = at::empty({(int64_t)sbytes}, f32.dtype(at::kByte));
+      if (g_poison) scratch.fill_(0xFF);
       const int st = vtgs_backward(&cam.c, (int32_t)n, means3D.data_ptr<float>(), colors.data_ptr<float>(), opac.data_ptr<float>(),
                                    scales.data_ptr<float>(), rot.data_ptr<float>(), color.data_ptr<float>(),
                                    grad_color.data_ptr<float>(), workspace.data_ptr(), (size_t)workspace.numel(),
@@ -156,4 +164,5 @@ std::vector<at::Tensor> rasterize(at::Tensor means3D, at::Tensor means2D, at::Te
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize", &rasterize, "GaussianRasterizer forward with a C++ autograd node behind it");
   m.def("abi_version", []() { return (int64_t)vtgs_abi_version(); });
+  m.def("set_poison", [](bool on) { g_poison = on; });
 }

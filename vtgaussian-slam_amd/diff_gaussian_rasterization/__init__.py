@@ -52,8 +52,9 @@ class _VtgsProfileEntry(ctypes.Structure):
 
 
 VTGS_OK, VTGS_ERR_INSTANCE_OVERFLOW = 0, 3
-ABI_VERSION = 12
+ABI_VERSION = 13
 VTGS_FORWARD_SYNC, VTGS_FORWARD_ASYNC, VTGS_FORWARD_CHECKED = 0, 1, 2
+VTGS_FORWARD_EXPECT_SHORT_LISTS = 4        # hint: no list beyond 512 entries expected (skips the pre-sort pass for bins <= 1024)
 _P, _U64, _I32, _SZ = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
 
 _SIGNATURES = {
@@ -100,7 +101,7 @@ def _load_library() -> ctypes.CDLL:
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError here == ABI mismatch, fail loudly
         fn.restype, fn.argtypes = res, args
-    if lib.vtgs_abi_version() != ABI_VERSION and os.environ.get("VTGS_ABI_ANY") != "1":   # (A/B timing of older builds only)
+    if lib.vtgs_abi_version() != ABI_VERSION:      # (no escape hatch: record sizes and signatures change with the number)
         raise ImportError(f"libvtgs.so ABI {lib.vtgs_abi_version()} != expected {ABI_VERSION}; rebuild it")
     return lib
 
@@ -162,10 +163,19 @@ _caps_in_use = {}            # same key -> (instance capacity, tile capacity) of
 _async_ok = {}               # same key -> the (capacities) of which the last forward of this shape used < 80 %, else None
 _need_hist = {}              # same key -> (instances, longest tile list) of the last three forwards
 _last_info = {}
-# "auto" (default): a forward in grad mode returns without waiting for its result record when the previous forward of the
-# same shape left >= 20 % headroom in both capacities; the record is read after the backward has been enqueued.  "checked":
-# every forward waits for its record (round 2's behaviour).  Forwards in no-grad mode are always checked.
+# "auto" (default): a forward in grad mode returns without waiting for its result record ("runs ahead") when the last three
+# forwards of its shape needed about the same AND both capacities hold at least _RUN_AHEAD_HEADROOM (3) times what the last
+# one needed -- a steady loop (tracking; mapping over neighbouring keyframes) whose next view would have to bin three times
+# the instances, or grow its longest tile list threefold, to overflow.  Everything else -- the first forwards of a shape, a
+# loop whose views differ, dense maps whose bins cannot be given that much room, planned bins, no-grad forwards -- is CHECKED:
+# the forward waits for its record (about a quarter into the forward) and answers an overflow itself, before the caller sees
+# an image.  "checked": always.  (Round 3 ran ahead with 25 % of headroom; ADVICE r3 / VERDICT r3 item 3.)
 _FORWARD_MODE = os.environ.get("VTGS_FORWARD_MODE", "auto")
+if _FORWARD_MODE not in ("auto", "checked"):
+    raise ImportError("VTGS_FORWARD_MODE must be auto or checked")
+_RUN_AHEAD_HEADROOM = 3.0
+_RUN_AHEAD_MAX_BIN = 1024        # uniform bins up to this many slots can be sorted inside the forward composite (no pre-sort pass)
+_SHORT_LIST_HINT = 400           # longest list of the last forward up to which the next one is launched with EXPECT_SHORT_LISTS
 
 
 def last_forward_info() -> dict:
@@ -349,7 +359,7 @@ class _SlotPool:
 
 
 _slot_pools: dict = {}       # (device index, stream) -> _SlotPool
-_slot_lock = threading.Lock()
+_slot_lock = threading.RLock()       # re-entrant: _settle takes it itself and is also called under it
 
 
 def _slot_pool(device, stream) -> "_SlotPool":
@@ -420,11 +430,18 @@ def _settle(fs) -> None:
     """Read the result record of an asynchronous forward (waiting for it if the device has not written it yet -- by the time
     a backward has been enqueued it has: the record leaves right after the binning).  An overflow here means that the image
     the caller already holds is invalid: raise, after growing the capacities so that the next forward fits."""
+    if fs.pending is None:
+        return                                     # (checked forward, already read, or captured into a graph)
+    with _slot_lock:                               # (the backward path calls this from an autograd thread: ADVICE r3)
+        _settle_locked(fs)
+
+
+def _settle_locked(fs) -> None:
     pend = fs.pending
     if pend is None:
-        return                                     # (checked forward, already read, or captured into a graph)
+        return
     fs.pending = None
-    pool, i, device = pend
+    pool, i, device, stream = pend
     info = pool.info[i]
     if not info.complete:
         # The device has not reached the end of this forward's binning yet (the host is running ahead of it).  Poll the pinned
@@ -434,7 +451,8 @@ def _settle(fs) -> None:
         while not info.complete:
             spins += 1
             if spins & 0xFFF == 0:
-                if torch.cuda.current_stream(device).query() and not info.complete:
+                # (the stream the forward was ENQUEUED on -- the caller of _settle may sit on another one: ADVICE r3)
+                if _stream_done(device, stream) and not info.complete:
                     raise RuntimeError("vtgs_forward: result record never arrived")
                 if time.perf_counter() - t0 > 20.0:
                     raise RuntimeError("vtgs_forward: timed out waiting for the result record")
@@ -451,12 +469,18 @@ def _settle(fs) -> None:
         _tile_cap_hint[key] = max(int(info.max_tile_list), 1)
         _async_ok[key] = None
         raise RuntimeError(
-            "vtgs_forward (asynchronous mode): the workspace of the previous forward overflowed -- the instance count grew by "
-            "more than 25 % between two forwards of the same shape -- so the image it returned is INVALID. The capacities "
-            "have been raised; redo the iteration, or set VTGS_FORWARD_MODE=checked to have every forward verified before "
-            "it returns.")
+            "vtgs_forward (run-ahead mode): the workspace of the previous forward overflowed -- after three forwards of this "
+            "shape that needed the same, this one binned more than three times as much -- so the image it returned (the "
+            "background colour) is INVALID. The capacities have been raised; redo the iteration, or set "
+            "VTGS_FORWARD_MODE=checked to have every forward verified before it returns.")
     fs._instances = int(info.instances)
     _record_info(key, n, fs.cam.W, fs.cam.H, fs.capacity, info)
+
+
+def _stream_done(device, stream) -> bool:
+    """hipStreamQuery of a raw stream handle."""
+    with _device_guard(device):
+        return torch.cuda.ExternalStream(int(stream), device=device).query() if int(stream) else torch.cuda.default_stream(device).query()
 
 
 def _tile_capacity_for(max_list: int) -> int:
@@ -525,17 +549,33 @@ def _choose_capacities(key, n):
     if not need_i:
         return 8 * n + 65536, (PLANNED | 512) if _BINS_MODE == "planned" else 512
     cap, tcap = _caps_in_use.get(key, (0, 0))
-    if need_i * 1.1 > cap or need_i * 4 < cap:
-        cap = max(int(need_i * 1.5) + 4096, 4 * n + 4096)
+    # Instance capacity (it sizes the backward's scratch, of which only the used records are touched): room for a run-ahead
+    # forward, i.e. _RUN_AHEAD_HEADROOM x the last need; moved only when that room is lost or ten times too much is held.
+    if need_i * _RUN_AHEAD_HEADROOM > cap or need_i * 12 < cap:
+        cap = max(int(need_i * (_RUN_AHEAD_HEADROOM * 1.2)) + 4096, 4 * n + 4096)
     if _wants_planned(key, _tile_capacity_for(need_t)):
         tiles, need_s = _tiles8(key[2], key[3]), _slots_hint[key]
         have = (tcap & ~PLANNED) * tiles if tcap & PLANNED else 0
         if need_s * 1.1 > have or need_s * 4 < have:
             tcap = _planned_capacity(key, need_s)
-    elif tcap & PLANNED or need_t * 1.1 > tcap or need_t * 4 < tcap:
-        tcap = _tile_capacity_for(need_t)
+    else:
+        # Uniform bins: the same room where it is free -- up to _RUN_AHEAD_MAX_BIN slots the forward composite sorts every
+        # list itself; larger bins bring a pre-sort pass, so denser views keep 1.5 x and stay in the checked mode.
+        roomy_cap = (int(need_t * (_RUN_AHEAD_HEADROOM * 1.2)) + 63) // 64 * 64
+        if roomy_cap <= _RUN_AHEAD_MAX_BIN:
+            if tcap & PLANNED or need_t * _RUN_AHEAD_HEADROOM > tcap or tcap > _RUN_AHEAD_MAX_BIN or need_t * 12 < tcap:
+                tcap = max(64, roomy_cap)
+        elif tcap & PLANNED or need_t * 1.1 > tcap or need_t * 4 < tcap:
+            tcap = _tile_capacity_for(need_t)
     _caps_in_use[key] = (cap, tcap)
     return cap, tcap
+
+
+def _forward_hints(key, tile_cap: int) -> int:
+    """Flag bits OR-ed to the mode of the next forward of `key`."""
+    if not (tile_cap & PLANNED) and tile_cap <= _RUN_AHEAD_MAX_BIN and 0 < _tile_cap_hint.get(key, 0) <= _SHORT_LIST_HINT:
+        return VTGS_FORWARD_EXPECT_SHORT_LISTS
+    return 0
 
 
 def _grow_after_overflow(key, n, device, info, capacity, tile_cap, workspace):
@@ -566,7 +606,7 @@ def _record_info(key, n, W, H, capacity, info):
     _slots_hint[key] = need_s or 1
     cap, tcap = _caps_in_use.get(key, (0, 0))                  # the capacities this forward ran with
     # Run-ahead is for STEADY loops (tracking, mapping on one frame): the last three forwards of this shape must have needed
-    # about the same (within 10 % of each other) and at most 80 % of both capacities.  A loop that alternates between views
+    # about the same (within 10 % of each other) and at most a THIRD of both capacities.  A loop that alternates between views
     # with very different instance counts under one shape (mapping over random keyframes) therefore stays in the checked mode.
     hist = _need_hist.get(key)
     if hist is None:
@@ -576,11 +616,11 @@ def _record_info(key, n, W, H, capacity, info):
     if len(hist) == 3:
         (a0, b0), (a1, b1), (a2, b2) = hist
         steady = (max(a0, a1, a2) <= 1.1 * max(1, min(a0, a1, a2))) and (max(b0, b1, b2) <= 1.1 * max(1, min(b0, b1, b2)))
-    if tcap & PLANNED:            # every bin already has half again its own list; the plan as a whole must fit the workspace
-        bins_roomy = need_s <= 0.9 * (tcap & ~PLANNED) * _tiles8(W, H)
+    if tcap & PLANNED:            # a bin holds half again its own list, not three times it: planned bins never run ahead
+        bins_roomy = False
     else:
-        bins_roomy = need_t <= 0.8 * tcap
-    roomy = bool(cap and tcap and need_i <= 0.8 * cap and bins_roomy)
+        bins_roomy = need_t * _RUN_AHEAD_HEADROOM <= tcap
+    roomy = bool(cap and tcap and need_i * _RUN_AHEAD_HEADROOM <= cap and bins_roomy)
     _async_ok[key] = (cap, tcap) if (roomy and steady) else None   # ... are the only ones the next forward may run ahead with
     global _last_raw
     _last_raw = (int(info.instances), int(info.tiles16_touched), int(info.visible), need_t, n, W, H, int(capacity))
@@ -599,7 +639,31 @@ def _workspace(n, W, H, capacity, tile_cap, device):
             f"the forward workspace would need {nbytes / 2**30:.1f} GiB (every one of the {((W + 7) // 8) * ((H + 7) // 8)} "
             f"8x8 tiles gets a bin of {tile_cap} entries, sized by the longest tile list): some tile is hit by an "
             f"extreme number of splats. Raise VTGS_MAX_WORKSPACE_GB if that is intended.")
-    return nbytes, torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    if _poison:
+        ws.fill_(0xFF)
+    return nbytes, ws
+
+
+_poison = False
+
+
+def poison_workspaces(on: bool) -> None:
+    """Tests only: every forward workspace and backward scratch block starts as 0xFF bytes and the output images as NaN, instead
+    of whatever the caching allocator hands back.  A kernel that reads a slot nobody wrote passes silently on clean memory;
+    under poison it gathers through id 0xFFFFFFFF or adds a NaN record (tests/test_gpu_poison.py; the GPU fault of round 3,
+    DESIGN.md 7, was such a read)."""
+    global _poison
+    _poison = bool(on)
+    if _ext is not None:
+        _ext.set_poison(_poison)
+
+
+def _scratch(nbytes: int, device) -> torch.Tensor:
+    t = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    if _poison:
+        t.fill_(0xFF)
+    return t
 
 
 def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, want_async: bool = False, colors_b=None):
@@ -620,6 +684,8 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
     H, W = cam.H, cam.W
     nd = 3 if colors_b is not None else 1
     images = torch.empty((3 + nd, H, W), dtype=torch.float32, device=device)      # one allocation for both images
+    if _poison:
+        images.fill_(float("nan"))
     color, depth = images[:3], images[3:]
     radii = torch.empty((n,), dtype=torch.int32, device=device)
     stream = _stream_ptr(device)
@@ -664,7 +730,8 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
         nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
         pool.info[slot].complete = 0
         with _device_guard(device):
-            _check(launch(workspace, nbytes, capacity, tile_cap, pool.ptr[slot], VTGS_FORWARD_ASYNC), "vtgs_forward")
+            _check(launch(workspace, nbytes, capacity, tile_cap, pool.ptr[slot], VTGS_FORWARD_ASYNC | _forward_hints(key, tile_cap)),
+                   "vtgs_forward")
         fs.workspace, fs.capacity, fs.tile_cap, fs._instances = workspace, capacity, tile_cap, None
         fs.captured = (pool, slot)
         _captured_states.append(fs)
@@ -682,14 +749,15 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
                 # record -- written by the device right after the binning -- is read by _settle once the backward is queued.
                 nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
                 info.complete = 0
-                _check(launch(workspace, nbytes, capacity, tile_cap, pool.ptr[slot], VTGS_FORWARD_ASYNC), "vtgs_forward")
+                _check(launch(workspace, nbytes, capacity, tile_cap, pool.ptr[slot], VTGS_FORWARD_ASYNC | _forward_hints(key, tile_cap)),
+                       "vtgs_forward")
                 fs.workspace, fs.capacity, fs.tile_cap, fs._instances = workspace, capacity, tile_cap, None
-                fs.pending = (pool, slot, device)
+                fs.pending = (pool, slot, device, stream)
                 pool.pending.append(fs)
                 return color, radii, depth, fs
             for _attempt in range(6):
                 nbytes, workspace = _workspace(n, W, H, capacity, tile_cap, device)
-                st = launch(workspace, nbytes, capacity, tile_cap, pool.ptr[slot], VTGS_FORWARD_CHECKED)
+                st = launch(workspace, nbytes, capacity, tile_cap, pool.ptr[slot], VTGS_FORWARD_CHECKED | _forward_hints(key, tile_cap))
                 if st == VTGS_ERR_INSTANCE_OVERFLOW:          # the record says what is needed: grow whichever was short
                     capacity, tile_cap = _grow_after_overflow(key, n, device, info, capacity, tile_cap, workspace)
                     continue
@@ -728,7 +796,7 @@ def _forward_ext(cam: _Camera, means3D, means2D, colors, opacities, scales, rota
             plan = _plan_for(key, device, tile_cap).data_ptr() if tile_cap & PLANNED else 0
             color, radii, depth, workspace, status = _ext.rasterize(
                 means3D, means2D, colors, opacities, scales, rotations, cam.bytes, cam.bg, cam.view, cam.proj, capacity, tile_cap,
-                plan, pool.ptr[slot], VTGS_FORWARD_ASYNC if run_ahead else VTGS_FORWARD_CHECKED, stream)
+                plan, pool.ptr[slot], (VTGS_FORWARD_ASYNC if run_ahead else VTGS_FORWARD_CHECKED) | _forward_hints(key, tile_cap), stream)
             if run_ahead:
                 break
             if int(status) == VTGS_ERR_INSTANCE_OVERFLOW:     # the record says what is needed: grow whichever was short
@@ -740,7 +808,7 @@ def _forward_ext(cam: _Camera, means3D, means2D, colors, opacities, scales, rota
         fs.workspace, fs.capacity, fs.tile_cap = workspace, capacity, tile_cap
         if run_ahead:
             fs._instances = None
-            fs.pending = (pool, slot, device)
+            fs.pending = (pool, slot, device, stream)
             pool.pending.append(fs)
         else:
             pool.owner[slot] = None
@@ -792,7 +860,7 @@ def _run_backward(fs: _ForwardState, means3D, colors, opacities, scales, rotatio
     if n == 0 or total == 0:
         return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
     sbytes = _lib.vtgs_backward_scratch_bytes(n, _scratch_instances(fs))
-    scratch = torch.empty((sbytes,), dtype=torch.uint8, device=device)
+    scratch = _scratch(sbytes, device)
     state_ptr = fs.image_state.data_ptr() if fs.image_state is not None else None
     with _device_guard(device):
         st = _lib.vtgs_backward(ctypes.byref(fs.cam.c), n, means3D.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
@@ -816,7 +884,7 @@ def _run_backward_dual(fs: _ForwardState, means3D, colors_a, colors_b, opacities
     if n == 0:
         return g_means3D, g_means2D, g_ca, g_opac, g_scales, g_rot, g_cb
     sbytes = _lib.vtgs_backward_dual_scratch_bytes(n, _scratch_instances(fs))
-    scratch = torch.empty((sbytes,), dtype=torch.uint8, device=device)
+    scratch = _scratch(sbytes, device)
     with _device_guard(device):
         st = _lib.vtgs_backward_dual(ctypes.byref(fs.cam.c), n, means3D.data_ptr(), colors_a.data_ptr(), colors_b.data_ptr(),
                                      opacities.data_ptr(), scales.data_ptr(), rotations.data_ptr(), out_a.data_ptr(),

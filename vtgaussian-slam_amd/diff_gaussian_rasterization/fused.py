@@ -28,7 +28,7 @@ import torch
 import os
 
 from . import (_Camera, _ForwardState, _RADIUS_RULES, _check, _device_guard, _lib, _run_backward, _run_backward_dual,
-               _run_forward, _scratch_instances, _settle, _stream_ptr, _I32, _P)
+               _run_forward, _scratch, _scratch_instances, _settle, _stream_ptr, _I32, _P)
 
 _lib.vtgs_pose_partial_rows.restype, _lib.vtgs_pose_partial_rows.argtypes = ctypes.c_uint32, [_I32]
 _lib.vtgs_prepare_frame.restype, _lib.vtgs_prepare_frame.argtypes = ctypes.c_int, [_I32] + [_P] * 13
@@ -134,7 +134,7 @@ def _backward_fused(ctx, g_im, g_ds):
     g_q = g_t = None
     if n > 0:
         sbytes = _lib.vtgs_backward_dual_scratch_bytes(n, _scratch_instances(fs))
-        scratch = torch.empty((sbytes,), dtype=torch.uint8, device=dev)
+        scratch = _scratch(sbytes, dev)
         with _device_guard(dev):
           _check(_lib.vtgs_backward_dual_frame(
             ctypes.byref(fs.cam.c), n, means_cam.data_ptr(), rgb.data_ptr(), dcol.data_ptr(), opac.data_ptr(),
