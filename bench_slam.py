@@ -18,6 +18,8 @@ import argparse
 import json
 import math
 import os
+
+import numpy as np
 import sys
 import time
 
@@ -59,6 +61,20 @@ def parse_args(argv=None):
                     help="K > 0: every mapping iteration makes the reference's SECOND get_loss call as well, over the global "
                          "set = K fixed submaps (+) the current one (src/vtgaussian_slam.py:2545-2556, 944-977): (K+1) N "
                          "Gaussians rendered, gradients to the current submap only (needs --get-loss)")
+    ap.add_argument("--base-frame-every", type=int, default=0,
+                    help="E > 0: frame t (1-based) is a BASE frame when t %% E == 0, the others are ordinary frames of the "
+                         "current submap -- the two mapping regimes of the reference (configs/replica/room0.py:35: E = 40).  "
+                         "Ordinary frame: every mapping iteration draws ONE keyframe at random from the frames of the submap so "
+                         "far (src/vtgaussian_slam.py:2563-2585) and renders THAT view; with --global-submaps the second "
+                         "get_loss call is made when the draw is the submap's base frame (:2600-2604).  Base frame: the "
+                         "current view every iteration and, with --global-submaps, BOTH calls every iteration (:2545-2557).  "
+                         "0 (default): every frame maps on its own view, second call (if any) every iteration -- round 3's loop")
+    ap.add_argument("--emulate-window", type=int, default=0,
+                    help="W > 0 (with --base-frame-every): an ordinary frame draws its keyframe as if the submap already held W "
+                         "frames -- with probability 1/W the submap's base frame (then the second get_loss call is made), else "
+                         "one of the frames really present.  A short run has windows of 2-3 frames, where the base frame is "
+                         "drawn every second or third iteration; over the 39 ordinary frames of a 40-frame submap the mean of "
+                         "1/(i+1) is 0.084, i.e. W = 12")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N ranks (started by torch.distributed.run): 'nccl' = RCCL, one GPU per rank; 'gloo' = rehearsal of the "
                          "N-rank code path with every rank on GPU 0 and the collectives staged through the host")
@@ -69,6 +85,8 @@ def parse_args(argv=None):
         ap.error("--global-submaps needs --get-loss")
     if args.graph and not args.get_loss:
         ap.error("--graph needs --get-loss")
+    if args.graph and args.base_frame_every:
+        ap.error("--graph replays ONE captured view: it cannot follow the per-iteration keyframe draw of --base-frame-every")
     return args
 
 
@@ -244,7 +262,9 @@ def run(args) -> dict:
     track_ms, map_ms, errs_before, errs_after = [], [], [], []
     torch.cuda.synchronize()
     t_all = time.perf_counter()
+    frame_kind, frame_s, second_frac = [], [], []
     for t in range(1, T):
+        torch.cuda.synchronize(); t_frame = time.perf_counter()
         gt_im, gt_depth = gts[t]
         with torch.no_grad():                     # forward-propagate the previous pose (constant-position prior)
             params["cam_unnorm_rots"][..., t] = params["cam_unnorm_rots"][..., t - 1]
@@ -306,9 +326,30 @@ def run(args) -> dict:
         errs_after.append(pose_error(t))
         # ---- mapping
         opt = make_adam([{"params": [v], "name": k, "lr": map_lrs[k]} for k, v in params.items()], lr=0.0, eps=1e-15)
+        # Which view an iteration renders, and whether it makes the second call over the global set (module docstring of
+        # --base-frame-every).  The draw is the reference's np.random.randint over the submap's frames so far; the same seed
+        # on every rank of the N-rank loop.
+        E = args.base_frame_every
+        is_base = E > 0 and t % E == 0
+        w0 = (t // E) * E if E > 0 else t                 # first frame of the current submap's window (its base frame)
+        window = list(range(w0, t + 1))
+        rng = np.random.RandomState(1000 + t)
+        frame_kind.append("base" if (is_base or E == 0) else "ordinary")
+        second_calls = 0
         torch.cuda.synchronize(); t0 = time.perf_counter()
         graph = None
         for it in range(args.mapping_iters):
+            if E > 0 and not is_base and args.emulate_window > 0:
+                draw = rng.randint(0, args.emulate_window)
+                kf = w0 if draw == 0 else (window[1 + (draw - 1) % (len(window) - 1)] if len(window) > 1 else w0)
+                second = bool(fixed) and kf == w0 and kf % E == 0
+            elif E > 0 and not is_base:
+                kf = window[rng.randint(0, len(window))]
+                second = bool(fixed) and kf == w0 and kf % E == 0
+            else:
+                kf, second = t, bool(fixed)
+            second_calls += int(second)
+            gt_im, gt_depth = gts[kf]
             if args.graph:
                 if graph is None:
                     def map_fn():
@@ -325,15 +366,15 @@ def run(args) -> dict:
                 opt.step()
                 continue
             if args.get_loss:                      # (the mapping loops call it the same way, without the threshold lists)
-                loss, variables, _losses = mirror_get_loss(params, curr_data(t), variables, t, {"im": 1.0, "depth": 1.0}, False,
+                loss, variables, _losses = mirror_get_loss(params, curr_data(kf), variables, kf, {"im": 1.0, "depth": 1.0}, False,
                                                            0.99, True, False, mapping=True, dataset_name="replica")
-                if fixed:                          # the second call of the reference's mapping iteration (:2551-2556)
+                if second:                         # the second call of the reference's mapping iteration (:2551-2556, :2600-2604)
                     loss_global, variables_global, _lg = mirror_get_loss(
-                        concat_global(), curr_data(t), variables_global, t, {"im": 1.0, "depth": 1.0}, False, 0.99, True, False,
+                        concat_global(), curr_data(kf), variables_global, kf, {"im": 1.0, "depth": 1.0}, False, 0.99, True, False,
                         mapping=True, dataset_name="replica")
                     loss = loss + loss_global
             else:
-                im, depth_sil, _ = render_pair(params, t, gaussians_grad=True, camera_grad=False, tile_rows=band)
+                im, depth_sil, _ = render_pair(params, kf, gaussians_grad=True, camera_grad=False, tile_rows=band)
                 loss = map_loss(im, depth_sil, gt_im, gt_depth)
             loss.backward()
             if world > 1:                          # trainable per-Gaussian gradients: one flat all-reduce, 20 B per Gaussian
@@ -346,11 +387,14 @@ def run(args) -> dict:
             dgr.forget_captured()
             opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize(); map_ms.append((time.perf_counter() - t0) * 1e3 / args.mapping_iters)
+        frame_s.append(time.perf_counter() - t_frame)
+        second_frac.append(second_calls / max(args.mapping_iters, 1))
         if os.environ.get("VTGS_SLAM_VERBOSE"):
             print(f"[bench_slam] frame {t}: tracking {track_ms[-1]:.3f} ms/it, mapping {map_ms[-1]:.3f} ms/it, "
                   f"instances {dgr.last_forward_info().get('instances')}, longest tile list {dgr.last_forward_info().get('max_tile_list')}", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     total = time.perf_counter() - t_all
+    map_ms_frames = list(map_ms)
     if world > 1:                                  # the slowest rank's clock
         tmax = torch.tensor([total, sum(track_ms) / len(track_ms), sum(map_ms) / len(map_ms)], dtype=torch.float64)
         if backend == "nccl":
@@ -358,6 +402,27 @@ def run(args) -> dict:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         total = float(tmax[0])
         track_ms, map_ms = [float(tmax[1])], [float(tmax[2])]
+    regimes = None
+    if args.base_frame_every:
+        if world > 1:                              # the slowest rank's clock, frame by frame
+            fs = torch.tensor(frame_s, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(fs, op=dist.ReduceOp.MAX)
+            frame_s = [float(x) for x in fs]
+        mean = lambda xs: sum(xs) / len(xs) if xs else None
+        ord_s = [x for x, k in zip(frame_s, frame_kind) if k == "ordinary"]
+        base_s = [x for x, k in zip(frame_s, frame_kind) if k == "base"]
+        regimes = {
+            "ordinary_frame": {"frames": len(ord_s), "s_per_frame": mean(ord_s),
+                               "mapping_ms_per_iter": mean([m for m, k in zip(map_ms_frames, frame_kind) if k == "ordinary"]),
+                               "second_get_loss_call_frac": mean([f for f, k in zip(second_frac, frame_kind) if k == "ordinary"]),
+                               "mapping_view": "one keyframe drawn per iteration from the submap's frames so far"},
+            "base_frame": {"frames": len(base_s), "s_per_frame": mean(base_s),
+                           "mapping_ms_per_iter": mean([m for m, k in zip(map_ms_frames, frame_kind) if k == "base"]),
+                           "second_get_loss_call_frac": mean([f for f, k in zip(second_frac, frame_kind) if k == "base"]),
+                           "mapping_view": "the current frame, both get_loss calls every iteration" if fixed else "the current frame"},
+        }
+        if ord_s and base_s:                       # configs/replica/room0.py:35: one base frame in 40
+            regimes["frames_per_s_mix_39_to_1"] = round(40.0 / (39.0 * mean(ord_s) + mean(base_s)), 3)
     out = {
         "metric": "SLAM frames/s, tracking+mapping loop (synthetic Replica-room0-like sequence)",
         "value": round(args.frames / total, 3), "unit": "frames/s", "n_gpus": world, "higher_is_better": True,
@@ -366,7 +431,8 @@ def run(args) -> dict:
                                f"mapping iterations per frame, 2 renders fwd+bwd per iteration (configs/replica/room0.py)",
                    "frames": args.frames, "shared_geometry": bool(args.shared_geometry or args.fused), "fused_callers": bool(args.fused),
                    "through_get_loss_mirror": bool(args.get_loss), "iteration_replayed_from_a_hipgraph": bool(args.graph),
-                   "mapping_get_loss_calls_per_iteration": 2 if fixed else 1,
+                   "mapping_get_loss_calls_per_iteration": (2 if fixed else 1) if not args.base_frame_every else "see regimes",
+                   "base_frame_every": args.base_frame_every or None, "emulated_window_frames": args.emulate_window or None,
                    "gaussians_in_global_set": N * (1 + len(fixed)) if fixed else None,
                    "partition": "none" if world == 1 else f"tile-row bands x{world} ({backend}): all-reduce of the pose gradient "
                                                           "(tracking); SSIM halo rows + 8 loss sums + 20 B/Gaussian (mapping)"},
@@ -374,6 +440,7 @@ def run(args) -> dict:
         "mapping_ms_per_iter": round(sum(map_ms) / len(map_ms), 3),
         "pose_error_before_tracking_cm_deg": [[round(a, 3), round(b, 4)] for a, b in errs_before],
         "pose_error_after_tracking_cm_deg": [[round(a, 3), round(b, 4)] for a, b in errs_after],
+        "regimes": regimes,
     }
     ms = torch.cuda.memory_stats()
     out["allocator"] = {"device_allocs": ms.get("num_device_alloc", 0), "device_frees": ms.get("num_device_free", 0),

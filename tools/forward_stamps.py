@@ -24,7 +24,9 @@ fs = rast._last_state
 out = (ctypes.c_uint64 * 12)()
 dgr._lib.vtgs_debug_layout(fs.n, fs.cam.W, fs.cam.H, fs.capacity, fs.tile_cap, out)
 tiles = int(out[7])
-st = fs.workspace[int(out[9]) + 256: int(out[9]) + 256 + 32 * tiles].view(torch.int32).reshape(tiles, 8).cpu().double()
+st_raw = fs.workspace[int(out[9]) + 256: int(out[9]) + 256 + 48 * tiles].view(torch.int32).reshape(tiles, 12).cpu()
+st = st_raw[:, :8].double()
+fwd_raw = st_raw.clone()
 names = ["sort (entry -> sorted list re-readable)", "first append", "all appends", "all steps", "whole wavefront", "steps", "list length"]
 for i, nm in enumerate(names):
     c = st[:, i]
@@ -44,7 +46,8 @@ for _ in range(3):
     c.backward(g)
 torch.cuda.synchronize()
 fs = rast._last_state
-st = fs.workspace[int(out[9]) + 256: int(out[9]) + 256 + 32 * tiles].view(torch.int32).reshape(tiles, 8).cpu().double()
+st_raw = fs.workspace[int(out[9]) + 256: int(out[9]) + 256 + 48 * tiles].view(torch.int32).reshape(tiles, 12).cpu()
+st = st_raw[:, :8].double()
 print("backward:")
 if dgr.get_option("VTGS_BWD_IMPL") == 3:
     w7 = st[:, 7].long() & 0xFFFFFFFF
@@ -59,3 +62,32 @@ else:
 for nm, c in cols:
     print(f"{nm:42s} mean {c.mean():10.1f}  median {c.median():10.1f}  p90 {c.quantile(0.9):10.1f}  max {c.max():10.1f}")
 print(f"ticks per batch / step (median tile) {((st[:, 3] if dgr.get_option('VTGS_BWD_IMPL') != 3 else st[:, 1] + st[:, 2] + st[:, 3] + st[:, 6]) / st[:, 5].clamp(min=1)).median():.0f}")
+
+
+def timeline(raw, name):
+    """Occupancy over the kernel's life from the per-wavefront start / end stamps (10 ns units of the chip-wide constant clock):
+    how many of the wavefronts are resident at each instant, and how much of the kernel runs below 50 / 80 % of the peak."""
+    import numpy as np
+    t0 = (raw[:, 8].long() & 0xFFFFFFFF).numpy().astype(np.int64)
+    t1 = (raw[:, 9].long() & 0xFFFFFFFF).numpy().astype(np.int64)
+    ok = (t1 >= t0) & ((raw[:, 9] != 0).numpy())
+    t0, t1 = t0[ok], t1[ok]
+    base = t0.min()
+    t0, t1 = (t0 - base) * 0.01, (t1 - base) * 0.01            # us
+    span = t1.max()
+    grid = np.linspace(0, span, 400)
+    occ = np.array([((t0 <= g) & (t1 > g)).sum() for g in grid])
+    peak = occ.max()
+    xcc = (raw[:, 11].long() & 0xF).numpy()[ok]
+    print(f"{name}: {ok.sum()} wavefronts, span {span:.1f} us, mean wavefront life {np.mean(t1 - t0):.1f} us (p10 {np.quantile(t1 - t0, .1):.1f}, p90 {np.quantile(t1 - t0, .9):.1f}), "
+          f"peak residency {peak}, mean residency {occ.mean():.0f} ({occ.mean() / peak:.2f} of peak)")
+    print(f"   time below 80 % of peak: {(occ < 0.8 * peak).mean() * span:.1f} us, below 50 %: {(occ < 0.5 * peak).mean() * span:.1f} us; "
+          f"wavefront-us = {np.sum(t1 - t0):.0f} => at peak residency the work would take {np.sum(t1 - t0) / peak:.1f} us")
+    print("   residency at 10 % steps of the span:", [int(occ[int(i * 39.9)]) for i in range(0, 11)])
+    print("   wavefronts per XCC:", [int((xcc == x).sum()) for x in range(8)])
+    starts = np.sort(t0)
+    print("   start times (us) of every 1000th wavefront:", [round(float(starts[i]), 1) for i in range(0, len(starts), 1000)])
+
+
+timeline(st_raw, "backward")
+timeline(fwd_raw, "forward")

@@ -874,6 +874,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   constexpr int NG = DUAL ? 6 : 3;                            // image-gradient channels
 #ifdef VTGS_Q_STAMPS
   const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long st_gather = 0ull, st_batch = 0ull, st_loop0 = 0ull;
   uint32_t nbatches = 0u;
 #endif
@@ -1142,10 +1143,12 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   }
 #ifdef VTGS_Q_STAMPS
   if (dbg && l == 0) {
-    uint32_t* o = dbg + 64 + 8 * tc.tile;
+    uint32_t* o = dbg + 64 + kStampWords * tc.tile;
     const unsigned long long se = __builtin_amdgcn_s_memtime();
     o[0] = (uint32_t)(st_loop0 - st0); o[1] = 0u; o[2] = (uint32_t)st_gather; o[3] = (uint32_t)st_batch;
     o[4] = (uint32_t)(se - st0); o[5] = nbatches; o[6] = e - s; o[7] = 0u;
+    o[8] = (uint32_t)rt0; o[9] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    o[10] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); o[11] = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // HW_ID, XCC_ID
   }
 #endif
 }

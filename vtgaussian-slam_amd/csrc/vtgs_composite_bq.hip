@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
   }
 #ifdef VTGS_Q_STAMPS
   if (step_counters && l == 0) {
-    uint32_t* o = step_counters + 64 + 8 * tile;
+    uint32_t* o = step_counters + 64 + kStampWords * tile;
     const unsigned long long se = __builtin_amdgcn_s_memtime();
     o[0] = (uint32_t)st_app; o[1] = (uint32_t)st_pop; o[2] = (uint32_t)st_sweep; o[3] = (uint32_t)st_contr;
     o[4] = (uint32_t)(se - st0); o[5] = nsteps; o[6] = (uint32_t)st_acc; o[7] = (uint32_t)st_prom | ((uint32_t)(st_ret >> 4) << 20);

@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
 #endif
 #ifdef VTGS_Q_STAMPS
   const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long st1 = st0, st2 = st0, st_app = 0ull, st_step = 0ull;
   unsigned long long st_sort[2] = {st0, st0};
 #define VTGS_SORT_STAMP st_sort
@@ -495,7 +496,9 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
   }
 #ifdef VTGS_Q_STAMPS
   if (step_counters && l == 0) {
-    uint32_t* o = step_counters + 64 + 8 * qc.tile;
+    uint32_t* o = step_counters + 64 + kStampWords * qc.tile;
+    o[8] = (uint32_t)rt0; o[9] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    o[10] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); o[11] = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // HW_ID, XCC_ID
     const unsigned long long se = __builtin_amdgcn_s_memtime();
     o[0] = (uint32_t)(st1 - st0); o[1] = (uint32_t)(st2 - st1); o[2] = (uint32_t)st_app; o[3] = (uint32_t)st_step;
     o[4] = (uint32_t)(se - st0); o[5] = nsteps; o[6] = e - s;

@@ -54,6 +54,8 @@ struct alignas(16) BlockStats { uint32_t visible, pad; unsigned long long r16; }
 constexpr int kGradRec = 10;       // floats per instance gradient record: 6 moments, 3 colour sums, tile id (40-byte stride, float2 access)
 constexpr int kGradRecDual = 14;   // dual render: 6 moments + 6 colour sums + tile id + one pad word (56-byte stride, float2 access)
 
+constexpr int kStampWords = 12;    // -DVTGS_Q_STAMPS: words per tile in the debug region (8 phase stamps, start / end in 10 ns units of
+                                   // the chip-wide constant clock, HW_ID, XCC_ID)
 struct WsLayout {
   size_t counters, geom, gaux, block_stats, tile_cnt, keys, vals, sorted_gid, sorted_inst, final_T, qmask, dbg, plan, total;
   uint32_t tiles8, tile_cap;      // tile_cap: slots per bin (uniform bins) or the average over the bins (planned bins)
@@ -84,7 +86,7 @@ inline WsLayout make_layout(int32_t n, int32_t w, int32_t h, uint64_t cap, uint3
   L.final_T = o;     o += align256((size_t)w * h * 4);
   L.qmask = o;       o += align256(slots);               // quadrant mask (4 bits) of every sorted list entry, written by composite_forward_q
 #ifdef VTGS_Q_STAMPS
-  L.dbg = o;         o += align256(256 + (size_t)L.tiles8 * 32);   // diagnostic build: + 8 words of cycle stamps per tile
+  L.dbg = o;         o += align256(256 + (size_t)L.tiles8 * kStampWords * 4);   // diagnostic build: + 12 words of stamps per tile
 #else
   L.dbg = o;         o += 256;                           // 64 step counters (measurement only, VTGS_COUNT_STEPS)
 #endif
