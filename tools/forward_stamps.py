@@ -85,6 +85,21 @@ def timeline(raw, name):
           f"wavefront-us = {np.sum(t1 - t0):.0f} => at peak residency the work would take {np.sum(t1 - t0) / peak:.1f} us")
     print("   residency at 10 % steps of the span:", [int(occ[int(i * 39.9)]) for i in range(0, 11)])
     print("   wavefronts per XCC:", [int((xcc == x).sum()) for x in range(8)])
+    # life of a wavefront against WHEN it started (late starters run on an emptying chip): is a wavefront faster alone?
+    order = np.argsort(t0)
+    life = (t1 - t0)[order]
+    per_unit = None
+    if name == "backward":
+        bat = raw[:, 3].double().numpy()[ok][order] / np.maximum(raw[:, 5].double().numpy()[ok][order], 1)   # ticks per batch
+        per_unit = bat
+    else:
+        stp = raw[:, 3].double().numpy()[ok][order] / np.maximum(raw[:, 5].double().numpy()[ok][order], 1)   # ticks per step
+        per_unit = stp
+    n = len(life)
+    print("   by start order (tenths): mean life us", [round(float(life[i * n // 10:(i + 1) * n // 10].mean()), 1) for i in range(10)])
+    print("   by start order (tenths): ticks per batch/step", [int(per_unit[i * n // 10:(i + 1) * n // 10].mean()) for i in range(10)])
+    last = order[-600:]
+    print(f"   the last 600 starters: mean life {float((t1 - t0)[last].mean()):.1f} us, ticks per batch/step {float(per_unit[-600:].mean()):.0f}")
     starts = np.sort(t0)
     print("   start times (us) of every 1000th wavefront:", [round(float(starts[i]), 1) for i in range(0, len(starts), 1000)])
 

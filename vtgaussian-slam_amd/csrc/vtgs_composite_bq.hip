@@ -149,7 +149,13 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
     const float* __restrict__ final_T, float* __restrict__ grad_inst, const Counters* __restrict__ ctr,
     uint32_t* __restrict__ step_counters) {
   __shared__ __attribute__((aligned(16))) float lds_img[4][4 * 256];          // one image per wavefront: u', then w
-  __shared__ float lds_acc[4][(kBqRing + 1) * kAccRow];                       // per ring slot: 6 moments + 3 colour sums
+  // per ring slot: U0 UX UY UXX | UXY UYY | c0 c1 c2 (pad) -- three arrays so that one lane moves one splat's sums with
+  // ds_read/write_b128 + _b64 + _b128.  Round 4: plain read-modify-write, one quadrant after the other (see the merge below);
+  // ds_add_f32 costs ~768 cycles per wave-wide instruction on gfx950 -- LDS float atomics are applied one lane at a time,
+  // 12 cycles each, whatever the addresses (tests/micro/lds_accumulate.hip, profiles/r4_lds_accumulate.md)
+  __shared__ __attribute__((aligned(16))) float4 lds_accA[4][kBqRing + 1];
+  __shared__ __attribute__((aligned(16))) float2 lds_accB[4][kBqRing + 1];
+  __shared__ __attribute__((aligned(16))) float4 lds_accW[4][kBqRing + 1];
   __shared__ uint32_t lds_gid[4][kBqRing + 1], lds_inst[4][kBqRing + 1];
   __shared__ uint8_t lds_q[4][4][kBqRing];
   __shared__ __attribute__((aligned(16))) float lds_phi[4 * 8 * kPhiRow];     // [quadrant][column 0..7][16 px + 4 pad]
@@ -201,7 +207,9 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
     lds_phi[idx] = (t < 16) ? v : 0.f;
   }
   float* __restrict__ img = lds_img[wv];
-  float* __restrict__ acc = lds_acc[wv];
+  float4* __restrict__ accA = lds_accA[wv];
+  float2* __restrict__ accB = lds_accB[wv];
+  float4* __restrict__ accW = lds_accW[wv];
   uint32_t* __restrict__ tgid = lds_gid[wv];
   uint32_t* __restrict__ tinst = lds_inst[wv];
   // dL/dcolor as the B operand of the colour contraction: [quadrant][channel 0..2, 3 = 0][16 px + 4 pad], from the lanes' own
@@ -210,7 +218,9 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
 #pragma unroll
   for (int c = 0; c < 4; ++c) gimg[(4 * q + c) * kPhiRow + i] = (c < 3) ? gown[c < 3 ? c : 0] : 0.f;
   // ring state: accumulators start at zero (and are zeroed again when a chunk retires); dummy slot included
-  for (int k = l; k < (kBqRing + 1) * kAccRow; k += 64) acc[k] = 0.f;
+  for (int k = l; k < kBqRing + 1; k += 64) {
+    accA[k] = make_float4(0.f, 0.f, 0.f, 0.f); accB[k] = make_float2(0.f, 0.f); accW[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   if (l == 0) { tgid[kBqDummy] = 0u; tinst[kBqDummy] = 0u; }
   __syncthreads();                                              // before any per-wavefront exit
   if (overflow) return;                                         // uniform over the grid: the forward did not complete
@@ -342,18 +352,19 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
       BQ_STAMP(st_sweep)
       // ---- colour sums: w x dL/dcolor over the quadrant's 16 pixels (the image holds w now) ---------------------------------
       f32x4 Pw = {0.f, 0.f, 0.f, 0.f};
-      {
-        float4 wa[4], ga[4];
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-          wa[t4] = *reinterpret_cast<const float4*>(img + img_read_off(q, row, t4));
-          ga[t4] = G4[t4];
+      for (int h2 = 0; h2 < 2; ++h2) {                            // two pixel granules at a time: 16 operand registers, not 32
+        float4 wa[2], ga[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          wa[t] = *reinterpret_cast<const float4*>(img + img_read_off(q, row, 2 * h2 + t));
+          ga[t] = G4[2 * h2 + t];
         }
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-          const float wav[4] = {wa[t4].x, wa[t4].y, wa[t4].z, wa[t4].w}, gav[4] = {ga[t4].x, ga[t4].y, ga[t4].z, ga[t4].w};
+        for (int t = 0; t < 2; ++t) {
+          const float wav[4] = {wa[t].x, wa[t].y, wa[t].z, wa[t].w}, gav[4] = {ga[t].x, ga[t].y, ga[t].z, ga[t].w};
 #pragma unroll
-          for (int e4 = 0; e4 < 4; ++e4) Pw = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], gav[e4], Pw, 0, 0, 0);
+          for (int e4 = 0; e4 < 4; ++e4) Pw = __builtin_amdgcn_mfma_f32_4x4x1f32(gav[e4], wav[e4], Pw, 0, 0, 0);
         }
       }
       // ---- back to front: u'_k = G_k T_k (g.c_k - A), A <- A + alpha_k (g.c_k - A); u' takes the image over from w -----------
@@ -365,21 +376,22 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
         A = fmaf(a[k], t, A);
       }
       f32x4 Pa = {0.f, 0.f, 0.f, 0.f}, Pb = {0.f, 0.f, 0.f, 0.f};
-      {
-        float4 ua[4], pa4[4], pb4[4];
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-          ua[t4] = *reinterpret_cast<const float4*>(img + img_read_off(q, row, t4));
-          pa4[t4] = PhiA4[t4]; pb4[t4] = PhiB4[t4];
+      for (int h2 = 0; h2 < 2; ++h2) {
+        float4 ua[2], pa4[2], pb4[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          ua[t] = *reinterpret_cast<const float4*>(img + img_read_off(q, row, 2 * h2 + t));
+          pa4[t] = PhiA4[2 * h2 + t]; pb4[t] = PhiB4[2 * h2 + t];
         }
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
+        for (int t4 = 0; t4 < 2; ++t4) {
           const float uav[4] = {ua[t4].x, ua[t4].y, ua[t4].z, ua[t4].w};
           const float bav[4] = {pa4[t4].x, pa4[t4].y, pa4[t4].z, pa4[t4].w}, bbv[4] = {pb4[t4].x, pb4[t4].y, pb4[t4].z, pb4[t4].w};
 #pragma unroll
           for (int e4 = 0; e4 < 4; ++e4) {
-            Pa = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bav[e4], Pa, 0, 0, 0);
-            Pb = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bbv[e4], Pb, 0, 0, 0);
+            Pa = __builtin_amdgcn_mfma_f32_4x4x1f32(bav[e4], uav[e4], Pa, 0, 0, 0);
+            Pb = __builtin_amdgcn_mfma_f32_4x4x1f32(bbv[e4], uav[e4], Pb, 0, 0, 0);
           }
         }
       }
@@ -387,17 +399,27 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
       asm volatile("" :: "v"(Pa[0]), "v"(Pb[0]), "v"(Pw[0]));
 #endif
       BQ_STAMP(st_contr)
-      // ---- add the quadrant's partial sums to the splats' ring accumulators: lane (q, sg, cj) holds rows 4 sg + 0..3 -----
-      {
-        const int s0 = quad_bcast<0>(cur_slot), s1 = quad_bcast<1>(cur_slot), s2 = quad_bcast<2>(cur_slot), s3 = quad_bcast<3>(cur_slot);
-        const int sl4[4] = {s0, s1, s2, s3};
+      // ---- add the quadrant's partial sums to the splats' ring accumulators.  With the column operand first, lane (q, j) holds
+      // all nine sums of ITS OWN splat (row j = the entry it popped): Pa = U0 UX UY UXX, Pb = UXY UYY, Pw = c0 c1 c2.  Two
+      // quadrants can hold the same splat in the same step, so the quadrants take turns -- four exec-masked read-modify-write
+      // rounds; the LDS operations of one wavefront execute in order, a round reads what the round before it wrote.  Fixed
+      // order (0, 1, 2, 3 within a step, steps in sequence): bitwise reproducible.
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float* ar = acc + sl4[r] * kAccRow;
-          __hip_atomic_fetch_add(ar + cj, Pa[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (cj < 2) __hip_atomic_fetch_add(ar + 4 + cj, Pb[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (cj < 3) __hip_atomic_fetch_add(ar + 6 + cj, Pw[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (int qq = 0; qq < 4; ++qq) {
+        if (q == qq) {
+          float4 a = accA[cur_slot];
+          float2 b = accB[cur_slot];
+          float4 w = accW[cur_slot];
+          a.x += Pa[0]; a.y += Pa[1]; a.z += Pa[2]; a.w += Pa[3];
+          b.x += Pb[0]; b.y += Pb[1];
+          w.x += Pw[0]; w.y += Pw[1]; w.z += Pw[2];
+          accA[cur_slot] = a; accB[cur_slot] = b; accW[cur_slot] = w;
         }
+        // the next round's loads must stay BEHIND this round's stores: to the compiler the rounds are mutually exclusive
+        // branches of one thread (it would hoist or merge the loads: lost updates -- the first build of this merge did
+        // exactly that); a wavefront-scope fence costs no instruction, the hardware keeps one wavefront's LDS operations in order
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
 #ifdef VTGS_Q_STAMPS
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -423,15 +445,14 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
     // ---- retire: the oldest chunk has left all four queues AND the step still to be computed holds none of its entries ---
     while (inflight > 0 && __ballot(c0 > 0) == 0ull && __ballot(have_cur && cur_d0 > 0) == 0ull) {
       const int slot = (int)rslot + l;
-      float v[kAccRow];
-#pragma unroll
-      for (int k = 0; k < kAccRow; ++k) { v[k] = acc[slot * kAccRow + k]; }
-#pragma unroll
-      for (int k = 0; k < kAccRow; ++k) acc[slot * kAccRow + k] = 0.f;
+      const float4 a = accA[slot];
+      const float2 b = accB[slot];
+      const float4 w = accW[slot];
+      accA[slot] = make_float4(0.f, 0.f, 0.f, 0.f); accB[slot] = make_float2(0.f, 0.f); accW[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (l < n0) {
         float2* p = reinterpret_cast<float2*>(grad_inst + (size_t)tinst[slot] * kGradRec);
-        p[0] = make_float2(v[0], v[1]); p[1] = make_float2(v[2], v[3]); p[2] = make_float2(v[4], v[5]);
-        p[3] = make_float2(v[6], v[7]); p[4] = make_float2(v[8], __uint_as_float(tile_bits));
+        p[0] = make_float2(a.x, a.y); p[1] = make_float2(a.z, a.w); p[2] = b;
+        p[3] = make_float2(w.x, w.y); p[4] = make_float2(w.z, __uint_as_float(tile_bits));
       }
       c0 = c1; c1 = c2; c2 = 0; n0 = n1; n1 = n2; n2 = 0;
       cur_d0 = cur_d1; cur_d1 = cur_d2; cur_d2 = 0;              // what the step in flight holds of the NEW oldest chunk
@@ -445,10 +466,12 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
   while (inflight > 0) {
     const int slot = (int)rslot + l;
     if (l < n0) {
-      const float* a = acc + slot * kAccRow;
+      const float4 a = accA[slot];
+      const float2 b = accB[slot];
+      const float4 w = accW[slot];
       float2* p = reinterpret_cast<float2*>(grad_inst + (size_t)tinst[slot] * kGradRec);
-      p[0] = make_float2(a[0], a[1]); p[1] = make_float2(a[2], a[3]); p[2] = make_float2(a[4], a[5]);
-      p[3] = make_float2(a[6], a[7]); p[4] = make_float2(a[8], __uint_as_float(tile_bits));
+      p[0] = make_float2(a.x, a.y); p[1] = make_float2(a.z, a.w); p[2] = b;
+      p[3] = make_float2(w.x, w.y); p[4] = make_float2(w.z, __uint_as_float(tile_bits));
     }
     n0 = n1; n1 = n2; n2 = 0;
     rslot = (rslot == (uint32_t)(kBqRing - 64)) ? 0u : rslot + 64u; --inflight;
