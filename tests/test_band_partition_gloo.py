@@ -1,6 +1,22 @@
 """Tile-row partition across ranks: bands tile the image exactly, and band renders + summed band
 gradients reproduce the full-frame result.  Runs world_size=2 over gloo on the CPU, with the oracle standing in
-for the device operator (the partition arithmetic and the collective pattern are what is under test)."""
+for the device operator and tests/band_cpu_ref.py for the device loss kernels: the partition arithmetic and the collective
+pattern of the PRODUCT module (halo exchange, sums, median, gradient all-reduce, threshold pick) are what is under test.
+The HIP band kernels themselves are covered on the GPU (tests/test_band_loss_gpu.py, incl. two ranks on one GPU)."""
+
+def test_band_losses_refuse_cpu_tensors():
+    """The product has no CPU path: the band losses raise on CPU tensors instead of silently running torch code."""
+    import pytest as _pytest
+    import torch as _torch
+    from diff_gaussian_rasterization import partition as pt
+    im, ds = _torch.zeros(3, 32, 16), _torch.zeros(3, 32, 16)
+    gi, gd = _torch.zeros(3, 32, 16), _torch.ones(1, 32, 16)
+    for call in (lambda: pt.band_mapping_loss(im, ds, gi, gd, (0, 1), 0, 1), lambda: pt.band_tracking_loss(im, ds, gi, gd, (0, 1), 0.5),
+                 lambda: pt.band_silhouette_threshold(im, ds[1], gi, gd, (0, 1), 1)):
+        with _pytest.raises(RuntimeError, match="no CPU path"):
+            call()
+
+
 import os
 import socket
 
@@ -125,8 +141,9 @@ def _mapping_worker(rank, world, port, out, outlier):
     p = params()
     band = band_for_rank(H, world, rank)
     im, ds = render(p, band)
-    share = pt.band_mapping_loss(im, ds, gt_im, gt_depth, band, rank, world, w_im=0.5, w_depth=1.0,
-                                 ignore_outlier_depth_loss=outlier)
+    import band_cpu_ref as ref_cpu                                      # the loss arithmetic on the CPU (test tree); collectives: product
+    share = ref_cpu.band_mapping_loss(im, ds, gt_im, gt_depth, band, rank, world, w_im=0.5, w_depth=1.0,
+                                      ignore_outlier_depth_loss=outlier)
     share.backward()
     nbytes = pt.allreduce_param_grads(p)
     total = share.detach().clone()
@@ -176,8 +193,10 @@ def _tracking_worker(rank, world, port, out):
     band = band_for_rank(H, world, rank)
     im, ds = render(p, band)
     cands = (0.5, 0.8, 0.9, 0.95, 0.99)
-    thr = pt.band_silhouette_threshold(im.detach(), ds.detach()[1], gt_im, gt_depth, band, world, cands)
-    share = pt.band_tracking_loss(im, ds, gt_im, gt_depth, band, thr, w_im=0.5, w_depth=1.0)
+    import band_cpu_ref as ref_cpu
+    thr = pt.band_silhouette_threshold(im.detach(), ds.detach()[1], gt_im, gt_depth, band, world, cands,
+                                       sums=ref_cpu.band_sweep_sums(im.detach(), ds.detach()[1], gt_im, gt_depth, band, cands))
+    share = ref_cpu.band_tracking_loss(im, ds, gt_im, gt_depth, band, thr, w_im=0.5, w_depth=1.0)
     share.backward()
     pt.allreduce_param_grads(p)
     total = pt.all_reduce_sum(share.detach().clone().reshape(1))

@@ -27,6 +27,23 @@ tiles = int(out[7])
 st_raw = fs.workspace[int(out[9]) + 256: int(out[9]) + 256 + 48 * tiles].view(torch.int32).reshape(tiles, 12).cpu()
 st = st_raw[:, :8].double()
 fwd_raw = st_raw.clone()
+# ---- project_and_bin: 8 words per workgroup behind the per-tile stamps
+nblk = (N + 1023) // 1024
+poff = int(out[9]) + ((256 + 48 * tiles + 255) // 256) * 256
+pj = fs.workspace[poff: poff + 32 * nblk].view(torch.int32).reshape(nblk, 8).cpu()
+pjd = pj.double()
+print("project_and_bin (ticks per workgroup of 1024 Gaussians):")
+for i, nm in enumerate(["inputs + projection + walk set-up", "table clear + pass 1 (reach tests, LDS histogram)",
+                        "scans + instance atomic + per-tile global reservations", "records + pass 2 (slots, bin entries)", "whole workgroup"]):
+    c = pjd[:, i]
+    print(f"  {nm:58s} mean {c.mean():9.1f}  median {c.median():9.1f}  p90 {c.quantile(0.9):9.1f}  max {c.max():9.1f}")
+import numpy as np
+pt0 = (pj[:, 5].long() & 0xFFFFFFFF).numpy().astype(np.int64); pt1 = (pj[:, 6].long() & 0xFFFFFFFF).numpy().astype(np.int64)
+okp = pt1 >= pt0
+b0 = pt0[okp].min()
+life = (pt1[okp] - pt0[okp]) * 0.01
+print(f"  {okp.sum()} workgroups, span {(pt1[okp].max() - b0) * 0.01:.1f} us, workgroup life mean {life.mean():.1f} us (p10 {np.quantile(life, .1):.1f}, p90 {np.quantile(life, .9):.1f}); "
+      f"starts: {[round(float(x), 1) for x in np.sort((pt0[okp] - b0) * 0.01)[::100]]}")
 names = ["sort (entry -> sorted list re-readable)", "first append", "all appends", "all steps", "whole wavefront", "steps", "list length"]
 for i, nm in enumerate(names):
     c = st[:, i]

@@ -120,6 +120,9 @@ static CamScalars scalars_of(const VtgsCamera* cam, int row8_begin, int row8_end
   cs.radius_rule = cam->radius_rule;
   cs.row8_begin = row8_begin; cs.row8_end = row8_end;
   cs.bin_plan = nullptr; cs.bin_limit = 0u;                  // planned bins: set by the caller once the workspace layout is known
+#ifdef VTGS_Q_STAMPS
+  cs.dbg_proj = nullptr;
+#endif
   return cs;
 }
 
@@ -270,6 +273,9 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   char* ws = (char*)workspace;
   CamScalars cs = scalars_of(cam, r8b, r8e);
   Counters* ctr = (Counters*)(ws + L.counters);
+#ifdef VTGS_Q_STAMPS
+  cs.dbg_proj = (uint32_t*)(ws + L.dbg + align256(256 + (size_t)L.tiles8 * kStampWords * 4));
+#endif
   if (L.planned) {
     // this forward (and its backward) bins into a COPY of the caller's plan: the persistent one is rewritten for the next
     // forward by finalize_forward.  A plan that does not fit the workspace (its total is on the device) makes every bin

@@ -141,6 +141,14 @@ __device__ __forceinline__ void project_and_bin_body(
     Counters* __restrict__ ctr, BlockStats* __restrict__ block_stats, unsigned long long capacity, uint32_t tile_cap) {
   constexpr int kWaves = kProjBlock / 64;
   extern __shared__ uint32_t lds_tile[];                         // LDSBINS: one entry per 8x8 tile of this call's band
+#ifdef VTGS_Q_STAMPS
+  unsigned long long pst[6];
+  pst[0] = __builtin_amdgcn_s_memtime();
+  const unsigned long long prt0 = __builtin_amdgcn_s_memrealtime();
+#define VTGS_P_STAMP(i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pst[i] = __builtin_amdgcn_s_memtime(); }
+#else
+#define VTGS_P_STAMP(i)
+#endif
   const CamParams cam = load_cam(cs, Vp, PVp);
   const int tile0 = cam.row8_begin * cam.gx8;                    // first tile of the band (tile-row multi-GPU partition)
   const int tiles8 = (cam.row8_end - cam.row8_begin) * cam.gx8;
@@ -207,6 +215,7 @@ __device__ __forceinline__ void project_and_bin_body(
     if (x1 > x0 && y1 > y0) { w.cx0 = x0; w.cy0 = y0; w.cw = x1 - x0; w.ch = y1 - y0; }
     else { w.cw = 0; w.ch = 0; }
   }
+  VTGS_P_STAMP(1)                                                // inputs arrived, projection + walk set up
   const int area_all = w.cw * w.ch;
   const bool big = area_all > kBigArea;                        // left to the wavefront, at the end of the kernel
   const int area = big ? 0 : area_all;
@@ -227,6 +236,7 @@ __device__ __forceinline__ void project_and_bin_body(
     if constexpr (LDSBINS) { if (hit) atomicAdd(&lds_tile[(w.cy0 + ty) * cam.gx8 + w.cx0 + tx - tile0], 1u); }
     if (++tx == w.cw) { tx = 0; ++ty; }
   }
+  VTGS_P_STAMP(2)                                                // table cleared, pass 1 (reach tests + LDS histogram)
   // Instances of one splat are contiguous: reserve [base, base+cnt).  ONE atomic per workgroup on the
   // global counter: same-address atomics serialise at the memory side (~14 ns each measured), so per-wavefront
   // atomics on one cache line cost more than the whole projection.
@@ -254,6 +264,7 @@ __device__ __forceinline__ void project_and_bin_body(
     }
   }
   __syncthreads();
+  VTGS_P_STAMP(3)                                                // scans, the instance-range atomic, per-tile global reservations
   uint32_t wave_base = s_block_base;
   for (int k = 0; k < wv; ++k) wave_base += s_wave_cnt[k];
   const uint32_t inst_base = wave_base + incl - cnt;
@@ -346,6 +357,15 @@ __device__ __forceinline__ void project_and_bin_body(
   }
   }  // (global-atomic form)
 
+  VTGS_P_STAMP(4)                                                // records + pass 2 (slots, bin entries stored)
+#ifdef VTGS_Q_STAMPS
+  if (threadIdx.x == 0 && cs.dbg_proj) {
+    uint32_t* o = cs.dbg_proj + 8 * blockIdx.x;
+    o[0] = (uint32_t)(pst[1] - pst[0]); o[1] = (uint32_t)(pst[2] - pst[1]); o[2] = (uint32_t)(pst[3] - pst[2]);
+    o[3] = (uint32_t)(pst[4] - pst[3]); o[4] = (uint32_t)(pst[4] - pst[0]);
+    o[5] = (uint32_t)prt0; o[6] = (uint32_t)__builtin_amdgcn_s_memrealtime(); o[7] = (uint32_t)area_all;
+  }
+#endif
   // ---- the big splats of this wavefront, one after the other, every lane a tile --------------------------------------------
   for (unsigned long long rest = __ballot(big); rest; rest &= rest - 1ull) {      // wave-uniform
     const int src = __builtin_ctzll(rest);

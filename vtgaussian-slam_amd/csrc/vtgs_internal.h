@@ -86,7 +86,8 @@ inline WsLayout make_layout(int32_t n, int32_t w, int32_t h, uint64_t cap, uint3
   L.final_T = o;     o += align256((size_t)w * h * 4);
   L.qmask = o;       o += align256(slots);               // quadrant mask (4 bits) of every sorted list entry, written by composite_forward_q
 #ifdef VTGS_Q_STAMPS
-  L.dbg = o;         o += align256(256 + (size_t)L.tiles8 * kStampWords * 4);   // diagnostic build: + 12 words of stamps per tile
+  L.dbg = o;         o += align256(256 + (size_t)L.tiles8 * kStampWords * 4)    // diagnostic build: + 12 words of stamps per tile
+                          + align256(((size_t)(n + 1023) / 1024 + 1) * 32);         // ... + 8 per workgroup of project_and_bin
 #else
   L.dbg = o;         o += 256;                           // 64 step counters (measurement only, VTGS_COUNT_STEPS)
 #endif
@@ -104,6 +105,9 @@ struct CamScalars {
   int row8_begin, row8_end;
   const uint32_t* bin_plan;       // planned bins: offsets [tiles8 + 1] (the workspace's copy); NULL = uniform bins of tile_cap slots
   uint32_t bin_limit;             // ... and the slots the workspace holds: no bin reaches past it, whatever the plan says
+#ifdef VTGS_Q_STAMPS
+  uint32_t* dbg_proj;             // diagnostic build: 8 words of stamps per workgroup of project_and_bin
+#endif
 };
 
 // where tile t's bin lives: a wave-uniform branch on a kernel argument (uniform bins pay nothing for the planned form)

@@ -87,6 +87,13 @@ def pose7_reduce(points, g_points):
 SSIM_HALO = 5                      # rows a band needs from each neighbour: (11 - 1) / 2
 
 
+def _need_device(t, what: str) -> None:
+    """The band losses are HIP kernels (csrc/vtgs_loss.hip); this package has no CPU path.  (Round 3 carried pure-torch CPU
+    branches here for the gloo tests: they live in tests/band_cpu_ref.py now, on top of this module's collectives.)"""
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
+
+
 def allreduce_radii(radii, group=None):
     """A rank of the partition skips the Gaussians that cannot meet its rows (radius 0 there): the radii of the frame --
     variables['max_2D_radius'] / ['seen'] of the reference, src/vtgaussian_slam.py:681-689 -- are the element-wise maximum
@@ -233,50 +240,21 @@ def band_mapping_loss(im, depth_sil, gt_im, gt_depth, band: Tuple[int, int], ran
     H, W = im.shape[-2], im.shape[-1]
     y0, y1 = pixel_rows(band, H)
     rows = slice(y0, y1)
-    if im.is_cuda:
-        # the HIP route: the band forms of the loss kernels (vtgs_slam_loss_band_*): SSIM over the band's rows with the
-        # neighbours' rows as context, masked sums, ONE 8-float all-reduce (global mask count), gradient images in 2 launches
-        from . import losses as _l
-        full = halo_exchange(im, band, H, rank, world, SSIM_HALO, group) if world > 1 else im
-        extra = None
-        if ignore_outlier_depth_loss:
-            gd, d = gt_depth[:, rows], depth_sil[0:1, rows].detach()
-            err = torch.abs(gd - d) * (gd > 0)
-            med = global_median(err, group) if world > 1 else err.median()
-            extra = torch.zeros((H, W), dtype=torch.float32, device=im.device)
-            extra[rows] = ((err < 50 * med) & (gd > 0))[0].to(torch.float32)
-        red = (lambda t: all_reduce_sum(t, group)) if world > 1 else None
-        return _l.band_loss(full, depth_sil, gt_im, gt_depth, (y0, y1), "mapping", w_im=w_im, w_depth=w_depth,
-                            extra_mask=extra, reduce=red, first_band=(rank == 0))
-    depth = depth_sil[0:1, rows]
-    unc = (depth_sil[2:3, rows] - depth ** 2).detach()
-    gd = gt_depth[:, rows]
+    _need_device(im, "band_mapping_loss")
+    # the band forms of the loss kernels (vtgs_slam_loss_band_*): SSIM over the band's rows with the neighbours' rows as
+    # context, masked sums, ONE 8-float all-reduce (global mask count), gradient images in 2 launches
+    from . import losses as _l
+    full = halo_exchange(im, band, H, rank, world, SSIM_HALO, group) if world > 1 else im
+    extra = None
     if ignore_outlier_depth_loss:
-        err = torch.abs(gd - depth.detach()) * (gd > 0)
-        mask = (err < 50 * global_median(err, group)) & (gd > 0)
-    else:
-        mask = gd > 0
-    mask = (mask & ~torch.isnan(depth) & ~torch.isnan(unc)).detach()
-    stats = torch.stack([mask.sum().to(torch.float32)])
-    all_reduce_sum(stats, group)                       # global mask count: the depth term is a MEAN over the frame
-    l_depth = torch.abs(gd - depth)[mask].sum() / stats[0]
-    numel = float(3 * H * W)
-    l1 = torch.abs(im[:, rows] - gt_im[:, rows]).sum() / numel
-    # SSIM map of this band: blur needs SSIM_HALO rows of context on both sides, rendered by the neighbours
-    full = halo_exchange(im, band, H, rank, world, SSIM_HALO, group)
-    c0, c1 = max(y0 - SSIM_HALO, 0), min(y1 + SSIM_HALO, H)
-    a, b = full[None, :, c0:c1], gt_im[None, :, c0:c1]
-    g1 = torch.tensor([__import__("math").exp(-(i - 5) ** 2 / (2 * 1.5 ** 2)) for i in range(11)], dtype=a.dtype, device=a.device)
-    g1 = g1 / g1.sum()
-    win = (g1[:, None] @ g1[None, :]).expand(3, 1, 11, 11).contiguous()
-    blur = lambda t: F.conv2d(t, win, padding=5, groups=3)     # zero padding: at the frame border like calc_ssim, and at the
-    mu1, mu2 = blur(a), blur(b)                                # crop's artificial borders only inside the discarded halo rows
-    s11, s22, s12 = blur(a * a) - mu1 * mu1, blur(b * b) - mu2 * mu2, blur(a * b) - mu1 * mu2
-    c_1, c_2 = 0.01 ** 2, 0.03 ** 2
-    smap = ((2 * mu1 * mu2 + c_1) * (2 * s12 + c_2)) / ((mu1 * mu1 + mu2 * mu2 + c_1) * (s11 + s22 + c_2))
-    ssim_share = smap[0, :, y0 - c0:y1 - c0].sum() / numel
-    const = 0.2 if rank == 0 else 0.0                          # the "1" of (1 - SSIM) belongs to one rank
-    return w_im * (0.8 * l1 + const - 0.2 * ssim_share) + w_depth * l_depth
+        gd, d = gt_depth[:, rows], depth_sil[0:1, rows].detach()
+        err = torch.abs(gd - d) * (gd > 0)
+        med = global_median(err, group) if world > 1 else err.median()
+        extra = torch.zeros((H, W), dtype=torch.float32, device=im.device)
+        extra[rows] = ((err < 50 * med) & (gd > 0))[0].to(torch.float32)
+    red = (lambda t: all_reduce_sum(t, group)) if world > 1 else None
+    return _l.band_loss(full, depth_sil, gt_im, gt_depth, (y0, y1), "mapping", w_im=w_im, w_depth=w_depth,
+                        extra_mask=extra, reduce=red, first_band=(rank == 0))
 
 
 def band_tracking_loss(im, depth_sil, gt_im, gt_depth, band: Tuple[int, int], sil_thres: float, w_im: float = 0.5,
@@ -287,41 +265,24 @@ def band_tracking_loss(im, depth_sil, gt_im, gt_depth, band: Tuple[int, int], si
     import torch
     H = im.shape[-2]
     y0, y1 = pixel_rows(band, H)
-    if im.is_cuda:
-        from . import losses as _l
-        return _l.band_loss(im, depth_sil, gt_im, gt_depth, (y0, y1), "tracking", sil_thres=sil_thres, w_im=w_im,
-                            w_depth=w_depth, extra_mask=extra_mask, colour_over_all_pixels=colour_over_all_pixels)
-    rows = slice(y0, y1)
-    depth, sil = depth_sil[0:1, rows], depth_sil[1:2, rows]
-    unc = (depth_sil[2:3, rows] - depth ** 2).detach()
-    gd = gt_depth[:, rows]
-    mask = (gd > 0) & ~torch.isnan(depth) & ~torch.isnan(unc) & (sil > sil_thres)
-    if extra_mask is not None:
-        mask = mask & extra_mask.reshape(1, H, -1)[:, rows].bool()
-    mask = mask.detach()
-    l_depth = torch.abs(gd - depth)[mask].sum()
-    diff = torch.abs(gt_im[:, rows] - im[:, rows])
-    l_im = diff.sum() if colour_over_all_pixels else diff[mask.expand_as(diff)].sum()
-    return w_im * l_im + w_depth * l_depth
+    _need_device(im, "band_tracking_loss")
+    from . import losses as _l
+    return _l.band_loss(im, depth_sil, gt_im, gt_depth, (y0, y1), "tracking", sil_thres=sil_thres, w_im=w_im,
+                        w_depth=w_depth, extra_mask=extra_mask, colour_over_all_pixels=colour_over_all_pixels)
 
 
 def band_silhouette_threshold(im, silhouette, gt_im, gt_depth, band: Tuple[int, int], world: int,
-                              candidates=(0.990, 0.993, 0.995, 0.997, 0.999), group=None):
+                              candidates=(0.990, 0.993, 0.995, 0.997, 0.999), group=None, sums=None):
     """The threshold pick of tracking iteration 0 (src/vtgaussian_slam.py:472-510) over a partitioned frame: every rank
     sums its band's squared error and pixel count per candidate (one kernel), ONE all-reduce of 2 x K floats, the same
-    arg-min on every rank."""
-    import torch
+    arg-min on every rank.  `sums` ([K, 2] float64: squared error, pixel count per candidate over the band) lets a caller
+    that formed the band's sums elsewhere use the reduction and the pick alone (the CPU tests do, tests/band_cpu_ref.py)."""
     H = im.shape[-2]
     y0, y1 = pixel_rows(band, H)
-    if im.is_cuda:
+    if sums is None:
+        _need_device(im, "band_silhouette_threshold")
         from . import losses as _l
         sums = _l.silhouette_sweep(im, silhouette, gt_im, gt_depth, candidates, rows=(y0, y1))
-    else:
-        rows = slice(y0, y1)
-        sq = ((gt_im[:, rows] - im[:, rows]) ** 2).sum(0).to(torch.float64)
-        valid = gt_depth[0, rows] > 0
-        sums = torch.stack([torch.stack([sq[valid & (silhouette[rows] > c)].sum(),
-                                         (valid & (silhouette[rows] > c)).sum().to(torch.float64)]) for c in candidates])
     if world > 1:
         all_reduce_sum(sums, group)
     sums = sums.cpu()
