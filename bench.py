@@ -459,9 +459,9 @@ def main():
         # Gaussians -- every iteration), the others are ordinary frames (one keyframe drawn per iteration from the submap's
         # frames so far; the second call when the draw is the submap's base frame).  `value` is the mix for one base frame in
         # forty (configs/replica/room0.py:35).  On N > 1 GPUs the fused N-rank loop has no global set yet: keyframe draw only.
-        E = max(args.slam_frames, 2)
+        E = args.slam_frames + 1                                    # one untimed warm-up frame, then `slam_frames`; the last is the base frame
         route = (["--get-loss", "--global-submaps", "2"] if world == 1 else ["--fused", "--backend", args.backend]) + \
-                ["--base-frame-every", str(E), "--emulate-window", "12"]
+                ["--base-frame-every", str(E), "--emulate-window", "12", "--warmup-frames", "1"]
         try:
             rec = bench_slam.run(bench_slam.parse_args(["--frames", str(args.slam_frames)] + route))
             reg = rec.get("regimes") or {}

@@ -69,6 +69,9 @@ def parse_args(argv=None):
                          "get_loss call is made when the draw is the submap's base frame (:2600-2604).  Base frame: the "
                          "current view every iteration and, with --global-submaps, BOTH calls every iteration (:2545-2557).  "
                          "0 (default): every frame maps on its own view, second call (if any) every iteration -- round 3's loop")
+    ap.add_argument("--warmup-frames", type=int, default=0,
+                    help="frames processed BEFORE the clock starts (tracked and mapped like the others, not counted): the first "
+                         "frame of a process settles capacities, allocator pools and clocks and runs 1.5-3 x slower per iteration")
     ap.add_argument("--emulate-window", type=int, default=0,
                     help="W > 0 (with --base-frame-every): an ordinary frame draws its keyframe as if the submap already held W "
                          "frames -- with probability 1/W the submap's base frame (then the second get_loss call is made), else "
@@ -123,7 +126,8 @@ def run(args) -> dict:
     from oracle import gs_oracle as go            # scene generator only
     from parity_util import to_settings
 
-    N, W, H, T = args.n, args.width, args.height, args.frames + 1
+    WU = max(0, getattr(args, "warmup_frames", 0))
+    N, W, H, T = args.n, args.width, args.height, args.frames + WU + 1
     from diff_gaussian_rasterization import partition as pt
     band = pt.band_for_rank(H, world, rank) if world > 1 else None
     scene, cam = go.view_tied_scene(N, W, H, seed=0)
@@ -264,6 +268,10 @@ def run(args) -> dict:
     t_all = time.perf_counter()
     frame_kind, frame_s, second_frac = [], [], []
     for t in range(1, T):
+        if t == WU + 1 and WU:                     # the clock starts here: drop what the warm-up frames recorded
+            torch.cuda.synchronize()
+            track_ms, map_ms, errs_before, errs_after, frame_kind, frame_s, second_frac = [], [], [], [], [], [], []
+            t_all = time.perf_counter()
         torch.cuda.synchronize(); t_frame = time.perf_counter()
         gt_im, gt_depth = gts[t]
         with torch.no_grad():                     # forward-propagate the previous pose (constant-position prior)
@@ -429,7 +437,7 @@ def run(args) -> dict:
         "data": "synthetic", "dtype": "f32",
         "config": {"workload": f"view-tied submap N={N}, {W}x{H}; {args.tracking_iters} tracking + {args.mapping_iters} "
                                f"mapping iterations per frame, 2 renders fwd+bwd per iteration (configs/replica/room0.py)",
-                   "frames": args.frames, "shared_geometry": bool(args.shared_geometry or args.fused), "fused_callers": bool(args.fused),
+                   "frames": args.frames, "warmup_frames_not_counted": WU, "shared_geometry": bool(args.shared_geometry or args.fused), "fused_callers": bool(args.fused),
                    "through_get_loss_mirror": bool(args.get_loss), "iteration_replayed_from_a_hipgraph": bool(args.graph),
                    "mapping_get_loss_calls_per_iteration": (2 if fixed else 1) if not args.base_frame_every else "see regimes",
                    "base_frame_every": args.base_frame_every or None, "emulated_window_frames": args.emulate_window or None,

@@ -16,11 +16,14 @@
 //     blocks are its four splat groups, so there is no cross-lane sum afterwards -- through ONE 4 KB LDS image per
 //     wavefront (XOR-swizzled rows, no padding) that w and u' use one after the other: the front sweep writes w, the colour
 //     products read it, the back sweep overwrites it with u' (LDS operations of a wavefront execute in order);
-//   * a splat's sums arrive from up to four quadrants in different steps: they are added into a per-wavefront LDS table
-//     (ds_add_f32, 9 floats per ring slot) and leave as ONE 40-byte record per (splat, tile) instance -- the format
-//     gather_splat_grads reads -- when the chunk retires: when all four queues have popped its last entry, the same
-//     invariant that frees the chunk's ring slots.  LDS float adds of one instruction are applied in a fixed lane order
-//     and the step sequence of a tile is a function of its list alone, so gradients stay bitwise reproducible run to run.
+//   * a splat's sums arrive from up to four quadrants in different steps: they are added into per-wavefront LDS accumulators
+//     (three row-contiguous arrays, 9 floats per ring slot) and leave as ONE 40-byte record per (splat, tile) instance -- the
+//     format gather_splat_grads reads -- when the chunk retires: when all four queues have popped its last entry, the same
+//     invariant that frees the chunk's ring slots.  Round 4: the add is a plain read-modify-write, one quadrant after the other
+//     (the contraction runs with the column operand first, so a lane holds all nine sums of the splat it popped itself);
+//     round 3 used ds_add_f32, which gfx950 applies one lane at a time -- 768 cycles per wave-wide instruction
+//     (profiles/r4_lds_accumulate.md): 445 us then, 194 us now.  Fixed order (quadrants 0..3 within a step, steps in
+//     sequence, the step sequence of a tile a function of its list alone): bitwise reproducible run to run.
 //
 // Semantics: SURVEY.md Appendix A4 as restated in vtgs_composite.hip (the recurrences of px_backward_batch).
 #include "vtgs_internal.h"
@@ -35,7 +38,6 @@ namespace vtgs {
 constexpr int kBqChunks = VTGS_BQ_CHUNKS;      // 64-entry chunks of the list in flight
 constexpr int kBqRing = 64 * kBqChunks;        // ring slots (accumulators, ids, queue capacity)
 constexpr int kBqDummy = kBqRing;              // slot of a lane that popped past the end of its queue
-constexpr int kAccRow = 9;                     // floats per accumulator row: 6 moments + 3 colour sums (odd: bank spread)
 
 __device__ __forceinline__ uint32_t quadrant_mask_bq(const float4& g0, const float4& g1, float sx, float sy) {
   // the same box test as composite_forward_q (vtgs_composite_q.hip): only used when that kernel did not leave its masks
