@@ -155,3 +155,23 @@ def test_planned_bins_entry_points_check_their_arguments(lib):
     assert lib.vtgs_debug_layout(5, 33, 17, 64, PLANNED | 32, out) == 0 and out[11] == 15 * 32 and out[10] > out[8]
     args = [None, 0] + [None] * 9 + [ctypes.c_size_t(0), ctypes.c_uint64(1)]
     assert lib.vtgs_forward_planned(*args, ctypes.c_uint32(PLANNED | 64), None, None, 0, None) == 1
+
+
+def test_cross_check_kernels_live_in_the_test_only_library():
+    """libvtgs.so (the product) carries the default composites only; the scalar / quad-form / lane = pixel forward and the
+    quadrant-queue backward -- cross-checks for the GPU tests -- are in libvtgs_xcheck.so, which exports its three entry points
+    and is opened by libvtgs.so only when an implementation switch asks (csrc/vtgs_xcheck.hip)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "vtgaussian-slam_amd", "lib")
+    x = ctypes.CDLL(os.path.join(lib_dir, "libvtgs_xcheck.so"))
+    for name in ("vtgs_xcheck_abi_version", "vtgs_xcheck_forward", "vtgs_xcheck_backward"):
+        assert hasattr(x, name), name
+    x.vtgs_xcheck_abi_version.restype = ctypes.c_uint32
+    main = ctypes.CDLL(os.path.join(lib_dir, "libvtgs.so"))
+    main.vtgs_abi_version.restype = ctypes.c_uint32
+    assert x.vtgs_xcheck_abi_version() == main.vtgs_abi_version()
+    host = subprocess.run(["nm", "-C", os.path.join(lib_dir, "libvtgs.so")], capture_output=True, text=True, check=True).stdout
+    for kernel in ("composite_forward_mx", "composite_forward_px", "composite_backward_q", "vtgs::composite_forward(", "vtgs::composite_backward("):
+        assert kernel not in host, kernel
+    assert "composite_forward_q" in host and "composite_backward_mx<4, false, true>" in host and "gather_splat_grads" in host

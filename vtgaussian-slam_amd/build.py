@@ -2,14 +2,18 @@
 
     python vtgaussian-slam_amd/build.py [--force]
 
-The library lands in vtgaussian-slam_amd/lib/ (git-ignored, shipped to the GPU box by gpurun).
+The library lands in vtgaussian-slam_amd/lib/ (git-ignored, shipped to the GPU box by gpurun), with the test-only
+libvtgs_xcheck.so (cross-check implementations of the composites) next to it.
 """
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", f) for f in ("vtgs_api.hip", "vtgs_binning.hip", "vtgs_composite.hip", "vtgs_composite_q.hip", "vtgs_composite_bq.hip", "vtgs_frame.hip", "vtgs_loss.hip", "vtgs_p2p.hip")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("vtgs_api.hip", "vtgs_binning.hip", "vtgs_composite.hip", "vtgs_composite_q.hip", "vtgs_frame.hip", "vtgs_loss.hip", "vtgs_p2p.hip")]
+# the cross-check composites (scalar, quad form, lane = pixel forward, quadrant-queue backward): a TEST-ONLY library next to the
+# product, built from the same sources with -DVTGS_XCHECK_BUILD=1; libvtgs.so opens it when an implementation switch asks
+XCHECK_SRC = [os.path.join(HERE, "csrc", f) for f in ("vtgs_xcheck.hip", "vtgs_composite.hip", "vtgs_composite_bq.hip")]
 HDR = [os.path.join(HERE, "csrc", f) for f in ("vtgs_internal.h", "vtgs_math.h", "vtgs_composite_common.h", "vtgs_sort_common.h")] + \
       [os.path.join(HERE, "..", "include", "vtgs.h")]
 OUT = os.path.join(HERE, "lib", "libvtgs.so")
@@ -18,11 +22,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
 
 
+def xcheck_path(out: str) -> str:
+    return out[:-3] + "_xcheck.so"
+
+
 def up_to_date() -> bool:
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(xcheck_path(OUT)):
         return False
-    t = os.path.getmtime(OUT)
-    return all(os.path.getmtime(f) <= t for f in SRC + HDR + [os.path.abspath(__file__)])
+    t = min(os.path.getmtime(OUT), os.path.getmtime(xcheck_path(OUT)))
+    return all(os.path.getmtime(f) <= t for f in SRC + XCHECK_SRC + HDR + [os.path.abspath(__file__)])
 
 
 def build(force: bool = False, verbose: bool = False, out: str = OUT, extra=()) -> str:
@@ -30,10 +38,15 @@ def build(force: bool = False, verbose: bool = False, out: str = OUT, extra=()) 
     if out == OUT and not extra and not force and up_to_date():
         return OUT
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    cmd = [HIPCC] + [f for f in FLAGS if f] + list(extra) + SRC + ["-o", out]
+    cmd = [HIPCC] + [f for f in FLAGS if f] + list(extra) + SRC + ["-ldl", "-o", out]
+    xcmd = [HIPCC] + [f for f in FLAGS if f] + list(extra) + ["-DVTGS_XCHECK_BUILD=1"] + XCHECK_SRC + ["-o", xcheck_path(out)]
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+        print(" ".join(xcmd))
+    procs = [subprocess.Popen(c) for c in (cmd, xcmd)]               # the two libraries share no object: build them side by side
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        raise subprocess.CalledProcessError(max(codes), cmd if codes[0] else xcmd)
     return out
 
 

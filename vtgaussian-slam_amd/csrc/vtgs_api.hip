@@ -3,9 +3,11 @@
 #include "../../include/vtgs.h"
 #include "vtgs_internal.h"
 
+#include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
 #include <mutex>
+#include <string>
 
 namespace vtgs {
 // kernels (vtgs_binning.hip / vtgs_composite.hip)
@@ -24,30 +26,14 @@ __global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint
                            const Counters*, int, const uint32_t*, uint32_t, unsigned long long, int);
 __global__ void sort_long_lists(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t,
                                 const Counters*, const uint32_t*, uint32_t, unsigned long long, int, uint32_t);
-__global__ void composite_forward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
-                                  const GeomRec*, const float*, float*, float*, float*, const Counters*);
-template <int WAVES, bool DUAL>
-__global__ void composite_forward_mx(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
-                                     const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*,
-                                     float*);
-template <int WAVES, bool DUAL>
-__global__ void composite_forward_px(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
-                                     const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*,
-                                     float*);
 template <bool DUAL>
 __global__ void composite_forward_q(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*,
                                     const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*,
                                     float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs, uint8_t*, uint32_t*);
-__global__ void composite_backward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
-                                   const uint32_t*, const GeomRec*, const float*, const float*, const float*,
-                                   const float*, float*, const Counters*);
 template <int WAVES, bool DUAL, bool PX>
 __global__ void composite_backward_mx(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                       const uint32_t*, const GeomRec*, const float*, const float*, const float*,
                                       const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*);
-__global__ void composite_backward_q(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
-                                     const uint32_t*, const uint8_t*, const GeomRec*, const float*, const float*, const float*,
-                                     const float*, float*, const Counters*, uint32_t*);
 template <bool DUAL, bool FRAME>
 __global__ void gather_splat_grads(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
                                    const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*,
@@ -72,6 +58,41 @@ static int hip_fail(hipError_t e, const char* what) {
     hipError_t e__ = (call);                                  \
     if (e__ != hipSuccess) return hip_fail(e__, #call);       \
   } while (0)
+
+// ---- the cross-check composites (scalar, quad form, lane = pixel forward, quadrant-queue backward) are NOT in this library:
+// they live in the test-only libvtgs_xcheck.so (csrc/vtgs_xcheck.hip), opened next to this library the first time an
+// implementation switch asks for one of them.
+typedef int (*XcheckForwardFn)(int, int, const CamScalars*, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
+                               const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*, void*);
+typedef int (*XcheckBackwardFn)(int, int, const CamScalars*, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
+                                const uint32_t*, const uint8_t*, const GeomRec*, const float*, const float*, const float*,
+                                const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*, void*);
+static XcheckForwardFn g_xcheck_forward = nullptr;
+static XcheckBackwardFn g_xcheck_backward = nullptr;
+static std::once_flag g_xcheck_once;
+static bool xcheck_available() {
+  std::call_once(g_xcheck_once, [] {
+    Dl_info self;
+    if (!dladdr((const void*)&vtgs_abi_version, &self) || !self.dli_fname) return;
+    std::string path(self.dli_fname);                                 // .../libvtgs.so -> .../libvtgs_xcheck.so (an experiment
+    const size_t dot = path.rfind(".so");                             // build libfoo.so looks for ITS libfoo_xcheck.so)
+    if (dot == std::string::npos) return;
+    path = path.substr(0, dot) + "_xcheck.so";
+    void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    typedef uint32_t (*AbiFn)(void);
+    AbiFn abi = (AbiFn)dlsym(h, "vtgs_xcheck_abi_version");
+    if (!abi || abi() != VTGS_ABI_VERSION) return;                       // built from other headers: not usable
+    g_xcheck_forward = (XcheckForwardFn)dlsym(h, "vtgs_xcheck_forward");
+    g_xcheck_backward = (XcheckBackwardFn)dlsym(h, "vtgs_xcheck_backward");
+  });
+  return g_xcheck_forward && g_xcheck_backward;
+}
+static int xcheck_missing() {
+  snprintf(g_hip_err, sizeof(g_hip_err), "a cross-check implementation was selected (VTGS_FWD_IMPL / VTGS_BWD_IMPL) but the test-only "
+                                         "libvtgs_xcheck.so is not next to libvtgs.so (or was built from another ABI)");
+  return VTGS_ERR_INVALID_ARGUMENT;
+}
 
 // ---- optional per-kernel event timing (vtgs_profile_*) -------------------------------------------------
 struct ProfSlot { const char* name; hipEvent_t a, b; };
@@ -223,31 +244,14 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
                          (const Counters*)(ws + L.counters), (const float*)nullptr, (float*)nullptr, sort_mode,
                          (const unsigned long long*)(ws + L.keys), (const uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_inst), fin,
                          write_qmask ? (uint8_t*)(ws + L.qmask) : (uint8_t*)nullptr, steps);
-    else if (colors_b && impl != 1)
-      hipLaunchKernelGGL((composite_forward_px<4, true>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
-                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
-                         (const GeomRec*)(ws + L.geom), colors, out_color, (float*)nullptr, image_state,
-                         (const Counters*)(ws + L.counters), colors_b, out_color_b);
-    else if (colors_b)
-      hipLaunchKernelGGL((composite_forward_mx<4, true>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
-                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
-                         (const GeomRec*)(ws + L.geom), colors, out_color, (float*)nullptr, image_state,
-                         (const Counters*)(ws + L.counters), colors_b, out_color_b);
-    else if (impl == 2)                                     // lane = pixel, exponents from the broadcast 16-block MFMA
-      hipLaunchKernelGGL((composite_forward_px<4, false>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
-                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
-                         (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
-                         (const Counters*)(ws + L.counters), (const float*)nullptr, (float*)nullptr);
-    else if (impl == 1)
-      hipLaunchKernelGGL((composite_forward_mx<4, false>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
-                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
-                         (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
-                         (const Counters*)(ws + L.counters), (const float*)nullptr, (float*)nullptr);
-    else
-      hipLaunchKernelGGL(composite_forward, dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
-                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
-                         (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
-                         (const Counters*)(ws + L.counters));
+    else {                                                  // a cross-check implementation: the test-only library
+      if (!xcheck_available()) return xcheck_missing();
+      const int rc = g_xcheck_forward(impl, colors_b ? 1 : 0, &cs, cam->bg, nblk, (const uint32_t*)(ws + L.tile_cnt), L.tile_cap,
+                                      (const uint32_t*)(ws + L.sorted_gid), (const GeomRec*)(ws + L.geom), colors, out_color,
+                                      colors_b ? (float*)nullptr : out_depth, image_state, (const Counters*)(ws + L.counters),
+                                      colors_b, out_color_b, (void*)st);
+      if (rc != 0) return hip_fail(hipGetLastError(), "vtgs_xcheck_forward");
+    }
   }
   VTGS_HIP(hipGetLastError());
   return VTGS_OK;
@@ -562,34 +566,21 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
                          (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
                          grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), colors_b, out_color_b,
                          grad_color_b, dbg);
-    else if (dual)
-      hipLaunchKernelGGL((composite_backward_mx<4, true, false>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
-                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
-                         (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
-                         grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), colors_b, out_color_b,
-                         grad_color_b, dbg);
-    else if (bwd_impl == 3)                                 // per-quadrant splat queues (vtgs_composite_bq.hip)
-      hipLaunchKernelGGL(composite_backward_q, dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
-                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
-                         (const uint32_t*)(ws + L.sorted_inst), (const uint8_t*)(ws + L.qmask), (const GeomRec*)(ws + L.geom), colors,
-                         out_color, grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), dbg);
-    else if (bwd_impl == 2)                                 // lane = pixel replay
+    else if (!dual && bwd_impl == 2)                        // lane = pixel replay (the default)
       hipLaunchKernelGGL((composite_backward_mx<4, false, true>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
                          grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), (const float*)nullptr,
                          (const float*)nullptr, (const float*)nullptr, dbg);
-    else if (bwd_impl == 1)
-      hipLaunchKernelGGL((composite_backward_mx<4, false, false>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
-                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
-                         (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
-                         grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), (const float*)nullptr,
-                         (const float*)nullptr, (const float*)nullptr, dbg);
-    else
-      hipLaunchKernelGGL(composite_backward, dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
-                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
-                         (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
-                         grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters));
+    else {                                                  // quad form, scalar, quadrant queues: the test-only library
+      if (!xcheck_available()) return xcheck_missing();
+      const int rc = g_xcheck_backward(bwd_impl, dual ? 1 : 0, &cs, cam->bg, nblk16, (const uint32_t*)(ws + L.tile_cnt), L.tile_cap,
+                                       (const uint32_t*)(ws + L.sorted_gid), (const uint32_t*)(ws + L.sorted_inst),
+                                       (const uint8_t*)(ws + L.qmask), (const GeomRec*)(ws + L.geom), colors, out_color, grad_color,
+                                       state, (float*)scratch, (const Counters*)(ws + L.counters), colors_b, out_color_b,
+                                       grad_color_b, dbg, (void*)st);
+      if (rc != 0) return hip_fail(hipGetLastError(), "vtgs_xcheck_backward");
+    }
   }
   VTGS_HIP(hipGetLastError());
   {

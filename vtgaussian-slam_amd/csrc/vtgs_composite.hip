@@ -41,8 +41,17 @@
 #define VTGS_BWD_PREFETCH 1
 #endif
 
+// Which kernels this translation unit emits.  libvtgs.so (the product) holds the DEFAULT composites only -- the quadrant-queue
+// forward (vtgs_composite_q.hip), the lane = pixel backward, the gradient gather; the other implementations (scalar, quad form,
+// lane = pixel forward, quadrant-queue backward) are independent cross-checks for the tests and live in the test-only
+// libvtgs_xcheck.so, built from the same sources with -DVTGS_XCHECK_BUILD=1 (csrc/vtgs_xcheck.hip).
+#ifndef VTGS_XCHECK_BUILD
+#define VTGS_XCHECK_BUILD 0
+#endif
+
 namespace vtgs {
 
+#if VTGS_XCHECK_BUILD
 // Scalar ("readlane") forward composite: lane = pixel, splats broadcast one at a time.  Kept as an independent
 // second implementation (VTGS_FWD_IMPL=0) that the GPU tests cross-check against the matrix-core kernel.
 __global__ __launch_bounds__(256) void composite_forward(
@@ -94,6 +103,8 @@ __global__ __launch_bounds__(256) void composite_forward(
   }
 }
 
+#endif  // VTGS_XCHECK_BUILD
+
 // ---------------------------------------------------------------------------------------------------
 // Forward composite, matrix-core form ("mx").
 //
@@ -122,6 +133,7 @@ __device__ __forceinline__ f32x16 mx_exponents(const float (&K)[6], const float 
   return d;
 }
 
+#if VTGS_XCHECK_BUILD
 template <bool DUAL>
 struct MxFwdState {
   float Tb[4];             // transmittance of pixel (blk, j) at the start of the batch; 0 = finished (replicated over q)
@@ -303,7 +315,10 @@ __global__ __launch_bounds__(64 * WAVES, DUAL ? 3 : 4) void composite_forward_mx
 }
 template __global__ void composite_forward_mx<4, false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*);
 template __global__ void composite_forward_mx<4, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*);
+#endif  // VTGS_XCHECK_BUILD
 
+
+#if VTGS_XCHECK_BUILD
 // ---------------------------------------------------------------------------------------------------
 // Forward composite, lane = pixel ("px").  Same bilinear exponent, but from v_mfma_f32_4x4x1_16b_f32 with the A operand
 // broadcast (cbsz = 4, abid = g): all 16 blocks multiply the four splats held by lanes 4g..4g+3 with their own four
@@ -454,7 +469,10 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_forward_px(
 }
 template __global__ void composite_forward_px<4, false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*);
 template __global__ void composite_forward_px<4, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*);
+#endif  // VTGS_XCHECK_BUILD
 
+
+#if VTGS_XCHECK_BUILD
 // ---------------------------------------------------------------------------------------------------
 // Backward composite.  Pixel-major replay produces, per (splat k, pixel p), two scalars:
 //     u_kp = G_kp * dL/dalpha_kp      and      w_kp = alpha_kp * T_kp
@@ -589,6 +607,8 @@ __global__ __launch_bounds__(256) void composite_backward(
     }
   }
 }
+
+#endif  // VTGS_XCHECK_BUILD
 
 // ---------------------------------------------------------------------------------------------------
 // Backward composite, matrix-core form.  Same lane layout as composite_forward_mx (lane = pixel column j x splat
@@ -1152,11 +1172,16 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   }
 #endif
 }
+#if VTGS_XCHECK_BUILD
 template __global__ void composite_backward_mx<4, false, false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*);
 template __global__ void composite_backward_mx<4, true, false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*);
+#else
 template __global__ void composite_backward_mx<4, false, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*);
 template __global__ void composite_backward_mx<4, true, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*);
+#endif
 
+
+#if !VTGS_XCHECK_BUILD
 // one thread per Gaussian: re-centre and sum its instance records (fixed order), then the projection backward.
 // FRAME (dual render of the fused caller chain): the adjoint of vtgs_prepare_frame runs here, on the gradients while they
 // are still in registers -- same formulas and the same block reduction as prepare_frame_backward_kernel (vtgs_frame.hip);
@@ -1380,5 +1405,7 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(const float* __restri
   const float tz = fmaf(Vp[2], x, fmaf(Vp[6], y, fmaf(Vp[10], z, Vp[14])));
   out[gid] = tz > kNearCull ? 1 : 0;
 }
+
+#endif  // !VTGS_XCHECK_BUILD
 
 }  // namespace vtgs

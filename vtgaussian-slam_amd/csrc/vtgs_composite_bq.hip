@@ -29,6 +29,11 @@
 #include "vtgs_internal.h"
 #include "vtgs_composite_common.h"
 
+#ifndef VTGS_XCHECK_BUILD
+#define VTGS_XCHECK_BUILD 0
+#endif
+#if VTGS_XCHECK_BUILD                          // a cross-check implementation: test-only library (csrc/vtgs_xcheck.hip)
+
 #ifndef VTGS_BQ_CHUNKS
 #define VTGS_BQ_CHUNKS 2
 #endif
@@ -498,3 +503,5 @@ __global__ __launch_bounds__(256, 3) void composite_backward_q(
 }
 
 }  // namespace vtgs
+
+#endif  // VTGS_XCHECK_BUILD
