@@ -44,14 +44,15 @@ b0 = pt0[okp].min()
 life = (pt1[okp] - pt0[okp]) * 0.01
 print(f"  {okp.sum()} workgroups, span {(pt1[okp].max() - b0) * 0.01:.1f} us, workgroup life mean {life.mean():.1f} us (p10 {np.quantile(life, .1):.1f}, p90 {np.quantile(life, .9):.1f}); "
       f"starts: {[round(float(x), 1) for x in np.sort((pt0[okp] - b0) * 0.01)[::100]]}")
-names = ["sort (entry -> sorted list re-readable)", "first append", "all appends", "all steps", "whole wavefront", "steps", "list length"]
+names = ["sort (entry -> sorted list re-readable)", "first append", "all appends", "all steps", "whole wavefront", "steps", "entry -> loop exit (before the image stores)"]
 for i, nm in enumerate(names):
     c = st[:, i]
     print(f"{nm:42s} mean {c.mean():10.1f}  median {c.median():10.1f}  p90 {c.quantile(0.9):10.1f}  max {c.max():10.1f}")
-w7 = st[:, 7].long() & 0xFFFFFFFF
-keys_in, network = (w7 & 0xFFFFF).double(), ((w7 >> 20) * 16).double()
-for nm, c in (("  of the sort: entry -> keys in registers", keys_in), ("  of the sort: network", network),
-              ("  of the sort: stores, vals gather, fence", st[:, 0] - keys_in - network)):
+pro = st[:, 7] - st[:, 0]                       # sort end -> loop entry: LDS init, the first three chunks' gathers and appends
+loop = st[:, 6] - st[:, 7]                      # loop entry -> loop exit
+ctl = loop - st[:, 3] - (st[:, 2] - 0)          # minus steps, minus the stamped appends (the prologue's first append is in both: see below)
+for nm, c in (("  sort end -> loop entry (prologue)", pro), ("  loop entry -> loop exit", loop),
+              ("  loop minus steps minus appends (control, retire, waits)", ctl)):
     print(f"{nm:42s} mean {c.mean():10.1f}  median {c.median():10.1f}  p90 {c.quantile(0.9):10.1f}  max {c.max():10.1f}")
 per_step = (st[:, 3] / st[:, 5].clamp(min=1)).median()
 print(f"ticks per step (median tile) {per_step:.0f}")

@@ -428,6 +428,9 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     if (base < e) VTGS_Q_APPEND(g0_c, g1_c, c0_c, c1_c, c2_c, d0_c, d1_c, d2_c)
     fetch(gid_cur);                                                // the fourth chunk's records: in flight during the first steps
   }
+#ifdef VTGS_Q_STAMPS
+  const unsigned long long st3 = __builtin_amdgcn_s_memtime();   // loop entry: everything up to here is sort + prologue
+#endif
 
   for (;;) {
     if (inflight < kQChunks && base < e) {
@@ -495,14 +498,15 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
 #endif
   }
 #ifdef VTGS_Q_STAMPS
+  const unsigned long long st_loop_end = __builtin_amdgcn_s_memtime();
   if (step_counters && l == 0) {
     uint32_t* o = step_counters + 64 + kStampWords * qc.tile;
     o[8] = (uint32_t)rt0; o[9] = (uint32_t)__builtin_amdgcn_s_memrealtime();
     o[10] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); o[11] = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // HW_ID, XCC_ID
     const unsigned long long se = __builtin_amdgcn_s_memtime();
     o[0] = (uint32_t)(st1 - st0); o[1] = (uint32_t)(st2 - st1); o[2] = (uint32_t)st_app; o[3] = (uint32_t)st_step;
-    o[4] = (uint32_t)(se - st0); o[5] = nsteps; o[6] = e - s;
-    o[7] = (uint32_t)(st_sort[0] - st0) | ((uint32_t)((st_sort[1] - st_sort[0]) >> 4) << 20);   // keys arrived (20 bits) | network / 16
+    o[4] = (uint32_t)(se - st0); o[5] = nsteps; o[6] = (uint32_t)(st_loop_end - st0);   // (list length: tile_cnt)
+    o[7] = (uint32_t)(st3 - st0);                                // entry -> loop entry (sort + LDS init + the prologue's three appends)
   }
 #endif
   if (step_counters && l == 0) atomicAdd(&step_counters[blockIdx.x & 63u], nsteps);   // measurement only (VTGS_COUNT_STEPS)
