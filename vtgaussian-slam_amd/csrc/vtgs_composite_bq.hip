@@ -48,9 +48,11 @@ __device__ __forceinline__ uint32_t quadrant_mask_bq(const float4& g0, const flo
   // the same box test as composite_forward_q (vtgs_composite_q.hip): only used when that kernel did not leave its masks
   float tau = (__log2f(g1.y) + 7.99435344f) * 0.69314718f;               // ln(255 o)
   tau += 1e-4f * tau + 1e-4f;
-  const float idet = 1.f / fmaxf(g0.z * g1.x - g0.w * g0.w, 1e-30f);
+  // (hardware reciprocal and square root, 1 ulp each: the IEEE forms expand to ~35 instructions per list entry and append;
+  //  the box only has to be conservative, and it carries 1e-6 relative + 1e-5 px of slack)
+  const float idet = __builtin_amdgcn_rcpf(fmaxf(g0.z * g1.x - g0.w * g0.w, 1e-30f));
   const float k2 = 2.f * fmaxf(tau, 0.f) * idet;
-  const float hx = sqrtf(k2 * g1.x) * 1.000001f + 1e-5f, hy = sqrtf(k2 * g0.z) * 1.000001f + 1e-5f;
+  const float hx = __builtin_amdgcn_sqrtf(k2 * g1.x) * 1.000002f + 1e-5f, hy = __builtin_amdgcn_sqrtf(k2 * g0.z) * 1.000002f + 1e-5f;
   const bool left = sx - hx <= -0.5f && sx + hx >= -3.5f, right = sx + hx >= 0.5f && sx - hx <= 3.5f;
   const bool top = sy - hy <= -0.5f && sy + hy >= -3.5f, bottom = sy + hy >= 0.5f && sy - hy <= 3.5f;
   return (left && top ? 1u : 0u) | (right && top ? 2u : 0u) | (left && bottom ? 4u : 0u) | (right && bottom ? 8u : 0u);
