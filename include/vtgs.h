@@ -387,6 +387,12 @@ typedef struct VtgsAdamGroup {
 } VtgsAdamGroup;
 int vtgs_adam_step(const VtgsAdamGroup* groups, int32_t n_groups, int32_t step, float beta1, float beta2, void* stream);
 
+/* The bookkeeping at the end of get_loss (src/vtgaussian_slam.py:681-689) in one launch instead of three element-wise ones:
+ *   seen[i] = radii[i] > 0;   max_2D_radius[i] = max(max_2D_radius[i], (float)radii[i])   (a culled Gaussian has radius 0 and
+ *   the running maximum is never negative, so the unmasked maximum equals the reference's masked update).
+ * radii[N] int32 (the operator's second output), max_2d_radius[N] float32 in place, seen[N] one byte per Gaussian (0 / 1). */
+int vtgs_seen_and_max_radius(int32_t n, const int32_t* radii, float* max_2d_radius, uint8_t* seen, void* stream);
+
 /* ---- Point-to-plane consistency of two depth frames -----------------------------------------------
  * Replaces the host path of compute_point2plane_dist (src/vtgaussian_slam.py:1070-1155: kornia normals, numpy, Open3D
  * KD-tree) that the reference runs per tracking iteration at base-frame boundaries (:1929, :1956, :2158, :2185).

@@ -294,6 +294,21 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamLaunch a) {
   g.param[i] -= (g.lr * a.step_size_scale) * (m / denom);
 }
 
+// seen = radius > 0 and the running maximum of the screen-space radius (src/vtgaussian_slam.py:681-689): four Gaussians per thread
+__global__ __launch_bounds__(256) void seen_and_max_radius_kernel(int n, const int32_t* __restrict__ radii, float* __restrict__ mx,
+                                                                  uint8_t* __restrict__ seen) {
+  const int i0 = (int)(blockIdx.x * 1024u + threadIdx.x * 4u);
+  if (i0 + 3 < n) {
+    const int4 r = *reinterpret_cast<const int4*>(radii + i0);
+    float4 m = *reinterpret_cast<const float4*>(mx + i0);
+    m.x = fmaxf(m.x, (float)r.x); m.y = fmaxf(m.y, (float)r.y); m.z = fmaxf(m.z, (float)r.z); m.w = fmaxf(m.w, (float)r.w);
+    *reinterpret_cast<float4*>(mx + i0) = m;
+    *reinterpret_cast<uint32_t*>(seen + i0) = (r.x > 0 ? 1u : 0u) | (r.y > 0 ? 0x100u : 0u) | (r.z > 0 ? 0x10000u : 0u) | (r.w > 0 ? 0x1000000u : 0u);
+  } else {
+    for (int i = i0; i < n; ++i) { mx[i] = fmaxf(mx[i], (float)radii[i]); seen[i] = radii[i] > 0 ? 1 : 0; }
+  }
+}
+
 // ---- whole loss of get_loss in a handful of launches (src/vtgaussian_slam.py:519-608, 678-679) ----------------------------
 // value:    masked_l1_kernel (no gradient images) [+ ssim_forward_kernel] + loss_finalize_kernel
 //           out = {loss, mask count, sum |gt_im - im|, sum |gt_depth - depth|, mean SSIM}
@@ -430,6 +445,14 @@ int vtgs_adam_step(const VtgsAdamGroup* groups, int32_t n_groups, int32_t step, 
   a.beta2 = beta2;
   hipLaunchKernelGGL(adam_step_kernel, dim3((uint32_t)((longest + 255) / 256), (uint32_t)n_groups), dim3(256), 0,
                      (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+int vtgs_seen_and_max_radius(int32_t n, const int32_t* radii, float* max_2d_radius, uint8_t* seen, void* stream) {
+  if (n < 0 || (n > 0 && (!radii || !max_2d_radius || !seen))) return VTGS_ERR_INVALID_ARGUMENT;
+  if (n == 0) return VTGS_OK;
+  hipLaunchKernelGGL(seen_and_max_radius_kernel, dim3((uint32_t)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, n, radii,
+                     max_2d_radius, seen);
   return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
 }
 

@@ -152,8 +152,14 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
     # max_2D_radius[seen] = max(radius[seen], max_2D_radius[seen]) without the boolean-mask gathers (each of them waits for
     # the device to count its elements -- 0.3 - 1.2 ms per iteration at 1 M Gaussians): a culled Gaussian has radius 0 and
     # the running maximum is never negative, so the element-wise maximum over ALL Gaussians is the same in-place update
-    seen = radius > 0
-    torch.maximum(variables["max_2D_radius"], radius.to(variables["max_2D_radius"].dtype), out=variables["max_2D_radius"])
+    mx = variables["max_2D_radius"]
+    if mx.dtype == torch.float32 and mx.is_contiguous() and radius.dtype == torch.int32 and radius.is_contiguous() \
+            and mx.data_ptr() % 16 == 0 and radius.data_ptr() % 16 == 0:
+        seen = torch.empty(radius.shape, dtype=torch.bool, device=radius.device)         # one launch: vtgs_seen_and_max_radius
+        _l.seen_and_max_radius(radius, mx, seen)
+    else:
+        seen = radius > 0
+        torch.maximum(mx, radius.to(mx.dtype), out=mx)
     variables["seen"] = seen
     weighted_losses["loss"] = loss
     if presence_sil_mask_mse_ls is not None:

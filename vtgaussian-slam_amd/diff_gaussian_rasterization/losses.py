@@ -53,6 +53,18 @@ def fused_ssim(img1: torch.Tensor, img2: torch.Tensor) -> torch.Tensor:
     return _FusedSSIM.apply(img1, img2)
 
 
+_lib.vtgs_seen_and_max_radius.restype, _lib.vtgs_seen_and_max_radius.argtypes = ctypes.c_int, [_I32, _P, _P, _P, _P]
+
+
+def seen_and_max_radius(radius: torch.Tensor, max_2d_radius: torch.Tensor, seen: torch.Tensor) -> None:
+    """`seen = radius > 0` and `max_2D_radius = max(max_2D_radius, radius)` (src/vtgaussian_slam.py:681-689) in one launch:
+    radius int32 [N], max_2d_radius float32 [N] updated in place, seen bool [N] written."""
+    if not radius.is_cuda:
+        raise RuntimeError("seen_and_max_radius needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
+    _check(_lib.vtgs_seen_and_max_radius(radius.numel(), radius.data_ptr(), max_2d_radius.data_ptr(), seen.data_ptr(),
+                                         _stream_ptr(radius.device)), "vtgs_seen_and_max_radius")
+
+
 _lib.vtgs_masked_l1_partial_rows.restype, _lib.vtgs_masked_l1_partial_rows.argtypes = ctypes.c_uint32, [_I32]
 _lib.vtgs_masked_l1.restype = ctypes.c_int
 _lib.vtgs_masked_l1.argtypes = [_P, _P, _P, _P, _I32, ctypes.c_float, _I32, _P, _P, _P, _P]
