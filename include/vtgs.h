@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VTGS_ABI_VERSION 13
+#define VTGS_ABI_VERSION 14
 
 typedef enum VtgsStatus {
   VTGS_OK = 0,
@@ -279,6 +279,44 @@ int vtgs_backward_dual_frame(const VtgsCamera* cam, int32_t n, const float* mean
                              const float* means3D, const float* unnorm_rotations, const float* cam_q, const float* cam_t,
                              const float* depth_w2c, float* g_rgb_colors, float* g_means3D, float* g_logit_opacities,
                              float* g_log_scales, float* g_unnorm_rotations, float* pose_partials, void* stream);
+
+/* ---- Owned sets of the tile-row partition ---------------------------------------------------------
+ * A rank of the partition renders a band of tile rows (VtgsCamera.tile_row_begin / _end); 7 of 8 Gaussians of the map
+ * cannot meet it.  Instead of running the per-Gaussian kernels (vtgs_prepare_frame, projection and binning, the gradient
+ * gather) over the whole map on every rank, the rank keeps a LIST of the Gaussians that could meet its rows for any pose /
+ * scale near the current ones and hands the rasterizer the compact arrays of those (the reference has no counterpart: its
+ * rasterizer is single-GPU, src/vtgaussian_slam.py:431-468 renders the whole map).
+ *
+ * vtgs_band_owner_mask: the band test of the projection kernel (mean + scale only) for all n Gaussians of the map under the
+ *   pose (cam_q, cam_t) -- with the radius widened by margin_px and the scale multiplied by growth (>= 1).
+ *   mask_out (may be NULL): 1 byte per Gaussian, 1 = could meet the band: the caller compacts the indices (ascending).
+ *   escapes (may be NULL; needs owned = a mask written earlier): *escapes += the number of Gaussians with owned[i] == 0
+ *   that could meet the band now.  Called with (margin 1 px, growth 1) before a render of the list it proves, while the
+ *   counter stays 0, that the render equals the render of the whole map on the band: a Gaussian outside the list would have
+ *   been dropped by the projection kernel's own band test.  The counter is the caller's (zeroed when the list is built).
+ * vtgs_prepare_frame_owned: vtgs_prepare_frame for the rows owned_idx[0..n_owned) of the map, written to compact rows
+ *   0..n_owned; the colours are gathered too (out_rgb_colors [n_owned,3]) -- everything the rasterizer reads has n_owned rows.
+ * vtgs_backward_dual_frame_owned: vtgs_backward_dual_frame over the compact arrays (n = n_owned); means3D,
+ *   unnorm_rotations and the g_* outputs are the MAP's arrays, read / written at row owned_idx[i]; rows outside the list are
+ *   not touched (the caller zero-fills them).  owned_idx == NULL is vtgs_backward_dual_frame.  pose_partials has
+ *   vtgs_pose_partial_rows(n_owned) rows.                                                                              */
+int vtgs_band_owner_mask(const VtgsCamera* cam, int32_t n, const float* means3D, const float* log_scales, const float* cam_q,
+                         const float* cam_t, const float* depth_w2c, float margin_px, float growth, const uint8_t* owned,
+                         uint8_t* mask_out, uint32_t* escapes, void* stream);
+int vtgs_prepare_frame_owned(int32_t n_owned, const int32_t* owned_idx, const float* means3D, const float* logit_opacities,
+                             const float* log_scales, const float* unnorm_rotations, const float* rgb_colors,
+                             const float* cam_q, const float* cam_t, const float* depth_w2c, float* out_means_cam,
+                             float* out_opacities, float* out_scales, float* out_rotations, float* out_depth_colors,
+                             float* out_rgb_colors, void* stream);
+int vtgs_backward_dual_frame_owned(const VtgsCamera* cam, int32_t n, const int32_t* owned_idx, const float* means_cam,
+                                   const float* colors_a, const float* colors_b, const float* opacities, const float* scales,
+                                   const float* rotations, const float* out_color_a, const float* out_color_b,
+                                   const float* grad_color_a, const float* grad_color_b, const void* workspace,
+                                   size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity, void* scratch,
+                                   size_t scratch_bytes, uint32_t flags, const float* means3D, const float* unnorm_rotations,
+                                   const float* cam_q, const float* cam_t, const float* depth_w2c, float* g_rgb_colors,
+                                   float* g_means3D, float* g_logit_opacities, float* g_log_scales, float* g_unnorm_rotations,
+                                   float* pose_partials, void* stream);
 
 /* ---- SSIM of the mapping loss ------------------------------------------------------------------
  * Replaces utils/slam_external.py:66-97 (calc_ssim): mean SSIM of two [C,H,W] images with the 11x11 Gaussian window

@@ -39,6 +39,8 @@ __global__ void gather_splat_grads(CamScalars, const float*, const float*, int, 
                                    const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*,
                                    float*, const Counters*, float*, FrameEpilogue);
 __global__ void mark_visible_kernel(const float*, int, const float*, uint8_t*);
+__global__ void band_owner_kernel(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*,
+                                  const float*, float, float, const uint8_t*, uint8_t*, uint32_t*);
 __global__ void uniform_plan_kernel(uint32_t* plan, uint32_t entries, uint32_t slots_per_bin) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i < entries) plan[i] = i * slots_per_bin;
@@ -635,14 +637,48 @@ int vtgs_backward_dual_frame(const VtgsCamera* cam, int32_t n, const float* mean
                              const float* means3D, const float* unnorm_rotations, const float* cam_q, const float* cam_t,
                              const float* depth_w2c, float* g_rgb_colors, float* g_means3D, float* g_logit_opacities,
                              float* g_log_scales, float* g_unnorm_rotations, float* pose_partials, void* stream) {
+  return vtgs_backward_dual_frame_owned(cam, n, nullptr, means_cam, colors_a, colors_b, opacities, scales, rotations, out_color_a,
+                                        out_color_b, grad_color_a, grad_color_b, workspace, workspace_bytes, instance_capacity,
+                                        tile_capacity, scratch, scratch_bytes, flags, means3D, unnorm_rotations, cam_q, cam_t,
+                                        depth_w2c, g_rgb_colors, g_means3D, g_logit_opacities, g_log_scales, g_unnorm_rotations,
+                                        pose_partials, stream);
+}
+
+int vtgs_backward_dual_frame_owned(const VtgsCamera* cam, int32_t n, const int32_t* owned_idx, const float* means_cam,
+                                   const float* colors_a, const float* colors_b, const float* opacities, const float* scales,
+                                   const float* rotations, const float* out_color_a, const float* out_color_b,
+                                   const float* grad_color_a, const float* grad_color_b, const void* workspace,
+                                   size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity, void* scratch,
+                                   size_t scratch_bytes, uint32_t flags, const float* means3D, const float* unnorm_rotations,
+                                   const float* cam_q, const float* cam_t, const float* depth_w2c, float* g_rgb_colors,
+                                   float* g_means3D, float* g_logit_opacities, float* g_log_scales, float* g_unnorm_rotations,
+                                   float* pose_partials, void* stream) {
   FrameEpilogue f;
   f.flags = flags;
   f.means3D_world = means3D; f.unnorm_rot = unnorm_rotations; f.cam_q = cam_q; f.cam_t = cam_t; f.depth_w2c = depth_w2c;
   f.g_rgb = g_rgb_colors; f.g_means3D = g_means3D; f.g_logit = g_logit_opacities; f.g_log_scales = g_log_scales;
   f.g_unnorm_rot = g_unnorm_rotations; f.pose_partials = pose_partials;
+  f.idx = owned_idx;
   return backward_impl(cam, n, means_cam, colors_a, colors_b, opacities, scales, rotations, out_color_a, out_color_b,
                        grad_color_a, grad_color_b, workspace, workspace_bytes, instance_capacity, tile_capacity, nullptr,
                        scratch, scratch_bytes, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream, true, &f);
+}
+
+int vtgs_band_owner_mask(const VtgsCamera* cam, int32_t n, const float* means3D, const float* log_scales, const float* cam_q,
+                         const float* cam_t, const float* depth_w2c, float margin_px, float growth, const uint8_t* owned,
+                         uint8_t* mask_out, uint32_t* escapes, void* stream) {
+  if (!cam_ok(cam) || n < 0 || !cam_q || !cam_t || !depth_w2c || !(margin_px >= 0.f) || !(growth >= 1.f) ||
+      (!mask_out && !escapes) || (escapes && !owned))
+    return VTGS_ERR_INVALID_ARGUMENT;
+  int r8b, r8e, rows16, row16_0;
+  if (!band_of(cam, &r8b, &r8e, &rows16, &row16_0)) return VTGS_ERR_INVALID_ARGUMENT;
+  if (n == 0) return VTGS_OK;
+  if (!means3D || !log_scales) return VTGS_ERR_INVALID_ARGUMENT;
+  const CamScalars cs = scalars_of(cam, r8b, r8e);
+  hipLaunchKernelGGL(band_owner_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, cs, cam->viewmatrix,
+                     cam->projmatrix, n, means3D, log_scales, cam_q, cam_t, depth_w2c, margin_px, growth, owned, mask_out, escapes);
+  VTGS_HIP(hipGetLastError());
+  return VTGS_OK;
 }
 
 int vtgs_profile_enable(int on) {

@@ -1203,13 +1203,14 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     // gets DEFINED gradients -- zeros -- instead of whatever the output buffers held.
     if (gid < n) {
       if constexpr (FRAME) {
+        const int row = fe.idx ? fe.idx[gid] : gid;
         if (fe.flags & 1u) {
-          fe.g_means3D[3 * gid] = fe.g_means3D[3 * gid + 1] = fe.g_means3D[3 * gid + 2] = 0.f;
-          reinterpret_cast<float4*>(fe.g_unnorm_rot)[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
+          fe.g_means3D[3 * row] = fe.g_means3D[3 * row + 1] = fe.g_means3D[3 * row + 2] = 0.f;
+          reinterpret_cast<float4*>(fe.g_unnorm_rot)[row] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (fe.flags & 4u) {
-          fe.g_logit[gid] = 0.f; fe.g_log_scales[gid] = 0.f;
-          fe.g_rgb[3 * gid] = fe.g_rgb[3 * gid + 1] = fe.g_rgb[3 * gid + 2] = 0.f;
+          fe.g_logit[row] = 0.f; fe.g_log_scales[row] = 0.f;
+          fe.g_rgb[3 * row] = fe.g_rgb[3 * row + 1] = fe.g_rgb[3 * row + 2] = 0.f;
         }
       } else {
         for (int i = 0; i < 3; ++i) {
@@ -1339,7 +1340,8 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     for (int k = 0; k < 12; ++k) acc[k] = 0.f;
     if (live) {
       const FramePose P = load_pose(fe.cam_q, fe.cam_t, fe.depth_w2c);
-      const float x = fe.means3D_world[3 * gid], y = fe.means3D_world[3 * gid + 1], z = fe.means3D_world[3 * gid + 2];
+      const int row = fe.idx ? fe.idx[gid] : gid;                              // owned sets: the Gaussian's row in the map
+      const float x = fe.means3D_world[3 * row], y = fe.means3D_world[3 * row + 1], z = fe.means3D_world[3 * row + 2];
       const float cx = P.R[0] * x + P.R[1] * y + P.R[2] * z + P.t[0];
       const float cy = P.R[3] * x + P.R[4] * y + P.R[5] * z + P.t[1];
       const float cz = P.R[6] * x + P.R[7] * y + P.R[8] * z + P.t[2];
@@ -1347,21 +1349,21 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
       const float dz = cb0 + 2.f * zz * cb2;                                   // colours of the second render: [z, 1, z^2]
       const float g0 = g.mean3D[0] + dz * P.zr[0], g1 = g.mean3D[1] + dz * P.zr[1], g2 = g.mean3D[2] + dz * P.zr[2];
       if (fe.flags & 1u) {
-        fe.g_means3D[3 * gid] = P.R[0] * g0 + P.R[3] * g1 + P.R[6] * g2;
-        fe.g_means3D[3 * gid + 1] = P.R[1] * g0 + P.R[4] * g1 + P.R[7] * g2;
-        fe.g_means3D[3 * gid + 2] = P.R[2] * g0 + P.R[5] * g1 + P.R[8] * g2;
-        const float4 u = reinterpret_cast<const float4*>(fe.unnorm_rot)[gid];
+        fe.g_means3D[3 * row] = P.R[0] * g0 + P.R[3] * g1 + P.R[6] * g2;
+        fe.g_means3D[3 * row + 1] = P.R[1] * g0 + P.R[4] * g1 + P.R[7] * g2;
+        fe.g_means3D[3 * row + 2] = P.R[2] * g0 + P.R[5] * g1 + P.R[8] * g2;
+        const float4 u = reinterpret_cast<const float4*>(fe.unnorm_rot)[row];
         const float un = rsqrtf(fmaxf(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w, 1e-24f));
         const float r[4] = {u.x * un, u.y * un, u.z * un, u.w * un};
         const float dot = r[0] * g.rot[0] + r[1] * g.rot[1] + r[2] * g.rot[2] + r[3] * g.rot[3];
-        reinterpret_cast<float4*>(fe.g_unnorm_rot)[gid] = make_float4((g.rot[0] - r[0] * dot) * un, (g.rot[1] - r[1] * dot) * un,
+        reinterpret_cast<float4*>(fe.g_unnorm_rot)[row] = make_float4((g.rot[0] - r[0] * dot) * un, (g.rot[1] - r[1] * dot) * un,
                                                                        (g.rot[2] - r[2] * dot) * un, (g.rot[3] - r[3] * dot) * un);
       }
       if (fe.flags & 4u) {
         const float o = opacities[gid];                                        // = sigmoid(logit), the forward's value
-        fe.g_logit[gid] = g.opacity * o * (1.f - o);
-        fe.g_log_scales[gid] = scales[3 * gid] * (g.scale[0] + g.scale[1] + g.scale[2]);
-        fe.g_rgb[3 * gid] = g.color[0]; fe.g_rgb[3 * gid + 1] = g.color[1]; fe.g_rgb[3 * gid + 2] = g.color[2];
+        fe.g_logit[row] = g.opacity * o * (1.f - o);
+        fe.g_log_scales[row] = scales[3 * gid] * (g.scale[0] + g.scale[1] + g.scale[2]);
+        fe.g_rgb[3 * row] = g.color[0]; fe.g_rgb[3 * row + 1] = g.color[1]; fe.g_rgb[3 * row + 2] = g.color[2];
       }
       if (fe.flags & 2u) {
         acc[0] = g0; acc[1] = g1; acc[2] = g2;

@@ -11,27 +11,63 @@
 
 namespace vtgs {
 
+// `idx` (may be NULL): row i of the outputs is Gaussian idx[i] of the map -- the owned set of a rank of the tile-row partition
+// (vtgs_prepare_frame_owned); the colours are then copied to compact rows too, so that the rasterizer sees n rows of everything.
 __global__ __launch_bounds__(256) void prepare_frame_kernel(
-    int n, const float* __restrict__ means3D, const float* __restrict__ logit_op, const float* __restrict__ log_scales,
-    const float* __restrict__ unnorm_rot, const float* __restrict__ cam_q, const float* __restrict__ cam_t,
+    int n, const int32_t* __restrict__ idx, const float* __restrict__ means3D, const float* __restrict__ logit_op,
+    const float* __restrict__ log_scales, const float* __restrict__ unnorm_rot, const float* __restrict__ rgb,
+    const float* __restrict__ cam_q, const float* __restrict__ cam_t,
     const float* __restrict__ depth_w2c, float* __restrict__ means_cam, float* __restrict__ opac,
-    float* __restrict__ scales, float* __restrict__ rot, float* __restrict__ dcol) {
+    float* __restrict__ scales, float* __restrict__ rot, float* __restrict__ dcol, float* __restrict__ rgb_out) {
   const FramePose P = load_pose(cam_q, cam_t, depth_w2c);
   const int i = (int)(blockIdx.x * 256u + threadIdx.x);
   if (i >= n) return;
-  const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+  const int row = idx ? idx[i] : i;
+  const float x = means3D[3 * row], y = means3D[3 * row + 1], z = means3D[3 * row + 2];
   const float cx = P.R[0] * x + P.R[1] * y + P.R[2] * z + P.t[0];
   const float cy = P.R[3] * x + P.R[4] * y + P.R[5] * z + P.t[1];
   const float cz = P.R[6] * x + P.R[7] * y + P.R[8] * z + P.t[2];
   means_cam[3 * i] = cx; means_cam[3 * i + 1] = cy; means_cam[3 * i + 2] = cz;
-  opac[i] = 1.f / (1.f + __expf(-logit_op[i]));
-  const float s = __expf(log_scales[i]);
+  opac[i] = 1.f / (1.f + __expf(-logit_op[row]));
+  const float s = __expf(log_scales[row]);
   scales[3 * i] = s; scales[3 * i + 1] = s; scales[3 * i + 2] = s;
-  const float4 u = reinterpret_cast<const float4*>(unnorm_rot)[i];
+  const float4 u = reinterpret_cast<const float4*>(unnorm_rot)[row];
   const float un = rsqrtf(fmaxf(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w, 1e-24f));
   reinterpret_cast<float4*>(rot)[i] = make_float4(u.x * un, u.y * un, u.z * un, u.w * un);
   const float zz = P.zr[0] * cx + P.zr[1] * cy + P.zr[2] * cz + P.zr[3];
   dcol[3 * i] = zz; dcol[3 * i + 1] = 1.f; dcol[3 * i + 2] = zz * zz;
+  if (rgb_out) { rgb_out[3 * i] = rgb[3 * row]; rgb_out[3 * i + 1] = rgb[3 * row + 1]; rgb_out[3 * i + 2] = rgb[3 * row + 2]; }
+}
+
+// Owned sets of the tile-row partition: which Gaussians of the map can meet this rank's rows?  The test is the one
+// project_and_bin makes on a band (outside_tile_rows, on the camera-frame mean and the exponentiated scale), here with a margin:
+//   mask_out != NULL   mask_out[i] = 1 when Gaussian i could meet the rows with its radius widened by margin_px and its
+//                      scale multiplied by growth (the list is built from this, for the poses / scales of the coming iterations)
+//   escapes  != NULL   counts (atomically, accumulating) the Gaussians with owned[i] == 0 that could meet the rows NOW
+//                      (the caller passes margin 1 px, growth 1): while the count stays 0 every render of the compact list was
+//                      exactly the render of the whole map on those rows.
+__global__ __launch_bounds__(256) void band_owner_kernel(
+    CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n, const float* __restrict__ means3D,
+    const float* __restrict__ log_scales, const float* __restrict__ cam_q, const float* __restrict__ cam_t,
+    const float* __restrict__ depth_w2c, float margin_px, float growth, const uint8_t* __restrict__ owned,
+    uint8_t* __restrict__ mask_out, uint32_t* __restrict__ escapes) {
+  const CamParams cam = load_cam(cs, Vp, PVp);
+  const FramePose P = load_pose(cam_q, cam_t, depth_w2c);
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+  bool touch = false;
+  if (i < n) {
+    const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+    const float mean[3] = {P.R[0] * x + P.R[1] * y + P.R[2] * z + P.t[0], P.R[3] * x + P.R[4] * y + P.R[5] * z + P.t[1],
+                           P.R[6] * x + P.R[7] * y + P.R[8] * z + P.t[2]};
+    const float s = __expf(log_scales[i]);
+    const float sc[3] = {s, s, s};
+    touch = !outside_tile_rows_ext(cam, mean, sc, cam.row8_begin / 2, (cam.row8_end + 1) / 2, margin_px, growth);
+    if (mask_out) mask_out[i] = touch ? 1 : 0;
+  }
+  if (escapes) {
+    const unsigned long long b = __ballot(touch && i < n && !owned[i]);
+    if (b && lane_id() == 0) atomicAdd(escapes, (uint32_t)__popcll(b));
+  }
 }
 
 // flags: bit 0 = gradients to the Gaussian geometry (means3D, unnorm_rotations), bit 1 = to the pose,
@@ -201,9 +237,25 @@ int vtgs_prepare_frame(int32_t n, const float* means3D, const float* logit_opaci
   if (!means3D || !logit_opacities || !log_scales || !unnorm_rotations || !out_means_cam || !out_opacities || !out_scales ||
       !out_rotations || !out_depth_colors)
     return VTGS_ERR_INVALID_ARGUMENT;
-  hipLaunchKernelGGL(prepare_frame_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, means3D,
-                     logit_opacities, log_scales, unnorm_rotations, cam_q, cam_t, depth_w2c, out_means_cam, out_opacities,
-                     out_scales, out_rotations, out_depth_colors);
+  hipLaunchKernelGGL(prepare_frame_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, (const int32_t*)nullptr,
+                     means3D, logit_opacities, log_scales, unnorm_rotations, (const float*)nullptr, cam_q, cam_t, depth_w2c,
+                     out_means_cam, out_opacities, out_scales, out_rotations, out_depth_colors, (float*)nullptr);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+int vtgs_prepare_frame_owned(int32_t n_owned, const int32_t* owned_idx, const float* means3D, const float* logit_opacities,
+                             const float* log_scales, const float* unnorm_rotations, const float* rgb_colors,
+                             const float* cam_q, const float* cam_t, const float* depth_w2c, float* out_means_cam,
+                             float* out_opacities, float* out_scales, float* out_rotations, float* out_depth_colors,
+                             float* out_rgb_colors, void* stream) {
+  if (n_owned < 0 || !cam_q || !cam_t || !depth_w2c) return VTGS_ERR_INVALID_ARGUMENT;
+  if (n_owned == 0) return VTGS_OK;
+  if (!owned_idx || !means3D || !logit_opacities || !log_scales || !unnorm_rotations || !rgb_colors || !out_means_cam ||
+      !out_opacities || !out_scales || !out_rotations || !out_depth_colors || !out_rgb_colors)
+    return VTGS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(prepare_frame_kernel, dim3((n_owned + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_owned, owned_idx,
+                     means3D, logit_opacities, log_scales, unnorm_rotations, rgb_colors, cam_q, cam_t, depth_w2c,
+                     out_means_cam, out_opacities, out_scales, out_rotations, out_depth_colors, out_rgb_colors);
   return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
 }
 

@@ -334,10 +334,13 @@ __device__ __forceinline__ FramePose load_pose(const float* __restrict__ q, cons
 
 // What vtgs_prepare_frame_backward needs besides the operator gradients, for the backward that runs it in the gather
 // kernel (vtgs_backward_dual_frame): flags as there (bit 0 geometry, bit 1 pose, bit 2 appearance).
+// `idx` (owned sets of the tile-row partition, vtgs_prepare_frame_owned): the rasterizer saw the compact arrays of the listed
+// Gaussians; row gid of them is Gaussian idx[gid] of the map, which is where the parameters are read and the gradients land.
 struct FrameEpilogue {
   uint32_t flags;
   const float* means3D_world; const float* unnorm_rot; const float* cam_q; const float* cam_t; const float* depth_w2c;
   float* g_rgb; float* g_means3D; float* g_logit; float* g_log_scales; float* g_unnorm_rot; float* pose_partials;
+  const int32_t* idx;
 };
 
 }  // namespace vtgs

@@ -175,7 +175,11 @@ VTGS_HD bool project_splat(const CamParams& cam, const float mean[3], const floa
 //   smax(Rw)^2 <= the largest absolute row sum of Rw^T Rw (exactly 1 for a rigid view matrix),
 // and the radius of either rule is at most ceil(3 sqrt(lam)), lam <= lambda_max + sqrt(0.1) (the floor inside the root).
 // Two pixels of slack cover ceil() and the float32 rounding of v on both sides; a NaN makes every comparison false: not skipped.
-VTGS_HD bool outside_tile_rows(const CamParams& cam, const float mean[3], const float scale[3], int row_b, int row_e) {
+// `margin_px` widens the radius and `growth` multiplies the scales: the owned sets of the tile-row partition
+// (vtgs_band_owner_mask) ask "could this Gaussian meet the rows after the pose has moved a little / the scales have grown";
+// (0, 1) is the test project_and_bin makes, to the bit (r + 0 and smax * 1 are exact).
+VTGS_HD bool outside_tile_rows_ext(const CamParams& cam, const float mean[3], const float scale[3], int row_b, int row_e,
+                                   float margin_px, float growth) {
   const float x = mean[0], y = mean[1], z = mean[2];
   const float* V = cam.V;
   const float tz = fmaf(V[2], x, fmaf(V[6], y, fmaf(V[10], z, V[14])));
@@ -184,7 +188,7 @@ VTGS_HD bool outside_tile_rows(const CamParams& cam, const float mean[3], const 
   const float hy = fmaf(P[1], x, fmaf(P[5], y, fmaf(P[9], z, P[13])));
   const float hw = fmaf(P[3], x, fmaf(P[7], y, fmaf(P[11], z, P[15])));
   const float v = ((hy * (1.f / (hw + 1e-7f)) + 1.f) * (float)cam.H - 1.f) * 0.5f;
-  const float smax = cam.mod * fmaxf(fabsf(scale[0]), fmaxf(fabsf(scale[1]), fabsf(scale[2])));
+  const float smax = cam.mod * fmaxf(fabsf(scale[0]), fmaxf(fabsf(scale[1]), fabsf(scale[2]))) * growth;
   float gram = 0.f;                                            // smax(Rw)^2 <= max_i sum_j |(Rw^T Rw)_ij|
   for (int i = 0; i < 3; ++i) {
     float row = 0.f;
@@ -199,11 +203,15 @@ VTGS_HD bool outside_tile_rows(const CamParams& cam, const float mean[3], const 
   const float hd = 0.5f * (ja - jc);
   const float j2 = (0.5f * (ja + jc) + sqrtf(hd * hd + jb * jb)) * iz * iz;
   const float lam = j2 * gram * smax * smax * 1.001f + kDilation + 0.32f;
-  const float r = 3.f * sqrtf(lam) + 2.f;                      // ceil() and one pixel of slack
+  const float r = 3.f * sqrtf(lam) + 2.f + margin_px;          // ceil() and one pixel of slack
   const float it = 1.f / (float)kBinTile;
   const bool above = (v + r + (float)(kBinTile - 1)) * it + kRectEps < (float)row_b + 1.f;   // => y1 = floor(.) <= row_b
   const bool below = (v - r) * it >= (float)row_e;                                          // => y0 = floor(. + eps) >= row_e
   return above || below;
+}
+
+VTGS_HD bool outside_tile_rows(const CamParams& cam, const float mean[3], const float scale[3], int row_b, int row_e) {
+  return outside_tile_rows_ext(cam, mean, scale, row_b, row_e, 0.f, 1.f);
 }
 
 // Smallest value of q(d) = 1/2 (A dx^2 + C dy^2) + B dx dy over the pixel-centre rectangle

@@ -52,7 +52,7 @@ class _VtgsProfileEntry(ctypes.Structure):
 
 
 VTGS_OK, VTGS_ERR_INSTANCE_OVERFLOW = 0, 3
-ABI_VERSION = 13
+ABI_VERSION = 14
 VTGS_FORWARD_SYNC, VTGS_FORWARD_ASYNC, VTGS_FORWARD_CHECKED = 0, 1, 2
 VTGS_FORWARD_EXPECT_SHORT_LISTS = 4        # hint: no list beyond 512 entries expected (skips the pre-sort pass for bins <= 1024)
 _P, _U64, _I32, _SZ = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
@@ -78,6 +78,10 @@ _SIGNATURES = {
                            + [_P] * 8),
     "vtgs_backward_dual_frame": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32] + [_P] * 11 + [_SZ, _U64, ctypes.c_uint32, _P, _SZ,
                                                 ctypes.c_uint32] + [_P] * 12),
+    "vtgs_backward_dual_frame_owned": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32] + [_P] * 12 + [_SZ, _U64, ctypes.c_uint32, _P,
+                                                      _SZ, ctypes.c_uint32] + [_P] * 12),
+    "vtgs_band_owner_mask": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32] + [_P] * 5 + [ctypes.c_float, ctypes.c_float]
+                             + [_P] * 4),
     "vtgs_forward_planned": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _U64,
                                             ctypes.c_uint32, _P, _P, ctypes.c_uint32, _P]),
     "vtgs_forward_dual_planned": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ,

@@ -35,24 +35,40 @@ _lib.vtgs_prepare_frame.restype, _lib.vtgs_prepare_frame.argtypes = ctypes.c_int
 _lib.vtgs_prepare_frame_backward.restype = ctypes.c_int
 _lib.vtgs_prepare_frame_backward.argtypes = [_I32, ctypes.c_uint32] + [_P] * 22
 _lib.vtgs_pose_gradient.restype, _lib.vtgs_pose_gradient.argtypes = ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P]
+_lib.vtgs_prepare_frame_owned.restype, _lib.vtgs_prepare_frame_owned.argtypes = ctypes.c_int, [_I32] + [_P] * 16
 
 
 class _RenderFrame(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, rgb, unnorm_rot, logit_op, log_scales, cam_q, cam_t, depth_w2c, cam: _Camera, flags: int):
+    def forward(ctx, means3D, rgb, unnorm_rot, logit_op, log_scales, cam_q, cam_t, depth_w2c, cam: _Camera, flags: int,
+                owned=None):
         dev = means3D.device
-        n = means3D.shape[0]
+        n_map = means3D.shape[0]
+        n = n_map if owned is None else int(owned.idx.numel())       # rows the rasterizer sees
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         means3D, rgb, unnorm_rot, logit_op, log_scales = map(f32, (means3D, rgb, unnorm_rot, logit_op, log_scales))
         cam_q, cam_t, depth_w2c = f32(cam_q).reshape(-1), f32(cam_t).reshape(-1), f32(depth_w2c).reshape(-1)
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         means_cam, opac, scales, rot, dcol = new(n, 3), new(n, 1), new(n, 3), new(n, 4), new(n, 3)
         stream = _stream_ptr(dev)
-        _check(_lib.vtgs_prepare_frame(n, means3D.data_ptr(), logit_op.data_ptr(), log_scales.data_ptr(),
-                                       unnorm_rot.data_ptr(), cam_q.data_ptr(), cam_t.data_ptr(), depth_w2c.data_ptr(),
-                                       means_cam.data_ptr(), opac.data_ptr(), scales.data_ptr(), rot.data_ptr(),
-                                       dcol.data_ptr(), stream), "vtgs_prepare_frame")
         dual = os.environ.get("VTGS_DUAL", "1") != "0"             # read per call, like the other implementation switches
+        if owned is None:
+            _check(_lib.vtgs_prepare_frame(n, means3D.data_ptr(), logit_op.data_ptr(), log_scales.data_ptr(),
+                                           unnorm_rot.data_ptr(), cam_q.data_ptr(), cam_t.data_ptr(), depth_w2c.data_ptr(),
+                                           means_cam.data_ptr(), opac.data_ptr(), scales.data_ptr(), rot.data_ptr(),
+                                           dcol.data_ptr(), stream), "vtgs_prepare_frame")
+        else:
+            # a rank of the tile-row partition with a list of the Gaussians that can meet its rows (partition.OwnedSet): the
+            # rasterizer gets compact arrays of those -- colours included -- and the map's other rows are never read
+            if not dual or os.environ.get("VTGS_FRAME_EPILOGUE", "1") == "0":
+                raise RuntimeError("owned sets run on the dual render with the frame epilogue (VTGS_DUAL / VTGS_FRAME_EPILOGUE "
+                                   "select cross-check routes that have no list form)")
+            rgb_map, rgb = rgb, new(n, 3)
+            _check(_lib.vtgs_prepare_frame_owned(n, owned.idx.data_ptr(), means3D.data_ptr(), logit_op.data_ptr(),
+                                                 log_scales.data_ptr(), unnorm_rot.data_ptr(), rgb_map.data_ptr(),
+                                                 cam_q.data_ptr(), cam_t.data_ptr(), depth_w2c.data_ptr(), means_cam.data_ptr(),
+                                                 opac.data_ptr(), scales.data_ptr(), rot.data_ptr(), dcol.data_ptr(),
+                                                 rgb.data_ptr(), stream), "vtgs_prepare_frame_owned")
         state = None
         if dual:
             im, radii, depth_sil, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot, colors_b=dcol,
@@ -64,7 +80,9 @@ class _RenderFrame(torch.autograd.Function):
             _check(_lib.vtgs_forward_shared(ctypes.byref(cam.c), n, dcol.data_ptr(), depth_sil.data_ptr(), depth2.data_ptr(),
                                             fs.workspace.data_ptr(), fs.workspace.numel(), fs.capacity, fs.tile_cap,
                                             state.data_ptr(), stream), "vtgs_forward_shared")
-        ctx.fs, ctx.state, ctx.flags, ctx.n, ctx.dual = fs, state, flags, n, dual
+        ctx.fs, ctx.state, ctx.flags, ctx.n, ctx.dual, ctx.owned, ctx.n_map = fs, state, flags, n, dual, owned, n_map
+        if owned is not None:                       # the radii of the map: 0 outside the list (as on any band)
+            radii = torch.zeros(n_map, dtype=torch.int32, device=dev).index_copy_(0, owned.idx64, radii)
         ctx.save_for_backward(means3D, rgb, unnorm_rot, logit_op, log_scales, cam_q, cam_t, depth_w2c,
                               means_cam, opac, scales, rot, dcol, im, depth_sil)
         ctx.set_materialize_grads(False)            # no zero-filled gradient for the radii output
@@ -114,57 +132,65 @@ class _RenderFrame(torch.autograd.Function):
             g_q, g_t = new(4), new(3)
             _check(_lib.vtgs_pose_gradient(partials.data_ptr(), rows, cam_q.data_ptr(), g_q.data_ptr(), g_t.data_ptr(),
                                            _stream_ptr(dev)), "vtgs_pose_gradient")
-        return (g_means3D, ga[2] if want_a else None, g_ur, g_logit, g_ls, g_q, g_t, None, None, None)
+        return (g_means3D, ga[2] if want_a else None, g_ur, g_logit, g_ls, g_q, g_t, None, None, None, None)
 
 
 def _backward_fused(ctx, g_im, g_ds):
     (means3D, rgb, unnorm_rot, logit_op, log_scales, cam_q, cam_t, depth_w2c,
      means_cam, opac, scales, rot, dcol, im, depth_sil) = ctx.saved_tensors
-    dev, n, flags, fs = means3D.device, ctx.n, ctx.flags, ctx.fs
-    new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    dev, n, flags, fs, owned, n_map = means3D.device, ctx.n, ctx.flags, ctx.fs, ctx.owned, ctx.n_map
+    # with a list the kernel writes the rows of the list only: the map-sized gradients start as zeros
+    new = (lambda *s: torch.empty(s, dtype=torch.float32, device=dev)) if owned is None else \
+          (lambda *s: torch.zeros(s, dtype=torch.float32, device=dev))
     ptr = lambda t: None if t is None else t.data_ptr()
     want_g, want_p, want_a = bool(flags & 1), bool(flags & 2), bool(flags & 4)
-    g_means3D = new(n, 3) if want_g else None
-    g_ur = new(n, 4) if want_g else None
-    g_rgb = new(n, 3) if want_a else None
-    g_logit = new(n, 1) if want_a else None
-    g_ls = new(n, 1) if want_a else None
+    g_means3D = new(n_map, 3) if want_g else None
+    g_ur = new(n_map, 4) if want_g else None
+    g_rgb = new(n_map, 3) if want_a else None
+    g_logit = new(n_map, 1) if want_a else None
+    g_ls = new(n_map, 1) if want_a else None
     rows = int(_lib.vtgs_pose_partial_rows(n))
-    partials = new(max(rows, 1), 12) if want_p else None
+    partials = torch.empty((max(rows, 1), 12), dtype=torch.float32, device=dev) if want_p else None
     g_q = g_t = None
     if n > 0:
         sbytes = _lib.vtgs_backward_dual_scratch_bytes(n, _scratch_instances(fs))
         scratch = _scratch(sbytes, dev)
         with _device_guard(dev):
-          _check(_lib.vtgs_backward_dual_frame(
-            ctypes.byref(fs.cam.c), n, means_cam.data_ptr(), rgb.data_ptr(), dcol.data_ptr(), opac.data_ptr(),
+          _check(_lib.vtgs_backward_dual_frame_owned(
+            ctypes.byref(fs.cam.c), n, None if owned is None else owned.idx.data_ptr(), means_cam.data_ptr(), rgb.data_ptr(),
+            dcol.data_ptr(), opac.data_ptr(),
             scales.data_ptr(), rot.data_ptr(), im.data_ptr(), depth_sil.data_ptr(), g_im.data_ptr(), g_ds.data_ptr(),
             fs.workspace.data_ptr(), fs.workspace.numel(), fs.capacity, fs.tile_cap, scratch.data_ptr(), sbytes, flags,
             means3D.data_ptr(), unnorm_rot.data_ptr(), cam_q.data_ptr(), cam_t.data_ptr(), depth_w2c.data_ptr(),
             ptr(g_rgb), ptr(g_means3D), ptr(g_logit), ptr(g_ls), ptr(g_ur), ptr(partials), _stream_ptr(dev)),
-            "vtgs_backward_dual_frame")
+            "vtgs_backward_dual_frame_owned")
         _settle(fs)
         if want_p:                                                # 12 partial sums per workgroup -> dL/dq, dL/dt
-            g_q, g_t = new(4), new(3)
+            g_q, g_t = torch.empty(4, device=dev), torch.empty(3, device=dev)
             _check(_lib.vtgs_pose_gradient(partials.data_ptr(), rows, cam_q.data_ptr(), g_q.data_ptr(), g_t.data_ptr(),
                                            _stream_ptr(dev)), "vtgs_pose_gradient")
     elif want_p:                                                  # nothing rendered: zero pose gradient, no launch
         g_q, g_t = torch.zeros(4, device=dev), torch.zeros(3, device=dev)
-    return (g_means3D, g_rgb, g_ur, g_logit, g_ls, g_q, g_t, None, None, None)
+    return (g_means3D, g_rgb, g_ur, g_logit, g_ls, g_q, g_t, None, None, None, None)
 
 
 _RenderFrame._backward_fused = staticmethod(_backward_fused)
 
 
 def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings, first_frame_w2c: torch.Tensor,
-                 gaussians_grad: bool, camera_grad: bool, radius_rule: Optional[str] = None, tile_rows=None):
+                 gaussians_grad: bool, camera_grad: bool, radius_rule: Optional[str] = None, tile_rows=None, owned=None):
     """RGB render + [z,1,z^2] render of frame `time_idx` (see module docstring).  Returns (im [3,H,W],
     depth_sil [3,H,W], radii [N] int32).  `tile_rows=(begin, end)`: this rank's band of 16-pixel tile rows (multi-GPU
     partition, `partition.band_for_rank`): pixels outside the band come back as zero and the gradients are the band's
-    share -- the pose gradient of a rank is then 7 floats to all-reduce, with no dense per-Gaussian array behind it."""
+    share -- the pose gradient of a rank is then 7 floats to all-reduce, with no dense per-Gaussian array behind it.
+    `owned` (a `partition.OwnedSet` built for the same band): only the Gaussians of the list are transformed, projected and
+    binned, and only their gradients are gathered; the set checks on the device, before every render, that no Gaussian
+    outside the list could meet the band (`owned.escaped()` reads the count)."""
     dev = params["means3D"].device
     if dev.type != "cuda":
         raise RuntimeError("render_frame needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
+    if owned is not None and params["log_scales"].shape[1] != 1:
+        raise RuntimeError("owned sets are built for isotropic maps (log_scales [N,1], every reference config)")
     if params["log_scales"].shape[1] != 1:
         # anisotropic maps (log_scales [N,3]: no reference config, but transform_to_frame has the branch,
         # utils/slam_helpers.py:376-383 -- the rotations are composed with the camera's): the pose transform and the
@@ -187,9 +213,11 @@ def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings
     appearance = any(params[k].requires_grad for k in ("rgb_colors", "logit_opacities", "log_scales"))
     flags = ((1 if gaussians_grad and grad_on else 0) | (2 if camera_grad and grad_on else 0)
              | (4 if appearance and grad_on else 0))
+    if owned is not None:
+        owned.check(params, time_idx, cam, first_frame_w2c, tile_rows)
     return _RenderFrame.apply(g(params["means3D"]), params["rgb_colors"], g(params["unnorm_rotations"]),
                               params["logit_opacities"], params["log_scales"], q, t,
-                              first_frame_w2c.to(dev), cam, flags)
+                              first_frame_w2c.to(dev), cam, flags, owned)
 
 
 def render_frame_unfused(params, time_idx: int, raster_settings, first_frame_w2c, gaussians_grad: bool, camera_grad: bool,

@@ -29,6 +29,82 @@ def pixel_rows(band: Tuple[int, int], image_height: int) -> Tuple[int, int]:
     return band[0] * 16, min(band[1] * 16, int(image_height))
 
 
+class OwnedSet:
+    """The Gaussians of the map that can meet one rank's band of tile rows (include/vtgs.h, "Owned sets").
+
+    Every rank of the partition holds the whole map, but 7 of 8 Gaussians cannot meet its rows; without a list each rank still
+    runs the per-Gaussian kernels (pose transform, projection + binning, gradient gather) over all of them.  The set is built
+    with the band test of the projection kernel widened by `margin_px` pixels and `growth` x the scales, so that it stays valid
+    while the pose and the scales move a little (a tracking or mapping phase); `fused.render_frame(..., owned=set)` then hands
+    the rasterizer compact arrays of the listed Gaussians.
+
+    Validity is CHECKED, not assumed: before every render `check` runs the exact band test (1 px of slack for float32
+    rounding) over the whole map -- 16 bytes read per Gaussian -- and counts on the device the Gaussians outside the list that
+    could now meet the band.  While `escaped()` (one device read; call it at the end of a phase) is 0, every render of the
+    phase equals the band render of the whole map: image, radii and per-Gaussian gradients bit for bit (the list is ascending,
+    so equal depths sort as before), the pose gradient to float32 rounding (its partial sums group the Gaussians by rows of
+    256 of the list instead of the map).  A non-zero count means the margin was too small for how far the phase moved:
+    rebuild and redo the phase.
+    """
+
+    def __init__(self, params, time_idx: int, raster_settings, first_frame_w2c, band: Tuple[int, int], margin_px: float = 32.0,
+                 growth: float = 1.25, radius_rule=None):
+        import os
+
+        import torch
+
+        from . import _RADIUS_RULES, _Camera
+        self.band = (int(band[0]), int(band[1]))
+        self.margin_px, self.growth = float(margin_px), float(growth)
+        if self.margin_px < 1.0 or self.growth < 1.0:          # the check below tests with 1 px of slack: a tighter list fails it at once
+            raise ValueError("OwnedSet needs margin_px >= 1 and growth >= 1")
+        dev = params["means3D"].device
+        _need_device(params["means3D"], "OwnedSet")
+        if params["log_scales"].shape[1] != 1:
+            raise RuntimeError("owned sets are built for isotropic maps (log_scales [N,1], every reference config)")
+        rule = _RADIUS_RULES[radius_rule or os.environ.get("VTGS_RADIUS_RULE", "3sigma")]
+        cam = _Camera(raster_settings, dev, rule, self.band)
+        self.n_map = int(params["means3D"].shape[0])
+        self.mask = torch.empty(self.n_map, dtype=torch.uint8, device=dev)
+        self.escapes = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._launch(params, time_idx, cam, first_frame_w2c, self.margin_px, self.growth, None, self.mask, None)
+        self.idx64 = torch.nonzero(self.mask).reshape(-1)              # ascending; one device -> host read (the count)
+        self.idx = self.idx64.to(torch.int32)
+
+    def __len__(self) -> int:
+        return int(self.idx.numel())
+
+    @staticmethod
+    def _launch(params, time_idx, cam, first_frame_w2c, margin_px, growth, owned, mask_out, escapes):
+        import ctypes
+
+        import torch
+
+        from . import _check, _lib, _stream_ptr
+        dev = params["means3D"].device
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        means, ls = f32(params["means3D"]), f32(params["log_scales"])
+        q, t = f32(params["cam_unnorm_rots"][0, :, time_idx]), f32(params["cam_trans"][0, :, time_idx])
+        w2c = f32(first_frame_w2c.to(dev)).reshape(-1)
+        ptr = lambda x: None if x is None else x.data_ptr()
+        _check(_lib.vtgs_band_owner_mask(ctypes.byref(cam.c), means.shape[0], means.data_ptr(), ls.data_ptr(), q.data_ptr(),
+                                         t.data_ptr(), w2c.data_ptr(), margin_px, growth, ptr(owned), ptr(mask_out), ptr(escapes),
+                                         _stream_ptr(dev)), "vtgs_band_owner_mask")
+
+    def check(self, params, time_idx: int, cam, first_frame_w2c, band) -> None:
+        """Enqueue the exact band test of the whole map under the current pose / scales (no host wait)."""
+        if band is None or (int(band[0]), int(band[1])) != self.band:
+            raise ValueError(f"owned set built for tile rows {self.band}, render asks for {band}")
+        if int(params["means3D"].shape[0]) != self.n_map:
+            raise ValueError(f"owned set built for a map of {self.n_map} Gaussians, the map has {params['means3D'].shape[0]} "
+                             "(rebuild after densification / pruning)")
+        self._launch(params, time_idx, cam, first_frame_w2c, 1.0, 1.0, self.mask, None, self.escapes)
+
+    def escaped(self) -> int:
+        """Gaussians outside the list that could have met the band in some render since the set was built (device read)."""
+        return int(self.escapes.item())
+
+
 def _host_staged(group=None) -> bool:
     """gloo moves host memory: device tensors go through a CPU copy (the rehearsal of the N-rank path on one GPU box and the
     CPU tests); RCCL (backend "nccl") takes device tensors as they are."""
