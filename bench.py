@@ -95,6 +95,11 @@ def main():
                          "loop (src/vtgaussian_slam.py:428-449) -- means3D + the screen-space term, 24 B per Gaussian written "
                          "instead of 68 -- then the 7-float pose reduction and its all-reduce.  mapping: colours, opacities, "
                          "scales (the trainable set of the mapping loop), one flat all-reduce of 28 B per Gaussian")
+    ap.add_argument("--owned-sets", action="store_true",
+                    help="bands (N > 1 or --band): run the per-Gaussian kernels over the list of Gaussians that can meet the band "
+                         "(partition.OwnedSet) instead of over the whole map.  Off by default: through the plain operator the list "
+                         "is an index_select / index_add pair per input, which costs more than the shorter kernels save below "
+                         "a few million Gaussians (DESIGN.md 5); the fused frame route (bench_slam.py) gathers inside its kernels")
     ap.add_argument("--band", default=None, metavar="R/W",
                     help="rehearsal on one GPU: run rank R's band of a W-rank tile-row partition in this process, without "
                          "collectives (per-rank kernel times and the replicated share; tools/band_rehearsal.sh)")
@@ -151,7 +156,13 @@ def main():
         emulated = tuple(int(x) for x in args.band.split("/"))
         tile_rows = band_for_rank(H, emulated[1], emulated[0])
         args.slam_frames, args.audit_rows, args.no_cpu_baseline = 0, "", True
-    rast = dgr.GaussianRasterizer(raster_settings=settings, tile_rows=tile_rows)
+    # a band: the rank runs the per-Gaussian kernels over the LIST of Gaussians that can meet its rows (partition.OwnedSet: built
+    # once here -- the bench renders one view -- and checked on the device before every render), not over the whole map
+    own = None
+    if tile_rows is not None and args.owned_sets:
+        from diff_gaussian_rasterization.partition import OwnedSet
+        own = OwnedSet.for_operator(leaves["means3D"], leaves["scales"], settings, tile_rows)
+    rast = dgr.GaussianRasterizer(raster_settings=settings, tile_rows=tile_rows, owned=own)
 
     def step(leaves=leaves, mode=mode):
         for t in leaves.values():
@@ -420,11 +431,26 @@ def main():
         if tile_rows is not None and kern:
             # what every rank of the partition does over ALL Gaussians (projection, per-Gaussian gradient gather) beside what
             # it does for its band only (the two composites): SURVEY 8e "replicated work"
-            rep = sum(v["avg_us"] for k, v in kern.items() if not k.startswith("composite_"))
+            # With a list: only the check (band_owner_mask) reads the whole map; projection and gather run over the list, whose
+            # share beyond the band's own 1/W of the rows is what neighbouring ranks list too.
+            W_ranks = emulated[1] if emulated else world
+            ideal = (tile_rows[1] - tile_rows[0]) / float(gy16)
+            listed = (len(own) / float(N)) if own is not None else 1.0
+            whole = sum(v["avg_us"] for k, v in kern.items() if k == "band_owner_mask")
+            per_list = sum(v["avg_us"] for k, v in kern.items() if not k.startswith("composite_") and k != "band_owner_mask")
             tot = sum(v["avg_us"] for v in kern.values())
-            out["band"] = {"rank": emulated[0] if emulated else rank, "world": emulated[1] if emulated else world,
+            rep = whole + per_list * (1.0 - ideal / listed)
+            out["band"] = {"rank": emulated[0] if emulated else rank, "world": W_ranks,
                            "tile_rows": list(tile_rows), "kernel_us_total": round(tot, 2),
+                           "owned_set": None if own is None else {"listed": len(own), "listed_fraction": round(listed, 4),
+                                                                   "band_fraction_of_rows": round(ideal, 4), "margin_px": own.margin_px,
+                                                                   "scale_growth": own.growth, "escapes": own.escaped()},
+                           "whole_map_kernel_us": round(whole, 2), "per_gaussian_kernel_us": round(per_list, 2),
                            "replicated_kernel_us": round(rep, 2), "replicated_frac": round(rep / tot, 4),
+                           "replicated_note": "whole-map kernels + per-Gaussian kernels x (1 - band rows / listed fraction): the "
+                                              "work other ranks do too (no list: listed fraction = 1; the index_select / "
+                                              "index_add launches of the list route are torch's and not in kernels_us -- "
+                                              "ms_per_step has them)",
                            "emulated_in_one_process": bool(emulated)}
     # ---- slam block (BASELINE.json metric 2): a short run of bench_slam.py's loop through the get_loss mirror ---------------
     # The line above is complete without it.  On N > 1 GPUs the loop has collectives in it (never run on real multi-GPU

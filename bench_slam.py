@@ -78,6 +78,10 @@ def parse_args(argv=None):
                          "one of the frames really present.  A short run has windows of 2-3 frames, where the base frame is "
                          "drawn every second or third iteration; over the 39 ordinary frames of a 40-frame submap the mean of "
                          "1/(i+1) is 0.084, i.e. W = 12")
+    ap.add_argument("--owned-sets", default="auto", choices=["auto", "on", "off"],
+                    help="N-rank loop: run the per-Gaussian kernels over the list of Gaussians that can meet the rank's band "
+                         "(partition.OwnedSet, rebuilt at every phase) instead of over the whole map.  auto = from 2 M Gaussians up: "
+                         "below that the whole-map check before every render costs what the shorter kernels save (DESIGN.md 5)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N ranks (started by torch.distributed.run): 'nccl' = RCCL, one GPU per rank; 'gloo' = rehearsal of the "
                          "N-rank code path with every rank on GPU 0 and the collectives staged through the host")
@@ -163,9 +167,39 @@ def run(args) -> dict:
         map_loss = lambda im, ds, gi, gd: sc.mapping_loss(im, ds, gi, gd)
         pick_threshold, make_adam = sc.best_silhouette_threshold, torch.optim.Adam
 
+    # N ranks: the list of Gaussians that can meet this rank's band under the pose of view t_idx, built when a phase first
+    # renders that view and dropped at the end of the phase (owned_done: the device counters are read there -- a Gaussian that
+    # escaped a list would make the phase's renders differ from the band render of the whole map, and stops the run)
+    mode_owned = getattr(args, "owned_sets", "auto")
+    use_owned = world > 1 and args.fused and (mode_owned == "on" or (mode_owned == "auto" and args.n >= 2_000_000))
+    owned_sets, owned_stats = {}, {"built": 0, "listed": 0, "escapes": 0}
+
+    def owned_for(params, t_idx):
+        if not use_owned:
+            return None
+        own = owned_sets.get(t_idx)
+        if own is None:
+            own = owned_sets[t_idx] = pt.OwnedSet(params, t_idx, settings, first_w2c, band)
+            owned_stats["built"] += 1
+            owned_stats["listed"] += len(own)
+        return own
+
+    def owned_done():
+        if not use_owned:
+            return
+        esc_t = torch.zeros(1, dtype=torch.float32, device=dev)
+        for o in owned_sets.values():
+            esc_t += o.escapes
+        esc = int(pt.all_reduce_sum(esc_t).item())          # every rank learns of an escape on any rank (and stops with it)
+        owned_sets.clear()
+        owned_stats["escapes"] += esc
+        if esc:
+            raise SystemExit(f"bench_slam.py: {esc} Gaussians escaped an owned set within one phase (margin too small)")
+
     def render_pair(params, t_idx, gaussians_grad, camera_grad, tile_rows=None):
         if args.fused:
-            return render_frame(params, t_idx, settings, first_w2c, gaussians_grad, camera_grad, tile_rows=tile_rows)
+            return render_frame(params, t_idx, settings, first_w2c, gaussians_grad, camera_grad, tile_rows=tile_rows,
+                                owned=owned_for(params, t_idx) if tile_rows is not None else None)
         tg = sc.transform_to_frame(params, t_idx, gaussians_grad=gaussians_grad, camera_grad=camera_grad)
         rv = sc.transformed_params2rendervar(params, tg)
         dv = sc.transformed_params2depthplussilhouette(params, first_w2c, tg)
@@ -262,6 +296,7 @@ def run(args) -> dict:
         im, depth_sil, _ = render_pair(warm, 1, gaussians_grad=True, camera_grad=False, tile_rows=band)
         map_loss(im, depth_sil, gts[1][0], gts[1][1]).backward()
     del warm
+    owned_done()
 
     track_ms, map_ms, errs_before, errs_after = [], [], [], []
     torch.cuda.synchronize()
@@ -330,6 +365,7 @@ def run(args) -> dict:
             del graph
             dgr.forget_captured()
             opt.zero_grad(set_to_none=True)
+        owned_done()
         torch.cuda.synchronize(); track_ms.append((time.perf_counter() - t0) * 1e3 / args.tracking_iters)
         errs_after.append(pose_error(t))
         # ---- mapping
@@ -394,6 +430,7 @@ def run(args) -> dict:
             del graph
             dgr.forget_captured()
             opt.zero_grad(set_to_none=True)
+        owned_done()
         torch.cuda.synchronize(); map_ms.append((time.perf_counter() - t0) * 1e3 / args.mapping_iters)
         frame_s.append(time.perf_counter() - t_frame)
         second_frac.append(second_calls / max(args.mapping_iters, 1))
@@ -449,6 +486,9 @@ def run(args) -> dict:
         "pose_error_before_tracking_cm_deg": [[round(a, 3), round(b, 4)] for a, b in errs_before],
         "pose_error_after_tracking_cm_deg": [[round(a, 3), round(b, 4)] for a, b in errs_after],
         "regimes": regimes,
+        "owned_sets": None if not use_owned else {
+            "lists_built": owned_stats["built"], "mean_listed_fraction_of_map": round(owned_stats["listed"] / max(owned_stats["built"], 1) / N, 4),
+            "escapes": owned_stats["escapes"], "margin_px": 32.0, "scale_growth": 1.25, "rank": rank},
     }
     ms = torch.cuda.memory_stats()
     out["allocator"] = {"device_allocs": ms.get("num_device_alloc", 0), "device_frees": ms.get("num_device_free", 0),

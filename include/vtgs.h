@@ -287,8 +287,11 @@ int vtgs_backward_dual_frame(const VtgsCamera* cam, int32_t n, const float* mean
  * scale near the current ones and hands the rasterizer the compact arrays of those (the reference has no counterpart: its
  * rasterizer is single-GPU, src/vtgaussian_slam.py:431-468 renders the whole map).
  *
- * vtgs_band_owner_mask: the band test of the projection kernel (mean + scale only) for all n Gaussians of the map under the
- *   pose (cam_q, cam_t) -- with the radius widened by margin_px and the scale multiplied by growth (>= 1).
+ * vtgs_band_owner_mask: the band test of the projection kernel (mean + scale only) for all n Gaussians of the map -- with the
+ *   radius widened by margin_px and the scale multiplied by growth (>= 1).  means3D are world points moved by the pose
+ *   (cam_q [4] un-normalised, cam_t [3]; device pointers, as vtgs_prepare_frame takes them), or camera-frame points as the plain
+ *   operator gets them (cam_q = cam_t = NULL).  scales: log_scales [n] of an isotropic map (scales_are_log = 1) or the
+ *   operator's scales [n,3] (0).
  *   mask_out (may be NULL): 1 byte per Gaussian, 1 = could meet the band: the caller compacts the indices (ascending).
  *   escapes (may be NULL; needs owned = a mask written earlier): *escapes += the number of Gaussians with owned[i] == 0
  *   that could meet the band now.  Called with (margin 1 px, growth 1) before a render of the list it proves, while the
@@ -300,8 +303,8 @@ int vtgs_backward_dual_frame(const VtgsCamera* cam, int32_t n, const float* mean
  *   unnorm_rotations and the g_* outputs are the MAP's arrays, read / written at row owned_idx[i]; rows outside the list are
  *   not touched (the caller zero-fills them).  owned_idx == NULL is vtgs_backward_dual_frame.  pose_partials has
  *   vtgs_pose_partial_rows(n_owned) rows.                                                                              */
-int vtgs_band_owner_mask(const VtgsCamera* cam, int32_t n, const float* means3D, const float* log_scales, const float* cam_q,
-                         const float* cam_t, const float* depth_w2c, float margin_px, float growth, const uint8_t* owned,
+int vtgs_band_owner_mask(const VtgsCamera* cam, int32_t n, const float* means3D, const float* scales, int32_t scales_are_log,
+                         const float* cam_q, const float* cam_t, float margin_px, float growth, const uint8_t* owned,
                          uint8_t* mask_out, uint32_t* escapes, void* stream);
 int vtgs_prepare_frame_owned(int32_t n_owned, const int32_t* owned_idx, const float* means3D, const float* logit_opacities,
                              const float* log_scales, const float* unnorm_rotations, const float* rgb_colors,

@@ -187,8 +187,9 @@ def _problem(dev):
     return params, settings, gt_im, gt_depth, H
 
 
-def _iteration(params, settings, gt_im, gt_depth, H, rank, world, kind):
-    """One tracking / mapping iteration the way bench_slam.py's N-rank loop does it; returns (loss, gradients)."""
+def _iteration(params, settings, gt_im, gt_depth, H, rank, world, kind, owned_sets=False):
+    """One tracking / mapping iteration the way bench_slam.py's N-rank loop does it; returns (loss, gradients).
+    owned_sets: every rank renders from the list of Gaussians that can meet its band (partition.OwnedSet)."""
     import torch.distributed as dist
     from diff_gaussian_rasterization import losses, partition as pt
     from diff_gaussian_rasterization.fused import render_frame
@@ -196,8 +197,9 @@ def _iteration(params, settings, gt_im, gt_depth, H, rank, world, kind):
     p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     band = pt.band_for_rank(H, world, rank) if world > 1 else None
     first_w2c = torch.eye(4, device=dev)
+    own = pt.OwnedSet(p, 0, settings, first_w2c, band) if (owned_sets and world > 1) else None
     if kind == "tracking":
-        im, ds, _ = render_frame(p, 0, settings, first_w2c, False, True, tile_rows=band)
+        im, ds, _ = render_frame(p, 0, settings, first_w2c, False, True, tile_rows=band, owned=own)
         thr = (pt.band_silhouette_threshold(im, ds[1], gt_im, gt_depth, band, world) if world > 1
                else losses.best_silhouette_threshold(im, ds[1], gt_im, gt_depth))
         loss = (pt.band_tracking_loss(im, ds, gt_im, gt_depth, band, thr) if world > 1
@@ -206,7 +208,7 @@ def _iteration(params, settings, gt_im, gt_depth, H, rank, world, kind):
         grads = {k: p[k].grad.clone() for k in ("cam_unnorm_rots", "cam_trans")}
         grads["thr"] = torch.tensor([thr])
     else:
-        im, ds, _ = render_frame(p, 0, settings, first_w2c, True, False, tile_rows=band)
+        im, ds, _ = render_frame(p, 0, settings, first_w2c, True, False, tile_rows=band, owned=own)
         loss = (pt.band_mapping_loss(im, ds, gt_im, gt_depth, band, rank, world, ignore_outlier_depth_loss=True) if world > 1
                 else losses.mapping_loss(im, ds, gt_im, gt_depth, extra_mask=losses.outlier_depth_mask(gt_depth, ds[0:1])))
         loss.backward()
@@ -219,6 +221,9 @@ def _iteration(params, settings, gt_im, gt_depth, H, rank, world, kind):
             if v.is_cuda and v.numel() <= 16:
                 pt.all_reduce_sum(v)                                # the pose gradient: summed over the bands
         pt.all_reduce_sum(total)
+    if own is not None:
+        assert 0 < len(own) < params["means3D"].shape[0]
+        assert pt.phase_escapes([own]) == 0                         # (collective: every rank asks)
     return total, grads
 
 
@@ -229,8 +234,24 @@ def _rank_main(rank, world, port, out):
     dev = torch.device("cuda", 0)
     res = {}
     for kind in ("tracking", "mapping"):
-        loss, grads = _iteration(*_problem(dev), rank, world, kind)
+        loss, grads = _iteration(*_problem(dev), rank, world, kind, owned_sets=True)
         res[kind] = {"loss": loss.cpu(), **{k: v.cpu() for k, v in grads.items()}}
+    # margin violation: lists built with the smallest margin for a pose ~6 degrees away.  Rank 1's band receives Gaussians
+    # that are not on its list; BOTH ranks learn of it (phase_escapes is a collective) and rebuild; then nothing escapes.
+    from diff_gaussian_rasterization import partition as pt
+    from diff_gaussian_rasterization.fused import render_frame
+    params, settings, _gi, _gd, H = _problem(dev)
+    band, w2c = pt.band_for_rank(H, world, rank), torch.eye(4, device=dev)
+    stale = dict(params, cam_unnorm_rots=params["cam_unnorm_rots"] + torch.tensor([0, 0.05, 0, 0.0], device=dev).reshape(1, 4, 1))
+    own = pt.OwnedSet(stale, 0, settings, w2c, band, margin_px=1.0, growth=1.0)
+    with torch.no_grad():
+        render_frame(params, 0, settings, w2c, False, False, tile_rows=band, owned=own)
+    res["escapes_mine_before"] = own.escaped()
+    res["escapes_before_rebuild"] = pt.phase_escapes([own])
+    own = pt.OwnedSet(params, 0, settings, w2c, band, margin_px=1.0, growth=1.0)
+    with torch.no_grad():
+        render_frame(params, 0, settings, w2c, False, False, tile_rows=band, owned=own)
+    res["escapes_after_rebuild"] = pt.phase_escapes([own])
     if rank == 0:
         torch.save(res, out)
     dist.destroy_process_group()
@@ -242,6 +263,8 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_iteration(gpu_device, tm
     mp.get_context("spawn")
     mp.spawn(_rank_main, args=(2, _free_port(), out), nprocs=2, join=True)
     got = torch.load(out)
+    assert got["escapes_before_rebuild"] > 0 and got["escapes_before_rebuild"] >= got["escapes_mine_before"]
+    assert got["escapes_after_rebuild"] == 0
     for kind in ("tracking", "mapping"):
         loss, grads = _iteration(*_problem(gpu_device), 0, 1, kind)
         ref = {"loss": loss.cpu(), **{k: v.cpu() for k, v in grads.items()}}

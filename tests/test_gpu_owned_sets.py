@@ -131,3 +131,34 @@ def test_list_of_another_band_or_map_is_refused(gpu_device):
     smaller = {k: (torch.nn.Parameter(v[:4000].detach().clone()) if k in KEYS else v) for k, v in params.items()}
     with pytest.raises(ValueError, match="rebuild"):
         render_frame(smaller, 1, st, w2c, False, True, tile_rows=(2, 4), owned=own)
+
+
+def test_plain_operator_over_the_list_equals_its_band_render(gpu_device):
+    """`GaussianRasterizer(..., tile_rows=band, owned=OwnedSet.for_operator(...))`: the operator over the listed rows of its
+    inputs -- anisotropic scales included -- gives the band render of all rows, and the gradients of all six inputs, bit for bit."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization.partition import OwnedSet
+    dev = gpu_device
+    W, H, n, band = 208, 128, 30000, (3, 5)
+    scene, cam = go.view_tied_scene(n, W, H, seed=6)
+    g = torch.Generator().manual_seed(2)
+    scene["scales"] = scene["scales"] * (0.7 + 0.6 * torch.rand(n, 3, generator=g))
+    st = to_settings(cam, dev)
+    g1 = (torch.rand(3, H, W, generator=g) * 2 - 1).to(dev)
+
+    def run(owned):
+        leaves = {k: v.to(dev).requires_grad_(True) for k, v in scene.items()}
+        im, radii, depth = dgr.GaussianRasterizer(raster_settings=st, tile_rows=band, owned=owned)(**leaves)
+        (im * g1).sum().backward()
+        return im.detach(), radii, depth.detach(), {k: v.grad for k, v in leaves.items()}
+
+    own = OwnedSet.for_operator(scene["means3D"].to(dev), scene["scales"].to(dev), st, band, margin_px=4.0, growth=1.05)
+    assert 0 < len(own) < 0.75 * n
+    a, b = run(None), run(own)
+    assert own.escaped() == 0
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+    with pytest.raises(ValueError, match="for_operator"):
+        dgr.GaussianRasterizer(raster_settings=st, tile_rows=band, owned=OwnedSet(_params(dev, n, W, H, 6)[0], 1, st, torch.eye(4, device=dev), band))(
+            **{k: v.to(dev) for k, v in scene.items()})

@@ -48,19 +48,30 @@ __global__ __launch_bounds__(256) void prepare_frame_kernel(
 //                      exactly the render of the whole map on those rows.
 __global__ __launch_bounds__(256) void band_owner_kernel(
     CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n, const float* __restrict__ means3D,
-    const float* __restrict__ log_scales, const float* __restrict__ cam_q, const float* __restrict__ cam_t,
-    const float* __restrict__ depth_w2c, float margin_px, float growth, const uint8_t* __restrict__ owned,
-    uint8_t* __restrict__ mask_out, uint32_t* __restrict__ escapes) {
+    const float* __restrict__ scales, int scales_are_log, const float* __restrict__ cam_q, const float* __restrict__ cam_t,
+    float margin_px, float growth, const uint8_t* __restrict__ owned, uint8_t* __restrict__ mask_out,
+    uint32_t* __restrict__ escapes) {
   const CamParams cam = load_cam(cs, Vp, PVp);
-  const FramePose P = load_pose(cam_q, cam_t, depth_w2c);
+  float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, t[3] = {0.f, 0.f, 0.f};
+  if (cam_q) {                                     // (NULL: the means are already in the camera frame, as the plain operator gets them)
+    const float nq = rsqrtf(cam_q[0] * cam_q[0] + cam_q[1] * cam_q[1] + cam_q[2] * cam_q[2] + cam_q[3] * cam_q[3]);
+    const float qq[4] = {cam_q[0] * nq, cam_q[1] * nq, cam_q[2] * nq, cam_q[3] * nq};
+    quat_to_R(qq, R);
+    t[0] = cam_t[0]; t[1] = cam_t[1]; t[2] = cam_t[2];
+  }
   const int i = (int)(blockIdx.x * 256u + threadIdx.x);
   bool touch = false;
   if (i < n) {
     const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
-    const float mean[3] = {P.R[0] * x + P.R[1] * y + P.R[2] * z + P.t[0], P.R[3] * x + P.R[4] * y + P.R[5] * z + P.t[1],
-                           P.R[6] * x + P.R[7] * y + P.R[8] * z + P.t[2]};
-    const float s = __expf(log_scales[i]);
-    const float sc[3] = {s, s, s};
+    float mean[3] = {x, y, z};
+    if (cam_q) {
+      mean[0] = R[0] * x + R[1] * y + R[2] * z + t[0];
+      mean[1] = R[3] * x + R[4] * y + R[5] * z + t[1];
+      mean[2] = R[6] * x + R[7] * y + R[8] * z + t[2];
+    }
+    float sc[3];
+    if (scales_are_log) { sc[0] = sc[1] = sc[2] = __expf(scales[i]); }
+    else { sc[0] = scales[3 * i]; sc[1] = scales[3 * i + 1]; sc[2] = scales[3 * i + 2]; }
     touch = !outside_tile_rows_ext(cam, mean, sc, cam.row8_begin / 2, (cam.row8_end + 1) / 2, margin_px, growth);
     if (mask_out) mask_out[i] = touch ? 1 : 0;
   }

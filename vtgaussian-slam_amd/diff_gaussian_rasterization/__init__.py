@@ -80,7 +80,7 @@ _SIGNATURES = {
                                                 ctypes.c_uint32] + [_P] * 12),
     "vtgs_backward_dual_frame_owned": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32] + [_P] * 12 + [_SZ, _U64, ctypes.c_uint32, _P,
                                                       _SZ, ctypes.c_uint32] + [_P] * 12),
-    "vtgs_band_owner_mask": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32] + [_P] * 5 + [ctypes.c_float, ctypes.c_float]
+    "vtgs_band_owner_mask": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _I32, _P, _P, ctypes.c_float, ctypes.c_float]
                              + [_P] * 4),
     "vtgs_forward_planned": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _U64,
                                             ctypes.c_uint32, _P, _P, ctypes.c_uint32, _P]),
@@ -1001,10 +1001,15 @@ class GaussianRasterizer(nn.Module):
     Extras that the reference does not use and that default to its behaviour:
       radius_rule : "3sigma" (published rule, default; env VTGS_RADIUS_RULE) or "opacity".
       tile_rows   : (begin, end) band of 16-pixel tile rows to render (tile-row multi-GPU partition).
+      owned       : a `partition.OwnedSet.for_operator(...)` list for that band: the operator runs over the listed rows of its
+                    inputs only (an index_select in front of the node; the radii and, through autograd, the gradients of the other
+                    rows are zero) after counting on the device the rows outside the list that could meet the band.
     """
 
-    def __init__(self, raster_settings, radius_rule: Optional[str] = None, tile_rows: Optional[Tuple[int, int]] = None):
+    def __init__(self, raster_settings, radius_rule: Optional[str] = None, tile_rows: Optional[Tuple[int, int]] = None,
+                 owned=None):
         super().__init__()
+        self.__dict__["_owned"] = owned
         rule = radius_rule or os.environ.get("VTGS_RADIUS_RULE", "3sigma")
         if rule not in _RADIUS_RULES:
             raise ValueError(f"radius_rule must be one of {sorted(_RADIUS_RULES)}")
@@ -1037,6 +1042,21 @@ class GaussianRasterizer(nn.Module):
         if not means3D.is_cuda:
             raise RuntimeError("GaussianRasterizer needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
         cam = _camera_for(self.raster_settings, means3D.device, self._rule, self._tile_rows)
+        own = self._owned
+        if own is not None:
+            if own.scales_are_log:
+                raise ValueError("this owned set was built for fused.render_frame (OwnedSet(params, ...)); use OwnedSet.for_operator")
+            own.admit(means3D.shape[0], self._tile_rows)
+            f32 = lambda t: t.detach() if (t.dtype is torch.float32 and t.is_contiguous()) else t.detach().to(torch.float32).contiguous()
+            own.check(cam, f32(means3D), f32(scales))
+            n_map, pick = means3D.shape[0], (lambda t: None if t is None else t.index_select(0, own.idx64))
+            means3D, means2D, opacities, colors_precomp, scales, rotations = map(
+                pick, (means3D, means2D, opacities, colors_precomp, scales, rotations))
+            color, radii, depth = self._render(cam, means3D, means2D, opacities, colors_precomp, scales, rotations)
+            return color, torch.zeros(n_map, dtype=radii.dtype, device=radii.device).index_copy_(0, own.idx64, radii), depth
+        return self._render(cam, means3D, means2D, opacities, colors_precomp, scales, rotations)
+
+    def _render(self, cam, means3D, means2D, opacities, colors_precomp, scales, rotations):
         if _ext is not None and not torch.cuda.is_current_stream_capturing():
             if means2D is None:
                 means2D = torch.zeros_like(means3D)
@@ -1055,6 +1075,8 @@ class GaussianRasterizer(nn.Module):
         so that gradients reach them.  Opt-in; the plain call-by-call path stays the default."""
         if self._last_state is None:
             raise RuntimeError("render_shared needs a preceding forward() on the same module")
+        if self._owned is not None:
+            raise RuntimeError("render_shared over an owned set is not built: use fused.render_frame(..., owned=) for two renders")
         means3D, means2D, opacities, scales, rotations = like
         color, depth, _ = _RasterizeGaussians.apply(means3D, means2D, None, colors_precomp, opacities, scales, rotations,
                                                     None, self._last_state.cam, self._last_state)

@@ -27,7 +27,7 @@ import torch
 
 import os
 
-from . import (_Camera, _ForwardState, _RADIUS_RULES, _check, _device_guard, _lib, _run_backward, _run_backward_dual,
+from . import (_Camera, _ForwardState, _camera_for, _RADIUS_RULES, _check, _device_guard, _lib, _run_backward, _run_backward_dual,
                _run_forward, _scratch, _scratch_instances, _settle, _stream_ptr, _I32, _P)
 
 _lib.vtgs_pose_partial_rows.restype, _lib.vtgs_pose_partial_rows.argtypes = ctypes.c_uint32, [_I32]
@@ -45,7 +45,7 @@ class _RenderFrame(torch.autograd.Function):
         dev = means3D.device
         n_map = means3D.shape[0]
         n = n_map if owned is None else int(owned.idx.numel())       # rows the rasterizer sees
-        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        f32 = lambda t: t.detach() if (t.dtype is torch.float32 and t.is_contiguous()) else t.detach().to(torch.float32).contiguous()
         means3D, rgb, unnorm_rot, logit_op, log_scales = map(f32, (means3D, rgb, unnorm_rot, logit_op, log_scales))
         cam_q, cam_t, depth_w2c = f32(cam_q).reshape(-1), f32(cam_t).reshape(-1), f32(depth_w2c).reshape(-1)
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
@@ -63,6 +63,7 @@ class _RenderFrame(torch.autograd.Function):
             if not dual or os.environ.get("VTGS_FRAME_EPILOGUE", "1") == "0":
                 raise RuntimeError("owned sets run on the dual render with the frame epilogue (VTGS_DUAL / VTGS_FRAME_EPILOGUE "
                                    "select cross-check routes that have no list form)")
+            owned.check(cam, means3D, log_scales, cam_q, cam_t, stream)   # the exact band test of the whole map, counted
             rgb_map, rgb = rgb, new(n, 3)
             _check(_lib.vtgs_prepare_frame_owned(n, owned.idx.data_ptr(), means3D.data_ptr(), logit_op.data_ptr(),
                                                  log_scales.data_ptr(), unnorm_rot.data_ptr(), rgb_map.data_ptr(),
@@ -201,7 +202,7 @@ def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings
         return im, depth_sil, radii
     import os
     rule = _RADIUS_RULES[radius_rule or os.environ.get("VTGS_RADIUS_RULE", "3sigma")]
-    cam = _Camera(raster_settings, dev, rule, tile_rows)
+    cam = _camera_for(raster_settings, dev, rule, None if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1])))
     q = params["cam_unnorm_rots"][0, :, time_idx]
     t = params["cam_trans"][0, :, time_idx]
     if not camera_grad:
@@ -214,7 +215,9 @@ def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings
     flags = ((1 if gaussians_grad and grad_on else 0) | (2 if camera_grad and grad_on else 0)
              | (4 if appearance and grad_on else 0))
     if owned is not None:
-        owned.check(params, time_idx, cam, first_frame_w2c, tile_rows)
+        if not owned.scales_are_log:
+            raise ValueError("this owned set was built for the plain operator (OwnedSet.for_operator)")
+        owned.admit(params["means3D"].shape[0], tile_rows)
     return _RenderFrame.apply(g(params["means3D"]), params["rgb_colors"], g(params["unnorm_rotations"]),
                               params["logit_opacities"], params["log_scales"], q, t,
                               first_frame_w2c.to(dev), cam, flags, owned)

@@ -49,6 +49,30 @@ class OwnedSet:
 
     def __init__(self, params, time_idx: int, raster_settings, first_frame_w2c, band: Tuple[int, int], margin_px: float = 32.0,
                  growth: float = 1.25, radius_rule=None):
+        """The list for the fused caller chain: world-frame `params` under the pose of frame `time_idx`
+        (`fused.render_frame(..., owned=set)`).  `first_frame_w2c` is accepted for symmetry with render_frame; the band test
+        does not need it."""
+        import torch
+        _need_device(params["means3D"], "OwnedSet")
+        if params["log_scales"].shape[1] != 1:
+            raise RuntimeError("owned sets are built for isotropic maps (log_scales [N,1], every reference config)")
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        self._build(raster_settings, band, margin_px, growth, radius_rule, f32(params["means3D"]), f32(params["log_scales"]), True,
+                    f32(params["cam_unnorm_rots"][0, :, time_idx]), f32(params["cam_trans"][0, :, time_idx]))
+
+    @classmethod
+    def for_operator(cls, means3D, scales, raster_settings, band: Tuple[int, int], margin_px: float = 32.0, growth: float = 1.25,
+                     radius_rule=None):
+        """The list for the plain operator: camera-frame `means3D` [N,3] and `scales` [N,3] as `GaussianRasterizer.forward`
+        takes them (`GaussianRasterizer(raster_settings, tile_rows=band, owned=set)`)."""
+        import torch
+        _need_device(means3D, "OwnedSet")
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        self = cls.__new__(cls)
+        self._build(raster_settings, band, margin_px, growth, radius_rule, f32(means3D), f32(scales), False, None, None)
+        return self
+
+    def _build(self, raster_settings, band, margin_px, growth, radius_rule, means3D, scales, scales_are_log, cam_q, cam_t):
         import os
 
         import torch
@@ -56,53 +80,63 @@ class OwnedSet:
         from . import _RADIUS_RULES, _Camera
         self.band = (int(band[0]), int(band[1]))
         self.margin_px, self.growth = float(margin_px), float(growth)
-        if self.margin_px < 1.0 or self.growth < 1.0:          # the check below tests with 1 px of slack: a tighter list fails it at once
+        if self.margin_px < 1.0 or self.growth < 1.0:          # the check tests with 1 px of slack: a tighter list fails it at once
             raise ValueError("OwnedSet needs margin_px >= 1 and growth >= 1")
-        dev = params["means3D"].device
-        _need_device(params["means3D"], "OwnedSet")
-        if params["log_scales"].shape[1] != 1:
-            raise RuntimeError("owned sets are built for isotropic maps (log_scales [N,1], every reference config)")
+        dev = means3D.device
         rule = _RADIUS_RULES[radius_rule or os.environ.get("VTGS_RADIUS_RULE", "3sigma")]
         cam = _Camera(raster_settings, dev, rule, self.band)
-        self.n_map = int(params["means3D"].shape[0])
+        self.n_map, self.scales_are_log = int(means3D.shape[0]), bool(scales_are_log)
         self.mask = torch.empty(self.n_map, dtype=torch.uint8, device=dev)
         self.escapes = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._launch(params, time_idx, cam, first_frame_w2c, self.margin_px, self.growth, None, self.mask, None)
+        self._test(cam, means3D, scales, cam_q, cam_t, self.margin_px, self.growth, None, self.mask, None, None)
         self.idx64 = torch.nonzero(self.mask).reshape(-1)              # ascending; one device -> host read (the count)
         self.idx = self.idx64.to(torch.int32)
 
     def __len__(self) -> int:
         return int(self.idx.numel())
 
-    @staticmethod
-    def _launch(params, time_idx, cam, first_frame_w2c, margin_px, growth, owned, mask_out, escapes):
+    def _test(self, cam, means3D, scales, cam_q, cam_t, margin_px, growth, owned, mask_out, escapes, stream):
         import ctypes
 
-        import torch
-
         from . import _check, _lib, _stream_ptr
-        dev = params["means3D"].device
-        f32 = lambda t: t.detach().to(torch.float32).contiguous()
-        means, ls = f32(params["means3D"]), f32(params["log_scales"])
-        q, t = f32(params["cam_unnorm_rots"][0, :, time_idx]), f32(params["cam_trans"][0, :, time_idx])
-        w2c = f32(first_frame_w2c.to(dev)).reshape(-1)
         ptr = lambda x: None if x is None else x.data_ptr()
-        _check(_lib.vtgs_band_owner_mask(ctypes.byref(cam.c), means.shape[0], means.data_ptr(), ls.data_ptr(), q.data_ptr(),
-                                         t.data_ptr(), w2c.data_ptr(), margin_px, growth, ptr(owned), ptr(mask_out), ptr(escapes),
-                                         _stream_ptr(dev)), "vtgs_band_owner_mask")
+        _check(_lib.vtgs_band_owner_mask(ctypes.byref(cam.c), means3D.shape[0], means3D.data_ptr(), scales.data_ptr(),
+                                         1 if self.scales_are_log else 0, ptr(cam_q), ptr(cam_t), margin_px, growth, ptr(owned),
+                                         ptr(mask_out), ptr(escapes), _stream_ptr(means3D.device) if stream is None else stream),
+               "vtgs_band_owner_mask")
 
-    def check(self, params, time_idx: int, cam, first_frame_w2c, band) -> None:
-        """Enqueue the exact band test of the whole map under the current pose / scales (no host wait)."""
+    def admit(self, n_map: int, band) -> None:
+        """Is this the band and the map the list was built for?  (host-side, before a render)"""
         if band is None or (int(band[0]), int(band[1])) != self.band:
             raise ValueError(f"owned set built for tile rows {self.band}, render asks for {band}")
-        if int(params["means3D"].shape[0]) != self.n_map:
-            raise ValueError(f"owned set built for a map of {self.n_map} Gaussians, the map has {params['means3D'].shape[0]} "
+        if int(n_map) != self.n_map:
+            raise ValueError(f"owned set built for a map of {self.n_map} Gaussians, the map has {int(n_map)} "
                              "(rebuild after densification / pruning)")
-        self._launch(params, time_idx, cam, first_frame_w2c, 1.0, 1.0, self.mask, None, self.escapes)
+
+    def check(self, cam, means3D, scales, cam_q=None, cam_t=None, stream=None) -> None:
+        """Enqueue the exact band test of the whole map under the pose / scales of the render about to run (float32 contiguous
+        device tensors, as the autograd nodes hold them; no host wait)."""
+        self._test(cam, means3D, scales, cam_q, cam_t, 1.0, 1.0, self.mask, None, self.escapes, stream)
 
     def escaped(self) -> int:
         """Gaussians outside the list that could have met the band in some render since the set was built (device read)."""
         return int(self.escapes.item())
+
+
+def phase_escapes(owned_sets, group=None) -> int:
+    """End of a phase on N ranks: the escape counters of this rank's lists, summed over ALL ranks (one small all-reduce), so
+    that every rank takes the same decision -- 0: the phase stands; otherwise every rank rebuilds its lists (wider margin) and
+    redoes the phase.  A rank deciding alone would leave the others waiting in the next collective."""
+    import torch
+    import torch.distributed as dist
+    sets = list(owned_sets)
+    dev = sets[0].escapes.device if sets else "cpu"
+    total = torch.zeros(1, dtype=torch.float32, device=dev)
+    for o in sets:
+        total += o.escapes.to(torch.float32)
+    if dist.is_available() and dist.is_initialized():
+        all_reduce_sum(total, group)
+    return int(total.item())
 
 
 def _host_staged(group=None) -> bool:
