@@ -221,3 +221,30 @@ def test_two_rank_tracking_loss_threshold_and_gradients_match_full_frame(tmp_pat
     for k, v in p.items():
         ref = v.grad
         assert (got[k] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-9, k
+
+
+def _escape_worker(rank, world, port, out):
+    """The rebuild decision of the owned sets: a Gaussian escaped rank 1's list only -- both ranks must learn of it."""
+    from types import SimpleNamespace
+    from diff_gaussian_rasterization.partition import phase_escapes
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = [SimpleNamespace(escapes=torch.tensor([0], dtype=torch.int32)),
+            SimpleNamespace(escapes=torch.tensor([3 if rank == 1 else 0], dtype=torch.int32))]
+    first = phase_escapes(mine)                    # the phase that has to be redone
+    for o in mine:
+        o.escapes.zero_()                          # (rebuilt lists start at zero)
+    second = phase_escapes(mine)
+    torch.save({"first": first, "second": second}, f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_an_escape_on_one_rank_is_seen_by_every_rank(tmp_path):
+    """partition.phase_escapes is a collective: every rank gets the SUM of the escape counters, so that all ranks rebuild their
+    lists and redo the phase together (a rank deciding alone would leave the others waiting in the next all-reduce).  The
+    counters themselves are written by vtgs_band_owner_mask on the GPU (tests/test_gpu_owned_sets.py, test_band_loss_gpu.py)."""
+    out = str(tmp_path / "esc")
+    mp.spawn(_escape_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for rank in (0, 1):
+        got = torch.load(f"{out}.{rank}")
+        assert got["first"] == 3 and got["second"] == 0, (rank, got)
