@@ -25,6 +25,7 @@ bwd=os.environ.get('ABL_BWD','1')=='1'
 def step():
     c,r,d=rast(**leaves)
     if bwd: c.backward(g)
+if os.environ.get('ABL_SINGLE_THREAD_AUTOGRAD')=='1': torch.autograd.set_multithreading_enabled(False)   # backward on the calling thread: no hand-off to the engine's device thread
 for it in range(5): step()
 torch.cuda.synchronize()
 dgr.profile_enable(True)
