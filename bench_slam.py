@@ -82,6 +82,10 @@ def parse_args(argv=None):
                     help="N-rank loop: run the per-Gaussian kernels over the list of Gaussians that can meet the rank's band "
                          "(partition.OwnedSet, rebuilt at every phase) instead of over the whole map.  auto = from 2 M Gaussians up: "
                          "below that the whole-map check before every render costs what the shorter kernels save (DESIGN.md 5)")
+    ap.add_argument("--autograd-threads", default="auto", choices=["auto", "engine", "caller"],
+                    help="caller = torch.autograd.set_multithreading_enabled(False): backward() runs on the calling thread instead "
+                         "of being handed to the engine's device thread (~40 us per iteration).  auto = caller on N > 1 ranks, "
+                         "where a rank's iteration is bound by the host (DESIGN.md 5), the engine's default on one GPU")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N ranks (started by torch.distributed.run): 'nccl' = RCCL, one GPU per rank; 'gloo' = rehearsal of the "
                          "N-rank code path with every rank on GPU 0 and the collectives staged through the host")
@@ -124,6 +128,11 @@ def run(args) -> dict:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         torch.cuda.set_stream(side)
+
+    at_mode = getattr(args, "autograd_threads", "auto")
+    caller_thread = at_mode == "caller" or (at_mode == "auto" and world > 1)
+    if caller_thread:
+        torch.autograd.set_multithreading_enabled(False)
 
     import diff_gaussian_rasterization as dgr
     import slam_callers as sc
@@ -475,6 +484,7 @@ def run(args) -> dict:
         "config": {"workload": f"view-tied submap N={N}, {W}x{H}; {args.tracking_iters} tracking + {args.mapping_iters} "
                                f"mapping iterations per frame, 2 renders fwd+bwd per iteration (configs/replica/room0.py)",
                    "frames": args.frames, "warmup_frames_not_counted": WU, "shared_geometry": bool(args.shared_geometry or args.fused), "fused_callers": bool(args.fused),
+                   "autograd_backward_on": "calling thread" if caller_thread else "engine device thread (PyTorch default)",
                    "through_get_loss_mirror": bool(args.get_loss), "iteration_replayed_from_a_hipgraph": bool(args.graph),
                    "mapping_get_loss_calls_per_iteration": (2 if fixed else 1) if not args.base_frame_every else "see regimes",
                    "base_frame_every": args.base_frame_every or None, "emulated_window_frames": args.emulate_window or None,
