@@ -27,7 +27,10 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--rank", type=int, default=3)
     ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--caller-thread-autograd", action="store_true", help="torch.autograd.set_multithreading_enabled(False)")
     args = ap.parse_args()
+    if args.caller_thread_autograd:
+        torch.autograd.set_multithreading_enabled(False)
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import partition as pt
     from diff_gaussian_rasterization.fused import render_frame
