@@ -82,6 +82,10 @@ def parse_args(argv=None):
                     help="N-rank loop: run the per-Gaussian kernels over the list of Gaussians that can meet the rank's band "
                          "(partition.OwnedSet, rebuilt at every phase) instead of over the whole map.  auto = from 2 M Gaussians up: "
                          "below that the whole-map check before every render costs what the shorter kernels save (DESIGN.md 5)")
+    ap.add_argument("--mapping-exchange", default="allreduce", choices=["allreduce", "owner"],
+                    help="N-rank mapping: allreduce = one flat all-reduce of the trainable per-Gaussian gradients (20 B each) and Adam "
+                         "on every row on every rank; owner = partition.OwnerExchange (needs owned sets): halo gradients to the owner "
+                         "band, Adam on the owned rows, the updated rows back to the ranks that list them, one all-reduce per phase")
     ap.add_argument("--autograd-threads", default="auto", choices=["auto", "engine", "caller"],
                     help="caller = torch.autograd.set_multithreading_enabled(False): backward() runs on the calling thread instead "
                          "of being handed to the engine's device thread (~40 us per iteration).  auto = caller on N > 1 ranks, "
@@ -192,6 +196,26 @@ def run(args) -> dict:
             owned_stats["built"] += 1
             owned_stats["listed"] += len(own)
         return own
+
+    # --mapping-exchange owner: one exchange object per mapping phase, built on a union list whose margin covers every view of
+    # the submap's window (bound on the image shift between the phase's reference view and the window's views, from the poses)
+    use_owner = use_owned and getattr(args, "mapping_exchange", "allreduce") == "owner"
+    owner_stats = {"phases": 0, "bytes_sent": 0, "iterations": 0, "halo_rows": 0, "own_rows": 0}
+    if getattr(args, "mapping_exchange", "allreduce") == "owner" and not use_owned and world > 1:
+        raise SystemExit("bench_slam.py: --mapping-exchange owner needs owned sets (--owned-sets on, or auto with N >= 2 M)")
+
+    def make_exchange(params, t_ref, views):
+        with torch.no_grad():
+            q = torch.nn.functional.normalize(params["cam_unnorm_rots"][0].detach(), dim=0).cpu()      # [4, T]
+            tr = params["cam_trans"][0].detach().cpu()
+            ang = max(2.0 * math.acos(min(1.0, abs(float((q[:, t_ref] * q[:, v]).sum())))) for v in views)
+            dt = max(float((tr[:, t_ref] - tr[:, v]).norm()) for v in views)
+        lim = 1.3 * max(settings.tanfovx, settings.tanfovy)
+        shift = fx * (ang * (1.0 + lim * lim) + dt / 1.0)                    # (scene depths >= 1 m)
+        union = pt.OwnedSet(params, t_ref, settings, first_w2c, band, margin_px=32.0 + 1.5 * shift, with_centre_rows=True)
+        ex = pt.OwnerExchange(union, H, rank, world)
+        owner_stats["phases"] += 1; owner_stats["halo_rows"] += ex.halo_rows; owner_stats["own_rows"] += int(ex.own_rows.numel())
+        return ex
 
     def owned_done():
         if not use_owned:
@@ -391,6 +415,8 @@ def run(args) -> dict:
         second_calls = 0
         torch.cuda.synchronize(); t0 = time.perf_counter()
         graph = None
+        exchange = make_exchange(params, t, window) if use_owner else None
+        owner_checked = set()
         for it in range(args.mapping_iters):
             if E > 0 and not is_base and args.emulate_window > 0:
                 draw = rng.randint(0, args.emulate_window)
@@ -430,6 +456,17 @@ def run(args) -> dict:
                 im, depth_sil, _ = render_pair(params, kf, gaussians_grad=True, camera_grad=False, tile_rows=band)
                 loss = map_loss(im, depth_sil, gt_im, gt_depth)
             loss.backward()
+            if exchange is not None:               # halo gradients -> owner bands; Adam on the owned rows; updated rows -> listers
+                if kf not in owner_checked:
+                    owner_checked.add(kf)
+                    if not exchange.covers(owned_sets[kf]):
+                        raise SystemExit(f"bench_slam.py: the list of view {kf} is not inside the phase's union list")
+                owner_stats["bytes_sent"] += exchange.reduce_grads(params)
+                opt.step(rows=exchange.update_rows)
+                owner_stats["bytes_sent"] += exchange.publish(params)
+                owner_stats["iterations"] += 1
+                opt.zero_grad(set_to_none=True)
+                continue
             if world > 1:                          # trainable per-Gaussian gradients: one flat all-reduce, 20 B per Gaussian
                 pt.allreduce_param_grads(params)
             opt.step(); opt.zero_grad(set_to_none=True)
@@ -439,6 +476,8 @@ def run(args) -> dict:
             del graph
             dgr.forget_captured()
             opt.zero_grad(set_to_none=True)
+        if exchange is not None:
+            exchange.gather_all(params)            # every rank gets every owner's rows back before the next phase
         owned_done()
         torch.cuda.synchronize(); map_ms.append((time.perf_counter() - t0) * 1e3 / args.mapping_iters)
         frame_s.append(time.perf_counter() - t_frame)
@@ -499,6 +538,13 @@ def run(args) -> dict:
         "owned_sets": None if not use_owned else {
             "lists_built": owned_stats["built"], "mean_listed_fraction_of_map": round(owned_stats["listed"] / max(owned_stats["built"], 1) / N, 4),
             "escapes": owned_stats["escapes"], "margin_px": 32.0, "scale_growth": 1.25, "rank": rank},
+        "mapping_exchange": None if world == 1 else (
+            {"route": "all-reduce of 20 B per Gaussian, Adam on every row", "bytes_per_iteration": 20 * N} if not use_owner else
+            {"route": "owner bands: halo gradients -> owner, Adam on owned rows, updated rows -> listers; one all-reduce per phase",
+             "bytes_sent_per_iteration_this_rank": round(owner_stats["bytes_sent"] / max(owner_stats["iterations"], 1)),
+             "all_reduce_bytes_per_iteration_for_comparison": 20 * N,
+             "halo_rows_mean": round(owner_stats["halo_rows"] / max(owner_stats["phases"], 1)),
+             "own_rows_mean": round(owner_stats["own_rows"] / max(owner_stats["phases"], 1))}),
     }
     ms = torch.cuda.memory_stats()
     out["allocator"] = {"device_allocs": ms.get("num_device_alloc", 0), "device_frees": ms.get("num_device_free", 0),

@@ -297,6 +297,8 @@ int vtgs_backward_dual_frame(const VtgsCamera* cam, int32_t n, const float* mean
  *   that could meet the band now.  Called with (margin 1 px, growth 1) before a render of the list it proves, while the
  *   counter stays 0, that the render equals the render of the whole map on the band: a Gaussian outside the list would have
  *   been dropped by the projection kernel's own band test.  The counter is the caller's (zeroed when the list is built).
+ *   centre_rows (may be NULL): centre_rows[i] = the 16-pixel tile row of Gaussian i's projected centre, clamped to the image
+ *   (-1 behind the near plane) -- the OWNER band of the Gaussian, the same on every rank (partition.OwnerExchange).
  * vtgs_prepare_frame_owned: vtgs_prepare_frame for the rows owned_idx[0..n_owned) of the map, written to compact rows
  *   0..n_owned; the colours are gathered too (out_rgb_colors [n_owned,3]) -- everything the rasterizer reads has n_owned rows.
  * vtgs_backward_dual_frame_owned: vtgs_backward_dual_frame over the compact arrays (n = n_owned); means3D,
@@ -305,7 +307,7 @@ int vtgs_backward_dual_frame(const VtgsCamera* cam, int32_t n, const float* mean
  *   vtgs_pose_partial_rows(n_owned) rows.                                                                              */
 int vtgs_band_owner_mask(const VtgsCamera* cam, int32_t n, const float* means3D, const float* scales, int32_t scales_are_log,
                          const float* cam_q, const float* cam_t, float margin_px, float growth, const uint8_t* owned,
-                         uint8_t* mask_out, uint32_t* escapes, void* stream);
+                         uint8_t* mask_out, uint32_t* escapes, int32_t* centre_rows, void* stream);
 int vtgs_prepare_frame_owned(int32_t n_owned, const int32_t* owned_idx, const float* means3D, const float* logit_opacities,
                              const float* log_scales, const float* unnorm_rotations, const float* rgb_colors,
                              const float* cam_q, const float* cam_t, const float* depth_w2c, float* out_means_cam,
@@ -427,6 +429,12 @@ typedef struct VtgsAdamGroup {
   float eps;
 } VtgsAdamGroup;
 int vtgs_adam_step(const VtgsAdamGroup* groups, int32_t n_groups, int32_t step, float beta1, float beta2, void* stream);
+/* The same update for the listed ROWS only of per-Gaussian tensors (each group is [n_total_rows, count / n_total_rows], row-major):
+ * rows[n_rows] are row indices; every other row -- parameter and both moments -- is left as it is.  A rank of the tile-row
+ * partition that runs Adam for the Gaussians of its owner band only (partition.OwnerExchange; SURVEY.md 8e "each GPU runs Adam
+ * on its owned slice").  Element for element the arithmetic of vtgs_adam_step.                                          */
+int vtgs_adam_step_rows(const VtgsAdamGroup* groups, int32_t n_groups, int32_t step, float beta1, float beta2,
+                        const int32_t* rows, int32_t n_rows, int32_t n_total_rows, void* stream);
 
 /* The bookkeeping at the end of get_loss (src/vtgaussian_slam.py:681-689) in one launch instead of three element-wise ones:
  *   seen[i] = radii[i] > 0;   max_2D_radius[i] = max(max_2D_radius[i], (float)radii[i])   (a culled Gaussian has radius 0 and

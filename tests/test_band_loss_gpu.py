@@ -252,6 +252,45 @@ def _rank_main(rank, world, port, out):
     with torch.no_grad():
         render_frame(params, 0, settings, w2c, False, False, tile_rows=band, owned=own)
     res["escapes_after_rebuild"] = pt.phase_escapes([own])
+    # owner exchange: three mapping iterations with the gradients sent to the owner band, Adam on the owned
+    # rows, the updated rows published -- against the all-reduce + Adam-on-every-row route on a copy, both rendering from lists
+    from diff_gaussian_rasterization.optim import FusedAdam
+    map_lrs = dict(means3D=0.0, rgb_colors=0.0025, unnorm_rotations=0.0, logit_opacities=0.05, log_scales=0.005,
+                   cam_unnorm_rots=1e-8, cam_trans=1e-7)
+    params, settings, gt_im, gt_depth, H = _problem(dev)
+    pa = {k: torch.nn.Parameter(v.clone()) for k, v in params.items()}
+    pb = {k: torch.nn.Parameter(v.clone()) for k, v in params.items()}
+    union = pt.OwnedSet(pa, 0, settings, w2c, band, margin_px=48.0, with_centre_rows=True)
+    ex = pt.OwnerExchange(union, H, rank, world)
+    own = pt.OwnedSet(pa, 0, settings, w2c, band)
+    res["covers"] = ex.covers(own)
+    oa = FusedAdam([{"params": [v], "name": k, "lr": map_lrs[k]} for k, v in pa.items()], lr=0.0, eps=1e-15, skip_frozen=True)
+    ob = FusedAdam([{"params": [v], "name": k, "lr": map_lrs[k]} for k, v in pb.items()], lr=0.0, eps=1e-15, skip_frozen=True)
+    keys = ("rgb_colors", "logit_opacities", "log_scales")
+    worst, sent = 0.0, 0
+    for it in range(3):
+        for p, route in ((pa, "owner"), (pb, "allreduce")):
+            im, ds, _ = render_frame(p, 0, settings, w2c, True, False, tile_rows=band, owned=own)
+            pt.band_mapping_loss(im, ds, gt_im, gt_depth, band, rank, world, ignore_outlier_depth_loss=True).backward()
+        # (iteration 0: both copies hold the same parameters, so the two routes' summed gradients must agree on the owned rows)
+        local = {k: pa[k].grad.clone() for k in keys}
+        sent += ex.reduce_grads(pa)
+        pt.allreduce_param_grads(pb)
+        if it == 0:
+            for k in keys:
+                a, b = pa[k].grad[ex.own_rows], pb[k].grad[ex.own_rows]
+                worst = max(worst, float((a - b).abs().max() / b.abs().max()))
+        oa.step(rows=ex.update_rows); ob.step()
+        sent += ex.publish(pa)
+        oa.zero_grad(); ob.zero_grad()
+    listed = own.mask.bool()
+    res["listed_diff"] = max(float((pa[k].detach()[listed] - pb[k].detach()[listed]).abs().max()) for k in keys)
+    ex.gather_all(pa)
+    res["final_q99"] = {k: float((pa[k].detach() - pb[k].detach()).abs().reshape(-1).quantile(0.99)) for k in keys}
+    res["moved_median"] = {k: float((pb[k].detach() - params[k]).abs().median()) for k in keys}
+    res["reduced_grad_rel"], res["bytes_owner_route"] = worst, sent
+    res["bytes_allreduce_route"] = 3 * 20 * params["means3D"].shape[0]
+    res["halo_rows"], res["own_rows"] = ex.halo_rows, int(ex.own_rows.numel())
     if rank == 0:
         torch.save(res, out)
     dist.destroy_process_group()
@@ -265,6 +304,16 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_iteration(gpu_device, tm
     got = torch.load(out)
     assert got["escapes_before_rebuild"] > 0 and got["escapes_before_rebuild"] >= got["escapes_mine_before"]
     assert got["escapes_after_rebuild"] == 0
+    # owner exchange: the owner's summed gradient is the all-reduced one; three Adam iterations on the owned rows + publish leave
+    # the parameters where all-reduce + Adam on every row leaves them (Adam normalises noise-level gradients: quantiles, as in
+    # tests/test_loop_fixture.py), for a fraction of the bytes
+    assert got["covers"] and got["reduced_grad_rel"] <= 2e-6, got["reduced_grad_rel"]
+    for k, lr in (("rgb_colors", 0.0025), ("logit_opacities", 0.05), ("log_scales", 0.005)):
+        assert got["moved_median"][k] > 0.3 * lr, (k, got["moved_median"])
+        assert got["final_q99"][k] <= 0.02 * 3 * lr, (k, got["final_q99"])
+    assert got["listed_diff"] <= 3 * 0.05 and 0 < got["halo_rows"] < got["own_rows"]
+    # (a 160 x 112 frame in two bands with a 48-pixel margin is nearly all halo: the byte saving shows at real sizes, bench_slam.py)
+    assert got["bytes_owner_route"] < got["bytes_allreduce_route"], (got["bytes_owner_route"], got["bytes_allreduce_route"])
     for kind in ("tracking", "mapping"):
         loss, grads = _iteration(*_problem(gpu_device), 0, 1, kind)
         ref = {"loss": loss.cpu(), **{k: v.cpu() for k, v in grads.items()}}

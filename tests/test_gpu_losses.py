@@ -135,3 +135,39 @@ def test_fused_adam_matches_torch_adam(gpu_device, eps):
     for k in shapes:
         assert torch.equal(pc[k].detach(), pd[k].detach()), k
     assert pd["cam_unnorm_rots"] not in lean.state and pc["cam_unnorm_rots"] in full.state
+
+
+def test_adam_on_rows_is_adam_on_those_rows(gpu_device):
+    """vtgs_adam_step_rows (FusedAdam.step(rows=...)): the listed rows get the bits of the full step, every other row --
+    parameter and both moments -- is untouched; tensors that are not per-Gaussian (the poses) take the full step."""
+    from diff_gaussian_rasterization.optim import FusedAdam
+    dev = gpu_device
+    g = torch.Generator().manual_seed(3)
+    n = 5000
+    def make():
+        gg = torch.Generator().manual_seed(3)
+        return {"means3D": torch.nn.Parameter(torch.randn(n, 3, generator=gg).to(dev)),
+                "rgb_colors": torch.nn.Parameter(torch.randn(n, 3, generator=gg).to(dev)),
+                "logit_opacities": torch.nn.Parameter(torch.randn(n, 1, generator=gg).to(dev)),
+                "cam_trans": torch.nn.Parameter(torch.randn(1, 3, 4, generator=gg).to(dev))}
+    a, b = make(), make()
+    lrs = {"means3D": 0.0, "rgb_colors": 0.0025, "logit_opacities": 0.05, "cam_trans": 0.002}
+    oa = FusedAdam([{"params": [v], "name": k, "lr": lrs[k]} for k, v in a.items()], lr=0.0, eps=1e-15, skip_frozen=True)
+    ob = FusedAdam([{"params": [v], "name": k, "lr": lrs[k]} for k, v in b.items()], lr=0.0, eps=1e-15, skip_frozen=True)
+    rows = torch.randperm(n, generator=g)[:1700].sort().values.to(torch.int32).to(dev)
+    keep = torch.ones(n, dtype=torch.bool, device=dev)
+    keep[rows.long()] = False
+    for it in range(3):
+        for k in a:
+            gr = torch.randn(a[k].shape, generator=g).to(dev)
+            a[k].grad, b[k].grad = gr.clone(), gr.clone()
+        oa.step(rows=rows); ob.step()
+    for k in ("rgb_colors", "logit_opacities"):
+        assert torch.equal(a[k][rows.long()], b[k][rows.long()]), k
+        start = make()[k]
+        assert torch.equal(a[k][keep], start[keep]), k
+        assert float(oa.state[a[k]]["exp_avg"][keep].abs().max()) == 0 and float(oa.state[a[k]]["exp_avg_sq"][keep].abs().max()) == 0
+        assert torch.equal(oa.state[a[k]]["exp_avg"][rows.long()], ob.state[b[k]]["exp_avg"][rows.long()])
+    assert torch.equal(a["cam_trans"], b["cam_trans"]) and a["means3D"] not in oa.state
+    with pytest.raises(TypeError):
+        oa.step(rows=rows.long())

@@ -40,7 +40,7 @@ __global__ void gather_splat_grads(CamScalars, const float*, const float*, int, 
                                    float*, const Counters*, float*, FrameEpilogue);
 __global__ void mark_visible_kernel(const float*, int, const float*, uint8_t*);
 __global__ void band_owner_kernel(CamScalars, const float*, const float*, int, const float*, const float*, int, const float*,
-                                  const float*, float, float, const uint8_t*, uint8_t*, uint32_t*);
+                                  const float*, float, float, const uint8_t*, uint8_t*, uint32_t*, int32_t*);
 __global__ void uniform_plan_kernel(uint32_t* plan, uint32_t entries, uint32_t slots_per_bin) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i < entries) plan[i] = i * slots_per_bin;
@@ -666,9 +666,9 @@ int vtgs_backward_dual_frame_owned(const VtgsCamera* cam, int32_t n, const int32
 
 int vtgs_band_owner_mask(const VtgsCamera* cam, int32_t n, const float* means3D, const float* scales, int32_t scales_are_log,
                          const float* cam_q, const float* cam_t, float margin_px, float growth, const uint8_t* owned,
-                         uint8_t* mask_out, uint32_t* escapes, void* stream) {
+                         uint8_t* mask_out, uint32_t* escapes, int32_t* centre_rows, void* stream) {
   if (!cam_ok(cam) || n < 0 || (cam_q == nullptr) != (cam_t == nullptr) || !(margin_px >= 0.f) || !(growth >= 1.f) ||
-      (!mask_out && !escapes) || (escapes && !owned))
+      (!mask_out && !escapes && !centre_rows) || (escapes && !owned))
     return VTGS_ERR_INVALID_ARGUMENT;
   int r8b, r8e, rows16, row16_0;
   if (!band_of(cam, &r8b, &r8e, &rows16, &row16_0)) return VTGS_ERR_INVALID_ARGUMENT;
@@ -678,7 +678,7 @@ int vtgs_band_owner_mask(const VtgsCamera* cam, int32_t n, const float* means3D,
   ProfScope ps__("band_owner_mask", (hipStream_t)stream);
   hipLaunchKernelGGL(band_owner_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, cs, cam->viewmatrix,
                      cam->projmatrix, n, means3D, scales, scales_are_log ? 1 : 0, cam_q, cam_t, margin_px, growth, owned, mask_out,
-                     escapes);
+                     escapes, centre_rows);
   VTGS_HIP(hipGetLastError());
   return VTGS_OK;
 }

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void band_owner_kernel(
     CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n, const float* __restrict__ means3D,
     const float* __restrict__ scales, int scales_are_log, const float* __restrict__ cam_q, const float* __restrict__ cam_t,
     float margin_px, float growth, const uint8_t* __restrict__ owned, uint8_t* __restrict__ mask_out,
-    uint32_t* __restrict__ escapes) {
+    uint32_t* __restrict__ escapes, int32_t* __restrict__ centre_rows) {
   const CamParams cam = load_cam(cs, Vp, PVp);
   float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, t[3] = {0.f, 0.f, 0.f};
   if (cam_q) {                                     // (NULL: the means are already in the camera frame, as the plain operator gets them)
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void band_owner_kernel(
     else { sc[0] = scales[3 * i]; sc[1] = scales[3 * i + 1]; sc[2] = scales[3 * i + 2]; }
     touch = !outside_tile_rows_ext(cam, mean, sc, cam.row8_begin / 2, (cam.row8_end + 1) / 2, margin_px, growth);
     if (mask_out) mask_out[i] = touch ? 1 : 0;
+    if (centre_rows) centre_rows[i] = centre_tile_row(cam, mean);
   }
   if (escapes) {
     const unsigned long long b = __ballot(touch && i < n && !owned[i]);

@@ -294,6 +294,22 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamLaunch a) {
   g.param[i] -= (g.lr * a.step_size_scale) * (m / denom);
 }
 
+struct AdamRows { const int32_t* rows; int32_t n_rows; uint32_t width[VTGS_ADAM_MAX_GROUPS]; };
+__global__ __launch_bounds__(256) void adam_step_rows_kernel(AdamLaunch a, AdamRows r) {
+  const VtgsAdamGroup& g = a.g[blockIdx.y];
+  const uint32_t w = r.width[blockIdx.y];
+  const size_t j = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (w == 0u || j >= (size_t)r.n_rows * w) return;
+  const size_t i = (size_t)r.rows[j / w] * w + (j % w);
+  const float gr = g.grad[i];
+  const float m = g.exp_avg[i] + (1.f - a.beta1) * (gr - g.exp_avg[i]);            // (adam_step_kernel's lines)
+  const float v = a.beta2 * g.exp_avg_sq[i] + (1.f - a.beta2) * gr * gr;
+  g.exp_avg[i] = m;
+  g.exp_avg_sq[i] = v;
+  const float denom = sqrtf(v) / a.sqrt_bias2 + g.eps;
+  g.param[i] -= (g.lr * a.step_size_scale) * (m / denom);
+}
+
 // seen = radius > 0 and the running maximum of the screen-space radius (src/vtgaussian_slam.py:681-689): four Gaussians per thread
 __global__ __launch_bounds__(256) void seen_and_max_radius_kernel(int n, const int32_t* __restrict__ radii, float* __restrict__ mx,
                                                                   uint8_t* __restrict__ seen) {
@@ -445,6 +461,39 @@ int vtgs_adam_step(const VtgsAdamGroup* groups, int32_t n_groups, int32_t step, 
   a.beta2 = beta2;
   hipLaunchKernelGGL(adam_step_kernel, dim3((uint32_t)((longest + 255) / 256), (uint32_t)n_groups), dim3(256), 0,
                      (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+int vtgs_adam_step_rows(const VtgsAdamGroup* groups, int32_t n_groups, int32_t step, float beta1, float beta2,
+                        const int32_t* rows, int32_t n_rows, int32_t n_total_rows, void* stream) {
+  if (!groups || n_groups <= 0 || n_groups > VTGS_ADAM_MAX_GROUPS || step <= 0 || !(beta1 >= 0.f && beta1 < 1.f) ||
+      !(beta2 >= 0.f && beta2 < 1.f) || n_rows < 0 || n_total_rows <= 0 || (n_rows > 0 && !rows))
+    return VTGS_ERR_INVALID_ARGUMENT;
+  AdamLaunch a;
+  AdamRows r;
+  r.rows = rows; r.n_rows = n_rows;
+  uint64_t longest = 0;
+  for (int k = 0; k < VTGS_ADAM_MAX_GROUPS; ++k) {
+    r.width[k] = 0u;
+    if (k < n_groups) {
+      a.g[k] = groups[k];
+      if (a.g[k].count % (uint64_t)n_total_rows) return VTGS_ERR_INVALID_ARGUMENT;
+      if (a.g[k].count && (!a.g[k].param || !a.g[k].grad || !a.g[k].exp_avg || !a.g[k].exp_avg_sq)) return VTGS_ERR_INVALID_ARGUMENT;
+      r.width[k] = (uint32_t)(a.g[k].count / (uint64_t)n_total_rows);
+      const uint64_t work = (uint64_t)n_rows * r.width[k];
+      longest = work > longest ? work : longest;
+    } else {
+      a.g[k] = VtgsAdamGroup{nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0.f};
+    }
+  }
+  if (longest == 0) return VTGS_OK;
+  if (longest > (uint64_t)0x7fffffff * 256u) return VTGS_ERR_INVALID_ARGUMENT;
+  a.step_size_scale = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));
+  a.sqrt_bias2 = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  a.beta1 = beta1;
+  a.beta2 = beta2;
+  hipLaunchKernelGGL(adam_step_rows_kernel, dim3((uint32_t)((longest + 255) / 256), (uint32_t)n_groups), dim3(256), 0,
+                     (hipStream_t)stream, a, r);
   return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
 }
 

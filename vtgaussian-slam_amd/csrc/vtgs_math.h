@@ -210,6 +210,23 @@ VTGS_HD bool outside_tile_rows_ext(const CamParams& cam, const float mean[3], co
   return above || below;
 }
 
+// The 16-pixel tile row of a Gaussian's projected centre, clamped to the image (a centre above / below the image counts for the
+// first / last row); -1 behind the near plane.  Owner bands of the tile-row partition (partition.OwnerExchange): every rank
+// computes it from the same bytes, so every rank names the same owner.
+VTGS_HD int centre_tile_row(const CamParams& cam, const float mean[3]) {
+  const float x = mean[0], y = mean[1], z = mean[2];
+  const float* V = cam.V;
+  const float tz = fmaf(V[2], x, fmaf(V[6], y, fmaf(V[10], z, V[14])));
+  if (!(tz > kNearCull)) return -1;
+  const float* P = cam.PV;
+  const float hy = fmaf(P[1], x, fmaf(P[5], y, fmaf(P[9], z, P[13])));
+  const float hw = fmaf(P[3], x, fmaf(P[7], y, fmaf(P[11], z, P[15])));
+  const float v = ((hy * (1.f / (hw + 1e-7f)) + 1.f) * (float)cam.H - 1.f) * 0.5f;
+  const float r = floorf(v * (1.f / (float)kBinTile));
+  const float top = (float)(cam.gy16 - 1);
+  return (int)(r > 0.f ? (r < top ? r : top) : 0.f);              // (NaN: row 0)
+}
+
 VTGS_HD bool outside_tile_rows(const CamParams& cam, const float mean[3], const float scale[3], int row_b, int row_e) {
   return outside_tile_rows_ext(cam, mean, scale, row_b, row_e, 0.f, 1.f);
 }

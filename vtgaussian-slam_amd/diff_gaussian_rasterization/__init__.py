@@ -81,7 +81,7 @@ _SIGNATURES = {
     "vtgs_backward_dual_frame_owned": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32] + [_P] * 12 + [_SZ, _U64, ctypes.c_uint32, _P,
                                                       _SZ, ctypes.c_uint32] + [_P] * 12),
     "vtgs_band_owner_mask": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _I32, _P, _P, ctypes.c_float, ctypes.c_float]
-                             + [_P] * 4),
+                             + [_P] * 5),
     "vtgs_forward_planned": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _U64,
                                             ctypes.c_uint32, _P, _P, ctypes.c_uint32, _P]),
     "vtgs_forward_dual_planned": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ,

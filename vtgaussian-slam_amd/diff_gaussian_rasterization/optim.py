@@ -30,6 +30,8 @@ class _Group(ctypes.Structure):
 
 _lib.vtgs_adam_step.restype = ctypes.c_int
 _lib.vtgs_adam_step.argtypes = [ctypes.POINTER(_Group), _I32, _I32, ctypes.c_float, ctypes.c_float, _P]
+_lib.vtgs_adam_step_rows.restype = ctypes.c_int
+_lib.vtgs_adam_step_rows.argtypes = [ctypes.POINTER(_Group), _I32, _I32, ctypes.c_float, ctypes.c_float, _P, _I32, _I32, _P]
 
 
 class FusedAdam:
@@ -58,7 +60,15 @@ class FusedAdam:
                         p.grad.detach_().zero_()
 
     @torch.no_grad()
-    def step(self) -> None:
+    def step(self, rows: torch.Tensor = None) -> None:
+        """`rows` (int32 device tensor of row indices, `partition.OwnerExchange.update_rows`): the per-Gaussian tensors -- those
+        whose first dimension equals that of the first parameter group -- are updated on those rows only (parameter and both
+        moments; vtgs_adam_step_rows); every other tensor (the camera poses) as usual."""
+        n_total = None
+        if rows is not None:
+            if rows.dtype != torch.int32 or not rows.is_cuda or not rows.is_contiguous():
+                raise TypeError("FusedAdam.step(rows=): an int32 contiguous tensor on the HIP device")
+            n_total = int(self.param_groups[0]["params"][0].shape[0])
         # (step, betas) buckets: parameters that first received a gradient at different iterations have different
         # bias corrections, exactly as with torch's per-parameter step counters.
         buckets: Dict[tuple, List[_Group]] = {}
@@ -81,10 +91,15 @@ class FusedAdam:
                 keep.append(grad)
                 rec = _Group(p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                              p.numel(), float(g["lr"]), float(g["eps"]))
-                buckets.setdefault((st["step"], tuple(g["betas"]), p.device), []).append(rec)
-        for (step, betas, dev), recs in buckets.items():
+                by_rows = n_total is not None and p.dim() >= 1 and int(p.shape[0]) == n_total
+                buckets.setdefault((st["step"], tuple(g["betas"]), p.device, by_rows), []).append(rec)
+        for (step, betas, dev, by_rows), recs in buckets.items():
             for i in range(0, len(recs), _MAX):
                 chunk = recs[i:i + _MAX]
                 arr = (_Group * len(chunk))(*chunk)
-                _check(_lib.vtgs_adam_step(arr, len(chunk), int(step), float(betas[0]), float(betas[1]), _stream_ptr(dev)),
-                       "vtgs_adam_step")
+                if by_rows:
+                    _check(_lib.vtgs_adam_step_rows(arr, len(chunk), int(step), float(betas[0]), float(betas[1]), rows.data_ptr(),
+                                                    int(rows.numel()), n_total, _stream_ptr(dev)), "vtgs_adam_step_rows")
+                else:
+                    _check(_lib.vtgs_adam_step(arr, len(chunk), int(step), float(betas[0]), float(betas[1]), _stream_ptr(dev)),
+                           "vtgs_adam_step")

@@ -48,7 +48,7 @@ class OwnedSet:
     """
 
     def __init__(self, params, time_idx: int, raster_settings, first_frame_w2c, band: Tuple[int, int], margin_px: float = 32.0,
-                 growth: float = 1.25, radius_rule=None):
+                 growth: float = 1.25, radius_rule=None, with_centre_rows: bool = False):
         """The list for the fused caller chain: world-frame `params` under the pose of frame `time_idx`
         (`fused.render_frame(..., owned=set)`).  `first_frame_w2c` is accepted for symmetry with render_frame; the band test
         does not need it."""
@@ -58,7 +58,7 @@ class OwnedSet:
             raise RuntimeError("owned sets are built for isotropic maps (log_scales [N,1], every reference config)")
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         self._build(raster_settings, band, margin_px, growth, radius_rule, f32(params["means3D"]), f32(params["log_scales"]), True,
-                    f32(params["cam_unnorm_rots"][0, :, time_idx]), f32(params["cam_trans"][0, :, time_idx]))
+                    f32(params["cam_unnorm_rots"][0, :, time_idx]), f32(params["cam_trans"][0, :, time_idx]), with_centre_rows)
 
     @classmethod
     def for_operator(cls, means3D, scales, raster_settings, band: Tuple[int, int], margin_px: float = 32.0, growth: float = 1.25,
@@ -69,10 +69,11 @@ class OwnedSet:
         _need_device(means3D, "OwnedSet")
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         self = cls.__new__(cls)
-        self._build(raster_settings, band, margin_px, growth, radius_rule, f32(means3D), f32(scales), False, None, None)
+        self._build(raster_settings, band, margin_px, growth, radius_rule, f32(means3D), f32(scales), False, None, None, False)
         return self
 
-    def _build(self, raster_settings, band, margin_px, growth, radius_rule, means3D, scales, scales_are_log, cam_q, cam_t):
+    def _build(self, raster_settings, band, margin_px, growth, radius_rule, means3D, scales, scales_are_log, cam_q, cam_t,
+               with_centre_rows=False):
         import os
 
         import torch
@@ -88,21 +89,24 @@ class OwnedSet:
         self.n_map, self.scales_are_log = int(means3D.shape[0]), bool(scales_are_log)
         self.mask = torch.empty(self.n_map, dtype=torch.uint8, device=dev)
         self.escapes = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._test(cam, means3D, scales, cam_q, cam_t, self.margin_px, self.growth, None, self.mask, None, None)
+        # centre_rows: the 16-pixel tile row of every Gaussian's projected centre (-1 behind the near plane) -- its owner band
+        self.centre_rows = torch.empty(self.n_map, dtype=torch.int32, device=dev) if with_centre_rows else None
+        self._test(cam, means3D, scales, cam_q, cam_t, self.margin_px, self.growth, None, self.mask, None, None, self.centre_rows)
         self.idx64 = torch.nonzero(self.mask).reshape(-1)              # ascending; one device -> host read (the count)
         self.idx = self.idx64.to(torch.int32)
 
     def __len__(self) -> int:
         return int(self.idx.numel())
 
-    def _test(self, cam, means3D, scales, cam_q, cam_t, margin_px, growth, owned, mask_out, escapes, stream):
+    def _test(self, cam, means3D, scales, cam_q, cam_t, margin_px, growth, owned, mask_out, escapes, stream, centre_rows=None):
         import ctypes
 
         from . import _check, _lib, _stream_ptr
         ptr = lambda x: None if x is None else x.data_ptr()
         _check(_lib.vtgs_band_owner_mask(ctypes.byref(cam.c), means3D.shape[0], means3D.data_ptr(), scales.data_ptr(),
                                          1 if self.scales_are_log else 0, ptr(cam_q), ptr(cam_t), margin_px, growth, ptr(owned),
-                                         ptr(mask_out), ptr(escapes), _stream_ptr(means3D.device) if stream is None else stream),
+                                         ptr(mask_out), ptr(escapes), ptr(centre_rows),
+                                         _stream_ptr(means3D.device) if stream is None else stream),
                "vtgs_band_owner_mask")
 
     def admit(self, n_map: int, band) -> None:
@@ -137,6 +141,130 @@ def phase_escapes(owned_sets, group=None) -> int:
     if dist.is_available() and dist.is_initialized():
         all_reduce_sum(total, group)
     return int(total.item())
+
+
+class OwnerExchange:
+    """Mapping on N ranks without the 20 N-byte all-reduce ("reduce-scatter by Gaussian owner band ... sparse halo
+    exchange with the neighbouring bands only, then each GPU runs Adam on its owned slice").
+
+    Every Gaussian has ONE owner for the phase: the rank whose band holds the tile row of its projected centre under the phase's
+    reference pose (`OwnedSet.centre_rows`: computed from the same bytes on every rank, so every rank names the same owner).
+    `lists` is this rank's UNION list for the phase -- an `OwnedSet` built with `with_centre_rows=True` and a margin that covers
+    every view the phase renders (the per-view lists the renders use must be subsets of it: `covers()`).  Built collectively
+    (one all-gather of the ranks' N-byte masks).  Per iteration, after `backward()`:
+
+        ex.reduce_grads(params)        # halo rows -> their owners (point-to-point, only between ranks that share Gaussians)
+        optimizer.step(rows=ex.update_rows)   # Adam on the rows this rank owns (+ the rows nobody lists, replicated)
+        ex.publish(params)             # updated rows -> the ranks that list them
+
+    and `ex.gather_all(params)` at the end of the phase (or before lists are rebuilt) hands every rank every owner's rows.
+    Between those points a rank holds current values for the rows of ITS list only -- all it renders from.
+    The gradient of a row is its owner's own contribution plus the listers' in ascending rank order: the same on every run.
+    """
+
+    def __init__(self, lists, image_height: int, rank: int, world: int, keys=("rgb_colors", "logit_opacities", "log_scales"),
+                 group=None):
+        import torch
+        import torch.distributed as dist
+        if lists.centre_rows is None:
+            raise ValueError("OwnerExchange needs an OwnedSet built with with_centre_rows=True")
+        self.rank, self.world, self.group, self.keys = int(rank), int(world), group, tuple(keys)
+        dev = lists.mask.device
+        self.n_map = lists.n_map
+        ends = torch.tensor([e for _b, e in all_bands(image_height, world)], device=dev, dtype=torch.int32)
+        owner = torch.bucketize(lists.centre_rows.clamp(min=0), ends, right=True).clamp(max=world - 1)     # [N], same on every rank
+        staged = lists.mask.is_cuda and _host_staged(group)
+        mine = lists.mask.cpu() if staged else lists.mask
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine, group=group)
+        masks = torch.stack(gathered).to(dev).bool()                                                      # [world, N]
+        listed = masks.any(0)
+        own = (owner == rank) & listed
+        if bool((own & ~masks[rank]).any()):
+            raise RuntimeError("a Gaussian owned by this rank's band is missing from its list (margin below the band test's slack?)")
+        self.own_rows = torch.nonzero(own).reshape(-1)
+        self.update_rows = torch.nonzero(own | ~listed).reshape(-1).to(torch.int32)      # + the rows nobody lists: replicated Adam
+        self.listed = listed
+        self.union_mask = masks[rank]
+        # grads travel lister -> owner, parameters owner -> lister: the same two index sets per pair of ranks
+        self.to_owner = {q: torch.nonzero(masks[rank] & (owner == q)).reshape(-1) for q in range(world) if q != rank}
+        self.from_lister = {q: torch.nonzero(masks[q] & own).reshape(-1) for q in range(world) if q != rank}
+        self.to_owner = {q: v for q, v in self.to_owner.items() if v.numel()}
+        self.from_lister = {q: v for q, v in self.from_lister.items() if v.numel()}
+        self.halo_rows = int(sum(v.numel() for v in self.to_owner.values()))
+
+    def covers(self, owned) -> bool:
+        """Is the per-view list `owned` (what a render of this phase uses) inside this rank's union list?  (device read)"""
+        return not bool((owned.mask.bool() & ~self.union_mask).any())
+
+    def _flat(self, params, rows, grad: bool):
+        import torch
+        return torch.cat([(params[k].grad if grad else params[k].detach()).reshape(self.n_map, -1).index_select(0, rows)
+                          for k in self.keys], dim=1)
+
+    def _exchange(self, send, recv_rows, width, dev):
+        import torch
+        import torch.distributed as dist
+        staged = dev.type == "cuda" and _host_staged(self.group)
+        recv = {q: torch.empty((n, width), dtype=torch.float32, device="cpu" if staged else dev) for q, n in recv_rows.items()}
+        keep = {q: (t.cpu() if staged else t.contiguous()) for q, t in send.items()}
+        ops = [dist.P2POp(dist.irecv, recv[q], q, self.group) for q in sorted(recv)]
+        ops += [dist.P2POp(dist.isend, keep[q], q, self.group) for q in sorted(keep)]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return {q: r.to(dev) for q, r in recv.items()}
+
+    def reduce_grads(self, params) -> int:
+        """Send the gradients of the halo rows to their owners and add what the listers of this rank's rows send (in place on
+        `.grad`; a parameter without a gradient on this rank counts as zero).  Returns the bytes this rank sent."""
+        import torch
+        dev = params[self.keys[0]].device
+        for k in self.keys:
+            if params[k].grad is None:
+                params[k].grad = torch.zeros_like(params[k])
+        width = sum(int(params[k].numel() // self.n_map) for k in self.keys)
+        send = {q: self._flat(params, rows, True) for q, rows in self.to_owner.items()}
+        got = self._exchange(send, {q: int(r.numel()) for q, r in self.from_lister.items()}, width, dev)
+        for q in sorted(got):                                           # ascending rank: a fixed summation order
+            o = 0
+            for k in self.keys:
+                w = int(params[k].numel() // self.n_map)
+                params[k].grad.reshape(self.n_map, -1).index_add_(0, self.from_lister[q], got[q][:, o:o + w])
+                o += w
+        return sum(int(t.numel()) * 4 for t in send.values())
+
+    def publish(self, params) -> int:
+        """After the owner's Adam step: the updated rows go to the ranks that list them (in place on the parameters)."""
+        import torch
+        dev = params[self.keys[0]].device
+        width = sum(int(params[k].numel() // self.n_map) for k in self.keys)
+        send = {q: self._flat(params, rows, False) for q, rows in self.from_lister.items()}
+        got = self._exchange(send, {q: int(r.numel()) for q, r in self.to_owner.items()}, width, dev)
+        with torch.no_grad():
+            for q, buf in got.items():
+                o = 0
+                for k in self.keys:
+                    w = int(params[k].numel() // self.n_map)
+                    params[k].reshape(self.n_map, -1).index_copy_(0, self.to_owner[q], buf[:, o:o + w])
+                    o += w
+        return sum(int(t.numel()) * 4 for t in send.values())
+
+    def gather_all(self, params) -> None:
+        """End of the phase: every rank receives every owner's rows (one all-reduce of the owners' disjoint contributions);
+        the rows nobody lists were updated on every rank alike."""
+        import torch
+        with torch.no_grad():
+            width = sum(int(params[k].numel() // self.n_map) for k in self.keys)
+            flat = torch.zeros((self.n_map, width), dtype=torch.float32, device=params[self.keys[0]].device)
+            flat.index_copy_(0, self.own_rows, self._flat(params, self.own_rows, False))
+            all_reduce_sum(flat, self.group)
+            o = 0
+            for k in self.keys:
+                w = int(params[k].numel() // self.n_map)
+                p2 = params[k].reshape(self.n_map, -1)
+                p2.copy_(torch.where(self.listed[:, None], flat[:, o:o + w], p2))
+                o += w
 
 
 def _host_staged(group=None) -> bool:
