@@ -270,7 +270,8 @@ def _owner_worker(rank, world, port, out):
     g = torch.Generator().manual_seed(5)
     centre = torch.randint(-1, 7, (N,), generator=g).to(torch.int32)  # -1: behind the camera, listed nowhere
     b, e = all_bands(H, world)[rank]
-    mask = ((centre >= b - 1) & (centre < e + 1) & (centre >= 0)).to(torch.uint8)     # a band's list reaches one row into the neighbour
+    big = (torch.arange(N) % 37 == 0) & (centre >= 0)                  # a few splats large enough to be on EVERY rank's list
+    mask = ((((centre >= b - 1) & (centre < e + 1)) | big) & (centre >= 0)).to(torch.uint8)   # a list reaches one row into the neighbours
     ex = OwnerExchange(SimpleNamespace(mask=mask, centre_rows=centre, n_map=N), H, rank, world)
     keys, widths, lrs = ("rgb_colors", "logit_opacities", "log_scales"), (3, 1, 1), (0.0025, 0.05, 0.005)
     start = {k: torch.randn(N, w, generator=g) for k, w in zip(keys, widths)}
@@ -306,15 +307,17 @@ def _owner_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_owner_exchange_equals_allreduce_and_full_adam(tmp_path):
-    """partition.OwnerExchange on two ranks (gloo): the owner's summed gradient equals the all-reduced one on its rows, after
+@pytest.mark.parametrize("world", [2, 3])
+def test_owner_exchange_equals_allreduce_and_full_adam(tmp_path, world):
+    """partition.OwnerExchange on two and on three ranks (gloo; three: bands of 3 / 2 / 2 tile rows, so ranks 0 and 2 exchange only
+    the splats that are on every list): the owner's summed gradient equals the all-reduced one on its rows, after
     publish every rank's LISTED rows equal the all-reduce + full-Adam route, rows outside its list are stale until gather_all,
     and the rows nobody lists (behind the camera) are updated on every rank alike."""
     out = str(tmp_path / "own")
-    mp.spawn(_owner_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    got = [torch.load(f"{out}.{r}") for r in (0, 1)]
+    mp.spawn(_owner_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = [torch.load(f"{out}.{r}") for r in range(world)]
     for r in got:
-        assert r["worst_grad"] <= 1e-6 and r["final"] <= 1e-6, r
+        assert r["worst_grad"] <= 2e-6 and r["final"] <= 2e-6, r
         assert r["stale"] > 1e-3, r                                   # (the test would be vacuous if nothing was ever stale)
         assert r["halo_rows"] > 0 and r["update"] == r["own"] + r["behind"]
-    assert got[0]["own"] + got[1]["own"] + got[0]["behind"] == 500
+    assert sum(r["own"] for r in got) + got[0]["behind"] == 500
