@@ -159,9 +159,170 @@ std::vector<at::Tensor> rasterize(at::Tensor means3D, at::Tensor means2D, at::Te
                           slot_ptr, flags, stream);
 }
 
+// ---- the fused frame render (diff_gaussian_rasterization/fused.py: pose transform + render variables + both renders) ----------
+// Same division of labour: Python decides (capacities, mode, result record, which gradients are wanted, the owned set of a rank
+// of the tile-row partition); this node does the per-call work -- vtgs_prepare_frame[_owned], vtgs_forward_dual[_planned] and, in
+// the backward, vtgs_backward_dual_frame_owned + vtgs_pose_gradient -- without the interpreter.  Why now: with the kernels of
+// one BAND a rank's iteration is bound by this host path.
+// forward returns {im, depth_sil, radii, workspace, status}.
+struct RenderFrame : public torch::autograd::Function<RenderFrame> {
+  static variable_list forward(AutogradContext* ctx, at::Tensor means3D, at::Tensor rgb, at::Tensor unnorm_rot, at::Tensor logit_op,
+                               at::Tensor log_scales, at::Tensor cam_q, at::Tensor cam_t, at::Tensor depth_w2c, at::Tensor cam_bytes,
+                               at::Tensor bg, at::Tensor view, at::Tensor proj, int64_t capacity, int64_t tile_cap, int64_t bin_plan,
+                               int64_t slot_ptr, int64_t fwd_flags, int64_t frame_flags, int64_t stream,
+                               c10::optional<at::Tensor> owned_idx, c10::optional<at::Tensor> owned_idx64,
+                               c10::optional<at::Tensor> owned_mask, c10::optional<at::Tensor> owned_escapes) {
+    const at::Device dev = means3D.device();
+    TORCH_CHECK(dev.is_cuda(), "render_frame needs tensors on a HIP device (torch 'cuda'); no CPU path exists");
+    c10::DeviceGuard guard(dev);
+    const int64_t n_map = means3D.size(0);
+    const bool owned = owned_idx.has_value() && owned_idx->defined();
+    const int64_t n = owned ? owned_idx->numel() : n_map;
+    means3D = need(means3D, "means3D", 3, n_map, dev);
+    rgb = need(rgb, "rgb_colors", 3, n_map, dev);
+    unnorm_rot = need(unnorm_rot, "unnorm_rotations", 4, n_map, dev);
+    logit_op = need(logit_op, "logit_opacities", 1, n_map, dev);
+    log_scales = need(log_scales, "log_scales", 1, n_map, dev);
+    cam_q = need(cam_q, "camera rotation", 4, 1, dev);
+    cam_t = need(cam_t, "camera translation", 3, 1, dev);
+    depth_w2c = need(depth_w2c, "first-frame w2c", 16, 1, dev);
+    CamRecord cam = camera_from(cam_bytes, bg, view, proj);
+    const int64_t H = cam.c.image_height, W = cam.c.image_width;
+    const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
+    void* st_ = reinterpret_cast<void*>(stream);
+    // one block for the render variables: means_cam 3, opacities 1, scales 3, rotations 4, depth colours 3 (+ compact colours 3)
+    at::Tensor vars = at::empty({std::max<int64_t>(n, 1) * (owned ? 17 : 14)}, f32);
+    float* v = vars.data_ptr<float>();
+    float *means_cam = v, *opac = v + 3 * n, *scales = v + 4 * n, *rot = v + 7 * n, *dcol = v + 11 * n, *rgb_c = v + 14 * n;
+    int rc;
+    if (owned) {
+      TORCH_CHECK(owned_idx->scalar_type() == at::kInt && owned_idx->is_contiguous() && owned_idx->device() == dev &&
+                  owned_idx64.has_value() && owned_mask.has_value() && owned_escapes.has_value(), "owned set: int32 index list on the device");
+      rc = vtgs_band_owner_mask(&cam.c, (int32_t)n_map, means3D.data_ptr<float>(), log_scales.data_ptr<float>(), 1,
+                                cam_q.data_ptr<float>(), cam_t.data_ptr<float>(), 1.f, 1.f, owned_mask->data_ptr<uint8_t>(), nullptr,
+                                reinterpret_cast<uint32_t*>(owned_escapes->data_ptr<int32_t>()), nullptr, st_);
+      TORCH_CHECK(rc == VTGS_OK, "vtgs_band_owner_mask failed: ", vtgs_strerror(rc));
+      rc = vtgs_prepare_frame_owned((int32_t)n, owned_idx->data_ptr<int32_t>(), means3D.data_ptr<float>(), logit_op.data_ptr<float>(),
+                                    log_scales.data_ptr<float>(), unnorm_rot.data_ptr<float>(), rgb.data_ptr<float>(),
+                                    cam_q.data_ptr<float>(), cam_t.data_ptr<float>(), depth_w2c.data_ptr<float>(), means_cam, opac,
+                                    scales, rot, dcol, rgb_c, st_);
+    } else {
+      rc = vtgs_prepare_frame((int32_t)n, means3D.data_ptr<float>(), logit_op.data_ptr<float>(), log_scales.data_ptr<float>(),
+                              unnorm_rot.data_ptr<float>(), cam_q.data_ptr<float>(), cam_t.data_ptr<float>(),
+                              depth_w2c.data_ptr<float>(), means_cam, opac, scales, rot, dcol, st_);
+    }
+    TORCH_CHECK(rc == VTGS_OK, "vtgs_prepare_frame failed: ", vtgs_strerror(rc), " (", vtgs_last_hip_error(), ")");
+    const float* colors_a = owned ? rgb_c : rgb.data_ptr<float>();
+    at::Tensor images = at::empty({6, H, W}, f32);
+    at::Tensor im = images.narrow(0, 0, 3), depth_sil = images.narrow(0, 3, 3);
+    at::Tensor radii = at::empty({n}, f32.dtype(at::kInt));
+    const size_t nbytes = vtgs_workspace_bytes((int32_t)n, (int32_t)W, (int32_t)H, (uint64_t)capacity, (uint32_t)tile_cap);
+    at::Tensor workspace = at::empty({(int64_t)nbytes}, f32.dtype(at::kByte));
+    if (g_poison) { workspace.fill_(0xFF); images.fill_(std::nanf("")); }
+    const int st = bin_plan
+        ? vtgs_forward_dual_planned(&cam.c, (int32_t)n, means_cam, colors_a, dcol, opac, scales, rot, im.data_ptr<float>(),
+                                    depth_sil.data_ptr<float>(), radii.data_ptr<int32_t>(), workspace.data_ptr(), nbytes,
+                                    (uint64_t)capacity, (uint32_t)tile_cap, reinterpret_cast<uint32_t*>(bin_plan),
+                                    reinterpret_cast<VtgsForwardInfo*>(slot_ptr), (uint32_t)fwd_flags, st_)
+        : vtgs_forward_dual(&cam.c, (int32_t)n, means_cam, colors_a, dcol, opac, scales, rot, im.data_ptr<float>(),
+                            depth_sil.data_ptr<float>(), radii.data_ptr<int32_t>(), workspace.data_ptr(), nbytes, (uint64_t)capacity,
+                            (uint32_t)tile_cap, reinterpret_cast<VtgsForwardInfo*>(slot_ptr), (uint32_t)fwd_flags, st_);
+    TORCH_CHECK(st == VTGS_OK || st == VTGS_ERR_INSTANCE_OVERFLOW, "vtgs_forward_dual failed: ", vtgs_strerror(st), " (",
+                vtgs_last_hip_error(), ")");
+    if (owned)                                                    // the radii of the map: 0 outside the list
+      radii = at::zeros({n_map}, f32.dtype(at::kInt)).index_copy_(0, *owned_idx64, radii);
+    at::Tensor idx_saved = owned ? *owned_idx : at::Tensor();
+    ctx->save_for_backward({means3D, rgb, unnorm_rot, cam_q, cam_t, depth_w2c, vars, images, workspace, cam_bytes, bg, view, proj,
+                            idx_saved});
+    ctx->saved_data["capacity"] = capacity;
+    ctx->saved_data["tile_cap"] = tile_cap;
+    ctx->saved_data["stream"] = stream;
+    ctx->saved_data["n"] = n;
+    ctx->saved_data["n_map"] = n_map;
+    ctx->saved_data["frame_flags"] = frame_flags;
+    ctx->set_materialize_grads(false);
+    at::Tensor status = at::empty({}, at::TensorOptions().dtype(at::kLong));
+    status.fill_((int64_t)st);
+    ctx->mark_non_differentiable({radii, workspace, status});
+    return {im, depth_sil, radii, workspace, status};
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const at::Tensor &means3D = saved[0], &rgb = saved[1], &unnorm_rot = saved[2], &cam_q = saved[3], &cam_t = saved[4],
+                     &depth_w2c = saved[5], &vars = saved[6], &images = saved[7], &workspace = saved[8], &idx = saved[13];
+    const at::Device dev = means3D.device();
+    c10::DeviceGuard guard(dev);
+    CamRecord cam = camera_from(saved[9], saved[10], saved[11], saved[12]);
+    const int64_t n = ctx->saved_data["n"].toInt(), n_map = ctx->saved_data["n_map"].toInt(),
+                  capacity = ctx->saved_data["capacity"].toInt(), tile_cap = ctx->saved_data["tile_cap"].toInt(),
+                  stream = ctx->saved_data["stream"].toInt(), flags = ctx->saved_data["frame_flags"].toInt();
+    const bool owned = idx.defined();
+    void* st_ = reinterpret_cast<void*>(stream);
+    const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
+    at::Tensor im = images.narrow(0, 0, 3), depth_sil = images.narrow(0, 3, 3);
+    at::Tensor g_im = grads[0].defined() ? grads[0].to(at::kFloat).contiguous() : at::zeros_like(im);
+    at::Tensor g_ds = grads[1].defined() ? grads[1].to(at::kFloat).contiguous() : at::zeros_like(depth_sil);
+    const bool want_g = flags & 1, want_p = flags & 2, want_a = flags & 4;
+    // the map-sized gradients somebody asked for, one block (with a list the kernel writes the listed rows only: zeros first)
+    const int64_t width = (want_g ? 7 : 0) + (want_a ? 5 : 0);
+    at::Tensor flat = owned ? at::zeros({std::max<int64_t>(width, 1) * n_map}, f32) : at::empty({std::max<int64_t>(width, 1) * n_map}, f32);
+    float* f = flat.data_ptr<float>();
+    at::Tensor g_means3D, g_ur, g_rgb, g_logit, g_ls;
+    int64_t off = 0;
+    auto take = [&](int64_t w) { at::Tensor t = flat.narrow(0, off * n_map, w * n_map).view({n_map, w}); off += w; return t; };
+    if (want_g) { g_means3D = take(3); g_ur = take(4); }
+    if (want_a) { g_rgb = take(3); g_logit = take(1); g_ls = take(1); }
+    (void)f;
+    auto ptr = [](const at::Tensor& t) -> float* { return t.defined() ? t.data_ptr<float>() : nullptr; };
+    const uint32_t rows = vtgs_pose_partial_rows((int32_t)n);
+    at::Tensor partials = want_p ? at::empty({std::max<int64_t>(rows, 1), 12}, f32) : at::Tensor();
+    at::Tensor g_q, g_t;
+    if (n > 0 && flags != 0) {
+      const float* v = vars.data_ptr<float>();
+      const float *means_cam = v, *opac = v + 3 * n, *scales = v + 4 * n, *rot = v + 7 * n, *dcol = v + 11 * n, *rgb_c = v + 14 * n;
+      const size_t sbytes = vtgs_backward_dual_scratch_bytes((int32_t)n, (uint64_t)capacity);   // by the capacity (see Rasterize::backward)
+      at::Tensor scratch = at::empty({(int64_t)sbytes}, f32.dtype(at::kByte));
+      if (g_poison) scratch.fill_(0xFF);
+      const int st = vtgs_backward_dual_frame_owned(
+          &cam.c, (int32_t)n, owned ? idx.data_ptr<int32_t>() : nullptr, means_cam, owned ? rgb_c : rgb.data_ptr<float>(), dcol, opac,
+          scales, rot, im.data_ptr<float>(), depth_sil.data_ptr<float>(), g_im.data_ptr<float>(), g_ds.data_ptr<float>(),
+          workspace.data_ptr(), (size_t)workspace.numel(), (uint64_t)capacity, (uint32_t)tile_cap, scratch.data_ptr(), sbytes,
+          (uint32_t)flags, means3D.data_ptr<float>(), unnorm_rot.data_ptr<float>(), cam_q.data_ptr<float>(), cam_t.data_ptr<float>(),
+          depth_w2c.data_ptr<float>(), ptr(g_rgb), ptr(g_means3D), ptr(g_logit), ptr(g_ls), ptr(g_ur), ptr(partials), st_);
+      TORCH_CHECK(st == VTGS_OK, "vtgs_backward_dual_frame failed: ", vtgs_strerror(st), " (", vtgs_last_hip_error(), ")");
+      if (want_p) {
+        at::Tensor qt = at::empty({7}, f32);
+        g_q = qt.narrow(0, 0, 4); g_t = qt.narrow(0, 4, 3);
+        const int sp = vtgs_pose_gradient(partials.data_ptr<float>(), rows, cam_q.data_ptr<float>(), g_q.data_ptr<float>(),
+                                          g_t.data_ptr<float>(), st_);
+        TORCH_CHECK(sp == VTGS_OK, "vtgs_pose_gradient failed: ", vtgs_strerror(sp));
+      }
+    } else if (want_p) {                                           // nothing rendered: zero pose gradient, no launch
+      g_q = at::zeros({4}, f32); g_t = at::zeros({3}, f32);
+    }
+    if (n == 0 && !owned && width > 0) flat.zero_();
+    at::Tensor none;
+    return {g_means3D, g_rgb, g_ur, g_logit.defined() ? g_logit : none, g_ls.defined() ? g_ls : none, g_q, g_t,
+            none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
+  }
+};
+
+std::vector<at::Tensor> render_frame(at::Tensor means3D, at::Tensor rgb, at::Tensor unnorm_rot, at::Tensor logit_op, at::Tensor log_scales,
+                                     at::Tensor cam_q, at::Tensor cam_t, at::Tensor depth_w2c, at::Tensor cam_bytes, at::Tensor bg,
+                                     at::Tensor view, at::Tensor proj, int64_t capacity, int64_t tile_cap, int64_t bin_plan,
+                                     int64_t slot_ptr, int64_t fwd_flags, int64_t frame_flags, int64_t stream,
+                                     c10::optional<at::Tensor> owned_idx, c10::optional<at::Tensor> owned_idx64,
+                                     c10::optional<at::Tensor> owned_mask, c10::optional<at::Tensor> owned_escapes) {
+  return RenderFrame::apply(means3D, rgb, unnorm_rot, logit_op, log_scales, cam_q, cam_t, depth_w2c, cam_bytes, bg, view, proj, capacity,
+                            tile_cap, bin_plan, slot_ptr, fwd_flags, frame_flags, stream, owned_idx, owned_idx64, owned_mask,
+                            owned_escapes);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.def("render_frame", &render_frame, "fused.render_frame forward with a C++ autograd node behind it");
   m.def("rasterize", &rasterize, "GaussianRasterizer forward with a C++ autograd node behind it");
   m.def("abi_version", []() { return (int64_t)vtgs_abi_version(); });
   m.def("set_poison", [](bool on) { g_poison = on; });

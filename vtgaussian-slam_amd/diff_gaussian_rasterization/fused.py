@@ -178,6 +178,57 @@ def _backward_fused(ctx, g_im, g_ds):
 _RenderFrame._backward_fused = staticmethod(_backward_fused)
 
 
+def _render_frame_ext(means3D, rgb, unnorm_rot, logit_op, log_scales, q, t, depth_w2c, cam: _Camera, flags: int, owned):
+    """The same render through the C++ autograd node (csrc/vtgs_torch.cpp `RenderFrame`): the policy of `_run_forward` -- capacities,
+    checked or run-ahead mode, the pinned result record, the retry after an overflow -- stays here, the per-call work and the
+    whole backward run without the interpreter.  With the kernels of one band of the tile-row partition a rank's iteration is
+    bound by this host path."""
+    from . import (PLANNED, VTGS_ERR_INSTANCE_OVERFLOW, VTGS_FORWARD_ASYNC, VTGS_FORWARD_CHECKED, _FORWARD_MODE, _async_ok,
+                   _caps_in_use, _choose_capacities, _drain, _ext, _forward_hints, _grow_after_overflow, _plan_for, _record_info,
+                   _slot_lock, _slot_pool)
+    device = means3D.device
+    n = int(means3D.shape[0]) if owned is None else int(owned.idx.numel())
+    stream = _stream_ptr(device)
+    key = (device.index, n, cam.W, cam.H, cam.band)
+    fs = _ForwardState()
+    fs.cam, fs.n, fs.image_state, fs.key, fs.pending = cam, n, None, key, None
+    want_async = flags != 0
+    o = (None, None, None, None) if owned is None else (owned.idx, owned.idx64, owned.mask, owned.escapes)
+    with _slot_lock:
+        pool = _slot_pool(device, stream)
+        _drain(pool)
+        slot = pool.take(fs)
+        capacity, tile_cap = _choose_capacities(key, n)
+        run_ahead = want_async and _FORWARD_MODE == "auto" and _async_ok.get(key) == (capacity, tile_cap)
+        info = pool.info[slot]
+        for _attempt in range(6):
+            info.complete = 0
+            plan = _plan_for(key, device, tile_cap).data_ptr() if tile_cap & PLANNED else 0
+            im, depth_sil, radii, workspace, status = _ext.render_frame(
+                means3D, rgb, unnorm_rot, logit_op, log_scales, q, t, depth_w2c, cam.bytes, cam.bg, cam.view, cam.proj, capacity,
+                tile_cap, plan, pool.ptr[slot], (VTGS_FORWARD_ASYNC if run_ahead else VTGS_FORWARD_CHECKED) | _forward_hints(key, tile_cap),
+                flags, stream, *o)
+            if run_ahead:
+                break
+            if int(status) == VTGS_ERR_INSTANCE_OVERFLOW:     # the record says what is needed: grow whichever was short
+                capacity, tile_cap = _grow_after_overflow(key, n, device, info, capacity, tile_cap, workspace)
+                continue
+            break
+        else:
+            raise RuntimeError("vtgs_forward_dual: instance capacity kept overflowing")
+        fs.workspace, fs.capacity, fs.tile_cap = workspace, capacity, tile_cap
+        if run_ahead:
+            fs._instances = None
+            fs.pending = (pool, slot, device, stream)
+            pool.pending.append(fs)
+        else:
+            pool.owner[slot] = None
+            _caps_in_use.setdefault(key, (capacity, tile_cap))
+            _record_info(key, n, cam.W, cam.H, capacity, info)
+            fs._instances = int(info.instances)
+    return im, depth_sil, radii
+
+
 def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings, first_frame_w2c: torch.Tensor,
                  gaussians_grad: bool, camera_grad: bool, radius_rule: Optional[str] = None, tile_rows=None, owned=None):
     """RGB render + [z,1,z^2] render of frame `time_idx` (see module docstring).  Returns (im [3,H,W],
@@ -218,6 +269,12 @@ def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings
         if not owned.scales_are_log:
             raise ValueError("this owned set was built for the plain operator (OwnedSet.for_operator)")
         owned.admit(params["means3D"].shape[0], tile_rows)
+    from . import _ext
+    if (_ext is not None and hasattr(_ext, "render_frame") and os.environ.get("VTGS_DUAL", "1") != "0"
+            and os.environ.get("VTGS_FRAME_EPILOGUE", "1") != "0" and os.environ.get("VTGS_FUSED_EXT", "1") != "0"
+            and not torch.cuda.is_current_stream_capturing()):
+        return _render_frame_ext(g(params["means3D"]), params["rgb_colors"], g(params["unnorm_rotations"]), params["logit_opacities"],
+                                 params["log_scales"], q, t, first_frame_w2c.to(dev), cam, flags, owned)
     return _RenderFrame.apply(g(params["means3D"]), params["rgb_colors"], g(params["unnorm_rotations"]),
                               params["logit_opacities"], params["log_scales"], q, t,
                               first_frame_w2c.to(dev), cam, flags, owned)
