@@ -506,7 +506,9 @@ def main():
                     "gaussians_in_global_set": rec["config"]["gaussians_in_global_set"],
                     "pose_error_after_tracking_cm_deg": rec["pose_error_after_tracking_cm_deg"], "n_gpus": world,
                     "partition": rec["config"]["partition"],
-                    "note": "synthetic Replica-room0-like sequence through the get_loss mirror; tracking on the current view, mapping "
+                    "note": "synthetic Replica-room0-like sequence " + ("through the get_loss mirror" if world == 1 else
+                            f"on {world} ranks: the fused operators with the band forms of the losses (no second call over a global set)") +
+                            "; tracking on the current view, mapping "
                             "on the reference's schedule: ordinary frames draw one keyframe per iteration (ONE get_loss call, plus "
                             "the second one over the 3 N-Gaussian global set when the draw is the base frame), base frames make "
                             "BOTH calls every iteration.  " + ("The windows grow over the 40 ordinary frames as in the reference (the base frame, "
