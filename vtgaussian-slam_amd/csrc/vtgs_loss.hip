@@ -16,12 +16,15 @@ constexpr int kST = 32;                 // output tile edge
 constexpr int kSR = 5;                  // window radius
 constexpr int kSP = kST + 2 * kSR;      // staged patch edge (42)
 
+// The reference's 1-D window (utils/slam_external.py:54-56: float32(exp(-(x - 5)^2 / 4.5)) / their float32 sum), evaluated once
+// on the host.  Round 4: every thread of both kernels used to evaluate it itself -- 11 exponentials and 11 IEEE divisions, a
+// fifth of the forward kernel's instructions and over a quarter of the backward's.
 __device__ __forceinline__ void gauss11(float (&w)[11]) {
-  float s = 0.f;
+  constexpr float k[11] = {0.0010283802403137088f, 0.007598758675158024f, 0.036000773310661316f, 0.1093606948852539f,
+                           0.21300554275512695f,   0.2660117447376251f,   0.21300554275512695f,  0.1093606948852539f,
+                           0.036000773310661316f,  0.007598758675158024f, 0.0010283802403137088f};
 #pragma unroll
-  for (int i = 0; i < 11; ++i) { w[i] = __expf(-(float)((i - 5) * (i - 5)) / (2.f * 1.5f * 1.5f)); s += w[i]; }
-#pragma unroll
-  for (int i = 0; i < 11; ++i) w[i] /= s;
+  for (int i = 0; i < 11; ++i) w[i] = k[i];
 }
 
 __global__ __launch_bounds__(256) void ssim_forward_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
@@ -99,12 +102,13 @@ __global__ __launch_bounds__(256) void ssim_forward_kernel(const float* __restri
       if (gy < H && gx < W && gy >= rb && gy < re) {
         const float s11 = xx - m1 * m1, s22 = yy - m2 * m2, s12 = xy - m1 * m2;
         const float a1 = 2.f * m1 * m2 + c1, a2 = 2.f * s12 + c2, b1 = m1 * m1 + m2 * m2 + c1, b2 = s11 + s22 + c2;
-        const float ib = 1.f / (b1 * b2);
+        const float r1 = 1.f / b1, r2 = 1.f / b2;              // (two divisions per pixel instead of three)
+        const float ib = r1 * r2;
         const float ssim = a1 * a2 * ib;
         acc += ssim;
         if (gmaps) {
-          const float d_mu1 = 2.f * m2 * a2 * ib - ssim * 2.f * m1 / b1;
-          const float d_s11 = -ssim / b2, d_s12 = 2.f * a1 * ib;
+          const float d_mu1 = 2.f * m2 * a2 * ib - ssim * 2.f * m1 * r1;
+          const float d_s11 = -ssim * r2, d_s12 = 2.f * a1 * ib;
           const size_t o2 = plane + (size_t)gy * W + gx, P3 = (size_t)C * H * W;
           gmaps[o2] = d_mu1 - 2.f * m1 * d_s11 - m2 * d_s12;
           gmaps[P3 + o2] = d_s11;
