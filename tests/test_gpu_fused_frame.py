@@ -256,3 +256,49 @@ def test_pose7_reduce_matches_torch(gpu_device):
         ref = torch.cat([gr.double().sum(0), torch.cross(p.double(), gr.double(), dim=1).sum(0), gr[:, 2:3].double().sum(0)])
         got = pose7_reduce(p, gr).double()
         assert (got - ref).abs().max().item() <= 1e-4 * (ref.abs().max().item() + n ** 0.5)
+
+
+def test_cxx_node_equals_python_node_and_survives_capacity_growth(gpu_device, monkeypatch):
+    """fused.render_frame through the C++ autograd node (csrc/vtgs_torch.cpp RenderFrame, the default) against the Python
+    autograd.Function (VTGS_FUSED_EXT=0): images, radii and every gradient bit for bit -- both make the same C-ABI calls.  The
+    second scene has the same (N, W, H) as the first and several times its instances: the capacities the first render settled on
+    overflow, the checked forward grows them and runs again inside the policy wrapper of either route."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization.fused import render_frame
+    dev = gpu_device
+    if dgr._ext is None or not hasattr(dgr._ext, "render_frame"):
+        pytest.skip("lib/vtgs_torch.so not built")
+    W, H, n = 192, 128, 20000
+    small, cam = _params(dev, n, W, H, seed=21)
+    st = to_settings(cam, dev)
+    w2c = torch.eye(4, device=dev)
+    big = {k: torch.nn.Parameter(v.detach().clone()) for k, v in small.items()}
+    with torch.no_grad():
+        big["log_scales"] += 1.8                                   # 6 x the radius
+    g = torch.Generator().manual_seed(8)
+    g1 = (torch.rand(3, H, W, generator=g) * 2 - 1).to(dev)
+    g2 = (torch.rand(3, H, W, generator=g) * 2 - 1).to(dev)
+
+    def run(params):
+        for v in params.values():
+            v.grad = None
+        im, ds, radii = render_frame(params, 1, st, w2c, True, True)
+        ((im * g1).sum() + (ds * g2).sum()).backward()
+        dgr.settle_pending()
+        return im.detach().clone(), ds.detach().clone(), radii.clone(), {k: v.grad.clone() for k, v in params.items()}, \
+            dgr.last_forward_info()["instances"]
+
+    out = {}
+    for route in ("cxx", "python"):
+        monkeypatch.setenv("VTGS_FUSED_EXT", "1" if route == "cxx" else "0")
+        for state in (dgr._capacity_hint, dgr._tile_cap_hint, dgr._caps_in_use, dgr._async_ok, dgr._need_hist):
+            state.clear()                                              # both routes start from the first-forward capacities
+        a = run(small)
+        b = run(big)
+        assert b[4] > 3.7 * a[4] + 4096, (a[4], b[4])                # beyond the 3.6 x room the first render left: it overflowed
+        out[route] = (a, b)
+    for which in (0, 1):
+        x, y = out["cxx"][which], out["python"][which]
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2]), which
+        for k in x[3]:
+            assert torch.equal(x[3][k], y[3][k]), (which, k)
