@@ -162,3 +162,29 @@ def test_plain_operator_over_the_list_equals_its_band_render(gpu_device):
     with pytest.raises(ValueError, match="for_operator"):
         dgr.GaussianRasterizer(raster_settings=st, tile_rows=band, owned=OwnedSet(_params(dev, n, W, H, 6)[0], 1, st, torch.eye(4, device=dev), band))(
             **{k: v.to(dev) for k, v in scene.items()})
+
+
+@pytest.mark.parametrize("route", ["cxx", "python"])
+def test_an_empty_list_renders_the_background(gpu_device, monkeypatch, route):
+    """A band no Gaussian can meet (the whole map projects into the upper third of the frame): the list is empty, the render is
+    the band render of the map -- background -- and every gradient is zero, through either autograd node."""
+    from diff_gaussian_rasterization.fused import render_frame
+    from diff_gaussian_rasterization.partition import OwnedSet
+    monkeypatch.setenv("VTGS_FUSED_EXT", "1" if route == "cxx" else "0")
+    dev = gpu_device
+    W, H, n, band = 208, 128, 4000, (6, 8)
+    params, cam = _params(dev, n, W, H, seed=3)
+    with torch.no_grad():
+        m = params["means3D"]
+        m[:, 1] = -0.45 * m[:, 2] - 0.1 * m[:, 1].abs()           # y / z < -0.45: rows near the top edge and above it
+    st, w2c = to_settings(cam, dev), torch.eye(4, device=dev)
+    own = OwnedSet(params, 1, st, w2c, band, margin_px=4.0, growth=1.05)
+    assert len(own) == 0
+    g1 = torch.ones(3, H, W, device=dev)
+    a = _render(params, 1, st, w2c, band, None, g1, g1, True, True)
+    b = _render(params, 1, st, w2c, band, own, g1, g1, True, True)
+    assert own.escaped() == 0
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert float(b[0].abs().max()) == 0 and int(b[2].max()) == 0
+    for k, v in b[3].items():
+        assert v is None or float(v.abs().max()) == 0, k

@@ -221,6 +221,10 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
                                     float* image_state, hipStream_t st, const float* colors_b = nullptr,
                                     float* out_color_b = nullptr, int sort_mode = 0, FinalizeArgs fin = FinalizeArgs{},
                                     bool write_qmask = false) {
+  // dual render <=> a second output image.  (Round 4: this was inferred from colors_b, and an EMPTY dual render -- n = 0, where
+  // the header lets every per-Gaussian pointer be NULL -- took the single-render kernel with its NULL depth plane: a write
+  // through address 0 + the band's pixel offset, found by tests/test_gpu_owned_sets.py::test_an_empty_list_renders_the_background.)
+  const bool dual = out_color_b != nullptr;
   const int gx16 = (cam->image_width + kBinTile - 1) / kBinTile;
   uint32_t* steps = nullptr;                                 // measurement only: steps of the quadrant-queue forward, 64 partial sums
   if (option(OPT_COUNT_STEPS) == 1 && write_qmask) {
@@ -231,8 +235,8 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
   const int impl = option(OPT_FWD_IMPL);                     // 2 = lane-per-pixel matrix-core kernel (default), 1 = pixel x splat-quad
                                                            // matrix-core kernel, 0 = scalar kernel (read per call)
   {
-    ProfScope ps__(colors_b ? "composite_forward_dual" : "composite_forward", st);
-    if (impl == 3 && colors_b)                              // quadrant queues (vtgs_composite_q.hip)
+    ProfScope ps__(dual ? "composite_forward_dual" : "composite_forward", st);
+    if (impl == 3 && dual)                                  // quadrant queues (vtgs_composite_q.hip)
       hipLaunchKernelGGL((composite_forward_q<true>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (uint32_t*)(ws + L.sorted_gid),
                          (const GeomRec*)(ws + L.geom), colors, out_color, (float*)nullptr, image_state,
@@ -248,9 +252,9 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
                          write_qmask ? (uint8_t*)(ws + L.qmask) : (uint8_t*)nullptr, steps);
     else {                                                  // a cross-check implementation: the test-only library
       if (!xcheck_available()) return xcheck_missing();
-      const int rc = g_xcheck_forward(impl, colors_b ? 1 : 0, &cs, cam->bg, nblk, (const uint32_t*)(ws + L.tile_cnt), L.tile_cap,
+      const int rc = g_xcheck_forward(impl, dual ? 1 : 0, &cs, cam->bg, nblk, (const uint32_t*)(ws + L.tile_cnt), L.tile_cap,
                                       (const uint32_t*)(ws + L.sorted_gid), (const GeomRec*)(ws + L.geom), colors, out_color,
-                                      colors_b ? (float*)nullptr : out_depth, image_state, (const Counters*)(ws + L.counters),
+                                      dual ? (float*)nullptr : out_depth, image_state, (const Counters*)(ws + L.counters),
                                       colors_b, out_color_b, (void*)st);
       if (rc != 0) return hip_fail(hipGetLastError(), "vtgs_xcheck_forward");
     }
