@@ -302,3 +302,23 @@ def test_cxx_node_equals_python_node_and_survives_capacity_growth(gpu_device, mo
         assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2]), which
         for k in x[3]:
             assert torch.equal(x[3][k], y[3][k]), (which, k)
+
+
+@pytest.mark.parametrize("route", ["cxx", "python"])
+def test_render_frame_of_an_empty_map(gpu_device, monkeypatch, route):
+    """N = 0 (a submap before its first densification): both images are the background, the pose gradient is zero and the
+    per-Gaussian gradients are empty -- through either autograd node (an empty dual render once took the single-render kernel
+    with its NULL depth plane: DESIGN.md 7.6)."""
+    from diff_gaussian_rasterization.fused import render_frame
+    monkeypatch.setenv("VTGS_FUSED_EXT", "1" if route == "cxx" else "0")
+    dev = gpu_device
+    full, cam = _params(dev, 100, 96, 64, seed=2)
+    params = {k: torch.nn.Parameter(v.detach()[:0].clone() if k not in ("cam_unnorm_rots", "cam_trans") else v.detach().clone())
+              for k, v in full.items()}
+    st, w2c = to_settings(cam, dev), torch.eye(4, device=dev)
+    im, ds, radii = render_frame(params, 1, st, w2c, True, True)
+    (im.sum() + ds.sum()).backward()
+    assert im.shape == (3, 64, 96) and radii.shape == (0,) and float(im.detach().abs().max()) == 0 and float(ds.detach().abs().max()) == 0
+    assert float(params["cam_trans"].grad.abs().max()) == 0 and float(params["cam_unnorm_rots"].grad.abs().max()) == 0
+    for k in ("means3D", "rgb_colors", "logit_opacities", "log_scales", "unnorm_rotations"):
+        assert params[k].grad is None or params[k].grad.numel() == 0, k
