@@ -87,6 +87,10 @@ SCENES = {
     "random_iso": lambda: go.random_scene(4000, 200, 136, seed=3, anisotropic=False, w2c=_w2c(3)),
     "random_aniso": lambda: go.random_scene(4000, 200, 136, seed=4, anisotropic=True, w2c=_w2c(4)),
     "wide_fov_aniso": lambda: go.random_scene(1500, 96, 80, seed=5, anisotropic=True, w2c=_w2c(5), fov_scale=0.5),
+    # frames smaller than a tile, and a one-tile-row strip: most lanes / wavefronts of a workgroup have no pixel, a 16x16 block has
+    # one live 8x8 tile, the LDS tile table of the projection kernel has one to 38 entries
+    "tiny_17x9": lambda: go.random_scene(300, 17, 9, seed=7, anisotropic=False),
+    "strip_300x4": lambda: go.random_scene(800, 300, 4, seed=8, anisotropic=True),
 }
 
 
@@ -105,6 +109,23 @@ def test_forward_backward_parity(gpu_device, name):
     # a radius on the other side of float32 ceil() moves a whole tile rectangle: not a rounding-level difference
     taint |= tainted_gaussians(aux, tiles_of(aux, diff, cam), diff.numel())
     _check_grads(ref_g, got_g, taint)
+
+
+def test_a_frame_smaller_than_one_tile(gpu_device):
+    """5 x 3 pixels: one 8x8 tile with 15 live lanes, three of a workgroup's four wavefronts without a tile.  Images as
+    everywhere; the gradients against the largest element of their tensor (fifteen pixels under 25 anisotropic splats: the
+    per-element statistics of test_forward_backward_parity have nothing to average over)."""
+    scene, cam = go.random_scene(25, 5, 3, seed=6, anisotropic=True)
+    g = torch.Generator().manual_seed(99)
+    grad_color = torch.rand(3, 3, 5, generator=g) * 2 - 1
+    ref_c, ref_r, ref_d, ref_g, aux = run_oracle(scene, cam, grad_color)
+    got_c, got_r, got_d, got_g = run_hip(scene, cam, gpu_device, grad_color)
+    assert torch.equal(ref_r, got_r)
+    taint = _check_images(ref_c, ref_d, got_c, got_d, audit=(aux, scene["opacities"], cam))
+    for k in GRAD_KEYS:
+        scale = ref_g[k].abs().max().item()
+        d = (ref_g[k].double() - got_g[k].double()).abs()[~taint]
+        assert d.numel() == 0 or d.max().item() <= 2 * GRAD_TOL * max(scale, 1e-30), (k, d.max().item(), scale)
 
 
 def test_cfg_a_synthetic_10k_320x240(gpu_device):
