@@ -208,30 +208,50 @@ def main():
         print(f"[bench] timed region done: {ms_per_step:.3f} ms/step", file=sys.stderr, flush=True)
     value = N * P / (dt / args.steps) / 1e6
 
+    def event_steps(fn, k):
+        """HIP events on the op's stream around every one of k steps -> per-step ms (the record of an event is a
+        queue marker of its own, so this is a SECOND pass: the contract's `ms_per_step` above is the host-clocked mean of
+        exactly --steps steps without a marker in the queue)."""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+        ev[0].record()
+        for i in range(k):
+            fn()
+            ev[i + 1].record()
+        fence()
+        return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(k))
+
+    def pct(v, q):
+        return round(v[min(len(v) - 1, int(q * len(v)))], 4)
+
+    ev_ms = event_steps(step, max(50, args.steps))
+    step_events = {"n": len(ev_ms), "p10_ms": pct(ev_ms, 0.10), "p50_ms": pct(ev_ms, 0.50), "p90_ms": pct(ev_ms, 0.90),
+                   "note": "hipEvents on the op's stream around every step of a second pass (median + p10 / p90, SURVEY 8d); "
+                           "ms_per_step is the host-clocked mean of the first pass"}
+
     # ---- the SLAM loop's two steps through the same operator (extra keys; the headline above is `mode`) -------------------
     loop_steps = {}
     if not args.band:
         for m in ("tracking", "mapping"):
             if m == mode:
-                loop_steps[m + "_step_ms"] = round(ms_per_step, 4)
+                loop_steps[m + "_step_ms"] = step_events["p50_ms"]
                 continue
             lv = {k: v.detach().requires_grad_(k in WANTED[m]) for k, v in leaves.items()}
-            k_steps = max(5, min(20, args.steps))
-            for _ in range(3):
+            for _ in range(5):
                 step(lv, m)
             fence()
-            t1 = time.perf_counter()
-            for _ in range(k_steps):
-                step(lv, m)
-            fence()
-            d1 = time.perf_counter() - t1
+            # the MEDIAN of 30 event-timed steps (round 4 reported the mean of <= 20 host-clocked steps: ONE stall of a few
+            # milliseconds -- a first allocation of the mode's smaller gradient block, a clock ramp -- doubled it in the
+            # driver's record, 0.694 vs 0.365 ms; the spread is printed beside it now)
+            lm = event_steps(lambda: step(lv, m), 30)
+            med = pct(lm, 0.50)
             if dist is not None:
-                tm = torch.tensor([d1], dtype=torch.float64, device=dev)
+                tm = torch.tensor([med], dtype=torch.float64, device=dev)
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                d1 = float(tm.item())
-            loop_steps[m + "_step_ms"] = round(d1 / k_steps * 1e3, 4)
+                med = round(float(tm.item()), 4)
+            loop_steps[m + "_step_ms"] = med
+            loop_steps[m + "_step_p10_p90_ms"] = [pct(lm, 0.10), pct(lm, 0.90)]
             del lv
-        loop_steps["note"] = ("tracking: grads to means3D + means2D (Gaussians detached, src/vtgaussian_slam.py:428-449), 7-float "
+        loop_steps["note"] = ("median of 30 event-timed steps each; tracking: grads to means3D + means2D (Gaussians detached, src/vtgaussian_slam.py:428-449), 7-float "
                               "pose reduction + its all-reduce; mapping: grads to colours, opacities, scales, means2D + one flat "
                               "all-reduce of 28 B per Gaussian on N > 1")
         for t in leaves.values():
@@ -264,15 +284,21 @@ def main():
         if alg is not None:
             achieved = alg[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
             call_bytes = (112 + grad_bytes) * N + 28 * p_rank + 52 * r_rank
-            traffic = None           # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json)
+            # HBM bytes from the committed PMC passes of the same command (profiles/pmc_traffic.json: separate --pmc FETCH_SIZE /
+            # WRITE_SIZE runs, never collected inside this process): `traffic` = the DOMINANT KERNEL's bytes per launch,
+            # `traffic_step_total` = all kernels of one step
+            traffic = traffic_total = traffic_src = None
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
                 if tile_rows is None and mode == "rasterize" and (N, W, H) == (1_000_000, 1200, 680) and dom in pmc:
                     traffic = pmc[dom]["traffic_bytes"]
+                    traffic_total = sum(v["traffic_bytes"] for k, v in pmc.items() if isinstance(v, dict) and "traffic_bytes" in v)
+                    traffic_src = f"profiles/pmc_traffic.json (round {pmc.get('_round', '?')} build, rocprofv3 --pmc passes of this command; not measured in this run)"
             except (OSError, ValueError, KeyError):
                 pass
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "traffic_scope": f"{dom}, per launch", "traffic_step_total": traffic_total, "traffic_source": traffic_src,
                         "kernel_avg_us": round(kern[dom]["avg_us"], 2), "algorithmic_bytes": alg[dom],
                         "call_algorithmic_bytes": call_bytes,
                         "call_frac": round(call_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -426,6 +452,7 @@ def main():
                        "partition": "none" if tile_rows is None else f"tile-row bands x{emulated[1] if emulated else world} + " +
                                     ("all-reduce(28 B per Gaussian)" if mode == "mapping" else "all-reduce(7 floats)")},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "slam": None, "loop_steps": loop_steps or None,
+            "step_events": step_events,
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["avg_us"])},
         }
         if tile_rows is not None and kern:

@@ -148,6 +148,15 @@ size_t vtgs_workspace_bytes(int32_t n, int32_t width, int32_t height, uint64_t i
  * If the forward overflowed, the backward kernels see the device-side flag and write nothing.            */
 size_t vtgs_backward_scratch_bytes(int32_t n, uint64_t instances);
 
+/* EMPTY INPUT (n = 0) -- one rule for every entry point below.  A rank of the tile-row partition may own nothing, a map may
+ * be empty before its first frame: with n = 0 every PER-GAUSSIAN pointer (inputs, radii, per-Gaussian gradient outputs, index
+ * lists) may be NULL.  Everything that is not per-Gaussian keeps its requirements: a forward still needs its output images, its
+ * workspace and -- in the asynchronous / checked modes -- its record; it composites every tile as empty (background colour,
+ * depth 0, final transmittance 1) and reports zero instances.  A backward with n = 0 touches nothing and returns VTGS_OK; the
+ * pose-gradient helpers reduce zero rows to zeros.  No entry point infers a render VARIANT (single / dual, frame epilogue,
+ * owned set) from a per-Gaussian pointer: variants follow from which entry point was called and from the image / flag
+ * arguments (tests/test_gpu_empty_inputs.py calls all of them with n = 0 and NULL arrays on poisoned memory).             */
+
 /* Forward.  Replaces `_C.rasterize_gaussians` for the colors_precomp + scales/rotations signature
  * the reference uses (shs / cov3D_precomp are rejected in the Python layer).
  *   means3D[N,3] opacities[N,1] colors[N,3] scales[N,3] rotations[N,4](w,x,y,z)

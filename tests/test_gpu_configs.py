@@ -31,15 +31,15 @@ CONFIGS = {
 IMG_TOL, GRAD_TOL = 1e-4, 1e-3
 
 
-def _grad_check(ref, got, sel, what, max_tol, p999_tol, f32=None):
+def _grad_check(ref, got, sel, what, max_tol, p999_tol):
     """<= 1e-3 relative on the gradients, three ways: the largest difference against the largest gradient, the relative L2
     error, and the 99.9th percentile of the element-wise relative error (floor: 1e-3 of the largest gradient, as everywhere).
-    The loss of these tests lives on a few tile rows, so most selected Gaussians only graze it, their gradients span five
-    orders of magnitude and the small ones are sums of terms that cancel a hundredfold, each term carrying the ~3e-4 noise of
-    single-precision pixel centres: the element-wise figure of ANY float32 implementation sits at 1 - 1.6e-3 there
-    (DESIGN.md 2.1).  So the percentile is held to what the published algorithm itself achieves in float32 -- `f32`, the
-    float32 CPU oracle's gradients for the same rows -- by the same statistic, with a quarter of headroom, or to 1e-3 where
-    that is larger: no floor of the builder's choosing."""
+    The loss of these tests lives on a few tile rows, so most selected Gaussians only graze it and their gradients span five
+    orders of magnitude; the small ones are sums of terms that cancel a hundredfold.  Until round 4 every term carried the
+    ~3e-4 relative noise of float32 pixel centres (2^-24 x 1200 px against exponent slopes of a few per pixel) and the
+    percentile was held to 1.25 x what the float32 CPU oracle achieves (1.55e-3 at 1200x680).  Round 5: the kernels carry the
+    centre as a float32 pair (vtgs_math.h::project_splat, GeomRec::centre_lo) and the PLAIN 1e-3 holds at every BASELINE
+    shape -- the headline frame measures 2-4e-4 (profiles/r5_grad_error_breakdown.txt)."""
     for k in GRAD_KEYS:
         if k == "rotations":
             continue                      # isotropic scene: exactly zero in exact arithmetic
@@ -51,13 +51,8 @@ def _grad_check(ref, got, sel, what, max_tol, p999_tol, f32=None):
         mx = (d.max() / scale).item()
         l2 = (d.norm() / (r.norm() + 1e-300)).item()
         p999 = torch.quantile((d / (r.abs() + 1e-3 * scale)).reshape(-1)[:4_000_000], 0.999).item()
-        bound = p999_tol
-        if p999_tol is not None and f32 is not None:
-            d32 = (r - f32[k][sel].double()).abs()
-            p32 = torch.quantile((d32 / (r.abs() + 1e-3 * scale)).reshape(-1)[:4_000_000], 0.999).item()
-            bound = max(p999_tol, 1.25 * p32)
-        assert mx <= max_tol and l2 <= max_tol and (bound is None or p999 <= bound), \
-            f"{what} grad {k}: max {mx:.2e} of max|ref|, rel L2 {l2:.2e}, p99.9 rel {p999:.2e} (bound {bound})"
+        assert mx <= max_tol and l2 <= max_tol and (p999_tol is None or p999 <= p999_tol), \
+            f"{what} grad {k}: max {mx:.2e} of max|ref|, rel L2 {l2:.2e}, p99.9 rel {p999:.2e} (bound {p999_tol})"
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))
@@ -96,8 +91,7 @@ def test_config_rows_radii_and_properties(gpu_device, name):
     taint = tainted_gaussians(aux, a_c["tiles"] | a_d["tiles"], idx.numel())
     taint_full = torch.zeros(n, dtype=torch.bool)
     taint_full[idx[taint]] = True
-    _, _, _, f32_g, keep32, _, _ = oracle_rows(scene, cam, rows, grad_color, dtype=torch.float32)    # the float32 floor
-    _grad_check(ref_g, got_g, keep & keep32 & ~taint_full, f"{name} (clean)", GRAD_TOL, GRAD_TOL, f32_g)
+    _grad_check(ref_g, got_g, keep & ~taint_full, f"{name} (clean)", GRAD_TOL, GRAD_TOL)
     if taint_full.any():
         _grad_check(ref_g, got_g, taint_full, f"{name} (beside an outlier pixel)", 2e-2, None)
     # ---- (iii) full-frame properties ---------------------------------------------------------------------------

@@ -322,3 +322,49 @@ def test_render_frame_of_an_empty_map(gpu_device, monkeypatch, route):
     assert float(params["cam_trans"].grad.abs().max()) == 0 and float(params["cam_unnorm_rots"].grad.abs().max()) == 0
     for k in ("means3D", "rgb_colors", "logit_opacities", "log_scales", "unnorm_rotations"):
         assert params[k].grad is None or params[k].grad.numel() == 0, k
+
+
+@pytest.mark.parametrize("route", ["cxx", "python"])
+def test_run_ahead_overflow_surfaces_inside_backward_before_the_optimizer_step(gpu_device, monkeypatch, route):
+    """a run-ahead forward whose workspace overflows returned the background colour; the error has to
+    leave `loss.backward()` -- through the C++ node too, whose backward never enters the interpreter (a post-hook on its graph
+    node reads the record) -- so that an `optimizer.step()` written after it never runs on those gradients."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization.fused import render_frame
+    from diff_gaussian_rasterization.optim import FusedAdam
+    dev = gpu_device
+    if route == "cxx" and (dgr._ext is None or not hasattr(dgr._ext, "render_frame")):
+        pytest.skip("lib/vtgs_torch.so not built")
+    monkeypatch.setenv("VTGS_FUSED_EXT", "1" if route == "cxx" else "0")
+    W, H, n = 160, 96, 8001                                         # (n % 4 != 0: the C++ node's carved blocks stay aligned)
+    base, cam = _params(dev, n, W, H, seed=5)
+    st, w2c = to_settings(cam, dev), torch.eye(4, device=dev)
+    for state in (dgr._capacity_hint, dgr._tile_cap_hint, dgr._caps_in_use, dgr._async_ok, dgr._need_hist):
+        state.clear()
+    params = {k: torch.nn.Parameter(v.detach().clone()) for k, v in base.items()}
+    opt = FusedAdam([{"params": [v], "lr": 1e-3} for v in params.values()])
+    ahead = 0
+    for it in range(6):                                             # a steady loop: the later forwards run ahead
+        opt.zero_grad(set_to_none=True)
+        im, ds, _ = render_frame(params, 1, st, w2c, True, True)
+        (im.sum() + ds.sum()).backward()
+        opt.step()
+    dgr.settle_pending()
+    with torch.no_grad():
+        params["log_scales"] += 2.6                                 # ~13 x the radius: far beyond three times the last need
+    before = {k: v.detach().clone() for k, v in params.items()}
+    opt.zero_grad(set_to_none=True)
+    im, ds, _ = render_frame(params, 1, st, w2c, True, True)
+    stepped = False
+    with pytest.raises(RuntimeError, match="run-ahead mode"):
+        (im.sum() + ds.sum()).backward()
+        stepped = True                                              # (not reached: the error leaves backward())
+        opt.step()
+    assert not stepped
+    for k, v in params.items():
+        assert torch.equal(v.detach(), before[k]), k
+    opt.zero_grad(set_to_none=True)                                 # the capacities were raised by the failed settle: valid now
+    im, ds, _ = render_frame(params, 1, st, w2c, True, True)
+    (im.sum() + ds.sum()).backward()
+    dgr.settle_pending()
+    assert float(im.detach().abs().max()) > 0

@@ -114,7 +114,12 @@ def test_forward_backward_parity(gpu_device, name):
 def test_a_frame_smaller_than_one_tile(gpu_device):
     """5 x 3 pixels: one 8x8 tile with 15 live lanes, three of a workgroup's four wavefronts without a tile.  Images as
     everywhere; the gradients against the largest element of their tensor (fifteen pixels under 25 anisotropic splats: the
-    per-element statistics of test_forward_backward_parity have nothing to average over)."""
+    per-element statistics of test_forward_backward_parity have nothing to average over).  Audited in round 5
+    (tools/tiny_scene_audit.py, profiles/r5_tiny_scene_audit.txt): with 75 elements the "99.9th percentile" is the maximum,
+    and the 2.9e-3 of round 4 is ONE element of means2D whose reference value is 4.3e-5 of the tensor's largest -- its
+    absolute error is 3.8e-6 of the largest (float32 summation noise; the scalar cross-check kernels show 2.6e-6 at the same
+    element), divided by the 1e-3 floor.  No pair is wrong; the bound below (absolute, 2e-3 of the largest) is the statistic
+    that means something for this frame."""
     scene, cam = go.random_scene(25, 5, 3, seed=6, anisotropic=True)
     g = torch.Generator().manual_seed(99)
     grad_color = torch.rand(3, 3, 5, generator=g) * 2 - 1

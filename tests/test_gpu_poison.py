@@ -255,3 +255,4 @@ def test_alternating_views_never_raise(gpu_device):
                 assert torch.equal(x, y), it
     finally:
         dgr._FORWARD_MODE = os.environ.get("VTGS_FORWARD_MODE", "auto")
+

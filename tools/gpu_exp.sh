@@ -30,6 +30,11 @@ run() {   # run <log> <command...>
   echo "== $* > $log"
   timeout -k 10 $LIMIT "$@" > $log 2>&1
   local rc=$?
+  # a failing run keeps its log under a name no later run writes to (round 4: the fault text of DESIGN 7.6 was overwritten by
+  # the passing re-run of the same step and tag)
+  if [ $rc -ne 0 ] || grep -q -E "Memory access fault|Fatal Python error|Segmentation fault|core dumped|HSA_STATUS_ERROR" $log; then
+    cp $log ${log%.log}.FAILED.$(date +%H%M%S).log
+  fi
   if grep -q -E "Memory access fault|Fatal Python error|Segmentation fault|core dumped|HSA_STATUS_ERROR" $log; then
     echo "GPU FAULT / ABORT in $log:"; grep -E "Memory access fault|Fatal Python error|Segmentation fault|core dumped|HSA_STATUS_ERROR" $log | head -5
     fail=2; return 2

@@ -294,7 +294,9 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
     cs.bin_plan = (const uint32_t*)(ws + L.plan); cs.bin_limit = L.tiles8 * L.tile_cap;
   }
 
-  // counters + per-tile list lengths in one fill (adjacent in the layout, padded to 256 B)
+  // counters + per-tile list lengths in one fill (adjacent in the layout, padded to 256 B).  (Round 5, measured and dropped:
+  // clearing inside project_and_bin under a token costs +27 us -- the check sits on every workgroup's latency chain -- and a
+  // clear kernel of this library takes the same 4.6-5 us as the runtime's fill; profiles/r5_negative_results.md)
   VTGS_HIP(hipMemsetAsync(ws + L.counters, 0, 256 + align256(((size_t)L.tiles8 + 1) * 4), st));
   if (rows16 * kBinTile < cam->image_height || cam->tile_row_begin != 0) {
     // band mode: pixels outside the band are written as zero (include/vtgs.h); the caller keeps only
@@ -506,9 +508,9 @@ int vtgs_bin_plan_uniform(int32_t width, int32_t height, uint32_t slots_per_bin,
 int vtgs_forward_shared(const VtgsCamera* cam, int32_t n, const float* colors, float* out_color, float* out_depth,
                         const void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
                         float* image_state, void* stream) {
-  if (!cam_ok(cam) || n < 0 || !colors || !out_color || !out_depth || !workspace || !image_state ||
+  if (!cam_ok(cam) || n < 0 || (n > 0 && !colors) || !out_color || !out_depth || !workspace || !image_state ||
       instance_capacity == 0 || instance_capacity > 0xFFFFFFFFull || (tile_capacity & ~VTGS_TILE_CAPACITY_PLANNED) == 0)
-    return VTGS_ERR_INVALID_ARGUMENT;
+    return VTGS_ERR_INVALID_ARGUMENT;                          // (n = 0: per-Gaussian arrays may be NULL, include/vtgs.h)
   int r8b, r8e, rows16, row16_0;
   if (!band_of(cam, &r8b, &r8e, &rows16, &row16_0)) return VTGS_ERR_INVALID_ARGUMENT;
   const WsLayout L = make_layout(n, cam->image_width, cam->image_height, instance_capacity, tile_capacity);

@@ -74,8 +74,9 @@ __device__ __forceinline__ ReachForm make_reach_form(const Splat& sp) {
   ReachForm f;
   f.hA = 0.5f * sp.A; f.B = sp.B; f.hC = 0.5f * sp.C;
   f.regular = sp.A > 0.f && sp.C > 0.f;                        // always true for a projected (positive-definite) conic
-  f.kx = f.regular ? -sp.B / sp.C : 0.f;                       // dy* = kx dx on a vertical edge
-  f.ky = f.regular ? -sp.B / sp.A : 0.f;                       // dx* = ky dy on a horizontal edge
+  // (hardware reciprocals, 1 ulp: q is evaluated AT the clamped minimiser, so an error eps in it raises q by O(eps^2))
+  f.kx = f.regular ? -sp.B * __builtin_amdgcn_rcpf(sp.C) : 0.f;   // dy* = kx dx on a vertical edge
+  f.ky = f.regular ? -sp.B * __builtin_amdgcn_rcpf(sp.A) : 0.f;   // dx* = ky dy on a horizontal edge
   return f;
 }
 
@@ -170,6 +171,9 @@ __device__ __forceinline__ void project_and_bin_body(
     op = opacities[gid];
     vis = project_splat(cam, mean, sc, q, op, sp, aux);
     radii[gid] = vis ? sp.radius : 0;
+    // what float32 took from the pixel centre goes to its place in the geometry record NOW: carried to the record's store
+    // below it cost two vector registers, and with them the second workgroup per CU
+    if (vis) reinterpret_cast<uint32_t*>(geom + gid)[7] = pack_centre_lo(sp.ulo, sp.vlo);
   }
   if (valid && banded) {
     // a band: a Gaussian that cannot meet the band's rows is dropped on its mean and scales alone (outside_tile_rows),
@@ -182,6 +186,7 @@ __device__ __forceinline__ void project_and_bin_body(
       const float q[4] = {q4.x, q4.y, q4.z, q4.w};
       op = opacities[gid];
       vis = project_splat(cam, mean, sc, q, op, sp, aux);
+      if (vis) reinterpret_cast<uint32_t*>(geom + gid)[7] = pack_centre_lo(sp.ulo, sp.vlo);
     }
     radii[gid] = vis ? sp.radius : 0;
   }
@@ -197,7 +202,7 @@ __device__ __forceinline__ void project_and_bin_body(
   }
   // alpha = o*G >= 1/255 somewhere  <=>  q <= ln(255 o); slack keeps the test conservative
   float tau = -1.f;
-  if (vis && op * 255.f >= 1.f) { tau = logf(255.f * op); tau += 1e-4f * tau + 1e-4f; }
+  if (vis && op * 255.f >= 1.f) { tau = __log2f(255.f * op) * 0.69314718f; tau += 1e-4f * tau + 1e-4f; }   // (v_log_f32: 1 ulp, inside the slack)
   const bool reach = vis && tau >= 0.f;
   const ReachForm rf = make_reach_form(sp);
   TileWalk w = make_walk(cam, sp, reach);
@@ -205,8 +210,11 @@ __device__ __forceinline__ void project_and_bin_body(
     // shrink the walk to the tiles under the bounding box of the alpha >= 1/255 ellipse (half-widths sqrt(2 tau C / det),
     // sqrt(2 tau A / det); tau carries the slack): a few-pixel splat then tests ~4 candidates instead of the 16 under its
     // 16x16-tile rectangle.  The exact test below still decides; the box only removes tiles it cannot pass.
-    const float idet = 1.f / fmaxf(sp.A * sp.C - sp.B * sp.B, 1e-30f);
-    const float hx = sqrtf(2.f * tau * sp.C * idet), hy = sqrtf(2.f * tau * sp.A * idet);
+    // (hardware reciprocal / square root as in composite_forward_q's quadrant box, with the same 2e-6 relative + 1e-5 px of
+    //  slack: the IEEE forms are ~35 instructions per Gaussian and the box only has to be conservative)
+    const float idet = __builtin_amdgcn_rcpf(fmaxf(sp.A * sp.C - sp.B * sp.B, 1e-30f));
+    const float k2 = 2.f * tau * idet;
+    const float hx = __builtin_amdgcn_sqrtf(k2 * sp.C) * 1.000002f + 1e-5f, hy = __builtin_amdgcn_sqrtf(k2 * sp.A) * 1.000002f + 1e-5f;
     const float inv8 = 1.f / (float)kSubTile;
     const int bx0 = (int)ceilf((sp.u - hx - (float)(kSubTile - 1)) * inv8), bx1 = (int)floorf((sp.u + hx) * inv8);
     const int by0 = (int)ceilf((sp.v - hy - (float)(kSubTile - 1)) * inv8), by1 = (int)floorf((sp.v + hy) * inv8);
@@ -273,9 +281,10 @@ __device__ __forceinline__ void project_and_bin_body(
     // the geometry record is only ever reached through a tile list: a splat without instances (culled, or outside this
     // call's band of tile rows -- 7/8 of them on each rank of an 8-way partition) does not need one
     if (cnt) {
-      GeomRec g;
-      g.u = sp.u; g.v = sp.v; g.A = sp.A; g.B = sp.B; g.C = sp.C; g.opacity = op; g.depth = sp.depth; g.pad = 0.f;
-      geom[gid] = g;
+      float4* gp = reinterpret_cast<float4*>(geom + gid);       // words 0..6 (word 7, centre_lo, was stored after the projection)
+      gp[0] = make_float4(sp.u, sp.v, sp.A, sp.B);
+      float* gq = reinterpret_cast<float*>(gp + 1);
+      gq[0] = sp.C; gq[1] = op; gq[2] = sp.depth;
     }
     gaux[gid] = GaussAux{inst_base, cnt};
   }
@@ -404,9 +413,10 @@ __device__ __forceinline__ void project_and_bin_body(
     }
     if (l == src) {
       if (total) {
-        GeomRec g;
-        g.u = sp.u; g.v = sp.v; g.A = sp.A; g.B = sp.B; g.C = sp.C; g.opacity = op; g.depth = sp.depth; g.pad = 0.f;
-        geom[gid] = g;
+        float4* gp = reinterpret_cast<float4*>(geom + gid);
+        gp[0] = make_float4(sp.u, sp.v, sp.A, sp.B);
+        float* gq = reinterpret_cast<float*>(gp + 1);
+        gq[0] = sp.C; gq[1] = op; gq[2] = sp.depth;
       }
       gaux[gid] = GaussAux{base, total};
     }

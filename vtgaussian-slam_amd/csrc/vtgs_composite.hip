@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void composite_forward(
     const int n = (int)min(64u, e - base);
     const ChunkRec r = gather_chunk(sorted_gid, geom, colors, base + (uint32_t)l, l < n);
     for (int j = 0; j < n; ++j) {
-      const float dx = bcast_f(r.u, j) - pxf, dy = bcast_f(r.v, j) - pyf;
+      const float dx = (bcast_f(r.u, j) - pxf) + bcast_f(r.ulo, j), dy = (bcast_f(r.v, j) - pyf) + bcast_f(r.vlo, j);
       const float p2 = dx * (bcast_f(r.qa, j) * dx + bcast_f(r.qb, j) * dy) + bcast_f(r.qc, j) * dy * dy;
       const float alpha = fminf(kAlphaMax, bcast_f(r.op, j) * __builtin_amdgcn_exp2f(p2));
       const float Tn = T * (1.f - alpha);
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void composite_backward(
         const float su = bcast_f(r.u, j), sv = bcast_f(r.v, j);
         const float sa = bcast_f(r.qa, j), sb = bcast_f(r.qb, j), sc = bcast_f(r.qc, j);
         const float so = bcast_f(r.op, j);
-        const float dx = su - pxf, dy = sv - pyf;
+        const float dx = (su - pxf) + bcast_f(r.ulo, j), dy = (sv - pyf) + bcast_f(r.vlo, j);
         const float p2 = dx * (sa * dx + sb * dy) + sc * dy * dy;
         const float G = __builtin_amdgcn_exp2f(p2);
         const float alpha = fminf(kAlphaMax, so * G);
@@ -1258,7 +1258,8 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     }
   };
   // record = tile-local moments (U0, UX, UY, UXX, UXY, UYY), colour sums (3 or 6), tile id; (u, v) = the splat's centre
-  auto add_record = [&](SplatMoments& M, float& c0, float& c1, float& c2, float4 a, float4 b, float4 c, float4 d, float u, float v) {
+  auto add_record = [&](SplatMoments& M, float& c0, float& c1, float& c2, float4 a, float4 b, float4 c, float4 d, float u, float v,
+                        float ulo, float vlo) {
     uint32_t tile;
     if constexpr (DUAL) {
       tile = __float_as_uint(d.x);
@@ -1267,7 +1268,7 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
       tile = __float_as_uint(c.y);
     }
     const int ty = (int)(tile / (uint32_t)cam.gx8), tx = (int)(tile - (uint32_t)ty * (uint32_t)cam.gx8);
-    const float sx = u - ((float)(tx * kSubTile) + 3.5f), sy = v - ((float)(ty * kSubTile) + 3.5f);
+    const float sx = (u - ((float)(tx * kSubTile) + 3.5f)) + ulo, sy = (v - ((float)(ty * kSubTile) + 3.5f)) + vlo;   // as tile_coefficients
     const float U0 = a.x, UX = a.y, UY = a.z, UXX = a.w, UXY = b.x, UYY = b.y;
     M.m[0] += U0;
     M.m[1] += sx * U0 - UX;                                     // d = centre - pixel = s - X
@@ -1299,11 +1300,11 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     if (ok && !big) {
 #pragma unroll
       for (uint32_t i = 0; i < kGatherAhead; ++i)
-        if (i < ga.inst_cnt) add_record(mo, cb0, cb1, cb2, pa[i], pb[i], pc[i], pd[i], sp.u, sp.v);
+        if (i < ga.inst_cnt) add_record(mo, cb0, cb1, cb2, pa[i], pb[i], pc[i], pd[i], sp.u, sp.v, sp.ulo, sp.vlo);
       for (uint32_t i = kGatherAhead; i < ga.inst_cnt; ++i) {
         float4 a, b, c, d;
         load_record(ga.inst_base + i, a, b, c, d);
-        add_record(mo, cb0, cb1, cb2, a, b, c, d, sp.u, sp.v);
+        add_record(mo, cb0, cb1, cb2, a, b, c, d, sp.u, sp.v, sp.ulo, sp.vlo);
       }
     }
   }
@@ -1313,13 +1314,15 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)ga.inst_cnt, src);
     const float u = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sp.u), src));
     const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sp.v), src));
+    const float ulo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sp.ulo), src));
+    const float vlo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sp.vlo), src));
     SplatMoments part;
     for (int k = 0; k < 9; ++k) part.m[k] = 0.f;
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
     for (uint32_t i = (uint32_t)lane_id(); i < cnt; i += 64u) {   // lane-strided partial sums, then a butterfly: fixed order
       float4 a, b, c, d;
       load_record(base + i, a, b, c, d);
-      add_record(part, p0, p1, p2, a, b, c, d, u, v);
+      add_record(part, p0, p1, p2, a, b, c, d, u, v, ulo, vlo);
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) part.m[k] = wave_sum(part.m[k]);

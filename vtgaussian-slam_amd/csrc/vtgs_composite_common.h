@@ -8,17 +8,18 @@ namespace vtgs {
 constexpr float kLog2e = 1.4426950408889634f;
 
 struct ChunkRec {     // one splat of the current chunk, held by one lane
-  float u, v, qa, qb, qc, op, depth, c0, c1, c2;
+  float u, v, qa, qb, qc, op, depth, c0, c1, c2, ulo, vlo;
 };
 
 __device__ __forceinline__ ChunkRec gather_chunk(const uint32_t* __restrict__ sorted_gid, const GeomRec* __restrict__ geom,
                                                  const float* __restrict__ colors, uint32_t pos, bool in) {
-  ChunkRec r{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  ChunkRec r{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (in) {
     const uint32_t gid = sorted_gid[pos];
     const float4* gp = reinterpret_cast<const float4*>(geom + gid);
     const float4 g0 = gp[0], g1 = gp[1];
     r.u = g0.x; r.v = g0.y;
+    r.ulo = centre_lo_x(__float_as_uint(g1.w)); r.vlo = centre_lo_y(__float_as_uint(g1.w));
     r.qa = -0.5f * kLog2e * g0.z;     // exp(power) = exp2(dx*(qa*dx + qb*dy) + qc*dy*dy)
     r.qb = -kLog2e * g0.w;
     r.qc = -0.5f * kLog2e * g1.x;
@@ -76,7 +77,10 @@ constexpr float kClampGuard = 0.98f;
 // tested bit for bit against the lane = pixel one); contraction of the remaining products is switched off.
 __device__ __forceinline__ void tile_coefficients(const float4& g0, const float4& g1, float cx, float cy, float (&K)[6]) {
 #pragma clang fp contract(off)
-  const float sx = g0.x - cx, sy = g0.y - cy;
+  // centre relative to the tile centre: the float32 difference of two nearby numbers is exact (or rounds at the 1e-6 px
+  // level for a far splat), then the part of the centre that float32 could not hold (GeomRec::centre_lo)
+  const uint32_t lo = __float_as_uint(g1.w);
+  const float sx = (g0.x - cx) + centre_lo_x(lo), sy = (g0.y - cy) + centre_lo_y(lo);
   const float qa = -0.5f * kLog2e * g0.z, qb = -kLog2e * g0.w, qc = -0.5f * kLog2e * g1.x;
   K[0] = fmaf(qa * sx, sx, fmaf(qb * sx, sy, fmaf(qc * sy, sy, __log2f(g1.y))));
   K[1] = fmaf(-2.f * qa, sx, -(qb * sy));

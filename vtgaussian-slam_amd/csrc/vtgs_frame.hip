@@ -232,7 +232,7 @@ extern "C" {
 
 int vtgs_pose_gradient(const float* pose_partials, uint32_t rows, const float* cam_q, float* g_cam_q, float* g_cam_t,
                        void* stream) {
-  if (!pose_partials || !cam_q || !g_cam_q || !g_cam_t) return VTGS_ERR_INVALID_ARGUMENT;
+  if ((rows > 0 && !pose_partials) || !cam_q || !g_cam_q || !g_cam_t) return VTGS_ERR_INVALID_ARGUMENT;   // (rows = 0: an empty map)
   hipLaunchKernelGGL(pose_gradient_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pose_partials, rows, cam_q, g_cam_q,
                      g_cam_t);
   return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;

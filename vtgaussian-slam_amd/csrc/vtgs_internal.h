@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 #include "vtgs_math.h"
 #include "../../include/vtgs.h"
 
@@ -38,14 +39,23 @@ struct Counters {
   unsigned long long info_slots;
 };
 static_assert(sizeof(Counters) <= 256, "counters block");
+static_assert(offsetof(Counters, info_instances) == 64, "Counters layout");
 
 struct alignas(16) GeomRec {   // 32 bytes
-  float u, v;                  // pixel centre
+  float u, v;                  // pixel centre (float32)
   float A, B, C;               // conic
   float opacity;
   float depth;
-  float pad;
+  uint32_t centre_lo;          // what float32 rounding took from (u, v): two truncated-float32 halves (pack_centre_lo)
 };
+// (ulo, vlo) with |.| <= ulp(u)/2: sign + exponent + 7 mantissa bits each -- 2^-8 of 6e-5 px is more than enough
+__host__ __device__ inline uint32_t pack_centre_lo(float ulo, float vlo) {
+  union { float f; uint32_t u; } a, b;
+  a.f = ulo; b.f = vlo;
+  return (a.u & 0xFFFF0000u) | (b.u >> 16);
+}
+__host__ __device__ inline float centre_lo_x(uint32_t p) { union { float f; uint32_t u; } a; a.u = p & 0xFFFF0000u; return a.f; }
+__host__ __device__ inline float centre_lo_y(uint32_t p) { union { float f; uint32_t u; } a; a.u = p << 16; return a.f; }
 
 struct alignas(8) GaussAux { uint32_t inst_base, inst_cnt; };
 

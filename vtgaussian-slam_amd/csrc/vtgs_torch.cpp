@@ -36,6 +36,21 @@ at::Tensor need(const at::Tensor& t, const char* name, int64_t tail, int64_t n, 
 // clean memory -- shows up as a wrong result (the cause of the GPU fault of round 3).
 bool g_poison = false;
 
+// Rows of a carved block start at multiples of four floats: rotations / their gradients are read and written as float4, and a
+// segment that follows 3 n or 13 n floats is 16-byte aligned only when n % 4 == 0 (the owned lists of the tile-row
+// partition have any length).
+inline int64_t pad4(int64_t n) { return (n + 3) & ~int64_t(3); }
+
+// Instances a CHECKED (or SYNC) forward counted, read from its result record right after the call returned -- the backward's
+// scratch holds one record per instance, and the capacity policy keeps 3.6 x the last need as room for run-ahead forwards:
+// sizing the scratch by the capacity committed 3.6 x the memory (device memory is not demand-paged: ADVICE r4).  0 = not
+// known at this point (run-ahead forward, overflow): the backward then sizes by the capacity, which bounds every instance id.
+inline int64_t counted_instances(int status, int64_t fwd_flags, int64_t slot_ptr) {
+  if (status != VTGS_OK || (fwd_flags & VTGS_FORWARD_MODE_MASK) == VTGS_FORWARD_ASYNC || slot_ptr == 0) return 0;
+  const VtgsForwardInfo* info = reinterpret_cast<const VtgsForwardInfo*>(slot_ptr);
+  return (info->complete && !info->overflow) ? (int64_t)info->instances : 0;
+}
+
 struct CamRecord {            // VtgsCamera with the three device tensors it points at kept alive
   VtgsCamera c;
   at::Tensor bg, view, proj;
@@ -90,6 +105,7 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     TORCH_CHECK(st == VTGS_OK || st == VTGS_ERR_INSTANCE_OVERFLOW, "vtgs_forward failed: ", vtgs_strerror(st), " (",
                 vtgs_last_hip_error(), ")");
     ctx->save_for_backward({means3D, colors, opac, scales, rot, color, workspace, cam_bytes, bg, view, proj});
+    ctx->saved_data["instances"] = counted_instances(st, flags, slot_ptr);
     ctx->saved_data["capacity"] = capacity;
     ctx->saved_data["tile_cap"] = tile_cap;
     ctx->saved_data["stream"] = stream;
@@ -120,23 +136,24 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     int64_t total = 0;
     bool want[6];
     for (int i = 0; i < 6; ++i) { want[i] = ctx->needs_input_grad(i); total += want[i] ? kWidth[i] : 0; }
-    at::Tensor flat = at::empty({std::max<int64_t>(total, 1) * n}, f32);
+    const int64_t np = pad4(n);                                  // segment stride: every array starts 16-byte aligned
+    at::Tensor flat = at::empty({std::max<int64_t>(total, 1) * std::max<int64_t>(np, 1)}, f32);
     at::Tensor g[6];
     float* gp[6];
     int64_t off = 0;
     for (int i = 0; i < 6; ++i) {
       gp[i] = nullptr;
       if (!want[i]) continue;
-      g[i] = flat.narrow(0, off * n, kWidth[i] * n).view({n, kWidth[i]});
+      g[i] = flat.narrow(0, off * np, kWidth[i] * n).view({n, kWidth[i]});
       gp[i] = g[i].data_ptr<float>();
       off += kWidth[i];
     }
     if (n > 0 && total > 0) {
-      // The scratch is indexed by instance id, and the instance CAPACITY bounds the ids whatever the forward counted.  (Round 3
-      // sized it from the pinned result record behind slot_ptr; that slot is shared round-robin with later forwards, so a
-      // backward that runs 64 forwards after its own forward could read another forward's -- smaller -- count: ADVICE r3.
-      // Untouched tail pages of the block cost nothing.)
-      const size_t sbytes = vtgs_backward_scratch_bytes((int32_t)n, (uint64_t)capacity);
+      // The scratch is indexed by instance id: the count the forward read from its OWN record before it returned (checked
+      // forwards), else the instance capacity, which bounds the ids whatever was counted.  (Round 3 re-read the pinned slot
+      // here; it is shared round-robin with later forwards: ADVICE r3.)
+      const int64_t counted = ctx->saved_data["instances"].toInt();
+      const size_t sbytes = vtgs_backward_scratch_bytes((int32_t)n, (uint64_t)(counted > 0 ? counted : capacity));
       at::Tensor scratch = at::empty({(int64_t)sbytes}, f32.dtype(at::kByte));
       if (g_poison) scratch.fill_(0xFF);
       const int st = vtgs_backward(&cam.c, (int32_t)n, means3D.data_ptr<float>(), colors.data_ptr<float>(), opac.data_ptr<float>(),
@@ -191,9 +208,10 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
     const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
     void* st_ = reinterpret_cast<void*>(stream);
     // one block for the render variables: means_cam 3, opacities 1, scales 3, rotations 4, depth colours 3 (+ compact colours 3)
-    at::Tensor vars = at::empty({std::max<int64_t>(n, 1) * (owned ? 17 : 14)}, f32);
+    const int64_t np = pad4(n);                                   // segment stride (rot is read as float4)
+    at::Tensor vars = at::empty({std::max<int64_t>(np, 4) * (owned ? 17 : 14)}, f32);
     float* v = vars.data_ptr<float>();
-    float *means_cam = v, *opac = v + 3 * n, *scales = v + 4 * n, *rot = v + 7 * n, *dcol = v + 11 * n, *rgb_c = v + 14 * n;
+    float *means_cam = v, *opac = v + 3 * np, *scales = v + 4 * np, *rot = v + 7 * np, *dcol = v + 11 * np, *rgb_c = v + 14 * np;
     int rc;
     if (owned) {
       TORCH_CHECK(owned_idx->scalar_type() == at::kInt && owned_idx->is_contiguous() && owned_idx->device() == dev &&
@@ -234,6 +252,7 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
     at::Tensor idx_saved = owned ? *owned_idx : at::Tensor();
     ctx->save_for_backward({means3D, rgb, unnorm_rot, cam_q, cam_t, depth_w2c, vars, images, workspace, cam_bytes, bg, view, proj,
                             idx_saved});
+    ctx->saved_data["instances"] = counted_instances(st, fwd_flags, slot_ptr);
     ctx->saved_data["capacity"] = capacity;
     ctx->saved_data["tile_cap"] = tile_cap;
     ctx->saved_data["stream"] = stream;
@@ -266,11 +285,12 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
     const bool want_g = flags & 1, want_p = flags & 2, want_a = flags & 4;
     // the map-sized gradients somebody asked for, one block (with a list the kernel writes the listed rows only: zeros first)
     const int64_t width = (want_g ? 7 : 0) + (want_a ? 5 : 0);
-    at::Tensor flat = owned ? at::zeros({std::max<int64_t>(width, 1) * n_map}, f32) : at::empty({std::max<int64_t>(width, 1) * n_map}, f32);
+    const int64_t npm = std::max<int64_t>(pad4(n_map), 4);      // segment stride (g_unnorm_rotations is written as float4)
+    at::Tensor flat = owned ? at::zeros({std::max<int64_t>(width, 1) * npm}, f32) : at::empty({std::max<int64_t>(width, 1) * npm}, f32);
     float* f = flat.data_ptr<float>();
     at::Tensor g_means3D, g_ur, g_rgb, g_logit, g_ls;
     int64_t off = 0;
-    auto take = [&](int64_t w) { at::Tensor t = flat.narrow(0, off * n_map, w * n_map).view({n_map, w}); off += w; return t; };
+    auto take = [&](int64_t w) { at::Tensor t = flat.narrow(0, off * npm, w * n_map).view({n_map, w}); off += w; return t; };
     if (want_g) { g_means3D = take(3); g_ur = take(4); }
     if (want_a) { g_rgb = take(3); g_logit = take(1); g_ls = take(1); }
     (void)f;
@@ -280,8 +300,10 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
     at::Tensor g_q, g_t;
     if (n > 0 && flags != 0) {
       const float* v = vars.data_ptr<float>();
-      const float *means_cam = v, *opac = v + 3 * n, *scales = v + 4 * n, *rot = v + 7 * n, *dcol = v + 11 * n, *rgb_c = v + 14 * n;
-      const size_t sbytes = vtgs_backward_dual_scratch_bytes((int32_t)n, (uint64_t)capacity);   // by the capacity (see Rasterize::backward)
+      const int64_t np = pad4(n);
+      const float *means_cam = v, *opac = v + 3 * np, *scales = v + 4 * np, *rot = v + 7 * np, *dcol = v + 11 * np, *rgb_c = v + 14 * np;
+      const int64_t counted = ctx->saved_data["instances"].toInt();   // (see Rasterize::backward)
+      const size_t sbytes = vtgs_backward_dual_scratch_bytes((int32_t)n, (uint64_t)(counted > 0 ? counted : capacity));
       at::Tensor scratch = at::empty({(int64_t)sbytes}, f32.dtype(at::kByte));
       if (g_poison) scratch.fill_(0xFF);
       const int st = vtgs_backward_dual_frame_owned(

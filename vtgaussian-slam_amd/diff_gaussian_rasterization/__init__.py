@@ -90,6 +90,10 @@ _SIGNATURES = {
     "vtgs_bin_plan_uniform": (ctypes.c_int, [_I32, _I32, ctypes.c_uint32, _P, _P]),
     "vtgs_mark_visible": (ctypes.c_int, [ctypes.POINTER(_VtgsCamera), _I32, _P, _P, _P]),
     "vtgs_debug_layout": (ctypes.c_int, [_I32, _I32, _I32, _U64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]),
+    "vtgs_pose_partial_rows": (ctypes.c_uint32, [_I32]),
+    "vtgs_pose7_reduce": (ctypes.c_int, [_I32, _P, _P, _P, _P, _P]),   # (declared HERE, once: partition.pose7_reduce used to assign
+                                                                      #  the signature on every call, and a caller that reached the
+                                                                      #  symbol first passed 64-bit pointers as C ints)
     "vtgs_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "vtgs_profile_collect": (ctypes.c_int, [ctypes.POINTER(_VtgsProfileEntry), _I32, ctypes.POINTER(_I32)]),
 }
@@ -419,6 +423,23 @@ def check_captured(fs=None) -> None:
         raise RuntimeError("a forward replayed from a captured graph overflowed its workspace (instances "
                            f"{int(info.instances_needed)} of {fs.capacity}, longest tile list {int(info.max_tile_list)} of "
                            f"{fs.tile_cap}): the iteration's results are invalid; capture again")
+
+
+# the C++ autograd nodes never enter the interpreter in their backward, so the record of a RUN-AHEAD
+# forward was only read at the next forward (_drain) -- after optimizer.step() had already consumed gradients computed from
+# an image that an overflow had turned into the background colour.  A run-ahead forward through a C++ node therefore hangs a
+# post-hook on its graph node: it runs right after the node's backward has been enqueued (as the Python node's _settle
+# does), reads the record and raises out of loss.backward(), BEFORE any optimizer step.  VTGS_SETTLE_IN_BACKWARD=0 restores
+# the late check (a caller that settles itself: settle_pending() between backward() and step()).
+_SETTLE_IN_BACKWARD = os.environ.get("VTGS_SETTLE_IN_BACKWARD", "1") != "0"
+
+
+def _settle_after_backward(out: torch.Tensor, fs) -> None:
+    node = out.grad_fn
+    if _SETTLE_IN_BACKWARD and node is not None:
+        def hook(_grad_inputs, _grad_outputs, fs=fs):
+            _settle(fs)
+        node.register_hook(hook)
 
 
 def settle_pending() -> None:
@@ -814,6 +835,7 @@ def _forward_ext(cam: _Camera, means3D, means2D, colors, opacities, scales, rota
             fs._instances = None
             fs.pending = (pool, slot, device, stream)
             pool.pending.append(fs)
+            _settle_after_backward(color, fs)
         else:
             pool.owner[slot] = None
             _caps_in_use.setdefault(key, (capacity, tile_cap))

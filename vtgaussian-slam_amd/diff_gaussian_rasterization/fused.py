@@ -185,7 +185,7 @@ def _render_frame_ext(means3D, rgb, unnorm_rot, logit_op, log_scales, q, t, dept
     bound by this host path."""
     from . import (PLANNED, VTGS_ERR_INSTANCE_OVERFLOW, VTGS_FORWARD_ASYNC, VTGS_FORWARD_CHECKED, _FORWARD_MODE, _async_ok,
                    _caps_in_use, _choose_capacities, _drain, _ext, _forward_hints, _grow_after_overflow, _plan_for, _record_info,
-                   _slot_lock, _slot_pool)
+                   _settle_after_backward, _slot_lock, _slot_pool)
     device = means3D.device
     n = int(means3D.shape[0]) if owned is None else int(owned.idx.numel())
     stream = _stream_ptr(device)
@@ -221,6 +221,7 @@ def _render_frame_ext(means3D, rgb, unnorm_rot, logit_op, log_scales, q, t, dept
             fs._instances = None
             fs.pending = (pool, slot, device, stream)
             pool.pending.append(fs)
+            _settle_after_backward(im, fs)             # (the record is read inside loss.backward(), before any optimizer step)
         else:
             pool.owner[slot] = None
             _caps_in_use.setdefault(key, (capacity, tile_cap))

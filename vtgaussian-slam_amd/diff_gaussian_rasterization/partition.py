@@ -294,9 +294,7 @@ def pose7_reduce(points, g_points):
 
     import torch
 
-    from . import _I32, _P, _check, _lib, _stream_ptr
-    _lib.vtgs_pose_partial_rows.restype, _lib.vtgs_pose_partial_rows.argtypes = ctypes.c_uint32, [_I32]
-    _lib.vtgs_pose7_reduce.restype, _lib.vtgs_pose7_reduce.argtypes = ctypes.c_int, [_I32, _P, _P, _P, _P, _P]
+    from . import _check, _lib, _stream_ptr
     if not points.is_cuda:
         raise RuntimeError("pose7_reduce needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
     p = points.detach().to(torch.float32).contiguous()
