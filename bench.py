@@ -479,15 +479,52 @@ def main():
                                               "index_add launches of the list route are torch's and not in kernels_us -- "
                                               "ms_per_step has them)",
                            "emulated_in_one_process": bool(emulated)}
+    # ---- N > 1 ranks: what the first SCALE run has to show -- every rank's kernel times and replicated
+    # share, the world size the process group reports, and the collective's own latency (a 7-float all-reduce, event-timed) ----
+    if dist is not None:
+        mine = {"rank": rank, "tile_rows": list(tile_rows) if tile_rows is not None else None,
+                "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()}}
+        if tile_rows is not None and kern:
+            ideal = (tile_rows[1] - tile_rows[0]) / float(gy16)
+            listed = (len(own) / float(N)) if own is not None else 1.0
+            whole = sum(v["avg_us"] for k, v in kern.items() if k == "band_owner_mask")
+            per_list = sum(v["avg_us"] for k, v in kern.items() if not k.startswith("composite_") and k != "band_owner_mask")
+            tot = sum(v["avg_us"] for v in kern.values())
+            mine["kernel_us_total"] = round(tot, 2)
+            mine["replicated_frac"] = round((whole + per_list * (1.0 - ideal / listed)) / tot, 4) if tot else None
+        buf = torch.zeros(7, device=dev)
+        for _ in range(5):
+            all_reduce_sum(buf)
+        fence()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+        ev[0].record()
+        for i in range(20):
+            all_reduce_sum(buf)
+            ev[i + 1].record()
+        fence()
+        coll = sorted(ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(20))
+        mine["allreduce_7_floats_us"] = {"p10": round(coll[2], 1), "p50": round(coll[10], 1), "p90": round(coll[18], 1)}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        if rank == 0:
+            out["ranks"] = {"world_size": dist.get_world_size(), "backend": args.backend, "per_rank": every,
+                            "collective_us": max(r["allreduce_7_floats_us"]["p50"] for r in every),
+                            "step_kernel_us_max_over_ranks": max((r.get("kernel_us_total") or 0.0) for r in every),
+                            "note": "per_rank[r].kernels_us: HIP-event averages of rank r's own launches (its band); collective_us: "
+                                    "median latency of the step's 7-float all-reduce, the slowest rank's figure; the default route "
+                                    "is the plain operator + the 7-float all-reduce (the owner-band exchange stays opt-in)"}
     # ---- slam block (BASELINE.json metric 2): a short run of bench_slam.py's loop through the get_loss mirror ---------------
     # The line above is complete without it.  On N > 1 GPUs the loop has collectives in it (never run on real multi-GPU
     # hardware by the builder: DESIGN.md 5), so a watchdog on every rank prints the line without the block and ends the process
     # if the loop has not finished in time, instead of leaving the driver without a record.
+    if world > 1 and args.slam_frames > 3:
+        args.slam_frames = 3        # N ranks: a short run (one warm-up + two ordinary frames + one base frame, ~1 min): the N = 8
+                                    # case has to finish well inside the driver's 600 s, and its loop was never run on RCCL hardware
     if args.slam_frames > 0 and (N, W, H) == (1_000_000, 1200, 680):     # (every rank takes part in the N-rank loop)
         import bench_slam
         import threading
         finished = threading.Event()
-        limit = 420.0
+        limit = 300.0
 
         def bail():
             if finished.is_set():
@@ -519,7 +556,10 @@ def main():
         route = (["--get-loss", "--global-submaps", "2"] if world == 1 else ["--fused", "--backend", args.backend]) + \
                 ["--base-frame-every", str(E), "--warmup-frames", "1"] + ([] if whole_cycle else ["--emulate-window", "12"])
         try:
-            rec = bench_slam.run(bench_slam.parse_args(["--frames", str(args.slam_frames)] + route))
+            # one GPU: WITH the densification step of every ordinary frame (the reference's per-frame work),
+            # then the same cycle without it for comparison
+            rec = bench_slam.run(bench_slam.parse_args(["--frames", str(args.slam_frames)] + route + (["--densify"] if world == 1 else [])))
+            rec_plain = bench_slam.run(bench_slam.parse_args(["--frames", str(args.slam_frames)] + route)) if world == 1 else None
             reg = rec.get("regimes") or {}
             mix = reg.get("frames_per_s_mix_39_to_1")
             slam = {"metric": "SLAM frames/s, tracking+mapping loop", "value": mix if mix is not None else rec["value"],
@@ -532,6 +572,10 @@ def main():
                     "mapping_ms_per_iter": rec["mapping_ms_per_iter"], "regimes": reg, "workload": rec["config"]["workload"],
                     "gaussians_in_global_set": rec["config"]["gaussians_in_global_set"],
                     "pose_error_after_tracking_cm_deg": rec["pose_error_after_tracking_cm_deg"], "n_gpus": world,
+                    "densification": rec.get("densification"),
+                    "without_densification": None if rec_plain is None else {
+                        "value": (rec_plain.get("regimes") or {}).get("frames_per_s_mix_39_to_1") or rec_plain["value"],
+                        "tracking_ms_per_iter": rec_plain["tracking_ms_per_iter"], "mapping_ms_per_iter": rec_plain["mapping_ms_per_iter"]},
                     "partition": rec["config"]["partition"],
                     "note": "synthetic Replica-room0-like sequence " + ("through the get_loss mirror" if world == 1 else
                             f"on {world} ranks: the fused operators with the band forms of the losses (no second call over a global set)") +
@@ -543,7 +587,9 @@ def main():
                             "16 cm away, which lengthens the tile lists -- the first frames of a cycle run ~20 % faster than its mean.  "
                             if whole_cycle else "The ordinary frames draw as from a 12-frame window (second call in 1 of 12 iterations; the mean "
                             "over a 40-frame submap is 0.084).  ") +
-                            "No dataset I/O, no keyframe-overlap selection, no densification: a LOWER bound of the reference's per-frame work."}
+                            + ("Every ordinary frame runs the reference's densification step (forward-only render, depth_error.median(), "
+                               "new Gaussians appended: N grows over the cycle).  " if world == 1 else "No densification on N > 1 ranks.  ") +
+                            "No dataset I/O and no keyframe-overlap selection (host / small-tensor work outside the rasterizer path)."}
         except Exception as e:                                   # (the headline line must not be lost over the second metric)
             if world == 1:
                 raise

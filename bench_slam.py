@@ -78,6 +78,13 @@ def parse_args(argv=None):
                          "one of the frames really present.  A short run has windows of 2-3 frames, where the base frame is "
                          "drawn every second or third iteration; over the 39 ordinary frames of a 40-frame submap the mean of "
                          "1/(i+1) is 0.084, i.e. W = 12")
+    ap.add_argument("--densify", action="store_true",
+                    help="the densification step of every ORDINARY frame's mapping phase (src/vtgaussian_slam.py:2349-2380 -> "
+                         "add_new_gaussians_base_frame, :732-813): one forward-only silhouette render under the tracked pose, "
+                         "depth_error.median(), a Gaussian for every pixel whose silhouette is below 0.5 or whose rendered depth "
+                         "lies behind the observation by more than 50 x the median error -- plus, for one such pixel in twelve "
+                         "(the edge share of Appendix B), four half-scale Gaussians on the 2 x grid -- appended to the current "
+                         "submap, so N grows over a submap's 40 frames as in the reference.  One GPU only")
     ap.add_argument("--owned-sets", default="auto", choices=["auto", "on", "off"],
                     help="N-rank loop: run the per-Gaussian kernels over the list of Gaussians that can meet the rank's band "
                          "(partition.OwnedSet, rebuilt at every phase) instead of over the whole map.  auto = from 2 M Gaussians up: "
@@ -156,6 +163,25 @@ def run(args) -> dict:
         "unnorm_rotations": scene["rotations"].to(dev), "logit_opacities": torch.full((N, 1), 3.0, device=dev),
         "log_scales": torch.log(scene["scales"][:, :1]).to(dev),
     }
+    if getattr(args, "densify", False):
+        # The world beyond the first frame's frustum: a ring of view-tied Gaussians around the frame (96 px wide at frame 0,
+        # smooth depth), present in the OBSERVATIONS only.  The map starts as the first frame's back-projection, so the camera
+        # path uncovers ~1.6 px of unmapped border per frame -- what the reference's densification step finds in a real
+        # sequence (newly visible surface with valid depth; N grows by 10-30 % over a submap).
+        m = 96
+        yy, xx = torch.meshgrid(torch.arange(-m, H + m, dtype=torch.float32), torch.arange(-m, W + m, dtype=torch.float32), indexing="ij")
+        ring = ((xx < 0) | (xx >= W) | (yy < 0) | (yy >= H)).reshape(-1)
+        rx, ry = xx.reshape(-1)[ring], yy.reshape(-1)[ring]
+        rz = 3.5 + 1.2 * torch.sin(rx / 97.0) * torch.cos(ry / 71.0)
+        gr = torch.Generator().manual_seed(77)
+        ring_params = {
+            "means3D": torch.stack([(rx - (W / 2.0 - 0.5) + 0.5) / fx * rz, (ry - (H / 2.0 - 0.5) + 0.5) / fx * rz, rz], 1).to(dev),
+            "rgb_colors": torch.rand(rx.numel(), 3, generator=gr).to(dev),
+            "unnorm_rotations": torch.tensor([1.0, 0, 0, 0]).repeat(rx.numel(), 1).to(dev),
+            "logit_opacities": torch.full((rx.numel(), 1), 3.0, device=dev), "log_scales": torch.log(rz / fx)[:, None].to(dev)}
+        obs_params = {k: torch.cat([gt_params[k], ring_params[k]], 0) for k in gt_params}
+    else:
+        obs_params = gt_params
     # ground-truth camera path: 0.15 deg and 4 mm per frame
     gt_rots = torch.zeros(1, 4, T, device=dev)
     gt_trans = torch.zeros(1, 3, T, device=dev)
@@ -249,7 +275,7 @@ def run(args) -> dict:
     gts = []
     with torch.no_grad():
         for t in range(T):
-            p = dict(gt_params, cam_unnorm_rots=gt_rots, cam_trans=gt_trans)
+            p = dict(obs_params, cam_unnorm_rots=gt_rots, cam_trans=gt_trans)
             im, ds, _ = render_pair(p, t, False, False)
             sil = ds[1]
             depth = torch.where(sil > 0.5, ds[0] / sil.clamp(min=1e-6), torch.zeros_like(sil))[None]
@@ -332,6 +358,7 @@ def run(args) -> dict:
     owned_done()
 
     track_ms, map_ms, errs_before, errs_after = [], [], [], []
+    dens_added, dens_ms = [], []
     torch.cuda.synchronize()
     t_all = time.perf_counter()
     frame_kind, frame_s, second_frac = [], [], []
@@ -339,6 +366,7 @@ def run(args) -> dict:
         if t == WU + 1 and WU:                     # the clock starts here: drop what the warm-up frames recorded
             torch.cuda.synchronize()
             track_ms, map_ms, errs_before, errs_after, frame_kind, frame_s, second_frac = [], [], [], [], [], [], []
+            dens_added, dens_ms = [], []
             t_all = time.perf_counter()
         torch.cuda.synchronize(); t_frame = time.perf_counter()
         gt_im, gt_depth = gts[t]
@@ -401,6 +429,50 @@ def run(args) -> dict:
         owned_done()
         torch.cuda.synchronize(); track_ms.append((time.perf_counter() - t0) * 1e3 / args.tracking_iters)
         errs_after.append(pose_error(t))
+        # ---- densification (the reference's add_new_gaussians_base_frame, ordinary frames only: :2366-2375)
+        if getattr(args, "densify", False) and world == 1 and not (args.base_frame_every > 0 and t % args.base_frame_every == 0):
+            torch.cuda.synchronize(); td0 = time.perf_counter()
+            with torch.no_grad():
+                # forward only, under the tracked pose (the reference renders [z, 1, z^2] alone, :747; the fused route's dual pass
+                # renders the colour image beside it)
+                _im, ds, _r = render_pair(params, t, gaussians_grad=False, camera_grad=False)
+                sil, rd, gd = ds[1], ds[0], gts[t][1][0]
+                err = (gd - rd).abs() * (gd > 0)
+                hole = (sil < 0.5) | ((rd > gd) & (err > 50 * err.median()))          # :748-756
+                idx = (hole & (gd > 0)).reshape(-1).nonzero().reshape(-1)               # (a host read, like :758's torch.sum(...) > 0)
+                if idx.numel():
+                    fxy = W / 2.0                                                       # the synthetic camera of SURVEY 8d
+                    px, py = (idx % W).float(), (idx // W).float()
+                    dense = idx[idx % 12 == 0]                                          # the 2 x grid: one hole pixel in twelve, four sub-pixels each
+                    if dense.numel():
+                        off = torch.tensor([[-0.25, -0.25], [0.25, -0.25], [-0.25, 0.25], [0.25, 0.25]], device=dev)
+                        dx = ((dense % W).float()[:, None] + off[None, :, 0]).reshape(-1)
+                        dy = ((dense // W).float()[:, None] + off[None, :, 1]).reshape(-1)
+                        px, py = torch.cat([px, dx]), torch.cat([py, dy])
+                        src = torch.cat([idx, dense.repeat_interleave(4)])
+                        half = torch.cat([torch.ones(idx.numel(), device=dev), torch.full((4 * dense.numel(),), 0.5, device=dev)])
+                    else:
+                        src, half = idx, torch.ones(idx.numel(), device=dev)
+                    z = gd.reshape(-1)[src] * 1.005                                     # get_pointcloud, :76-121 (factor 1.005)
+                    pts_cam = torch.stack([(px - (W / 2.0 - 0.5) + 0.5) / fxy * z, (py - (H / 2.0 - 0.5) + 0.5) / fxy * z, z,
+                                           torch.ones_like(z)], 1)
+                    w2c_t = torch.eye(4, device=dev)
+                    w2c_t[:3, :3] = sc.build_rotation(torch.nn.functional.normalize(params["cam_unnorm_rots"][..., t].detach()))
+                    w2c_t[:3, 3] = params["cam_trans"][0, :, t].detach()
+                    new = {"means3D": (torch.inverse(w2c_t) @ pts_cam.T).T[:, :3].contiguous(),
+                           "rgb_colors": gts[t][0].reshape(3, -1).T[src].contiguous(),
+                           "unnorm_rotations": torch.tensor([1.0, 0, 0, 0], device=dev).repeat(src.numel(), 1),
+                           "logit_opacities": torch.zeros(src.numel(), 1, device=dev),      # initialize_new_params, :692-720
+                           "log_scales": torch.log(z / fxy * half)[:, None]}
+                    for k, v in new.items():
+                        params[k] = torch.nn.Parameter(torch.cat([params[k].detach(), v], 0))
+                    n_now = params["means3D"].shape[0]
+                    variables = {k: torch.zeros(n_now, device=dev) for k in ("max_2D_radius", "means2D_gradient_accum", "denom")}
+                    variables_global = {k: torch.zeros(n_now + N * len(fixed), device=dev) for k in variables}
+                    dens_added.append(src.numel())
+                else:
+                    dens_added.append(0)
+            torch.cuda.synchronize(); dens_ms.append((time.perf_counter() - td0) * 1e3)
         # ---- mapping
         opt = make_adam([{"params": [v], "name": k, "lr": map_lrs[k]} for k, v in params.items()], lr=0.0, eps=1e-15)
         # Which view an iteration renders, and whether it makes the second call over the global set (module docstring of
@@ -535,6 +607,11 @@ def run(args) -> dict:
         "pose_error_before_tracking_cm_deg": [[round(a, 3), round(b, 4)] for a, b in errs_before],
         "pose_error_after_tracking_cm_deg": [[round(a, 3), round(b, 4)] for a, b in errs_after],
         "regimes": regimes,
+        "densification": None if not getattr(args, "densify", False) else {
+            "frames": len(dens_added), "gaussians_added_per_frame_mean": round(sum(dens_added) / max(len(dens_added), 1), 1),
+            "ms_per_frame_mean": round(sum(dens_ms) / max(len(dens_ms), 1), 2), "gaussians_at_the_end": int(params["means3D"].shape[0]),
+            "what": "forward-only render + depth_error.median() + back-projection + append, every ordinary frame "
+                    "(src/vtgaussian_slam.py:732-813)"},
         "owned_sets": None if not use_owned else {
             "lists_built": owned_stats["built"], "mean_listed_fraction_of_map": round(owned_stats["listed"] / max(owned_stats["built"], 1) / N, 4),
             "escapes": owned_stats["escapes"], "margin_px": 32.0, "scale_growth": 1.25, "rank": rank},

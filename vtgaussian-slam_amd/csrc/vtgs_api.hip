@@ -143,6 +143,7 @@ static CamScalars scalars_of(const VtgsCamera* cam, int row8_begin, int row8_end
   cs.radius_rule = cam->radius_rule;
   cs.row8_begin = row8_begin; cs.row8_end = row8_end;
   cs.bin_plan = nullptr; cs.bin_limit = 0u;                  // planned bins: set by the caller once the workspace layout is known
+  cs.bwd_flags = 0u;
 #ifdef VTGS_Q_STAMPS
   cs.dbg_proj = nullptr;
 #endif
@@ -564,6 +565,9 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
   const uint32_t nblk16 = (uint32_t)(gx16 * rows16);
   uint32_t* dbg = option(OPT_COUNT_STEPS) == 1 ? (uint32_t*)(const_cast<char*>(ws) + L.dbg) : nullptr;   // measurement only
   int bwd_impl = option(OPT_BWD_IMPL);                       // 2 = lane-per-pixel matrix-core replay (default), 1 = pixel x splat-quad replay,
+  // dL/d(first colour set) not asked for (tracking: the Gaussians are detached, src/vtgaussian_slam.py:428-449, and the pose
+  // gradient flows through means3D and the SECOND set's [z, 1, z^2] only): the lane = pixel backward skips that contraction chain
+  if (frame ? !(frame->flags & 4u) : !g_colors) cs.bwd_flags |= 1u;
   if (dual && bwd_impl == 0) bwd_impl = 1;                   // 0 = scalar kernel (single render only); read per call
   if (dual && bwd_impl == 3) bwd_impl = 2;                   // 3 = quadrant queues (single render only so far)
   {

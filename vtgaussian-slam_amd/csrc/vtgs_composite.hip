@@ -1013,6 +1013,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   const float4* __restrict__ PhiA4 = reinterpret_cast<const float4*>(lds_phi + pq * kPhiQuarter + cj * kImgRow);
   const float4* __restrict__ PhiB4 = reinterpret_cast<const float4*>(lds_phi + pq * kPhiQuarter + (4 + cj) * kImgRow);
   const uint32_t tile_bits = (uint32_t)tc.tile;
+  const bool skip_a = PXL && (cs.bwd_flags & 1u) != 0u;
   // record columns: chain a -> 0..3, chain b -> 4, 5 (its lanes cj = 2, 3 hold padding and store nothing), chain w -> 6..8
   // and the tile id in 9 (dual: w -> 6..8 + tile id in 12, w2 -> 9..11, its lane cj = 3 stores nothing)
   const int col_b = 4 + cj;
@@ -1098,36 +1099,40 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
       }
       const int nb = min(16, n - 16 * b);
       f32x4 Pa = {0.f, 0.f, 0.f, 0.f}, Pb = {0.f, 0.f, 0.f, 0.f}, Pw = {0.f, 0.f, 0.f, 0.f}, Pw2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) {
-        const float4 ua = Ua4[t4], wa = Wa4[t4], ba = PhiA4[t4], bb = PhiB4[t4];
-        const float uav[4] = {ua.x, ua.y, ua.z, ua.w}, wav[4] = {wa.x, wa.y, wa.z, wa.w};
-        const float bav[4] = {ba.x, ba.y, ba.z, ba.w}, bbv[4] = {bb.x, bb.y, bb.z, bb.w};
-        float gav[4], gbv[4];
-        {
-          const float4 ga = Ga4[t4];
-          gav[0] = ga.x; gav[1] = ga.y; gav[2] = ga.z; gav[3] = ga.w;
-        }
-        if constexpr (DUAL) {
-          const float4 gb = Gb4[t4];
-          gbv[0] = gb.x; gbv[1] = gb.y; gbv[2] = gb.z; gbv[3] = gb.w;
-        } else {
-          gbv[0] = gbv[1] = gbv[2] = gbv[3] = 0.f;
-        }
-#pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {
-          Pa = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bav[e4], Pa, 0, 0, 0);
-          Pb = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bbv[e4], Pb, 0, 0, 0);
-          Pw = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], gav[e4], Pw, 0, 0, 0);
-          if constexpr (DUAL) Pw2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], gbv[e4], Pw2, 0, 0, 0);
-        }
+      // SKIPA (wave-uniform, CamScalars::bwd_flags bit 0): dL/d(first colour set) is wanted by nobody -- a tracking iteration --
+      // so chain w (16 of the 48 / 64 contraction MFMAs and its operand reads) is left out; its record columns stay unwritten
+      // and the gather kernel does not store what it sums from them
+#define VTGS_CONTRACT(SKIPA)                                                                                        \
+      {                                                                                                             \
+        _Pragma("unroll") for (int t4 = 0; t4 < 4; ++t4) {                                                          \
+          const float4 ua = Ua4[t4], wa = Wa4[t4], ba = PhiA4[t4], bb = PhiB4[t4];                                  \
+          const float uav[4] = {ua.x, ua.y, ua.z, ua.w}, wav[4] = {wa.x, wa.y, wa.z, wa.w};                         \
+          const float bav[4] = {ba.x, ba.y, ba.z, ba.w}, bbv[4] = {bb.x, bb.y, bb.z, bb.w};                         \
+          float gav[4] = {0.f, 0.f, 0.f, 0.f}, gbv[4] = {0.f, 0.f, 0.f, 0.f};                                       \
+          if constexpr (!(SKIPA)) {                                                                                 \
+            const float4 ga = Ga4[t4];                                                                              \
+            gav[0] = ga.x; gav[1] = ga.y; gav[2] = ga.z; gav[3] = ga.w;                                             \
+          }                                                                                                         \
+          if constexpr (DUAL) {                                                                                     \
+            const float4 gb = Gb4[t4];                                                                              \
+            gbv[0] = gb.x; gbv[1] = gb.y; gbv[2] = gb.z; gbv[3] = gb.w;                                             \
+          }                                                                                                         \
+          _Pragma("unroll") for (int e4 = 0; e4 < 4; ++e4) {                                                        \
+            Pa = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bav[e4], Pa, 0, 0, 0);                                 \
+            Pb = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bbv[e4], Pb, 0, 0, 0);                                 \
+            if constexpr (!(SKIPA)) Pw = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], gav[e4], Pw, 0, 0, 0);         \
+            if constexpr (DUAL) Pw2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], gbv[e4], Pw2, 0, 0, 0);           \
+          }                                                                                                         \
+        }                                                                                                           \
+        if (VTGS_PX_GROUP2) {                                                                                       \
+          __builtin_amdgcn_sched_group_barrier(0x100, (DUAL ? 24 : 20) - ((SKIPA) ? 4 : 0), 1);   /* the image / Phi / g reads first ... */ \
+          __builtin_amdgcn_sched_group_barrier(0x008, (DUAL ? 64 : 48) - ((SKIPA) ? 16 : 0), 1);  /* ... then the contraction MFMAs back to back */ \
+        }                                                                                                           \
       }
-#if VTGS_PX_GROUP2
-      __builtin_amdgcn_sched_group_barrier(0x100, DUAL ? 24 : 20, 1);   // the image / Phi / g reads first ...
-      __builtin_amdgcn_sched_group_barrier(0x008, DUAL ? 64 : 48, 1);   // ... then the contraction MFMAs back to back
-#endif
+      if (skip_a) VTGS_CONTRACT(true) else VTGS_CONTRACT(false)
+#undef VTGS_CONTRACT
       // lane (cj, sg, rho = l >> 4) ends up with the totals of splat 4 sg + rho
-      const float Fa = quarter_sum(Pa), Fb = quarter_sum(Pb), Fw = quarter_sum(Pw);
+      const float Fa = quarter_sum(Pa), Fb = quarter_sum(Pb), Fw = skip_a ? 0.f : quarter_sum(Pw);   // (skip_a is wave-uniform)
       const float Fw2 = DUAL ? quarter_sum(Pw2) : 0.f;           // cross-lane: must run with all lanes active
       const int srow = (l & 12) + (l >> 4);                     // 4 sg + rho
       const uint32_t inst = (uint32_t)__shfl((int)my_inst, 16 * b + srow, 64);

@@ -115,6 +115,8 @@ struct CamScalars {
   int row8_begin, row8_end;
   const uint32_t* bin_plan;       // planned bins: offsets [tiles8 + 1] (the workspace's copy); NULL = uniform bins of tile_cap slots
   uint32_t bin_limit;             // ... and the slots the workspace holds: no bin reaches past it, whatever the plan says
+  uint32_t bwd_flags;             // composite_backward_mx: bit 0 = nobody wants dL/d(first colour set) -- the tracking loop detaches
+                                  // the Gaussians, and the pose gradient does not need it: that contraction chain is skipped
 #ifdef VTGS_Q_STAMPS
   uint32_t* dbg_proj;             // diagnostic build: 8 words of stamps per workgroup of project_and_bin
 #endif

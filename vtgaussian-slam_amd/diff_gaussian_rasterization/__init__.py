@@ -571,8 +571,22 @@ def _choose_capacities(key, n):
     for identically sized workspaces (it can then recycle the blocks instead of calling hipMalloc/hipFree).
     The second value carries the PLANNED bit when the view runs with planned bins."""
     need_i, need_t = _capacity_hint.get(key, 0), _tile_cap_hint.get(key, 0)
+    view = (key[0], key[2], key[3], key[4])
     if not need_i:
-        return 8 * n + 65536, (PLANNED | 512) if _BINS_MODE == "planned" else 512
+        # A shape nobody has rendered yet.  The policy is keyed by n, and n changes whenever a map is densified or an owned
+        # list is rebuilt (every frame of a SLAM loop, every phase of a band rank): without a seed each new n cold-starts at
+        # 8 n + 65536 instances and 512 slots, overflows on a dense view, and stays checked for three forwards (ADVICE r4).
+        # The needs of the LAST shape of the same (device, W, H, band) scaled by n carry over -- as hints only: the forward
+        # is still checked until three forwards of the new shape have agreed.
+        seed = _last_shape.get(view)
+        if seed is not None and seed[0] > 0 and n > 0 and seed[0] != n:      # (the same n again: its tables were cleared on purpose)
+            scale = max(1.0, n / float(seed[0]))
+            _capacity_hint[key] = need_i = int(seed[1] * scale) + 1
+            _tile_cap_hint[key] = need_t = int(seed[2] * min(scale, 2.0)) + 1
+            if seed[3]:
+                _slots_hint[key] = int(seed[3] * scale) + 1
+        else:
+            return 8 * n + 65536, (PLANNED | 512) if _BINS_MODE == "planned" else 512
     cap, tcap = _caps_in_use.get(key, (0, 0))
     # Instance capacity (it sizes the backward's scratch, of which only the used records are touched): room for a run-ahead
     # forward, i.e. _RUN_AHEAD_HEADROOM x the last need; moved only when that room is lost or ten times too much is held.
@@ -623,12 +637,30 @@ def _grow_after_overflow(key, n, device, info, capacity, tile_cap, workspace):
     return capacity, tile_cap
 
 
+_last_shape = {}                        # (device, W, H, band) -> (n, instances, longest list, slots) of the last forward of that view
+_POLICY_KEYS_MAX = 256                  # shapes the per-key tables remember (a long run with a growing map meets thousands of n)
+
+
+def _evict_policy_keys() -> None:
+    """The per-shape tables are dicts keyed by n; a map that grows every frame would fill them for ever.  Oldest
+    first (dicts keep insertion order); _caps_in_use / _async_ok entries of an evicted shape go with it."""
+    while len(_capacity_hint) > _POLICY_KEYS_MAX:
+        old = next(iter(_capacity_hint))
+        for d in (_capacity_hint, _tile_cap_hint, _slots_hint, _caps_in_use, _async_ok, _need_hist):
+            d.pop(old, None)
+        for pk in [pk for pk in _bin_plans if pk[0] == old]:
+            del _bin_plans[pk]
+
+
 def _record_info(key, n, W, H, capacity, info):
     # (once per forward, on the host's critical path of the host-bound shapes: plain ints, no generator expressions)
     need_i, need_t, need_s = int(info.instances_needed), int(info.max_tile_list), int(info.bin_slots_needed)
+    if key not in _capacity_hint and len(_capacity_hint) >= _POLICY_KEYS_MAX:
+        _evict_policy_keys()
     _capacity_hint[key] = need_i or 1
     _tile_cap_hint[key] = need_t or 1
     _slots_hint[key] = need_s or 1
+    _last_shape[(key[0], key[2], key[3], key[4])] = (n, need_i, need_t, need_s)
     cap, tcap = _caps_in_use.get(key, (0, 0))                  # the capacities this forward ran with
     # Run-ahead is for STEADY loops (tracking, mapping on one frame): the last three forwards of this shape must have needed
     # about the same (within 10 % of each other) and at most a THIRD of both capacities.  A loop that alternates between views
