@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VTGS_ABI_VERSION 14
+#define VTGS_ABI_VERSION 15
 
 typedef enum VtgsStatus {
   VTGS_OK = 0,
@@ -158,7 +158,7 @@ size_t vtgs_backward_scratch_bytes(int32_t n, uint64_t instances);
  * arguments (tests/test_gpu_empty_inputs.py calls all of them with n = 0 and NULL arrays on poisoned memory).             */
 
 /* Forward.  Replaces `_C.rasterize_gaussians` for the colors_precomp + scales/rotations signature
- * the reference uses (shs / cov3D_precomp are rejected in the Python layer).
+ * the reference uses (cov3D_precomp: vtgs_forward_cov3d; shs: vtgs_sh_forward in front of this call).
  *   means3D[N,3] opacities[N,1] colors[N,3] scales[N,3] rotations[N,4](w,x,y,z)
  *   out_color[3,H,W] out_depth[1,H,W] out_radii[N] (0 = culled; in band mode also 0 for a Gaussian that cannot
  *   meet the band's rows -- it is skipped before it is projected -- so the radii of a partitioned frame are the
@@ -203,6 +203,32 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n,
                   const float* image_state, void* scratch, size_t scratch_bytes,
                   float* g_means3D, float* g_means2D, float* g_colors, float* g_opacities,
                   float* g_scales, float* g_rotations, void* stream);
+
+/* cov3D_precomp form of the operator (the other half of its both-or-neither check): the 3-D covariance of every
+ * Gaussian is given as six floats (xx xy xz yy yz zz, used as they are: no scale modifier) instead of scales + rotations, and
+ * the backward returns dL/dcov3D[N,6] (an off-diagonal entry fills two places of the symmetric matrix).  The reference never
+ * passes it (utils/slam_helpers.py:152-159); single render, uniform bins (tile_capacity without VTGS_TILE_CAPACITY_PLANNED),
+ * whole frame or a band.  Everything else as vtgs_forward / vtgs_backward (any gradient output may be NULL, not all).          */
+int vtgs_forward_cov3d(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* opacities,
+                       const float* cov3D, float* out_color, float* out_depth, int32_t* out_radii, void* workspace,
+                       size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity, VtgsForwardInfo* info,
+                       uint32_t flags, void* stream);
+int vtgs_backward_cov3d(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* opacities,
+                        const float* cov3D, const float* out_color, const float* grad_color, const void* workspace,
+                        size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity, void* scratch,
+                        size_t scratch_bytes, float* g_means3D, float* g_means2D, float* g_colors, float* g_opacities,
+                        float* g_cov3D, void* stream);
+
+/* Spherical-harmonics colours: the operator's `shs` argument (the other half of its colours-or-SHs check; the reference only
+ * passes colours, sh_degree = 0 at utils/recon_helpers.py:22).  Per-Gaussian pre- and post-op around the rasterizer, no kernel
+ * of which changes: colours[n,3] = clamp0(sum_k Y_k(dir) shs[n,k,:] + 0.5), dir = (mean - campos)/|mean - campos|, real SH basis
+ * of `degree` 0..3 ((degree+1)^2 <= coeffs <= 16 coefficients per channel, shs laid out [n, coeffs, 3]); out_clamped[n] holds one
+ * bit per channel that was negative.  The backward turns dL/dcolours into dL/dshs[n,coeffs,3] (0 beyond the active degree) and
+ * the viewing direction's share of dL/dmeans3D[n,3] (either output may be NULL, not both).                                    */
+int vtgs_sh_forward(int32_t n, int32_t degree, int32_t coeffs, const float* means3D, const float* campos, const float* shs,
+                    float* out_colors, uint8_t* out_clamped, void* stream);
+int vtgs_sh_backward(int32_t n, int32_t degree, int32_t coeffs, const float* means3D, const float* campos, const float* shs,
+                     const uint8_t* clamped, const float* g_colors, float* g_shs, float* g_means3D, void* stream);
 
 /* ---- Dual render ("6 channels") -------------------------------------------------------------------
  * The two back-to-back renders of get_loss (src/vtgaussian_slam.py:461 RGB, :466 [z,1,z^2]) as ONE composite pass:

@@ -202,6 +202,36 @@ def preprocess(means3D, means2D, opacities, scales, rotations, cam, radius_rule=
     return Splats(visible, xy, conic, tz, depth_sort_key(means3D, V), radii, rect)
 
 
+SH_C0 = 0.28209479177387814
+SH_C1 = 0.4886025119029199
+SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+         1.445305721320277, -0.5900435899266435)
+
+
+def sh_colors(means3D: torch.Tensor, shs: torch.Tensor, campos: torch.Tensor, degree: int) -> torch.Tensor:
+    """Colours from spherical harmonics, the operator's `shs` argument [UPSTREAM-PUBLIC: the published real-SH evaluation up to
+    degree 3, view direction = normalised (mean - campos), + 0.5, negative channels clamped to 0].  shs [N, K, 3] with
+    K >= (degree + 1)^2.  Differentiable (autograd is the backward oracle).  The reference never takes this path
+    (sh_degree = 0, colours only: utils/recon_helpers.py:22, utils/slam_helpers.py:152-159)."""
+    d = means3D - campos.reshape(1, 3).to(means3D.dtype)
+    d = d / d.norm(dim=1, keepdim=True)
+    x, y, z = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+    res = SH_C0 * shs[:, 0]
+    if degree > 0:
+        res = res - SH_C1 * y * shs[:, 1] + SH_C1 * z * shs[:, 2] - SH_C1 * x * shs[:, 3]
+    if degree > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        res = (res + SH_C2[0] * xy * shs[:, 4] + SH_C2[1] * yz * shs[:, 5] + SH_C2[2] * (2.0 * zz - xx - yy) * shs[:, 6]
+               + SH_C2[3] * xz * shs[:, 7] + SH_C2[4] * (xx - yy) * shs[:, 8])
+    if degree > 2:
+        res = (res + SH_C3[0] * y * (3.0 * xx - yy) * shs[:, 9] + SH_C3[1] * xy * z * shs[:, 10]
+               + SH_C3[2] * y * (4.0 * zz - xx - yy) * shs[:, 11] + SH_C3[3] * z * (2.0 * zz - 3.0 * xx - 3.0 * yy) * shs[:, 12]
+               + SH_C3[4] * x * (4.0 * zz - xx - yy) * shs[:, 13] + SH_C3[5] * z * (xx - yy) * shs[:, 14]
+               + SH_C3[6] * x * (xx - 3.0 * yy) * shs[:, 15])
+    return torch.clamp_min(res + 0.5, 0.0)
+
+
 def build_tile_lists(sp: Splats, gx: int, gy: int):
     """Stable (tile, depth-bits) ordering; returns sorted Gaussian ids and [tiles+1] offsets."""
     vis = torch.nonzero(sp.visible).reshape(-1)

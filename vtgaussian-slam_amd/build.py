@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", f) for f in ("vtgs_api.hip", "vtgs_binning.hip", "vtgs_composite.hip", "vtgs_composite_q.hip", "vtgs_frame.hip", "vtgs_loss.hip", "vtgs_p2p.hip")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("vtgs_api.hip", "vtgs_binning.hip", "vtgs_composite.hip", "vtgs_composite_q.hip", "vtgs_frame.hip", "vtgs_loss.hip", "vtgs_p2p.hip", "vtgs_sh.hip")]
 # the cross-check composites (scalar, quad form, lane = pixel forward, quadrant-queue backward): a TEST-ONLY library next to the
 # product, built from the same sources with -DVTGS_XCHECK_BUILD=1; libvtgs.so opens it when an implementation switch asks
 XCHECK_SRC = [os.path.join(HERE, "csrc", f) for f in ("vtgs_xcheck.hip", "vtgs_composite.hip", "vtgs_composite_bq.hip")]

@@ -34,7 +34,7 @@ template <int WAVES, bool DUAL, bool PX>
 __global__ void composite_backward_mx(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                       const uint32_t*, const GeomRec*, const float*, const float*, const float*,
                                       const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*);
-template <bool DUAL, bool FRAME>
+template <bool DUAL, bool FRAME, bool COV3D>
 __global__ void gather_splat_grads(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
                                    const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*,
                                    float*, const Counters*, float*, FrameEpilogue);
@@ -268,12 +268,13 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
                         const float* opacities, const float* scales, const float* rotations, float* out_color,
                         float* out_depth, float* out_color_b, int32_t* out_radii, void* workspace, size_t workspace_bytes,
                         uint64_t instance_capacity, uint32_t tile_capacity, VtgsForwardInfo* info, uint32_t flags,
-                        void* stream, bool dual, uint32_t* bin_plan = nullptr) {
+                        void* stream, bool dual, uint32_t* bin_plan = nullptr, bool cov3d = false) {
+  // cov3d: `scales` is cov3D_precomp [N,6] and `rotations` is not read (vtgs_forward_cov3d: single render, uniform bins)
   if (!cam_ok(cam) || n < 0 || !out_color || (dual ? !out_color_b : !out_depth) || !workspace || instance_capacity == 0 ||
       instance_capacity > 0xFFFFFFFFull || (tile_capacity & ~VTGS_TILE_CAPACITY_PLANNED) == 0 ||
-      ((tile_capacity & VTGS_TILE_CAPACITY_PLANNED) != 0) != (bin_plan != nullptr))
+      ((tile_capacity & VTGS_TILE_CAPACITY_PLANNED) != 0) != (bin_plan != nullptr) || (cov3d && (dual || bin_plan)))
     return VTGS_ERR_INVALID_ARGUMENT;
-  if (n > 0 && (!means3D || !colors || (dual && !colors_b) || !opacities || !scales || !rotations || !out_radii))
+  if (n > 0 && (!means3D || !colors || (dual && !colors_b) || !opacities || !scales || (!rotations && !cov3d) || !out_radii))
     return VTGS_ERR_INVALID_ARGUMENT;
   int r8b, r8e, rows16, row16_0;
   if (!band_of(cam, &r8b, &r8e, &rows16, &row16_0)) return VTGS_ERR_INVALID_ARGUMENT;
@@ -322,14 +323,16 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
         if (hipFuncSetAttribute((const void*)project_and_bin<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
             hipFuncSetAttribute((const void*)project_and_bin_capped<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
             hipFuncSetAttribute((const void*)project_and_bin_capped<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
-            hipFuncSetAttribute((const void*)project_and_bin_capped<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess) {
+            hipFuncSetAttribute((const void*)project_and_bin_capped<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
+            hipFuncSetAttribute((const void*)project_and_bin_capped<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
+            hipFuncSetAttribute((const void*)project_and_bin_capped<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess) {
           if (dev_id >= 0) raised[dev_id] = true;
         } else { (void)hipGetLastError(); lds_bins = false; }
       }
     }
     {
       ProfScope ps__("project_and_bin", st);
-      const int mode = ((r8b > 0 || r8e < (cam->image_height + kSubTile - 1) / kSubTile) ? 1 : 0) | (L.planned ? 2 : 0);
+      const int mode = ((r8b > 0 || r8e < (cam->image_height + kSubTile - 1) / kSubTile) ? 1 : 0) | (L.planned ? 2 : 0) | (cov3d ? 4 : 0);
 #define VTGS_LAUNCH_PROJECT(LDS, MODE, SHMEM)                                                                          \
       hipLaunchKernelGGL((VTGS_PROJECT_KERNEL(LDS, MODE)), dim3((n + 1023) / 1024), dim3(1024), SHMEM, st, cs,             \
                          cam->viewmatrix, cam->projmatrix, n, means3D, opacities, scales, rotations, out_radii,         \
@@ -343,6 +346,8 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
 #define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin_capped<LDS, MODE>
         else if (mode == 1) VTGS_LAUNCH_PROJECT(true, 1, table_bytes);
         else if (mode == 2) VTGS_LAUNCH_PROJECT(true, 2, table_bytes);
+        else if (mode == 4) VTGS_LAUNCH_PROJECT(true, 4, table_bytes);
+        else if (mode == 5) VTGS_LAUNCH_PROJECT(true, 5, table_bytes);
         else VTGS_LAUNCH_PROJECT(true, 3, table_bytes);
       } else {
 #undef VTGS_PROJECT_KERNEL
@@ -352,6 +357,8 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
 #define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin_capped<LDS, MODE>
         else if (mode == 1) VTGS_LAUNCH_PROJECT(false, 1, 0);
         else if (mode == 2) VTGS_LAUNCH_PROJECT(false, 2, 0);
+        else if (mode == 4) VTGS_LAUNCH_PROJECT(false, 4, 0);
+        else if (mode == 5) VTGS_LAUNCH_PROJECT(false, 5, 0);
         else VTGS_LAUNCH_PROJECT(false, 3, 0);
       }
 #undef VTGS_PROJECT_KERNEL
@@ -533,12 +540,13 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
                          const void* workspace, size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity,
                          const float* image_state, void* scratch, size_t scratch_bytes, float* g_means3D, float* g_means2D,
                          float* g_colors, float* g_colors_b, float* g_opacities, float* g_scales, float* g_rotations,
-                         void* stream, bool dual, const FrameEpilogue* frame = nullptr) {
+                         void* stream, bool dual, const FrameEpilogue* frame = nullptr, bool cov3d = false) {
   if (!cam_ok(cam) || n < 0 || !out_color || !grad_color || !workspace || !scratch || instance_capacity == 0 ||
       instance_capacity > 0xFFFFFFFFull || (tile_capacity & ~VTGS_TILE_CAPACITY_PLANNED) == 0 || (dual && (!out_color_b || !grad_color_b)) || (frame && !dual))
     return VTGS_ERR_INVALID_ARGUMENT;
-  if (n > 0 && (!means3D || !colors || !opacities || !scales || !rotations || (dual && !colors_b)))
+  if (n > 0 && (!means3D || !colors || !opacities || !scales || (!rotations && !cov3d) || (dual && !colors_b)))
     return VTGS_ERR_INVALID_ARGUMENT;
+  if (cov3d && (dual || frame)) return VTGS_ERR_INVALID_ARGUMENT;
   // any output may be NULL (a gradient nobody asked for -- the tracking loop detaches the Gaussians,
   // src/vtgaussian_slam.py:428-449 -- is then neither stored nor its array allocated), but not all of them
   if (n > 0 && !frame && !g_means3D && !g_means2D && !g_colors && !g_opacities && !g_scales && !g_rotations && !(dual && g_colors_b))
@@ -598,17 +606,22 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
   {
     ProfScope ps__(dual ? "gather_splat_grads_dual" : "gather_splat_grads", st);
     if (dual && frame)
-      hipLaunchKernelGGL((gather_splat_grads<true, true>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+      hipLaunchKernelGGL((gather_splat_grads<true, true, false>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
                          means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, 1,
                          (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                          (const Counters*)(ws + L.counters), (float*)nullptr, *frame);
     else if (dual)
-      hipLaunchKernelGGL((gather_splat_grads<true, false>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+      hipLaunchKernelGGL((gather_splat_grads<true, false, false>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
                          means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, 1,
                          g_means3D, g_means2D, g_colors, g_opacities, g_scales, g_rotations,
                          (const Counters*)(ws + L.counters), g_colors_b, FrameEpilogue{});
+    else if (cov3d)
+      hipLaunchKernelGGL((gather_splat_grads<false, false, true>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+                         means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, bwd_impl != 0 ? 1 : 0,
+                         g_means3D, g_means2D, g_colors, g_opacities, g_scales, (float*)nullptr,
+                         (const Counters*)(ws + L.counters), (float*)nullptr, FrameEpilogue{});
     else
-      hipLaunchKernelGGL((gather_splat_grads<false, false>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+      hipLaunchKernelGGL((gather_splat_grads<false, false, false>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
                          means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, bwd_impl != 0 ? 1 : 0,
                          g_means3D, g_means2D, g_colors, g_opacities, g_scales, g_rotations,
                          (const Counters*)(ws + L.counters), (float*)nullptr, FrameEpilogue{});
@@ -625,6 +638,24 @@ int vtgs_backward(const VtgsCamera* cam, int32_t n, const float* means3D, const 
   return backward_impl(cam, n, means3D, colors, nullptr, opacities, scales, rotations, out_color, nullptr, grad_color, nullptr,
                        workspace, workspace_bytes, instance_capacity, tile_capacity, image_state, scratch, scratch_bytes,
                        g_means3D, g_means2D, g_colors, nullptr, g_opacities, g_scales, g_rotations, stream, false);
+}
+
+int vtgs_forward_cov3d(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* opacities,
+                       const float* cov3D, float* out_color, float* out_depth, int32_t* out_radii, void* workspace,
+                       size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity, VtgsForwardInfo* info,
+                       uint32_t flags, void* stream) {
+  return forward_impl(cam, n, means3D, colors, nullptr, opacities, cov3D, nullptr, out_color, out_depth, nullptr, out_radii,
+                      workspace, workspace_bytes, instance_capacity, tile_capacity, info, flags, stream, false, nullptr, true);
+}
+
+int vtgs_backward_cov3d(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors, const float* opacities,
+                        const float* cov3D, const float* out_color, const float* grad_color, const void* workspace,
+                        size_t workspace_bytes, uint64_t instance_capacity, uint32_t tile_capacity, void* scratch,
+                        size_t scratch_bytes, float* g_means3D, float* g_means2D, float* g_colors, float* g_opacities,
+                        float* g_cov3D, void* stream) {
+  return backward_impl(cam, n, means3D, colors, nullptr, opacities, cov3D, nullptr, out_color, nullptr, grad_color, nullptr,
+                       workspace, workspace_bytes, instance_capacity, tile_capacity, nullptr, scratch, scratch_bytes,
+                       g_means3D, g_means2D, g_colors, nullptr, g_opacities, g_cov3D, nullptr, stream, false, nullptr, true);
 }
 
 int vtgs_backward_dual(const VtgsCamera* cam, int32_t n, const float* means3D, const float* colors_a, const float* colors_b,

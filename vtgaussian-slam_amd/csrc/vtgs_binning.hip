@@ -162,7 +162,20 @@ __device__ __forceinline__ void project_and_bin_body(
   bool vis = false;
   constexpr bool banded = (MODE & 1) != 0;                      // a rank of the tile-row partition
   constexpr bool planned = (MODE & 2) != 0;
-  if (valid && !banded) {
+  constexpr bool precomp = (MODE & 4) != 0;                     // `scales` holds cov3D_precomp [N,6], `rotations` is not read
+  if constexpr (precomp) {
+    if (valid) {                                                // (no row cull ahead of the projection: it is built on the scales)
+      const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
+      float c6[6];
+      for (int i = 0; i < 6; ++i) c6[i] = scales[6 * gid + i];
+      const float unused3[3] = {0.f, 0.f, 0.f}, unused4[4] = {1.f, 0.f, 0.f, 0.f};
+      op = opacities[gid];
+      vis = project_splat(cam, mean, unused3, unused4, op, sp, aux, c6);
+      radii[gid] = vis ? sp.radius : 0;
+      if (vis) reinterpret_cast<uint32_t*>(geom + gid)[7] = pack_centre_lo(sp.ulo, sp.vlo);
+    }
+  }
+  if (valid && !banded && !precomp) {
     // whole frame: the four input streams are requested together (one trip to memory on the kernel's latency chain)
     const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
     const float sc[3] = {scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
@@ -175,7 +188,7 @@ __device__ __forceinline__ void project_and_bin_body(
     // below it cost two vector registers, and with them the second workgroup per CU
     if (vis) reinterpret_cast<uint32_t*>(geom + gid)[7] = pack_centre_lo(sp.ulo, sp.vlo);
   }
-  if (valid && banded) {
+  if (valid && banded && !precomp) {
     // a band: a Gaussian that cannot meet the band's rows is dropped on its mean and scales alone (outside_tile_rows),
     // before the rotation / opacity loads and the covariance algebra -- 7/8 of them at 8 ranks.  It reports radius 0 on this
     // rank: radii are complete as the MAXIMUM over the ranks.  The survivors pay a second trip to memory.
@@ -457,6 +470,10 @@ template __global__ void project_and_bin_capped<false, 3>(CamScalars, const floa
 template __global__ void project_and_bin_capped<true, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
 template __global__ void project_and_bin_capped<true, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
 template __global__ void project_and_bin_capped<true, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<false, 4>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<false, 5>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<true, 4>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<true, 5>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
 
 // One workgroup right after the binning: longest tile list, statistics, overflow flags and the image of the
 // host-visible VtgsForwardInfo (finalize_block, vtgs_internal.h; the quadrant-queue forward runs it in its first workgroup

@@ -1192,7 +1192,9 @@ template __global__ void composite_backward_mx<4, true, true>(CamScalars, const 
 // are still in registers -- same formulas and the same block reduction as prepare_frame_backward_kernel (vtgs_frame.hip);
 // the results agree to float32 rounding -- instead of writing six dense [N, .] arrays for that kernel to read back
 // (~160 bytes per Gaussian less traffic, one launch less; on a rank of the tile-row partition no dense zero arrays at all).
-template <bool DUAL, bool FRAME = false>
+// COV3D (the operator's cov3D_precomp): `scales` holds the six covariance entries per Gaussian and g_scales receives their
+// six gradients; `rotations` / g_rotations are not touched.
+template <bool DUAL, bool FRAME = false, bool COV3D = false>
 __global__ __launch_bounds__(256) void gather_splat_grads(
     CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
     const float* __restrict__ means3D, const float* __restrict__ opacities,
@@ -1222,11 +1224,12 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
           if (g_means3D) g_means3D[3 * gid + i] = 0.f;
           if (g_means2D) g_means2D[3 * gid + i] = 0.f;
           if (g_colors) g_colors[3 * gid + i] = 0.f;
-          if (g_scales) g_scales[3 * gid + i] = 0.f;
+          if (g_scales && !COV3D) g_scales[3 * gid + i] = 0.f;
           if constexpr (DUAL) { if (g_colors_b) g_colors_b[3 * gid + i] = 0.f; }
         }
+        if constexpr (COV3D) { if (g_scales) for (int i = 0; i < 6; ++i) g_scales[6 * gid + i] = 0.f; }
         if (g_opacities) g_opacities[gid] = 0.f;
-        if (g_rotations) reinterpret_cast<float4*>(g_rotations)[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g_rotations && !COV3D) reinterpret_cast<float4*>(g_rotations)[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
     if constexpr (FRAME) {
@@ -1284,6 +1287,7 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     M.m[6] += b.z; M.m[7] += b.w; M.m[8] += c.x;
   };
   float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, op = 0.f;
+  float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   Splat sp{}; SplatAux aux{};
   SplatMoments mo;
   for (int k = 0; k < 9; ++k) mo.m[k] = 0.f;
@@ -1297,11 +1301,15 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     for (uint32_t i = 0; i < kGatherAhead; ++i)            // past the end: the last record again (a cache hit), unused
       load_record(ga.inst_base + min(i, ga.inst_cnt - 1u), pa[i], pb[i], pc[i], pd[i]);
     const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
-    sc[0] = scales[3 * gid]; sc[1] = scales[3 * gid + 1]; sc[2] = scales[3 * gid + 2];
-    const float4 q4 = reinterpret_cast<const float4*>(rotations)[gid];
-    q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+    if constexpr (COV3D) {
+      for (int i = 0; i < 6; ++i) c6[i] = scales[6 * gid + i];
+    } else {
+      sc[0] = scales[3 * gid]; sc[1] = scales[3 * gid + 1]; sc[2] = scales[3 * gid + 2];
+      const float4 q4 = reinterpret_cast<const float4*>(rotations)[gid];
+      q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+    }
     op = opacities[gid];
-    ok = project_splat(cam, mean, sc, q, op, sp, aux);
+    ok = project_splat(cam, mean, sc, q, op, sp, aux, COV3D ? c6 : nullptr);
     if (ok && !big) {
 #pragma unroll
       for (uint32_t i = 0; i < kGatherAhead; ++i)
@@ -1339,7 +1347,7 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
       const float io = 1.f / op;
       for (int k = 0; k < 6; ++k) mo.m[k] *= io;
     }
-    splat_backward(cam, sc, q, op, sp, aux, mo, g);
+    splat_backward(cam, sc, q, op, sp, aux, mo, g, COV3D ? g6 : nullptr);
   }
   if constexpr (FRAME) {
     __shared__ float red[4][12];
@@ -1398,14 +1406,19 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
   if (g_means3D) { for (int i = 0; i < 3; ++i) g_means3D[3 * gid + i] = g.mean3D[i]; }
   if (g_means2D) { for (int i = 0; i < 3; ++i) g_means2D[3 * gid + i] = g.mean2D[i]; }
   if (g_colors) { for (int i = 0; i < 3; ++i) g_colors[3 * gid + i] = g.color[i]; }
-  if (g_scales) { for (int i = 0; i < 3; ++i) g_scales[3 * gid + i] = g.scale[i]; }
+  if constexpr (COV3D) {
+    if (g_scales) { for (int i = 0; i < 6; ++i) g_scales[6 * gid + i] = g6[i]; }
+  } else {
+    if (g_scales) { for (int i = 0; i < 3; ++i) g_scales[3 * gid + i] = g.scale[i]; }
+    if (g_rotations) reinterpret_cast<float4*>(g_rotations)[gid] = make_float4(g.rot[0], g.rot[1], g.rot[2], g.rot[3]);
+  }
   if (g_opacities) g_opacities[gid] = g.opacity;
-  if (g_rotations) reinterpret_cast<float4*>(g_rotations)[gid] = make_float4(g.rot[0], g.rot[1], g.rot[2], g.rot[3]);
   if constexpr (DUAL) { if (g_colors_b) { g_colors_b[3 * gid] = cb0; g_colors_b[3 * gid + 1] = cb1; g_colors_b[3 * gid + 2] = cb2; } }
 }
 template __global__ void gather_splat_grads<false>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*, FrameEpilogue);
 template __global__ void gather_splat_grads<true>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*, FrameEpilogue);
 template __global__ void gather_splat_grads<true, true>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*, FrameEpilogue);
+template __global__ void gather_splat_grads<false, false, true>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*, FrameEpilogue);
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(const float* __restrict__ Vp, int n,
                                                            const float* __restrict__ means3D, uint8_t* __restrict__ out) {

@@ -107,8 +107,10 @@ VTGS_HD void ewa_M(const CamParams& cam, float tx, float ty, float tz, float M[6
 }
 
 // Forward projection of one Gaussian.  Returns false when culled (radius = 0).
+// cov_precomp != NULL: the caller gives the 3-D covariance itself (xx xy xz yy yz zz -- the operator's `cov3D_precomp`, used as
+// it is: no scale modifier) instead of scale + rotation; every existing caller passes the default and pays nothing.
 VTGS_HD bool project_splat(const CamParams& cam, const float mean[3], const float scale[3],
-                           const float quat[4], float opacity, Splat& out, SplatAux& aux) {
+                           const float quat[4], float opacity, Splat& out, SplatAux& aux, const float* cov_precomp = nullptr) {
   out.radius = 0; out.x0 = out.y0 = out.x1 = out.y1 = 0;
   const float x = mean[0], y = mean[1], z = mean[2];
   const float* V = cam.V;
@@ -146,8 +148,13 @@ VTGS_HD bool project_splat(const CamParams& cam, const float mean[3], const floa
     out.ulo = (float)(ud - (double)out.u); out.vlo = (float)(vd - (double)out.v);
   }
 
-  quat_to_R(quat, aux.R);
-  cov3_from_scale_rot(scale, cam.mod, aux.R, aux.cov3);
+  if (cov_precomp) {
+    for (int i = 0; i < 6; ++i) aux.cov3[i] = cov_precomp[i];
+    for (int i = 0; i < 9; ++i) aux.R[i] = 0.f;
+  } else {
+    quat_to_R(quat, aux.R);
+    cov3_from_scale_rot(scale, cam.mod, aux.R, aux.cov3);
+  }
 
   const float rx = tx / tz, ry = ty / tz;
   aux.xmul = (rx < -cam.limx || rx > cam.limx) ? 0.f : 1.f;
@@ -288,8 +295,10 @@ struct SplatGrads {
 
 // Backward of project_splat + the conic/opacity part of the composite.  `sp`/`aux` are recomputed
 // by the caller with project_splat on the same inputs.
+// g_cov6 != NULL (cov3D_precomp): dL/d(xx xy xz yy yz zz) is written there -- an off-diagonal entry fills two places of the
+// symmetric matrix, so it gets twice the matrix gradient -- and the scale / rotation gradients are zero.
 VTGS_HD void splat_backward(const CamParams& cam, const float scale[3], const float quat[4], float opacity,
-                            const Splat& sp, const SplatAux& aux, const SplatMoments& mo, SplatGrads& g) {
+                            const Splat& sp, const SplatAux& aux, const SplatMoments& mo, SplatGrads& g, float* g_cov6 = nullptr) {
   const float* m = mo.m;
   g.color[0] = m[6]; g.color[1] = m[7]; g.color[2] = m[8];
   g.opacity = m[0];
@@ -353,6 +362,13 @@ VTGS_HD void splat_backward(const CamParams& cam, const float scale[3], const fl
   for (int k = 0; k < 3; ++k) gm[k] += dhx * P[4 * k + 0] + dhy * P[4 * k + 1] + dhw * P[4 * k + 3];
   g.mean3D[0] = gm[0]; g.mean3D[1] = gm[1]; g.mean3D[2] = gm[2];
 
+  if (g_cov6) {
+    g_cov6[0] = G3[0]; g_cov6[1] = 2.f * G3[1]; g_cov6[2] = 2.f * G3[2];
+    g_cov6[3] = G3[4]; g_cov6[4] = 2.f * G3[5]; g_cov6[5] = G3[8];
+    g.scale[0] = g.scale[1] = g.scale[2] = 0.f;
+    g.rot[0] = g.rot[1] = g.rot[2] = g.rot[3] = 0.f;
+    return;
+  }
   // Sigma3 = R diag(s'^2) R^T, s' = mod*s:  dL/ds_i = 2 s'_i mod (R^T G3 R)_ii ; dL/dR = 2 G3 R diag(s'^2)
   const float* R = aux.R;
   float sp2[3], dR[9];

@@ -52,7 +52,7 @@ class _VtgsProfileEntry(ctypes.Structure):
 
 
 VTGS_OK, VTGS_ERR_INSTANCE_OVERFLOW = 0, 3
-ABI_VERSION = 14
+ABI_VERSION = 15
 VTGS_FORWARD_SYNC, VTGS_FORWARD_ASYNC, VTGS_FORWARD_CHECKED = 0, 1, 2
 VTGS_FORWARD_EXPECT_SHORT_LISTS = 4        # hint: no list beyond 512 entries expected (skips the pre-sort pass for bins <= 1024)
 _P, _U64, _I32, _SZ = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
@@ -1087,16 +1087,24 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
-        if shs is not None:
-            raise NotImplementedError("spherical-harmonics colours are outside this build's scope: the reference "
-                                      "only ever passes colors_precomp (utils/slam_helpers.py:152-159)")
-        if cov3D_precomp is not None:
-            raise NotImplementedError("cov3D_precomp is outside this build's scope: the reference passes "
-                                      "scales + rotations (utils/slam_helpers.py:152-159)")
         if not means3D.is_cuda:
             raise RuntimeError("GaussianRasterizer needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
         cam = _camera_for(self.raster_settings, means3D.device, self._rule, self._tile_rows)
         own = self._owned
+        if shs is not None or cov3D_precomp is not None:
+            # The halves of the surface the reference never uses (it passes colours, scales and rotations:
+            # utils/slam_helpers.py:152-159): SH colours are a per-Gaussian pre-op in front of the rasterizer, a precomputed
+            # covariance has its own entry points (surface.py).  Checked forwards, whole map (no owned lists).
+            from . import surface
+            if own is not None:
+                raise RuntimeError("owned sets serve the colours + scales + rotations signature")
+            if shs is not None:
+                st = self.raster_settings
+                colors_precomp = surface.sh_colors(means3D, shs, st.campos, int(st.sh_degree))
+            if cov3D_precomp is not None:
+                color, radii, depth = surface.rasterize_cov3d(cam, means3D, means2D, colors_precomp, opacities, cov3D_precomp)
+                self.__dict__["_last_state"] = None
+                return color, radii, depth
         if own is not None:
             if own.scales_are_log:
                 raise ValueError("this owned set was built for fused.render_frame (OwnedSet(params, ...)); use OwnedSet.for_operator")
