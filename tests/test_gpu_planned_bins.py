@@ -142,3 +142,41 @@ def test_fused_frame_and_shared_render_through_planned_bins(gpu_device, monkeypa
         for k, v in uni.items():
             if k != "planned":
                 assert torch.equal(v, pl[k]), k
+
+
+@pytest.mark.parametrize("order", ["raster", "shuffled"])
+def test_windowed_tile_table_equals_global_atomic_bins(gpu_device, order):
+    """Round 5: a frame with more 8x8 tiles than the LDS tile table holds (1752x1168: 32 K) bins through a WINDOW of the table
+    that follows the tile rows a workgroup's Gaussians reach -- one pass for a raster-ordered (view-tied) map, several passes
+    for a map in any order.  Same lists (after the sort), same image, same radii and bit-identical gradients as the
+    run-aggregated global-atomic binning (VTGS_BIN_IMPL = 0)."""
+    import diff_gaussian_rasterization as dgr
+    from oracle import gs_oracle as go
+    from parity_util import GRAD_KEYS, to_settings
+    dev = gpu_device
+    n, W, H = 300_000, 1752, 1168
+    scene, cam = go.view_tied_scene(n, W, H, seed=11)
+    if order == "shuffled":
+        perm = torch.randperm(n, generator=torch.Generator().manual_seed(3))
+        scene = {k: v[perm].contiguous() for k, v in scene.items()}
+    g = torch.Generator().manual_seed(4)
+    grad_color = (torch.rand(3, H, W, generator=g) * 2 - 1).to(dev)
+    out = {}
+    try:
+        for impl in (0, 1):
+            dgr.set_option("VTGS_BIN_IMPL", impl)
+            leaves = {k: v.to(dev).requires_grad_(True) for k, v in scene.items()}
+            rast = dgr.GaussianRasterizer(raster_settings=to_settings(cam, dev))
+            c, r, d = rast(**leaves)
+            c.backward(grad_color)
+            dgr.settle_pending()
+            offs, gid, _ = dgr.debug_tile_lists(rast)
+            out[impl] = (c.detach().clone(), r.clone(), d.detach().clone(), offs, gid, {k: leaves[k].grad.clone() for k in GRAD_KEYS})
+    finally:
+        dgr.set_option("VTGS_BIN_IMPL", -1)
+    a, b = out[0], out[1]
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])          # list lengths and the sorted lists
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for k in GRAD_KEYS:
+        assert torch.equal(a[5][k], b[5][k]), k
+    assert int(a[3][-1]) > n                                             # (something was binned)

@@ -11,11 +11,11 @@
 
 namespace vtgs {
 // kernels (vtgs_binning.hip / vtgs_composite.hip)
-template <bool LDSBINS, int MODE>
+template <int LDSBINS, int MODE>
 __global__ void project_and_bin(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
                                 const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*,
                                 Counters*, BlockStats*, unsigned long long, uint32_t);
-template <bool LDSBINS, int MODE>
+template <int LDSBINS, int MODE>
 __global__ void project_and_bin_capped(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
                                 const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*,
                                 Counters*, BlockStats*, unsigned long long, uint32_t);
@@ -315,17 +315,21 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
     // table and one workgroup per CU).
     const size_t table_bytes = (size_t)(r8e - r8b) * (size_t)((cam->image_width + kSubTile - 1) / kSubTile) * 4;
     bool lds_bins = table_bytes <= (79u << 10) && option(OPT_BIN_IMPL) == 1;
+    // a larger frame (1752x1168: 32 K tiles): the windowed table (VTGS_BIN_IMPL = 1, default) -- not for the cov3D form,
+    // which has no windowed instantiation; VTGS_BIN_IMPL = 0: global atomics everywhere (cross-check)
+    const bool win_bins = !lds_bins && option(OPT_BIN_IMPL) == 1 && !cov3d &&
+                          (uint32_t)((cam->image_width + kSubTile - 1) / kSubTile) <= 16384u;
     if (lds_bins && table_bytes > (64u << 10)) {
       static bool raised[64] = {false};                       // the attribute sticks to the function, per DEVICE
       int dev_id = 0;
       if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) { (void)hipGetLastError(); dev_id = -1; }
       if (dev_id < 0 || !raised[dev_id]) {
-        if (hipFuncSetAttribute((const void*)project_and_bin<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
-            hipFuncSetAttribute((const void*)project_and_bin_capped<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
-            hipFuncSetAttribute((const void*)project_and_bin_capped<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
-            hipFuncSetAttribute((const void*)project_and_bin_capped<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
-            hipFuncSetAttribute((const void*)project_and_bin_capped<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
-            hipFuncSetAttribute((const void*)project_and_bin_capped<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess) {
+        if (hipFuncSetAttribute((const void*)project_and_bin<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
+            hipFuncSetAttribute((const void*)project_and_bin_capped<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
+            hipFuncSetAttribute((const void*)project_and_bin_capped<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
+            hipFuncSetAttribute((const void*)project_and_bin_capped<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
+            hipFuncSetAttribute((const void*)project_and_bin_capped<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess &&
+            hipFuncSetAttribute((const void*)project_and_bin_capped<1, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10) == hipSuccess) {
           if (dev_id >= 0) raised[dev_id] = true;
         } else { (void)hipGetLastError(); lds_bins = false; }
       }
@@ -339,27 +343,37 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
                          (GeomRec*)(ws + L.geom), (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt),              \
                          (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), ctr,                            \
                          (BlockStats*)(ws + L.block_stats), (unsigned long long)instance_capacity, L.tile_cap)
+      // (LDS: 0 = run-aggregated global atomics, 1 = the band's whole tile table in LDS, 2 = a window of kWinEntries tiles)
       if (lds_bins) {
 #define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin<LDS, MODE>
-        if (mode == 0) VTGS_LAUNCH_PROJECT(true, 0, table_bytes);
+        if (mode == 0) VTGS_LAUNCH_PROJECT(1, 0, table_bytes);
 #undef VTGS_PROJECT_KERNEL
 #define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin_capped<LDS, MODE>
-        else if (mode == 1) VTGS_LAUNCH_PROJECT(true, 1, table_bytes);
-        else if (mode == 2) VTGS_LAUNCH_PROJECT(true, 2, table_bytes);
-        else if (mode == 4) VTGS_LAUNCH_PROJECT(true, 4, table_bytes);
-        else if (mode == 5) VTGS_LAUNCH_PROJECT(true, 5, table_bytes);
-        else VTGS_LAUNCH_PROJECT(true, 3, table_bytes);
+        else if (mode == 1) VTGS_LAUNCH_PROJECT(1, 1, table_bytes);
+        else if (mode == 2) VTGS_LAUNCH_PROJECT(1, 2, table_bytes);
+        else if (mode == 4) VTGS_LAUNCH_PROJECT(1, 4, table_bytes);
+        else if (mode == 5) VTGS_LAUNCH_PROJECT(1, 5, table_bytes);
+        else VTGS_LAUNCH_PROJECT(1, 3, table_bytes);
+      } else if (win_bins) {
+#undef VTGS_PROJECT_KERNEL
+#define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin<LDS, MODE>
+        if (mode == 0) VTGS_LAUNCH_PROJECT(2, 0, (size_t)(64u << 10));
+#undef VTGS_PROJECT_KERNEL
+#define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin_capped<LDS, MODE>
+        else if (mode == 1) VTGS_LAUNCH_PROJECT(2, 1, (size_t)(64u << 10));
+        else if (mode == 2) VTGS_LAUNCH_PROJECT(2, 2, (size_t)(64u << 10));
+        else VTGS_LAUNCH_PROJECT(2, 3, (size_t)(64u << 10));
       } else {
 #undef VTGS_PROJECT_KERNEL
 #define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin<LDS, MODE>
-        if (mode == 0) VTGS_LAUNCH_PROJECT(false, 0, 0);
+        if (mode == 0) VTGS_LAUNCH_PROJECT(0, 0, 0);
 #undef VTGS_PROJECT_KERNEL
 #define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin_capped<LDS, MODE>
-        else if (mode == 1) VTGS_LAUNCH_PROJECT(false, 1, 0);
-        else if (mode == 2) VTGS_LAUNCH_PROJECT(false, 2, 0);
-        else if (mode == 4) VTGS_LAUNCH_PROJECT(false, 4, 0);
-        else if (mode == 5) VTGS_LAUNCH_PROJECT(false, 5, 0);
-        else VTGS_LAUNCH_PROJECT(false, 3, 0);
+        else if (mode == 1) VTGS_LAUNCH_PROJECT(0, 1, 0);
+        else if (mode == 2) VTGS_LAUNCH_PROJECT(0, 2, 0);
+        else if (mode == 4) VTGS_LAUNCH_PROJECT(0, 4, 0);
+        else if (mode == 5) VTGS_LAUNCH_PROJECT(0, 5, 0);
+        else VTGS_LAUNCH_PROJECT(0, 3, 0);
       }
 #undef VTGS_PROJECT_KERNEL
 #undef VTGS_LAUNCH_PROJECT

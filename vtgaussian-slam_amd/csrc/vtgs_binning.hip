@@ -98,6 +98,7 @@ __device__ __forceinline__ bool tile_reached(const CamParams& cam, const Splat& 
 }
 
 constexpr int kProjBlock = 1024;     // threads per workgroup: one allocation atomic per 1024 Gaussians
+constexpr uint32_t kWinEntries = 16384;  // windowed LDS tile table (LDSBINS == 2): 64 KB, two workgroups per CU
 
 // A Gaussian whose candidate walk exceeds kBigArea tiles (a splat that has grown over a hole of the map can cover
 // thousands) is not walked by its own lane -- one thread iterating over 3,000 tiles held project_and_bin for up to 2 ms in
@@ -132,7 +133,7 @@ __device__ __forceinline__ BigWalk broadcast_walk(const TileWalk& w, const Splat
 // budget: either feature alone cost that case 13 us of 54 through s_load re-materialisation, batch P of round 3):
 //   bit 0  a band of the tile-row partition (row cull before the projection, early exit of workgroups with nothing in the band)
 //   bit 1  planned bins (bin t = [plan[t], plan[t+1]), include/vtgs.h)
-template <bool LDSBINS, int MODE>
+template <int LDSBINS, int MODE>
 __device__ __forceinline__ void project_and_bin_body(
     CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
     const float* __restrict__ means3D, const float* __restrict__ opacities,
@@ -243,7 +244,7 @@ __device__ __forceinline__ void project_and_bin_body(
 
   // the per-tile table is cleared only now: the input loads above are in flight while it happens, and the workgroups of a
   // band that left above never touch it
-  if constexpr (LDSBINS) {
+  if constexpr (LDSBINS == 1) {
     for (int i = (int)threadIdx.x; i < tiles8; i += kProjBlock) lds_tile[i] = 0u;
     __syncthreads();
   }
@@ -254,7 +255,7 @@ __device__ __forceinline__ void project_and_bin_body(
     const bool hit = tile_reached(cam, sp, rf, tau, w.cx0 + tx, w.cy0 + ty);
     cnt += hit ? 1u : 0u;
     if (i < 64 && hit) reach_mask |= 1ull << i;
-    if constexpr (LDSBINS) { if (hit) atomicAdd(&lds_tile[(w.cy0 + ty) * cam.gx8 + w.cx0 + tx - tile0], 1u); }
+    if constexpr (LDSBINS == 1) { if (hit) atomicAdd(&lds_tile[(w.cy0 + ty) * cam.gx8 + w.cx0 + tx - tile0], 1u); }
     if (++tx == w.cw) { tx = 0; ++ty; }
   }
   VTGS_P_STAMP(2)                                                // table cleared, pass 1 (reach tests + LDS histogram)
@@ -277,7 +278,7 @@ __device__ __forceinline__ void project_and_bin_body(
     bs.visible = v; bs.pad = 0; bs.r16 = r;
     block_stats[blockIdx.x] = bs;
   }
-  if constexpr (LDSBINS) {
+  if constexpr (LDSBINS == 1) {
     // one global reservation per tile this workgroup touches; the table entry becomes the running slot index
     for (int i = (int)threadIdx.x; i < tiles8; i += kProjBlock) {
       const uint32_t c = lds_tile[i];
@@ -306,7 +307,55 @@ __device__ __forceinline__ void project_and_bin_body(
   // atomic of step i is consumed in step i+1, so its round trip overlaps the next step's work.
   const unsigned long long key = ((unsigned long long)__float_as_uint(sp.depth) << 32) | (unsigned long long)(uint32_t)gid;
   uint32_t ord = 0;
-  if constexpr (LDSBINS) {
+  if constexpr (LDSBINS == 2) {
+    // ---- WINDOWED table (round 5): the frame has more 8x8 tiles than a table that leaves room for two workgroups per CU
+    // (> 20 K: 1752x1168 has 32 K), but the 1,024 Gaussians of a workgroup of a raster-ordered map reach a few tile ROWS.  The
+    // table covers kWinRows(gx8) rows at a time, starting at the first row any lane of the workgroup reaches: one pass for a
+    // view-tied map, ceil(rows / window) passes for a map in any order (each lane takes part with the tiles of that pass only;
+    // instance ids follow the walk order of the splat whatever the pass).  Before: run-aggregated global atomics, 404 us at
+    // 5 M Gaussians (profiles/r4_shapes.md).
+    __shared__ int s_wy0[kWaves], s_wy1[kWaves];
+    {
+      const int y0 = area > 0 ? w.cy0 : 0x7fffffff, y1 = area > 0 ? w.cy0 + w.ch : 0;
+      const int m0 = wave_min_i(y0), m1 = wave_max_i(y1);
+      if (l == 0) { s_wy0[wv] = m0; s_wy1[wv] = m1; }
+    }
+    __syncthreads();
+    int wy0 = 0x7fffffff, wy1 = 0;
+    for (int k = 0; k < kWaves; ++k) { wy0 = min(wy0, s_wy0[k]); wy1 = max(wy1, s_wy1[k]); }
+    const int win_rows = max(1, (int)(kWinEntries / (uint32_t)cam.gx8));
+    const int cwd = max(w.cw, 1);
+    for (int py = wy0; py < wy1; py += win_rows) {                 // (workgroup-uniform bounds)
+      const int rows = min(win_rows, wy1 - py), entries = rows * cam.gx8, t0 = py * cam.gx8;
+      for (int i = (int)threadIdx.x; i < entries; i += kProjBlock) lds_tile[i] = 0u;
+      __syncthreads();
+      for (unsigned long long m = reach_mask; m; m &= m - 1ull) {  // histogram of this pass's tiles
+        const int i = __builtin_ctzll(m), tty = w.cy0 + i / cwd, ttx = w.cx0 + (i - (i / cwd) * cwd);
+        if (tty >= py && tty < py + rows) atomicAdd(&lds_tile[tty * cam.gx8 + ttx - t0], 1u);
+      }
+      __syncthreads();
+      for (int i = (int)threadIdx.x; i < entries; i += kProjBlock) {   // one global reservation per touched tile
+        const uint32_t c = lds_tile[i];
+        if (c) lds_tile[i] = atomicAdd(&tile_cnt[t0 + i], c);
+      }
+      __syncthreads();
+      for (unsigned long long m = reach_mask; m; m &= m - 1ull) {
+        const int i = __builtin_ctzll(m), tty = w.cy0 + i / cwd, ttx = w.cx0 + (i - (i / cwd) * cwd);
+        if (tty >= py && tty < py + rows) {
+          const int tile = tty * cam.gx8 + ttx;
+          const uint32_t slot = atomicAdd(&lds_tile[tile - t0], 1u);
+          const unsigned long long id = (unsigned long long)inst_base + (uint32_t)__builtin_popcountll(reach_mask & ((1ull << i) - 1ull));
+          const BinRange br = planned ? bin_range(cs, (uint32_t)tile, tile_cap) : BinRange{(uint32_t)tile * tile_cap, tile_cap};
+          if (id < capacity && slot < br.cap) {
+            const size_t pos = (size_t)br.s + slot;
+            keys[pos] = key;
+            vals[pos] = (uint32_t)id;
+          }
+        }
+      }
+      if (py + win_rows < wy1) __syncthreads();                    // the next pass clears the table
+    }
+  } else if constexpr (LDSBINS == 1) {
     // pass 2, LDS form: every lane walks its own reached tiles; the slot comes from the LDS table
     for (int i = 0, tx = 0, ty = 0; i < area; ++i) {
       const int ttx = w.cx0 + tx, tty = w.cy0 + ty;
@@ -442,7 +491,7 @@ __device__ __forceinline__ void project_and_bin_body(
 // which costs the second workgroup per CU (13 us of 54 at the headline shape, profiles/r3_project_ab.txt): they are capped at
 // 80, a few scalars then live in vector-register lanes.  (The cap on MODE 0 would push it to 65 vector registers -- the same cliff
 // from the other side -- hence two definitions.)
-template <bool LDSBINS, int MODE>
+template <int LDSBINS, int MODE>
 __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
     const float* __restrict__ means3D, const float* __restrict__ opacities,
@@ -452,7 +501,7 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     Counters* __restrict__ ctr, BlockStats* __restrict__ block_stats, unsigned long long capacity, uint32_t tile_cap) {
   project_and_bin_body<LDSBINS, MODE>(cs, Vp, PVp, n, means3D, opacities, scales, rotations, radii, geom, gaux, tile_cnt, keys, vals, ctr, block_stats, capacity, tile_cap);
 }
-template <bool LDSBINS, int MODE>
+template <int LDSBINS, int MODE>
 __global__ __launch_bounds__(kProjBlock) __attribute__((amdgpu_num_sgpr(80))) void project_and_bin_capped(
     CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
     const float* __restrict__ means3D, const float* __restrict__ opacities,
@@ -462,18 +511,22 @@ __global__ __launch_bounds__(kProjBlock) __attribute__((amdgpu_num_sgpr(80))) vo
     Counters* __restrict__ ctr, BlockStats* __restrict__ block_stats, unsigned long long capacity, uint32_t tile_cap) {
   project_and_bin_body<LDSBINS, MODE>(cs, Vp, PVp, n, means3D, opacities, scales, rotations, radii, geom, gaux, tile_cnt, keys, vals, ctr, block_stats, capacity, tile_cap);
 }
-template __global__ void project_and_bin<false, 0>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin<true, 0>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<false, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<false, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<false, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<true, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<true, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<true, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<false, 4>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<false, 5>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<true, 4>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<true, 5>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin<0, 0>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin<1, 0>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin<2, 0>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<2, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<2, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<2, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<0, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<0, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<0, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<1, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<1, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<1, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<0, 4>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<0, 5>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<1, 4>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin_capped<1, 5>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
 
 // One workgroup right after the binning: longest tile list, statistics, overflow flags and the image of the
 // host-visible VtgsForwardInfo (finalize_block, vtgs_internal.h; the quadrant-queue forward runs it in its first workgroup
