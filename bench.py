@@ -587,7 +587,7 @@ def main():
                             "16 cm away, which lengthens the tile lists -- the first frames of a cycle run ~20 % faster than its mean.  "
                             if whole_cycle else "The ordinary frames draw as from a 12-frame window (second call in 1 of 12 iterations; the mean "
                             "over a 40-frame submap is 0.084).  ") +
-                            + ("Every ordinary frame runs the reference's densification step (forward-only render, depth_error.median(), "
+                            ("Every ordinary frame runs the reference's densification step (forward-only render, depth_error.median(), "
                                "new Gaussians appended: N grows over the cycle).  " if world == 1 else "No densification on N > 1 ranks.  ") +
                             "No dataset I/O and no keyframe-overlap selection (host / small-tensor work outside the rasterizer path)."}
         except Exception as e:                                   # (the headline line must not be lost over the second metric)

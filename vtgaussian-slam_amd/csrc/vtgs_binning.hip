@@ -97,6 +97,12 @@ __device__ __forceinline__ bool tile_reached(const CamParams& cam, const Splat& 
   return (inside ? 0.f : fminf(fminf(q0, q1), fminf(q2, q3))) <= tau;
 }
 
+__device__ __forceinline__ void store_geom(GeomRec* __restrict__ rec, const Splat& sp, float op) {
+  float4* gp = reinterpret_cast<float4*>(rec);
+  gp[0] = make_float4(sp.u, sp.v, sp.A, sp.B);
+  gp[1] = make_float4(sp.C, op, sp.depth, __uint_as_float(pack_centre_lo(sp.ulo, sp.vlo)));
+}
+
 constexpr int kProjBlock = 1024;     // threads per workgroup: one allocation atomic per 1024 Gaussians
 constexpr uint32_t kWinEntries = 16384;  // windowed LDS tile table (LDSBINS == 2): 64 KB, two workgroups per CU
 
@@ -173,7 +179,7 @@ __device__ __forceinline__ void project_and_bin_body(
       op = opacities[gid];
       vis = project_splat(cam, mean, unused3, unused4, op, sp, aux, c6);
       radii[gid] = vis ? sp.radius : 0;
-      if (vis) reinterpret_cast<uint32_t*>(geom + gid)[7] = pack_centre_lo(sp.ulo, sp.vlo);
+      if (vis) store_geom(geom + gid, sp, op);
     }
   }
   if (valid && !banded && !precomp) {
@@ -185,9 +191,10 @@ __device__ __forceinline__ void project_and_bin_body(
     op = opacities[gid];
     vis = project_splat(cam, mean, sc, q, op, sp, aux);
     radii[gid] = vis ? sp.radius : 0;
-    // what float32 took from the pixel centre goes to its place in the geometry record NOW: carried to the record's store
-    // below it cost two vector registers, and with them the second workgroup per CU
-    if (vis) reinterpret_cast<uint32_t*>(geom + gid)[7] = pack_centre_lo(sp.ulo, sp.vlo);
+    // the geometry record is stored NOW, whole (two dwordx4): carrying the centre's float32 remainder to a store behind the
+    // instance count cost two vector registers (and with them the second workgroup per CU), and storing the remainder alone
+    // here -- a 4-byte write into a 32-byte sector the record's other words fill later -- cost 27 MB of write traffic
+    if (vis) store_geom(geom + gid, sp, op);
   }
   if (valid && banded && !precomp) {
     // a band: a Gaussian that cannot meet the band's rows is dropped on its mean and scales alone (outside_tile_rows),
@@ -200,7 +207,7 @@ __device__ __forceinline__ void project_and_bin_body(
       const float q[4] = {q4.x, q4.y, q4.z, q4.w};
       op = opacities[gid];
       vis = project_splat(cam, mean, sc, q, op, sp, aux);
-      if (vis) reinterpret_cast<uint32_t*>(geom + gid)[7] = pack_centre_lo(sp.ulo, sp.vlo);
+      if (vis) store_geom(geom + gid, sp, op);
     }
     radii[gid] = vis ? sp.radius : 0;
   }
@@ -294,12 +301,7 @@ __device__ __forceinline__ void project_and_bin_body(
   if (valid && !big) {
     // the geometry record is only ever reached through a tile list: a splat without instances (culled, or outside this
     // call's band of tile rows -- 7/8 of them on each rank of an 8-way partition) does not need one
-    if (cnt) {
-      float4* gp = reinterpret_cast<float4*>(geom + gid);       // words 0..6 (word 7, centre_lo, was stored after the projection)
-      gp[0] = make_float4(sp.u, sp.v, sp.A, sp.B);
-      float* gq = reinterpret_cast<float*>(gp + 1);
-      gq[0] = sp.C; gq[1] = op; gq[2] = sp.depth;
-    }
+    // (its geometry record was stored right after the projection)
     gaux[gid] = GaussAux{inst_base, cnt};
   }
 
@@ -474,12 +476,6 @@ __device__ __forceinline__ void project_and_bin_body(
       done += (uint32_t)__builtin_popcountll(hb);
     }
     if (l == src) {
-      if (total) {
-        float4* gp = reinterpret_cast<float4*>(geom + gid);
-        gp[0] = make_float4(sp.u, sp.v, sp.A, sp.B);
-        float* gq = reinterpret_cast<float*>(gp + 1);
-        gq[0] = sp.C; gq[1] = op; gq[2] = sp.depth;
-      }
       gaux[gid] = GaussAux{base, total};
     }
   }
