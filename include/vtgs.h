@@ -279,6 +279,13 @@ int vtgs_mark_visible(const VtgsCamera* cam, int32_t n, const float* means3D,
  * takes the 12 -> 7 step through the quaternion.  No atomics: results are bitwise reproducible.  The four *_b inputs
  * may all be NULL (after vtgs_backward_dual the *_a set already holds the sum over both renders).                       */
 uint32_t vtgs_pose_partial_rows(int32_t n);
+/* The pose of frame t out of the reference's camera tensors, cam_unnorm_rots [1,4,frames] and cam_trans [1,3,frames]
+ * (src/vtgaussian_slam.py:160-167), as seven contiguous floats (q[4], t[3]); and its adjoint: full-size gradients that are zero
+ * except column t.  One launch each -- tensor indexing costs ten (two strided copies, four zero-fills, four slice copies). */
+int vtgs_pose_slot_gather(const float* cam_unnorm_rots, const float* cam_trans, int32_t frames, int32_t t, float* pose7, void* stream);
+int vtgs_pose_slot_scatter(const float* g_q, const float* g_t, int32_t frames, int32_t t, float* g_cam_unnorm_rots, float* g_cam_trans,
+                           void* stream);   /* g_q[4] / g_t[3]: either may be NULL (= zeros) */
+
 /* Sums the partial rows and takes the 12 -> 7 step through the normalised quaternion: g_cam_q[4], g_cam_t[3] (device). */
 int vtgs_pose_gradient(const float* pose_partials, uint32_t rows, const float* cam_q, float* g_cam_q, float* g_cam_t,
                        void* stream);

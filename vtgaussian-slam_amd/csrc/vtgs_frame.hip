@@ -224,11 +224,42 @@ __global__ __launch_bounds__(256) void pose7_final_kernel(const float* __restric
   if (threadIdx.x < 7) out[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// The camera parameters of the reference are [1, 4, T] / [1, 3, T] tensors holding every frame's pose
+// (src/vtgaussian_slam.py:160-167); an iteration uses column t.  Taken with tensor indexing that is two strided copies forward
+// and, per tensor, two zero-fills and two slice copies backward -- ten launches of ~5 us around a 7-float gradient.  One
+// launch each way instead: pose7 = (q[4], t[3]) of frame t; the backward writes full-size gradients, zero except column t.
+__global__ __launch_bounds__(64) void pose_slot_gather_kernel(const float* __restrict__ rots, const float* __restrict__ trans, int T,
+                                                             int t, float* __restrict__ pose7) {
+  const int i = (int)threadIdx.x;
+  if (i < 4) pose7[i] = rots[(size_t)i * T + t];
+  else if (i < 7) pose7[i] = trans[(size_t)(i - 4) * T + t];
+}
+__global__ __launch_bounds__(256) void pose_slot_scatter_kernel(const float* __restrict__ g_q, const float* __restrict__ g_t, int T, int t,
+                                                               float* __restrict__ g_rots, float* __restrict__ g_trans) {
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (i < 4 * T) { const int r = i / T, c = i - r * T; g_rots[i] = (c == t && g_q) ? g_q[r] : 0.f; }
+  else if (i < 7 * T) { const int k = i - 4 * T, r = k / T, c = k - r * T; g_trans[k] = (c == t && g_t) ? g_t[r] : 0.f; }
+}
+
 }  // namespace vtgs
 
 using namespace vtgs;
 
 extern "C" {
+
+int vtgs_pose_slot_gather(const float* cam_unnorm_rots, const float* cam_trans, int32_t frames, int32_t t, float* pose7, void* stream) {
+  if (!cam_unnorm_rots || !cam_trans || !pose7 || frames <= 0 || t < 0 || t >= frames) return VTGS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(pose_slot_gather_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cam_unnorm_rots, cam_trans, frames, t, pose7);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
+int vtgs_pose_slot_scatter(const float* g_q, const float* g_t, int32_t frames, int32_t t, float* g_cam_unnorm_rots, float* g_cam_trans,
+                           void* stream) {
+  if (!g_cam_unnorm_rots || !g_cam_trans || frames <= 0 || t < 0 || t >= frames) return VTGS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(pose_slot_scatter_kernel, dim3((7 * frames + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_q, g_t, frames, t,
+                     g_cam_unnorm_rots, g_cam_trans);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
 
 int vtgs_pose_gradient(const float* pose_partials, uint32_t rows, const float* cam_q, float* g_cam_q, float* g_cam_t,
                        void* stream) {

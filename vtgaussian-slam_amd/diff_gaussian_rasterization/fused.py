@@ -36,6 +36,51 @@ _lib.vtgs_prepare_frame_backward.restype = ctypes.c_int
 _lib.vtgs_prepare_frame_backward.argtypes = [_I32, ctypes.c_uint32] + [_P] * 22
 _lib.vtgs_pose_gradient.restype, _lib.vtgs_pose_gradient.argtypes = ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P]
 _lib.vtgs_prepare_frame_owned.restype, _lib.vtgs_prepare_frame_owned.argtypes = ctypes.c_int, [_I32] + [_P] * 16
+_lib.vtgs_pose_slot_gather.restype, _lib.vtgs_pose_slot_gather.argtypes = ctypes.c_int, [_P, _P, _I32, _I32, _P, _P]
+_lib.vtgs_pose_slot_scatter.restype, _lib.vtgs_pose_slot_scatter.argtypes = ctypes.c_int, [_P, _P, _I32, _I32, _P, _P, _P]
+
+
+class _PoseSlot(torch.autograd.Function):
+    """(q[4], t[3]) of frame `t_idx` out of the reference's camera tensors [1,4,T] / [1,3,T], and the adjoint, ONE launch each way.
+    `params['cam_unnorm_rots'][0, :, t]` is two `select`s: forward two strided copies (the kernels want contiguous floats),
+    backward two zero-fills and two slice copies per tensor -- ten launches of ~5 us around seven floats, 6 % of a tracking
+    iteration at 1 M Gaussians (kernel trace of round 5)."""
+
+    @staticmethod
+    def forward(ctx, rots, trans, t_idx: int):
+        T = int(rots.shape[2])
+        pose7 = torch.empty(7, dtype=torch.float32, device=rots.device)
+        with _device_guard(rots.device):
+            _check(_lib.vtgs_pose_slot_gather(rots.data_ptr(), trans.data_ptr(), T, int(t_idx), pose7.data_ptr(), _stream_ptr(rots.device)),
+                   "vtgs_pose_slot_gather")
+        ctx.T, ctx.t_idx, ctx.shapes = T, int(t_idx), (rots.shape, trans.shape)
+        return pose7[:4], pose7[4:]
+
+    @staticmethod
+    def backward(ctx, g_q, g_t):
+        ref = g_q if g_q is not None else g_t
+        dev = ref.device
+        g_rots = torch.empty(ctx.shapes[0], dtype=torch.float32, device=dev)
+        g_trans = torch.empty(ctx.shapes[1], dtype=torch.float32, device=dev)
+        c = lambda g: None if g is None else g.to(torch.float32).contiguous()
+        g_q, g_t = c(g_q), c(g_t)
+        ptr = lambda g: None if g is None else g.data_ptr()
+        with _device_guard(dev):
+            _check(_lib.vtgs_pose_slot_scatter(ptr(g_q), ptr(g_t), ctx.T, ctx.t_idx, g_rots.data_ptr(), g_trans.data_ptr(), _stream_ptr(dev)),
+                   "vtgs_pose_slot_scatter")
+        return g_rots, g_trans, None
+
+
+def _pose_of_frame(params, time_idx: int, camera_grad: bool):
+    rots, trans = params["cam_unnorm_rots"], params["cam_trans"]
+    if (rots.dim() == 3 and trans.dim() == 3 and rots.shape[0] == 1 and trans.shape[0] == 1 and rots.shape[1] == 4 and trans.shape[1] == 3
+            and rots.shape[2] == trans.shape[2] and rots.dtype is torch.float32 and trans.dtype is torch.float32
+            and rots.is_contiguous() and trans.is_contiguous() and rots.is_cuda and 0 <= int(time_idx) < rots.shape[2]):
+        if not camera_grad:
+            rots, trans = rots.detach(), trans.detach()
+        return _PoseSlot.apply(rots, trans, int(time_idx))
+    q, t = rots[0, :, time_idx], trans[0, :, time_idx]                 # any other layout: plain indexing
+    return (q, t) if camera_grad else (q.detach(), t.detach())
 
 
 class _RenderFrame(torch.autograd.Function):
@@ -255,10 +300,7 @@ def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings
     import os
     rule = _RADIUS_RULES[radius_rule or os.environ.get("VTGS_RADIUS_RULE", "3sigma")]
     cam = _camera_for(raster_settings, dev, rule, None if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1])))
-    q = params["cam_unnorm_rots"][0, :, time_idx]
-    t = params["cam_trans"][0, :, time_idx]
-    if not camera_grad:
-        q, t = q.detach(), t.detach()
+    q, t = _pose_of_frame(params, time_idx, camera_grad)
     # like the reference, gaussians_grad=False detaches only the geometry (means3D, unnorm_rotations); colours,
     # opacities and scales keep their gradient whenever they require one (utils/slam_helpers.py:362-367, 152-159)
     g = lambda x: x if gaussians_grad else x.detach()
