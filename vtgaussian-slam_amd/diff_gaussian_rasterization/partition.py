@@ -163,12 +163,13 @@ class OwnerExchange:
     """
 
     def __init__(self, lists, image_height: int, rank: int, world: int, keys=("rgb_colors", "logit_opacities", "log_scales"),
-                 group=None):
+                 group=None, frozen=("means3D", "unnorm_rotations")):
         import torch
         import torch.distributed as dist
         if lists.centre_rows is None:
             raise ValueError("OwnerExchange needs an OwnedSet built with with_centre_rows=True")
         self.rank, self.world, self.group, self.keys = int(rank), int(world), group, tuple(keys)
+        self._frozen_ok = frozenset(frozen)      # per-Gaussian parameters the caller steps with learning rate 0 (not exchanged)
         dev = lists.mask.device
         self.n_map = lists.n_map
         ends = torch.tensor([e for _b, e in all_bands(image_height, world)], device=dev, dtype=torch.int32)
@@ -208,8 +209,10 @@ class OwnerExchange:
         staged = dev.type == "cuda" and _host_staged(self.group)
         recv = {q: torch.empty((n, width), dtype=torch.float32, device="cpu" if staged else dev) for q, n in recv_rows.items()}
         keep = {q: (t.cpu() if staged else t.contiguous()) for q, t in send.items()}
-        ops = [dist.P2POp(dist.irecv, recv[q], q, self.group) for q in sorted(recv)]
-        ops += [dist.P2POp(dist.isend, keep[q], q, self.group) for q in sorted(keep)]
+        # (P2POp takes GLOBAL ranks; q is a rank of `group`: ADVICE r4)
+        peer = (lambda q: q) if self.group is None else (lambda q: dist.get_global_rank(self.group, q))
+        ops = [dist.P2POp(dist.irecv, recv[q], peer(q), self.group) for q in sorted(recv)]
+        ops += [dist.P2POp(dist.isend, keep[q], peer(q), self.group) for q in sorted(keep)]
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
@@ -220,6 +223,14 @@ class OwnerExchange:
         `.grad`; a parameter without a gradient on this rank counts as zero).  Returns the bytes this rank sent."""
         import torch
         dev = params[self.keys[0]].device
+        # A per-Gaussian parameter that is NOT exchanged but has a gradient would be stepped from this rank's band share alone
+        # and drift apart across the ranks (harmless only while its learning rate is 0, as for means3D / unnorm_rotations in
+        # the reference's mapping configs): refuse it here, once per call, instead of diverging silently (ADVICE r4).
+        for k, v in params.items():
+            if k not in self.keys and torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == self.n_map and v.grad is not None \
+                    and k not in self._frozen_ok:
+                raise RuntimeError(f"OwnerExchange: '{k}' has a per-Gaussian gradient but is not among the exchanged keys {self.keys}; "
+                                   f"add it to keys, or declare it frozen (learning rate 0) with OwnerExchange(..., frozen=('{k}',))")
         for k in self.keys:
             if params[k].grad is None:
                 params[k].grad = torch.zeros_like(params[k])
