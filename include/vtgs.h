@@ -312,7 +312,12 @@ int vtgs_prepare_frame_backward(int32_t n, uint32_t flags, const float* means3D,
  * rotations, colors_b = the outputs of vtgs_prepare_frame) plus means3D / unnorm_rotations / cam_q / cam_t / depth_w2c
  * as given to vtgs_prepare_frame; flags as vtgs_prepare_frame_backward.  Outputs (each may be NULL when its flag is
  * clear): bit 0 g_means3D [N,3], g_unnorm_rotations [N,4]; bit 1 pose_partials [vtgs_pose_partial_rows(n)][12];
- * bit 2 g_rgb_colors [N,3], g_logit_opacities [N], g_log_scales [N].  No screen-space (means2D) gradient.          */
+ * bit 2 g_rgb_colors [N,3], g_logit_opacities [N], g_log_scales [N].  No screen-space (means2D) gradient.
+ * flags bit 3 (8) is a PROMISE about an input: grad_color_b is zero outside its first channel (get_loss differentiates the
+ * [z, 1, z^2] render through z alone: the silhouette only feeds comparisons, z^2 a detached uncertainty,
+ * src/vtgaussian_slam.py:466-521).  Planes 1 and 2 of grad_color_b are then not read: four image-gradient channels instead of
+ * six, one colour of the second set per splat, 48-byte instead of 56-byte gradient records.  Results equal those without the
+ * bit whenever the promise holds (tests/test_gpu_fused_frame.py).  VTGS_DUAL_B1=0 / vtgs_set_option ignores the bit.  */
 int vtgs_backward_dual_frame(const VtgsCamera* cam, int32_t n, const float* means_cam, const float* colors_a, const float* colors_b,
                              const float* opacities, const float* scales, const float* rotations, const float* out_color_a,
                              const float* out_color_b, const float* grad_color_a, const float* grad_color_b,

@@ -174,4 +174,4 @@ def test_cross_check_kernels_live_in_the_test_only_library():
     host = subprocess.run(["nm", "-C", os.path.join(lib_dir, "libvtgs.so")], capture_output=True, text=True, check=True).stdout
     for kernel in ("composite_forward_mx", "composite_forward_px", "composite_backward_q", "vtgs::composite_forward(", "vtgs::composite_backward("):
         assert kernel not in host, kernel
-    assert "composite_forward_q" in host and "composite_backward_mx<4, false, true>" in host and "gather_splat_grads" in host
+    assert "composite_forward_q" in host and "composite_backward_mx<4, false, true, false>" in host and "gather_splat_grads" in host

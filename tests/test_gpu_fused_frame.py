@@ -368,3 +368,86 @@ def test_run_ahead_overflow_surfaces_inside_backward_before_the_optimizer_step(g
     (im.sum() + ds.sum()).backward()
     dgr.settle_pending()
     assert float(im.detach().abs().max()) > 0
+
+
+@pytest.mark.parametrize("route", ["cxx", "python"])
+@pytest.mark.parametrize("gaussians_grad,camera_grad", [(False, True), (True, False), (True, True)])
+def test_depth_only_backward_equals_the_full_dual_backward(gpu_device, monkeypatch, route, gaussians_grad, camera_grad):
+    """render_frame(depth_grad_only=True) -- frame flag 8: four image-gradient channels, 48-byte records, the second set's colour
+    sum in chain w's fourth column -- against the full dual backward (VTGS_DUAL_B1=0 makes the library ignore the flag) on a
+    gradient whose depth_sil planes 1 and 2 are zero, as get_loss sends it: the per-pair arithmetic is the same (the two
+    dropped terms were exact zeros), so what is left is the contraction order of the compiler: 2e-6 of each tensor's largest
+    gradient.  Tracking (Gaussians detached), mapping and bundle-adjustment flags, both autograd nodes."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization.fused import render_frame
+    dev = gpu_device
+    monkeypatch.setenv("VTGS_FUSED_EXT", "1" if route == "cxx" else "0")
+    params, cam = _params(dev, 40000, 232, 136, seed=21)
+    st = to_settings(cam, dev)
+    w2c = torch.eye(4, device=dev)
+    w2c[:3, 3] = torch.tensor([0.01, 0.02, -0.02], device=dev)
+    g = torch.Generator().manual_seed(9)
+    g1 = (torch.rand(3, 136, 232, generator=g) * 2 - 1).to(dev)
+    g2 = (torch.rand(3, 136, 232, generator=g) * 2 - 1).to(dev)
+    g2[1:] = 0.0
+    res = {}
+    try:
+        for b1 in (0, 1):
+            assert dgr._lib.vtgs_set_option(b"VTGS_DUAL_B1", b1) == 0
+            for v in params.values():
+                v.grad = None
+            im, ds, _ = render_frame(params, 1, st, w2c, gaussians_grad, camera_grad, depth_grad_only=True)
+            ((im * g1).sum() + (ds * g2).sum()).backward()
+            res[b1] = {k: (None if v.grad is None else v.grad.clone()) for k, v in params.items()}
+    finally:
+        dgr._lib.vtgs_set_option(b"VTGS_DUAL_B1", -1)
+    seen_any = False
+    for k in params:
+        a, b = res[0][k], res[1][k]
+        assert (a is None) == (b is None), k
+        if a is not None:
+            seen_any = True
+            scale = a.abs().max().item()
+            if k == "unnorm_rotations":                   # isotropic map: float noise around an exact zero in both routes
+                scale = res[0]["log_scales"].abs().max().item() if res[0]["log_scales"] is not None else 1.0
+            assert (a - b).abs().max().item() <= 2e-6 * scale + 1e-12, (k, (a - b).abs().max().item(), scale)
+    assert seen_any
+
+
+def test_get_loss_sends_no_gradient_into_silhouette_and_depth_squared(gpu_device, monkeypatch):
+    """The promise behind frame flag 8: whatever get_loss is asked for (tracking with the silhouette mask, mapping), the
+    gradient that reaches the [z, 1, z^2] render is zero in planes 1 and 2 (src/vtgaussian_slam.py:466-521).  Checked on the
+    Python node, whose output tensor takes a hook."""
+    from diff_gaussian_rasterization import fused, get_loss as gl
+    dev = gpu_device
+    monkeypatch.setenv("VTGS_FUSED_EXT", "0")
+    params, cam = _params(dev, 30000, 200, 136, seed=5)
+    st = to_settings(cam, dev)
+    w2c = torch.eye(4, device=dev)
+    with torch.no_grad():
+        im, ds, _ = fused.render_frame(params, 1, st, w2c, False, False)
+    gt = {"cam": st, "w2c": w2c, "im": (im + 0.05).clamp(0, 1), "depth": ds[0:1] * 1.02, "id": 1,
+          "intrinsics": torch.eye(3, device=dev), "iter_gt_w2c_list": [w2c, w2c]}
+    caught = []
+    real = fused.render_frame
+
+    def spy(*a, **k):
+        out = real(*a, **k)
+        if out[1].requires_grad:
+            out[1].register_hook(lambda g: caught.append(g.detach().clone()))
+        return out
+    monkeypatch.setattr(gl, "render_frame", spy)
+    variables = {"max_2D_radius": torch.zeros(params["means3D"].shape[0], device=dev),
+                 "means2D_gradient_accum": torch.zeros(params["means3D"].shape[0], device=dev),
+                 "denom": torch.zeros(params["means3D"].shape[0], device=dev)}
+    for tracking in (True, False):
+        for v in params.values():
+            v.grad = None
+        out = gl.get_loss(params, gt, variables, 1, {"im": 0.5, "depth": 1.0}, True, 0.5, True, True, tracking=tracking,
+                          mapping=not tracking, tracking_iteration=1, dataset_name="replica",
+                          presence_sil_mask_mse_ls=[0.0] if tracking else None, sil_thres_ls=[0.99] if tracking else None)
+        out[0].backward()
+    assert len(caught) == 2
+    for g in caught:
+        assert g[0].abs().max().item() > 0.0
+        assert g[1:].abs().max().item() == 0.0

@@ -30,11 +30,11 @@ template <bool DUAL>
 __global__ void composite_forward_q(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*,
                                     const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*,
                                     float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs, uint8_t*, uint32_t*);
-template <int WAVES, bool DUAL, bool PX>
+template <int WAVES, bool DUAL, bool PX, bool B1>
 __global__ void composite_backward_mx(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                       const uint32_t*, const GeomRec*, const float*, const float*, const float*,
                                       const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*);
-template <bool DUAL, bool FRAME, bool COV3D>
+template <bool DUAL, bool FRAME, bool COV3D, bool B1>
 __global__ void gather_splat_grads(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
                                    const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*,
                                    float*, const Counters*, float*, FrameEpilogue);
@@ -188,8 +188,10 @@ size_t vtgs_backward_dual_scratch_bytes(int32_t n, uint64_t instances) {
 // Implementation switches: defaults from the environment, read once; vtgs_set_option overrides them at run time.
 struct Option { const char* name; int dflt; int value; };
 static Option g_options[] = {{"VTGS_FWD_IMPL", 3, -1}, {"VTGS_BWD_IMPL", 2, -1}, {"VTGS_BIN_IMPL", 1, -1}, {"VTGS_SORT_PACKED", 1, -1},
-                             {"VTGS_SORT_FUSED", 1, -1}, {"VTGS_COUNT_STEPS", 0, -1}, {"VTGS_SORT_LONG_COUNTING", 1, -1}};
-enum { OPT_FWD_IMPL = 0, OPT_BWD_IMPL, OPT_BIN_IMPL, OPT_SORT_PACKED, OPT_SORT_FUSED, OPT_COUNT_STEPS, OPT_SORT_LONG_COUNTING, OPT_COUNT };
+                             {"VTGS_SORT_FUSED", 1, -1}, {"VTGS_COUNT_STEPS", 0, -1}, {"VTGS_SORT_LONG_COUNTING", 1, -1},
+                             {"VTGS_DUAL_B1", 1, -1}};   // 0: ignore frame flag 8 (the full dual backward: the cross-check of the one-channel form)
+enum { OPT_FWD_IMPL = 0, OPT_BWD_IMPL, OPT_BIN_IMPL, OPT_SORT_PACKED, OPT_SORT_FUSED, OPT_COUNT_STEPS, OPT_SORT_LONG_COUNTING, OPT_DUAL_B1,
+       OPT_COUNT };
 static std::once_flag g_options_once;
 static void options_init() {                                   // thread-safe: the first caller reads the environment
   std::call_once(g_options_once, [] {
@@ -592,16 +594,25 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
   if (frame ? !(frame->flags & 4u) : !g_colors) cs.bwd_flags |= 1u;
   if (dual && bwd_impl == 0) bwd_impl = 1;                   // 0 = scalar kernel (single render only); read per call
   if (dual && bwd_impl == 3) bwd_impl = 2;                   // 3 = quadrant queues (single render only so far)
+  // FrameEpilogue flag 8 (the caller's promise: grad_color_b is zero outside its first channel -- get_loss, whose loss reaches
+  // the [z, 1, z^2] render through z alone): four gradient channels instead of six, three contraction chains, 48-byte records
+  const bool b1 = dual && frame && (frame->flags & 8u) && bwd_impl == 2 && option(OPT_DUAL_B1) != 0;
   {
     ProfScope ps__(dual ? "composite_backward_dual" : "composite_backward", st);
-    if (dual && bwd_impl == 2)
-      hipLaunchKernelGGL((composite_backward_mx<4, true, true>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
+    if (b1)
+      hipLaunchKernelGGL((composite_backward_mx<4, true, true, true>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
+                         (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
+                         grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), colors_b, out_color_b,
+                         grad_color_b, dbg);
+    else if (dual && bwd_impl == 2)
+      hipLaunchKernelGGL((composite_backward_mx<4, true, true, false>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
                          grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), colors_b, out_color_b,
                          grad_color_b, dbg);
     else if (!dual && bwd_impl == 2)                        // lane = pixel replay (the default)
-      hipLaunchKernelGGL((composite_backward_mx<4, false, true>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
+      hipLaunchKernelGGL((composite_backward_mx<4, false, true, false>), dim3(nblk16), dim3(256), 0, st, cs, cam->bg, nblk16,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (const uint32_t*)(ws + L.sorted_gid),
                          (const uint32_t*)(ws + L.sorted_inst), (const GeomRec*)(ws + L.geom), colors, out_color,
                          grad_color, state, (float*)scratch, (const Counters*)(ws + L.counters), (const float*)nullptr,
@@ -619,23 +630,28 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
   VTGS_HIP(hipGetLastError());
   {
     ProfScope ps__(dual ? "gather_splat_grads_dual" : "gather_splat_grads", st);
-    if (dual && frame)
-      hipLaunchKernelGGL((gather_splat_grads<true, true, false>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+    if (b1)
+      hipLaunchKernelGGL((gather_splat_grads<true, true, false, true>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+                         means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, 1,
+                         (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                         (const Counters*)(ws + L.counters), (float*)nullptr, *frame);
+    else if (dual && frame)
+      hipLaunchKernelGGL((gather_splat_grads<true, true, false, false>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
                          means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, 1,
                          (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                          (const Counters*)(ws + L.counters), (float*)nullptr, *frame);
     else if (dual)
-      hipLaunchKernelGGL((gather_splat_grads<true, false, false>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+      hipLaunchKernelGGL((gather_splat_grads<true, false, false, false>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
                          means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, 1,
                          g_means3D, g_means2D, g_colors, g_opacities, g_scales, g_rotations,
                          (const Counters*)(ws + L.counters), g_colors_b, FrameEpilogue{});
     else if (cov3d)
-      hipLaunchKernelGGL((gather_splat_grads<false, false, true>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+      hipLaunchKernelGGL((gather_splat_grads<false, false, true, false>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
                          means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, bwd_impl != 0 ? 1 : 0,
                          g_means3D, g_means2D, g_colors, g_opacities, g_scales, (float*)nullptr,
                          (const Counters*)(ws + L.counters), (float*)nullptr, FrameEpilogue{});
     else
-      hipLaunchKernelGGL((gather_splat_grads<false, false, false>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
+      hipLaunchKernelGGL((gather_splat_grads<false, false, false, false>), dim3((n + 255) / 256), dim3(256), 0, st, cs, cam->viewmatrix, cam->projmatrix, n,
                          means3D, opacities, scales, rotations, (const GaussAux*)(ws + L.gaux), (const float*)scratch, bwd_impl != 0 ? 1 : 0,
                          g_means3D, g_means2D, g_colors, g_opacities, g_scales, g_rotations,
                          (const Counters*)(ws + L.counters), (float*)nullptr, FrameEpilogue{});

@@ -648,11 +648,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Per-pixel state; the two components of every f32x2 are the pixel blocks 2h and 2h+1 of half-pass h, so the
 // element-wise arithmetic below compiles to packed v_pk_{mul,add,fma}_f32 (two pixels per instruction).
-template <bool DUAL>
+template <int NG>
 struct MxBwdState {
   f32x2 Tb[2], Pb[2];      // transmittance / gradient prefix of pixel (blk, j) at the start of the batch (replicated over q)
   f32x2 CB[2];             // g.(out - T_final bg) + T_final (g.bg)
-  float gown[DUAL ? 6 : 3];   // dL/dcolor of the lane's OWN pixel (lane L <-> pixel L): B operand of the g.c products
+  float gown[NG];          // dL/dcolor of the lane's OWN pixel (lane L <-> pixel L): B operand of the g.c products
 };
 
 // g.c for 64 pixels x 16 splats: a rank-3 (dual: rank-6) bilinear form, so it comes out of the matrix cores in the
@@ -672,7 +672,7 @@ __device__ __forceinline__ f32x16 mx_gdotc(const MxSplat& m, const float (&g)[DU
 }
 
 template <int B, bool DUAL>
-__device__ __forceinline__ void mx_backward_batch(MxBwdState<DUAL>& st, const MxSplat& m, const float (&Phi)[6],
+__device__ __forceinline__ void mx_backward_batch(MxBwdState<DUAL ? 6 : 3>& st, const MxSplat& m, const float (&Phi)[6],
                                                   float4* __restrict__ lds_xch, float* __restrict__ Us,
                                                   float* __restrict__ Ws, int l) {
   const int j = l & 15, q = l >> 4;
@@ -783,14 +783,17 @@ __device__ __forceinline__ void mx_backward_batch(MxBwdState<DUAL>& st, const Mx
 // run inside the lane with the forward's recurrence (w = alpha T, T' = T - w: the stop decisions are the forward's by
 // construction); u' and w go to the same LDS images, so the contraction below is shared with the quad form.  A pixel that
 // has ended carries T = 0 and CB = P, which makes every later u' and w exactly zero without a mask.
-template <int G, bool DUAL>
-__device__ __forceinline__ f32x4 px_gdotc(const MxSplat& m, const float (&g)[DUAL ? 6 : 3]) {
+// NG = image-gradient channels: 3 (one render), 6 (dual render) or 4 (dual render whose second image passes a gradient
+// through its FIRST channel only -- the [z, 1, z^2] render under get_loss, where the silhouette only feeds comparisons and
+// z^2 a detached uncertainty, src/vtgaussian_slam.py:466-521)
+template <int G, int NG>
+__device__ __forceinline__ f32x4 px_gdotc(const MxSplat& m, const float (&g)[NG]) {
   f32x4 d = {0.f, 0.f, 0.f, 0.f};
   d = __builtin_amdgcn_mfma_f32_4x4x1f32(m.pay.x, g[0], d, 4, G, 0);
   d = __builtin_amdgcn_mfma_f32_4x4x1f32(m.pay.y, g[1], d, 4, G, 0);
   d = __builtin_amdgcn_mfma_f32_4x4x1f32(m.pay.z, g[2], d, 4, G, 0);
-  if constexpr (DUAL) {
-    d = __builtin_amdgcn_mfma_f32_4x4x1f32(m.pay.w, g[3], d, 4, G, 0);
+  if constexpr (NG >= 4) d = __builtin_amdgcn_mfma_f32_4x4x1f32(m.pay.w, g[3], d, 4, G, 0);
+  if constexpr (NG == 6) {
     d = __builtin_amdgcn_mfma_f32_4x4x1f32(m.pay2.x, g[4], d, 4, G, 0);
     d = __builtin_amdgcn_mfma_f32_4x4x1f32(m.pay2.y, g[5], d, 4, G, 0);
   }
@@ -807,14 +810,14 @@ struct PxBwdState { float T, P, CB; bool done; };   // T frozen once the pixel h
 //                   u'_k = alpha_unclamped_k dL/dalpha_k = G_k T_k (g.c_k - A_k)          (the reference's recurrence)
 // dL/dalpha_k = T_k g.c_k - (CB - P_k)/(1 - alpha_k) is the same thing since (CB - P_k)/(1 - alpha_k) = T_k A_k.
 // `exact` is the forward's switch: straight to the exact sweep while pixels keep ending.
-template <int B, bool DUAL, bool CLAMP, bool EXACT_FIRST>
+template <int B, int NG, bool CLAMP, bool EXACT_FIRST>
 __device__ __forceinline__ void px_backward_batch(PxBwdState& st, bool& exact, const MxSplat& m, const float (&Phi)[6],
-                                                  const float (&gown)[DUAL ? 6 : 3], float* __restrict__ Us,
+                                                  const float (&gown)[NG], float* __restrict__ Us,
                                                   float* __restrict__ Ws, int l) {
   const f32x4 d[4] = {px_exponents<4 * B>(m.K, Phi), px_exponents<4 * B + 1>(m.K, Phi), px_exponents<4 * B + 2>(m.K, Phi),
                       px_exponents<4 * B + 3>(m.K, Phi)};
-  const f32x4 gcv[4] = {px_gdotc<4 * B, DUAL>(m, gown), px_gdotc<4 * B + 1, DUAL>(m, gown), px_gdotc<4 * B + 2, DUAL>(m, gown),
-                        px_gdotc<4 * B + 3, DUAL>(m, gown)};
+  const f32x4 gcv[4] = {px_gdotc<4 * B, NG>(m, gown), px_gdotc<4 * B + 1, NG>(m, gown), px_gdotc<4 * B + 2, NG>(m, gown),
+                        px_gdotc<4 * B + 3, NG>(m, gown)};
   float* __restrict__ us = Us + (l >> 4) * kImgQuarter + (l & 15);   // image [pixel quarter][splat][16 px]
   float* __restrict__ ws = Ws + (l >> 4) * kImgQuarter + (l & 15);
   float a[16], gT[16];                                         // alpha_k and G_k T_k (0 where the pair contributes nothing)
@@ -844,7 +847,7 @@ __device__ __forceinline__ void px_backward_batch(PxBwdState& st, bool& exact, c
       Tn = Tn - w;
     }
 #if VTGS_PX_GROUP
-    __builtin_amdgcn_sched_group_barrier(0x008, DUAL ? 48 : 36, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 24 + 4 * NG, 0);
     __builtin_amdgcn_sched_group_barrier(0x302, 400, 0);
 #endif
     if (__ballot(!st.done && Tn < kTStop) == 0ull) { st.T = st.done ? st.T : Tn; swept = true; }
@@ -883,7 +886,12 @@ __device__ __forceinline__ void px_backward_batch(PxBwdState& st, bool& exact, c
   }
 }
 
-template <int WAVES, bool DUAL, bool PXL>
+// B1 (lane = pixel form of the dual render only): the second image's gradient is zero outside its first channel (CamScalars /
+// FrameEpilogue flag 8, promised by the caller -- get_loss, whose loss touches the [z, 1, z^2] render through z alone).  Then
+// g.c has four terms, not six; the second set's one colour sum rides in the idle fourth column of chain w (no fourth chain);
+// a splat brings one colour of the second set, which leaves the registers for the single render's record prefetch; and a
+// record is 12 floats (three aligned float4) instead of 14: 88 matrix instructions per batch instead of 112, 48-byte records.
+template <int WAVES, bool DUAL, bool PXL, bool B1 = false>
 __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
     const uint32_t* __restrict__ tile_cnt, uint32_t tile_cap, const uint32_t* __restrict__ sorted_gid,
@@ -891,14 +899,16 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     const float* __restrict__ out_color, const float* __restrict__ grad_color, const float* __restrict__ final_T,
     float* __restrict__ grad_inst, const Counters* __restrict__ ctr, const float* __restrict__ colors_b,
     const float* __restrict__ out_color_b, const float* __restrict__ grad_color_b, uint32_t* __restrict__ dbg) {
-  constexpr int NG = DUAL ? 6 : 3;                            // image-gradient channels
+  static_assert(!B1 || (DUAL && PXL), "B1 is a form of the lane = pixel dual backward");
+  constexpr int NG = DUAL ? (B1 ? 4 : 6) : 3;                 // image-gradient channels
+  constexpr bool DUAL6 = DUAL && !B1;                         // both colour sets in full
 #ifdef VTGS_Q_STAMPS
   const unsigned long long st0 = __builtin_amdgcn_s_memtime();
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long st_gather = 0ull, st_batch = 0ull, st_loop0 = 0ull;
   uint32_t nbatches = 0u;
 #endif
-  constexpr int REC = DUAL ? kGradRecDual : kGradRec;         // floats per (splat, tile) record
+  constexpr int REC = DUAL ? (B1 ? kGradRecDual1 : kGradRecDual) : kGradRec;   // floats per (splat, tile) record
   __shared__ float4 lds_xch_all[WAVES][PXL ? 1 : 128];
 #ifdef VTGS_AB_BWD_PAD                                          // occupancy experiment: extra LDS so that fewer workgroups fit a CU
   __shared__ float ab_pad[VTGS_AB_BWD_PAD];
@@ -908,7 +918,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   __shared__ __attribute__((aligned(16))) float lds_phi[4 * kPhiQuarter];
   // the contraction's dL/dcolor operands live in LDS ([wave][second set?][quarter][column][16 + 4]), not in 16 / 32 VGPRs:
   // round 3 -- the registers hold the NEXT chunk's geometry records instead (the gathers were 12 % of the wavefront's life)
-  __shared__ __attribute__((aligned(16))) float lds_g_all[WAVES][(DUAL ? 2 : 1) * 16 * kImgRow];
+  __shared__ __attribute__((aligned(16))) float lds_g_all[WAVES][(DUAL6 ? 2 : 1) * 16 * kImgRow];
   // Everything the wavefront needs before its first batch is requested up front -- flag, list length, image values, first
   // list entries -- and the flag is looked at afterwards: the prologue was four dependent round trips (15 % of the
   // wavefront's life, profiles/r3_stamps.md)
@@ -946,7 +956,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   const float Phi[6] = {1.f, X, Y, X * X, X * Y, Y * Y};
   const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
 
-  MxBwdState<DUAL> st;
+  MxBwdState<NG> st;
   PxBwdState ps{1.f, 0.f, 0.f, !tc.inside};
   bool px_exact = false;
   if (PXL && tc.inside) {                                        // lane L <-> pixel L
@@ -955,15 +965,19 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     const float Tf = final_T[pix];
     ps.CB = g0 * (out_color[pix] - Tf * b0) + g1 * (out_color[P + pix] - Tf * b1) + g2 * (out_color[2 * P + pix] - Tf * b2)
             + Tf * (g0 * b0 + g1 * b1 + g2 * b2);
-    if constexpr (DUAL) {
+    if constexpr (DUAL6) {
       const float g3 = grad_color_b[pix], g4 = grad_color_b[P + pix], g5 = grad_color_b[2 * P + pix];
       ps.CB += g3 * (out_color_b[pix] - Tf * b0) + g4 * (out_color_b[P + pix] - Tf * b1) + g5 * (out_color_b[2 * P + pix] - Tf * b2)
                + Tf * (g3 * b0 + g4 * b1 + g5 * b2);
+    } else if constexpr (B1) {
+      const float g3 = grad_color_b[pix];
+      ps.CB += g3 * (out_color_b[pix] - Tf * b0) + Tf * (g3 * b0);
     }
   }
 #pragma unroll
   for (int blk = 0; blk < 4; ++blk) {
     if (PXL) break;
+    if constexpr (!B1) {
     const int p = 16 * blk + j;
     const int qx = tx0 + (p & 7), qy = ty0 + (p >> 3);
     const bool in_img = qx < cs.W && qy < cs.H;
@@ -982,13 +996,15 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     }
     if (blk & 1) { st.Tb[blk >> 1].y = in_img ? 1.f : 0.f; st.CB[blk >> 1].y = cb; st.Pb[blk >> 1].y = 0.f; }
     else         { st.Tb[blk >> 1].x = in_img ? 1.f : 0.f; st.CB[blk >> 1].x = cb; st.Pb[blk >> 1].x = 0.f; }
+    }
   }
 #pragma unroll
   for (int c = 0; c < NG; ++c) st.gown[c] = 0.f;
   if (tc.inside) {                                              // lane L <-> pixel L (tc.px, tc.py)
     const size_t pix = (size_t)tc.py * cs.W + tc.px;
     st.gown[0] = grad_color[pix]; st.gown[1] = grad_color[P + pix]; st.gown[2] = grad_color[2 * P + pix];
-    if constexpr (DUAL) { st.gown[3] = grad_color_b[pix]; st.gown[4] = grad_color_b[P + pix]; st.gown[5] = grad_color_b[2 * P + pix]; }
+    if constexpr (DUAL) st.gown[3] = grad_color_b[pix];
+    if constexpr (DUAL6) { st.gown[4] = grad_color_b[P + pix]; st.gown[5] = grad_color_b[2 * P + pix]; }
   }
   // Contraction roles: l = cj + 4 sg + 16 pq -- column cj of every group, splat group sg, pixel quarter pq.
   // A operand: row (l & 3) of block (sg, pq) = splat 4 sg + (l & 3) = image row (l & 15); B operand: column cj.
@@ -999,8 +1015,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   float* lds_g = lds_g_all[wv];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    lds_g[(4 * pq + c) * kImgRow + j] = (c < 3) ? st.gown[c < 3 ? c : 0] : 0.f;
-    if constexpr (DUAL) lds_g[16 * kImgRow + (4 * pq + c) * kImgRow + j] = (c < 3) ? st.gown[3 + (c < 3 ? c : 0)] : 0.f;
+    lds_g[(4 * pq + c) * kImgRow + j] = (c < 3) ? st.gown[c < 3 ? c : 0] : (B1 ? st.gown[B1 ? 3 : 0] : 0.f);   // B1: the second set's
+    if constexpr (DUAL6) lds_g[16 * kImgRow + (4 * pq + c) * kImgRow + j] = (c < 3) ? st.gown[3 + (c < 3 ? c : 0)] : 0.f;   // one live channel
   }
   __syncthreads();                                            // the Phi table (and, per wavefront, the g image); before any exit
   if (overflow_flag) return;                                  // uniform over the grid: the forward did not complete
@@ -1013,12 +1029,13 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   const float4* __restrict__ PhiA4 = reinterpret_cast<const float4*>(lds_phi + pq * kPhiQuarter + cj * kImgRow);
   const float4* __restrict__ PhiB4 = reinterpret_cast<const float4*>(lds_phi + pq * kPhiQuarter + (4 + cj) * kImgRow);
   const uint32_t tile_bits = (uint32_t)tc.tile;
-  const bool skip_a = PXL && (cs.bwd_flags & 1u) != 0u;
+  const bool skip_a = PXL && !B1 && (cs.bwd_flags & 1u) != 0u;   // (B1: chain w also carries the second set's column)
   // record columns: chain a -> 0..3, chain b -> 4, 5 (its lanes cj = 2, 3 hold padding and store nothing), chain w -> 6..8
   // and the tile id in 9 (dual: w -> 6..8 + tile id in 12, w2 -> 9..11, its lane cj = 3 stores nothing)
   const int col_b = 4 + cj;
   const bool b_live = cj < 2;
-  const int col_w = (DUAL && cj == 3) ? 12 : 6 + cj;
+  // B1: chain w -> 6..9 (9 = the second set's first colour), the tile id in 10 from chain b's idle lane cj = 2
+  const int col_w = (DUAL6 && cj == 3) ? 12 : 6 + cj;
   const int col_w2 = 9 + cj;
 
   uint32_t base = s;
@@ -1037,16 +1054,17 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   uint32_t inst_cur = first_in ? inst_first : inst0;
   uint32_t gid_nxt = entry(sorted_gid, s + 64u), inst_nxt = entry(sorted_inst, s + 64u);
   float4 g0n, g1n;
-  float cn[DUAL ? 6 : 3];
+  float cn[NG];
   auto fetch = [&](uint32_t gid) {
     const float4* gp = reinterpret_cast<const float4*>(geom + gid);
     g0n = gp[0]; g1n = gp[1];
     cn[0] = colors[3 * gid]; cn[1] = colors[3 * gid + 1]; cn[2] = colors[3 * gid + 2];
-    if constexpr (DUAL) { cn[3] = colors_b[3 * gid]; cn[4] = colors_b[3 * gid + 1]; cn[5] = colors_b[3 * gid + 2]; }
+    if constexpr (DUAL) cn[3] = colors_b[3 * gid];
+    if constexpr (DUAL6) { cn[4] = colors_b[3 * gid + 1]; cn[5] = colors_b[3 * gid + 2]; }
   };
   // (dual render: 14 more registers in flight across the batches push the kernel into scratch -- there the records are
   // requested at the top of their own chunk, as in round 2; the entries still come one chunk ahead)
-  constexpr bool kRecordsAhead = !DUAL;
+  constexpr bool kRecordsAhead = !DUAL6;
   if constexpr (kRecordsAhead) fetch(gid_cur);
   for (; base < e; base += 64u) {
     const bool alive = PXL ? !ps.done : (st.Tb[0].x > 0.f || st.Tb[0].y > 0.f || st.Tb[1].x > 0.f || st.Tb[1].y > 0.f);
@@ -1063,7 +1081,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
       tile_coefficients(g0n, g1n, cx, cy, m.K);
       m.hot = g1n.y > kClampGuard;
       m.pay = make_float4(cn[0], cn[1], cn[2], DUAL ? cn[DUAL ? 3 : 0] : g1n.z);
-      if constexpr (DUAL) m.pay2 = make_float2(cn[4], cn[5]);
+      if constexpr (DUAL6) m.pay2 = make_float2(cn[DUAL6 ? 4 : 0], cn[DUAL6 ? 5 : 0]);
     }
     const uint32_t my_inst = (l < n) ? inst_cur : 0u;
     gid_cur = gid_nxt; inst_cur = inst_nxt;
@@ -1083,19 +1101,21 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
       if constexpr (PXL) {
 #define VTGS_PX_BWD(CL, EX)                                                                               \
         {                                                                                                 \
-          if (b == 0) px_backward_batch<0, DUAL, CL, EX>(ps, px_exact, m, Phi, st.gown, Us, Ws, l);       \
-          if (b == 1) px_backward_batch<1, DUAL, CL, EX>(ps, px_exact, m, Phi, st.gown, Us, Ws, l);       \
-          if (b == 2) px_backward_batch<2, DUAL, CL, EX>(ps, px_exact, m, Phi, st.gown, Us, Ws, l);       \
-          if (b == 3) px_backward_batch<3, DUAL, CL, EX>(ps, px_exact, m, Phi, st.gown, Us, Ws, l);       \
+          if (b == 0) px_backward_batch<0, NG, CL, EX>(ps, px_exact, m, Phi, st.gown, Us, Ws, l);         \
+          if (b == 1) px_backward_batch<1, NG, CL, EX>(ps, px_exact, m, Phi, st.gown, Us, Ws, l);         \
+          if (b == 2) px_backward_batch<2, NG, CL, EX>(ps, px_exact, m, Phi, st.gown, Us, Ws, l);         \
+          if (b == 3) px_backward_batch<3, NG, CL, EX>(ps, px_exact, m, Phi, st.gown, Us, Ws, l);         \
         }
         if (chunk_exact) VTGS_PX_BWD(true, true)                // (one exact-first body: the clamped form is always valid)
         else             { if (hot) VTGS_PX_BWD(true, false) else VTGS_PX_BWD(false, false) }
 #undef VTGS_PX_BWD
       } else {
-        if (b == 0) mx_backward_batch<0, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
-        if (b == 1) mx_backward_batch<1, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
-        if (b == 2) mx_backward_batch<2, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
-        if (b == 3) mx_backward_batch<3, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
+        if constexpr (!B1) {
+          if (b == 0) mx_backward_batch<0, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
+          if (b == 1) mx_backward_batch<1, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
+          if (b == 2) mx_backward_batch<2, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
+          if (b == 3) mx_backward_batch<3, DUAL>(st, m, Phi, lds_xch, Us, Ws, l);
+        }
       }
       const int nb = min(16, n - 16 * b);
       f32x4 Pa = {0.f, 0.f, 0.f, 0.f}, Pb = {0.f, 0.f, 0.f, 0.f}, Pw = {0.f, 0.f, 0.f, 0.f}, Pw2 = {0.f, 0.f, 0.f, 0.f};
@@ -1113,7 +1133,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
             const float4 ga = Ga4[t4];                                                                              \
             gav[0] = ga.x; gav[1] = ga.y; gav[2] = ga.z; gav[3] = ga.w;                                             \
           }                                                                                                         \
-          if constexpr (DUAL) {                                                                                     \
+          if constexpr (DUAL6) {                                                                                    \
             const float4 gb = Gb4[t4];                                                                              \
             gbv[0] = gb.x; gbv[1] = gb.y; gbv[2] = gb.z; gbv[3] = gb.w;                                             \
           }                                                                                                         \
@@ -1121,27 +1141,32 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
             Pa = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bav[e4], Pa, 0, 0, 0);                                 \
             Pb = __builtin_amdgcn_mfma_f32_4x4x1f32(uav[e4], bbv[e4], Pb, 0, 0, 0);                                 \
             if constexpr (!(SKIPA)) Pw = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], gav[e4], Pw, 0, 0, 0);         \
-            if constexpr (DUAL) Pw2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], gbv[e4], Pw2, 0, 0, 0);           \
+            if constexpr (DUAL6) Pw2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wav[e4], gbv[e4], Pw2, 0, 0, 0);          \
           }                                                                                                         \
         }                                                                                                           \
         if (VTGS_PX_GROUP2) {                                                                                       \
-          __builtin_amdgcn_sched_group_barrier(0x100, (DUAL ? 24 : 20) - ((SKIPA) ? 4 : 0), 1);   /* the image / Phi / g reads first ... */ \
-          __builtin_amdgcn_sched_group_barrier(0x008, (DUAL ? 64 : 48) - ((SKIPA) ? 16 : 0), 1);  /* ... then the contraction MFMAs back to back */ \
+          __builtin_amdgcn_sched_group_barrier(0x100, (DUAL6 ? 24 : 20) - ((SKIPA) ? 4 : 0), 1);  /* the image / Phi / g reads first ... */ \
+          __builtin_amdgcn_sched_group_barrier(0x008, (DUAL6 ? 64 : 48) - ((SKIPA) ? 16 : 0), 1); /* ... then the contraction MFMAs back to back */ \
         }                                                                                                           \
       }
       if (skip_a) VTGS_CONTRACT(true) else VTGS_CONTRACT(false)
 #undef VTGS_CONTRACT
       // lane (cj, sg, rho = l >> 4) ends up with the totals of splat 4 sg + rho
       const float Fa = quarter_sum(Pa), Fb = quarter_sum(Pb), Fw = skip_a ? 0.f : quarter_sum(Pw);   // (skip_a is wave-uniform)
-      const float Fw2 = DUAL ? quarter_sum(Pw2) : 0.f;           // cross-lane: must run with all lanes active
+      const float Fw2 = DUAL6 ? quarter_sum(Pw2) : 0.f;          // cross-lane: must run with all lanes active
       const int srow = (l & 12) + (l >> 4);                     // 4 sg + rho
       const uint32_t inst = (uint32_t)__shfl((int)my_inst, 16 * b + srow, 64);
       if (srow < nb) {
         float* __restrict__ rec = grad_inst + (size_t)inst * REC;
         rec[cj] = Fa;
         if (b_live) rec[col_b] = Fb;
-        rec[col_w] = (cj == 3) ? __uint_as_float(tile_bits) : Fw;
-        if constexpr (DUAL) { if (cj < 3) rec[col_w2] = Fw2; }
+        if constexpr (B1) {
+          if (cj == 2) rec[10] = __uint_as_float(tile_bits);
+          rec[col_w] = Fw;
+        } else {
+          rec[col_w] = (cj == 3) ? __uint_as_float(tile_bits) : Fw;
+        }
+        if constexpr (DUAL6) { if (cj < 3) rec[col_w2] = Fw2; }
       }
 #ifdef VTGS_Q_STAMPS
       ++nbatches;
@@ -1155,7 +1180,11 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
     const int n = (int)min(64u, e - base);
     if (l < n) {
       const uint32_t inst = sorted_inst[base + (uint32_t)l];
-      if constexpr (DUAL) {
+      if constexpr (B1) {
+        float4* p = reinterpret_cast<float4*>(grad_inst + (size_t)inst * REC);
+        p[0] = p[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        p[2] = make_float4(0.f, 0.f, __uint_as_float(tile_bits), 0.f);
+      } else if constexpr (DUAL) {
         float2* p = reinterpret_cast<float2*>(grad_inst + (size_t)inst * REC);
         p[0] = p[1] = p[2] = p[3] = p[4] = p[5] = make_float2(0.f, 0.f);
         p[6] = make_float2(__uint_as_float(tile_bits), 0.f);
@@ -1183,6 +1212,7 @@ template __global__ void composite_backward_mx<4, true, false>(CamScalars, const
 #else
 template __global__ void composite_backward_mx<4, false, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*);
 template __global__ void composite_backward_mx<4, true, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*);
+template __global__ void composite_backward_mx<4, true, true, true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*, const uint32_t*, const GeomRec*, const float*, const float*, const float*, const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*);
 #endif
 
 
@@ -1194,7 +1224,8 @@ template __global__ void composite_backward_mx<4, true, true>(CamScalars, const 
 // (~160 bytes per Gaussian less traffic, one launch less; on a rank of the tile-row partition no dense zero arrays at all).
 // COV3D (the operator's cov3D_precomp): `scales` holds the six covariance entries per Gaussian and g_scales receives their
 // six gradients; `rotations` / g_rotations are not touched.
-template <bool DUAL, bool FRAME = false, bool COV3D = false>
+// B1: the 12-float records of composite_backward_mx<.., B1> (second image differentiated through its first channel only).
+template <bool DUAL, bool FRAME = false, bool COV3D = false, bool B1 = false>
 __global__ __launch_bounds__(256) void gather_splat_grads(
     CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
     const float* __restrict__ means3D, const float* __restrict__ opacities,
@@ -1253,7 +1284,10 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
   const bool big = ga.inst_cnt > kBigInst;
   // dual: 14 floats = seven float2 (56-byte stride); single render: 10 floats = five float2 (40-byte stride)
   auto load_record = [&](uint32_t inst, float4& a, float4& b, float4& c, float4& d) {
-    if constexpr (DUAL) {
+    if constexpr (B1) {
+      const float4* rec = reinterpret_cast<const float4*>(grad_inst) + (size_t)inst * (kGradRecDual1 / 4);
+      a = rec[0]; b = rec[1]; c = rec[2]; d = c;
+    } else if constexpr (DUAL) {
       const float2* rec = reinterpret_cast<const float2*>(grad_inst) + (size_t)inst * (kGradRecDual / 2);
       const float2 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3 = rec[3], f4 = rec[4], f5 = rec[5], f6 = rec[6];
       a = make_float4(f0.x, f0.y, f1.x, f1.y); b = make_float4(f2.x, f2.y, f3.x, f3.y);
@@ -1269,7 +1303,10 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
   auto add_record = [&](SplatMoments& M, float& c0, float& c1, float& c2, float4 a, float4 b, float4 c, float4 d, float u, float v,
                         float ulo, float vlo) {
     uint32_t tile;
-    if constexpr (DUAL) {
+    if constexpr (B1) {
+      tile = __float_as_uint(c.z);
+      c0 += c.y;
+    } else if constexpr (DUAL) {
       tile = __float_as_uint(d.x);
       c0 += c.y; c1 += c.z; c2 += c.w;
     } else {
@@ -1418,6 +1455,7 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
 template __global__ void gather_splat_grads<false>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*, FrameEpilogue);
 template __global__ void gather_splat_grads<true>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*, FrameEpilogue);
 template __global__ void gather_splat_grads<true, true>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*, FrameEpilogue);
+template __global__ void gather_splat_grads<true, true, false, true>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*, FrameEpilogue);
 template __global__ void gather_splat_grads<false, false, true>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, const GaussAux*, const float*, int, float*, float*, float*, float*, float*, float*, const Counters*, float*, FrameEpilogue);
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(const float* __restrict__ Vp, int n,

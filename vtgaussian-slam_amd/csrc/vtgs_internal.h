@@ -63,6 +63,8 @@ struct alignas(16) BlockStats { uint32_t visible, pad; unsigned long long r16; }
 
 constexpr int kGradRec = 10;       // floats per instance gradient record: 6 moments, 3 colour sums, tile id (40-byte stride, float2 access)
 constexpr int kGradRecDual = 14;   // dual render: 6 moments + 6 colour sums + tile id + one pad word (56-byte stride, float2 access)
+constexpr int kGradRecDual1 = 12;  // dual render, second image differentiated through its first channel only: 6 moments + 3 + 1
+                                   // colour sums + tile id + one pad word (48-byte stride, three aligned float4)
 
 constexpr int kStampWords = 12;    // -DVTGS_Q_STAMPS: words per tile in the debug region (8 phase stamps, start / end in 10 ns units of
                                    // the chip-wide constant clock, HW_ID, XCC_ID)

@@ -20,7 +20,7 @@ __global__ void composite_forward_px(CamScalars, const float*, uint32_t, const u
 __global__ void composite_backward(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                    const uint32_t*, const GeomRec*, const float*, const float*, const float*,
                                    const float*, float*, const Counters*);
-template <int WAVES, bool DUAL, bool PX>
+template <int WAVES, bool DUAL, bool PX, bool B1>
 __global__ void composite_backward_mx(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, const uint32_t*,
                                       const uint32_t*, const GeomRec*, const float*, const float*, const float*,
                                       const float*, float*, const Counters*, const float*, const float*, const float*, uint32_t*);
@@ -68,14 +68,14 @@ int vtgs_xcheck_backward(int impl, int dual, const CamScalars* cs, const float* 
                          const float* out_color_b, const float* grad_color_b, uint32_t* dbg, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (dual)
-    hipLaunchKernelGGL((composite_backward_mx<4, true, false>), dim3(nblk), dim3(256), 0, st, *cs, bg, nblk, tile_cnt, tile_cap,
+    hipLaunchKernelGGL((composite_backward_mx<4, true, false, false>), dim3(nblk), dim3(256), 0, st, *cs, bg, nblk, tile_cnt, tile_cap,
                        sorted_gid, sorted_inst, geom, colors, out_color, grad_color, state, grad_inst, ctr, colors_b, out_color_b,
                        grad_color_b, dbg);
   else if (impl == 3)
     hipLaunchKernelGGL(composite_backward_q, dim3(nblk), dim3(256), 0, st, *cs, bg, nblk, tile_cnt, tile_cap, sorted_gid, sorted_inst,
                        qmask, geom, colors, out_color, grad_color, state, grad_inst, ctr, dbg);
   else if (impl == 1)
-    hipLaunchKernelGGL((composite_backward_mx<4, false, false>), dim3(nblk), dim3(256), 0, st, *cs, bg, nblk, tile_cnt, tile_cap,
+    hipLaunchKernelGGL((composite_backward_mx<4, false, false, false>), dim3(nblk), dim3(256), 0, st, *cs, bg, nblk, tile_cnt, tile_cap,
                        sorted_gid, sorted_inst, geom, colors, out_color, grad_color, state, grad_inst, ctr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, dbg);
   else

@@ -166,7 +166,7 @@ class _RenderFrame(torch.autograd.Function):
         partials = new(max(rows, 1), 12) if want_p else None
         if n > 0:
             _check(_lib.vtgs_prepare_frame_backward(
-                n, flags, means3D.data_ptr(), logit_op.data_ptr(), log_scales.data_ptr(), unnorm_rot.data_ptr(),
+                n, flags & 7, means3D.data_ptr(), logit_op.data_ptr(), log_scales.data_ptr(), unnorm_rot.data_ptr(),
                 cam_q.data_ptr(), cam_t.data_ptr(), depth_w2c.data_ptr(), ga[0].data_ptr(), ptr(gb[0]), g_dcol.data_ptr(),
                 ga[3].data_ptr(), ptr(gb[3]), ga[4].data_ptr(), ptr(gb[4]), ga[5].data_ptr(), ptr(gb[5]),
                 ptr(g_means3D), ptr(g_logit), ptr(g_ls), ptr(g_ur), ptr(partials), _stream_ptr(dev)),
@@ -276,14 +276,19 @@ def _render_frame_ext(means3D, rgb, unnorm_rot, logit_op, log_scales, q, t, dept
 
 
 def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings, first_frame_w2c: torch.Tensor,
-                 gaussians_grad: bool, camera_grad: bool, radius_rule: Optional[str] = None, tile_rows=None, owned=None):
+                 gaussians_grad: bool, camera_grad: bool, radius_rule: Optional[str] = None, tile_rows=None, owned=None,
+                 depth_grad_only: bool = False):
     """RGB render + [z,1,z^2] render of frame `time_idx` (see module docstring).  Returns (im [3,H,W],
     depth_sil [3,H,W], radii [N] int32).  `tile_rows=(begin, end)`: this rank's band of 16-pixel tile rows (multi-GPU
     partition, `partition.band_for_rank`): pixels outside the band come back as zero and the gradients are the band's
     share -- the pose gradient of a rank is then 7 floats to all-reduce, with no dense per-Gaussian array behind it.
     `owned` (a `partition.OwnedSet` built for the same band): only the Gaussians of the list are transformed, projected and
     binned, and only their gradients are gathered; the set checks on the device, before every render, that no Gaussian
-    outside the list could meet the band (`owned.escaped()` reads the count)."""
+    outside the list could meet the band (`owned.escaped()` reads the count).
+    `depth_grad_only=True` is the caller's PROMISE that the gradient it sends back into `depth_sil` is zero in channels 1 and 2
+    (get_loss: the silhouette only feeds comparisons and z^2 a detached uncertainty, src/vtgaussian_slam.py:466-521): the
+    backward then carries four image-gradient channels instead of six (frame flag 8, include/vtgs.h) -- whatever such a
+    caller did put into those two channels would be ignored."""
     dev = params["means3D"].device
     if dev.type != "cuda":
         raise RuntimeError("render_frame needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
@@ -308,6 +313,8 @@ def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings
     appearance = any(params[k].requires_grad for k in ("rgb_colors", "logit_opacities", "log_scales"))
     flags = ((1 if gaussians_grad and grad_on else 0) | (2 if camera_grad and grad_on else 0)
              | (4 if appearance and grad_on else 0))
+    if depth_grad_only and flags:
+        flags |= 8
     if owned is not None:
         if not owned.scales_are_log:
             raise ValueError("this owned set was built for the plain operator (OwnedSet.for_operator)")
