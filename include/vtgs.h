@@ -119,6 +119,15 @@ int vtgs_bin_plan_uniform(int32_t width, int32_t height, uint32_t slots_per_bin,
                                 /* pre-sort pass for long lists is then not launched; a list of 513..1024 entries that    */
                                 /* turns up anyway is sorted by the composite itself (slower, same result).  Ignored    */
                                 /* for larger and for planned bins.                                                      */
+#define VTGS_FORWARD_SECOND_IS_DEPTH 8u /* vtgs_forward_dual*, OR-ed to one of the modes: a PROMISE about colors_b and about how  */
+                                /* out_color_b is consumed.  colors_b is the fused caller chain's [z, 1, z^2]                 */
+                                /* (utils/slam_helpers.py transformed_params2depthplussilhouette) and the caller uses the     */
+                                /* second image as get_loss does (src/vtgaussian_slam.py:466-521): plane 0 (depth) in full,   */
+                                /* plane 1 (silhouette) in comparisons only, plane 2 only through isnan(plane 2 - plane 0^2). */
+                                /* Then plane 0 = sum w z as always, plane 1 = 1 - T_final (what sum w is, up to float32     */
+                                /* rounding) and plane 2 = plane 0 squared (NaN exactly where the true difference is) come    */
+                                /* from the single render's kernel with z in its depth column.  VTGS_DEPTH_LITE=0 /           */
+                                /* vtgs_set_option ignores the bit.                                                           */
 #define VTGS_FORWARD_MODE_MASK 3u
 
 uint32_t    vtgs_abi_version(void);

@@ -373,7 +373,7 @@ def test_run_ahead_overflow_surfaces_inside_backward_before_the_optimizer_step(g
 @pytest.mark.parametrize("route", ["cxx", "python"])
 @pytest.mark.parametrize("gaussians_grad,camera_grad", [(False, True), (True, False), (True, True)])
 def test_depth_only_backward_equals_the_full_dual_backward(gpu_device, monkeypatch, route, gaussians_grad, camera_grad):
-    """render_frame(depth_grad_only=True) -- frame flag 8: four image-gradient channels, 48-byte records, the second set's colour
+    """render_frame(get_loss_contract=True) -- frame flag 8: four image-gradient channels, 48-byte records, the second set's colour
     sum in chain w's fourth column -- against the full dual backward (VTGS_DUAL_B1=0 makes the library ignore the flag) on a
     gradient whose depth_sil planes 1 and 2 are zero, as get_loss sends it: the per-pair arithmetic is the same (the two
     dropped terms were exact zeros), so what is left is the contraction order of the compiler: 2e-6 of each tensor's largest
@@ -396,7 +396,7 @@ def test_depth_only_backward_equals_the_full_dual_backward(gpu_device, monkeypat
             assert dgr._lib.vtgs_set_option(b"VTGS_DUAL_B1", b1) == 0
             for v in params.values():
                 v.grad = None
-            im, ds, _ = render_frame(params, 1, st, w2c, gaussians_grad, camera_grad, depth_grad_only=True)
+            im, ds, _ = render_frame(params, 1, st, w2c, gaussians_grad, camera_grad, get_loss_contract=True)
             ((im * g1).sum() + (ds * g2).sum()).backward()
             res[b1] = {k: (None if v.grad is None else v.grad.clone()) for k, v in params.items()}
     finally:
@@ -451,3 +451,33 @@ def test_get_loss_sends_no_gradient_into_silhouette_and_depth_squared(gpu_device
     for g in caught:
         assert g[0].abs().max().item() > 0.0
         assert g[1:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("route", ["cxx", "python"])
+def test_get_loss_contract_forward_against_the_full_dual_forward(gpu_device, monkeypatch, route):
+    """VTGS_FORWARD_SECOND_IS_DEPTH (render_frame(get_loss_contract=True)): the single render's kernel with z in its depth
+    column against the full dual forward (VTGS_DEPTH_LITE=0 makes the library ignore the flag).  The colour image and plane 0
+    (sum w z) are the same sums of the same terms: bit-identical.  Plane 1 is 1 - T_final instead of sum w: equal up to the
+    rounding of ~35 float32 operations per pixel (2e-6).  Plane 2 is plane 0 squared: its difference to plane 0^2 -- all
+    get_loss asks of it -- is exactly zero where the full render's is finite."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization.fused import render_frame
+    dev = gpu_device
+    monkeypatch.setenv("VTGS_FUSED_EXT", "1" if route == "cxx" else "0")
+    params, cam = _params(dev, 60000, 264, 200, seed=31)
+    st = to_settings(cam, dev, bg=torch.tensor([0.1, 0.2, 0.3]))     # a background that shows in all six planes
+    w2c = torch.eye(4, device=dev)
+    out = {}
+    try:
+        for lite in (0, 1):
+            assert dgr._lib.vtgs_set_option(b"VTGS_DEPTH_LITE", lite) == 0
+            with torch.no_grad():
+                out[lite] = render_frame(params, 1, st, w2c, False, False, get_loss_contract=True)
+    finally:
+        dgr._lib.vtgs_set_option(b"VTGS_DEPTH_LITE", -1)
+    (im0, ds0, r0), (im1, ds1, r1) = out[0], out[1]
+    assert torch.equal(im0, im1) and torch.equal(r0, r1)
+    assert torch.equal(ds0[0], ds1[0])
+    assert (ds0[1] - ds1[1]).abs().max().item() <= 2e-6
+    assert torch.equal(ds1[2], ds1[0] * ds1[0])
+    assert torch.isfinite(ds0[2] - ds0[0] ** 2).all() and ds0[1].max().item() > 0.9

@@ -26,7 +26,7 @@ __global__ void sort_tiles(const uint32_t*, unsigned long long*, uint32_t*, uint
                            const Counters*, int, const uint32_t*, uint32_t, unsigned long long, int);
 __global__ void sort_long_lists(const uint32_t*, unsigned long long*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t,
                                 const Counters*, const uint32_t*, uint32_t, unsigned long long, int, uint32_t);
-template <bool DUAL>
+template <int MODE>
 __global__ void composite_forward_q(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*,
                                     const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*,
                                     float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs, uint8_t*, uint32_t*);
@@ -189,9 +189,10 @@ size_t vtgs_backward_dual_scratch_bytes(int32_t n, uint64_t instances) {
 struct Option { const char* name; int dflt; int value; };
 static Option g_options[] = {{"VTGS_FWD_IMPL", 3, -1}, {"VTGS_BWD_IMPL", 2, -1}, {"VTGS_BIN_IMPL", 1, -1}, {"VTGS_SORT_PACKED", 1, -1},
                              {"VTGS_SORT_FUSED", 1, -1}, {"VTGS_COUNT_STEPS", 0, -1}, {"VTGS_SORT_LONG_COUNTING", 1, -1},
-                             {"VTGS_DUAL_B1", 1, -1}};   // 0: ignore frame flag 8 (the full dual backward: the cross-check of the one-channel form)
+                             {"VTGS_DUAL_B1", 1, -1},    // 0: ignore frame flag 8 (the full dual backward: the cross-check of the one-channel form)
+                             {"VTGS_DEPTH_LITE", 1, -1}}; // 0: ignore VTGS_FORWARD_SECOND_IS_DEPTH (the full dual forward)
 enum { OPT_FWD_IMPL = 0, OPT_BWD_IMPL, OPT_BIN_IMPL, OPT_SORT_PACKED, OPT_SORT_FUSED, OPT_COUNT_STEPS, OPT_SORT_LONG_COUNTING, OPT_DUAL_B1,
-       OPT_COUNT };
+       OPT_DEPTH_LITE, OPT_COUNT };
 static std::once_flag g_options_once;
 static void options_init() {                                   // thread-safe: the first caller reads the environment
   std::call_once(g_options_once, [] {
@@ -223,7 +224,7 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
                                     char* ws, const float* colors, float* out_color, float* out_depth,
                                     float* image_state, hipStream_t st, const float* colors_b = nullptr,
                                     float* out_color_b = nullptr, int sort_mode = 0, FinalizeArgs fin = FinalizeArgs{},
-                                    bool write_qmask = false) {
+                                    bool write_qmask = false, bool second_is_depth = false) {
   // dual render <=> a second output image.  (Round 4: this was inferred from colors_b, and an EMPTY dual render -- n = 0, where
   // the header lets every per-Gaussian pointer be NULL -- took the single-render kernel with its NULL depth plane: a write
   // through address 0 + the band's pixel offset, found by tests/test_gpu_owned_sets.py::test_an_empty_list_renders_the_background.)
@@ -239,15 +240,22 @@ static int launch_composite_forward(const VtgsCamera* cam, const CamScalars& cs,
                                                            // matrix-core kernel, 0 = scalar kernel (read per call)
   {
     ProfScope ps__(dual ? "composite_forward_dual" : "composite_forward", st);
-    if (impl == 3 && dual)                                  // quadrant queues (vtgs_composite_q.hip)
-      hipLaunchKernelGGL((composite_forward_q<true>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
+    if (impl == 3 && dual && second_is_depth)               // the single render's kernel with z in its depth column (see the kernel)
+      hipLaunchKernelGGL((composite_forward_q<2>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
+                         (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (uint32_t*)(ws + L.sorted_gid),
+                         (const GeomRec*)(ws + L.geom), colors, out_color, (float*)nullptr, image_state,
+                         (const Counters*)(ws + L.counters), colors_b, out_color_b, sort_mode,
+                         (const unsigned long long*)(ws + L.keys), (const uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_inst), fin,
+                         write_qmask ? (uint8_t*)(ws + L.qmask) : (uint8_t*)nullptr, steps);
+    else if (impl == 3 && dual)                             // quadrant queues (vtgs_composite_q.hip)
+      hipLaunchKernelGGL((composite_forward_q<1>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (uint32_t*)(ws + L.sorted_gid),
                          (const GeomRec*)(ws + L.geom), colors, out_color, (float*)nullptr, image_state,
                          (const Counters*)(ws + L.counters), colors_b, out_color_b, sort_mode,
                          (const unsigned long long*)(ws + L.keys), (const uint32_t*)(ws + L.vals), (uint32_t*)(ws + L.sorted_inst), fin,
                          write_qmask ? (uint8_t*)(ws + L.qmask) : (uint8_t*)nullptr, steps);
     else if (impl == 3)
-      hipLaunchKernelGGL((composite_forward_q<false>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
+      hipLaunchKernelGGL((composite_forward_q<0>), dim3(nblk), dim3(256), 0, st, cs, cam->bg, nblk,
                          (const uint32_t*)(ws + L.tile_cnt), L.tile_cap, (uint32_t*)(ws + L.sorted_gid),
                          (const GeomRec*)(ws + L.geom), colors, out_color, out_depth, image_state,
                          (const Counters*)(ws + L.counters), (const float*)nullptr, (float*)nullptr, sort_mode,
@@ -437,7 +445,8 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   VTGS_HIP(hipGetLastError());
   int rc = launch_composite_forward(cam, cs, rows16, L, ws, colors, out_color, out_depth, (float*)(ws + L.final_T), st,
                                     dual ? colors_b : nullptr, dual ? out_color_b : nullptr,
-                                    fused_sort ? ((packed ? 1 : 2) | (pre512 ? 4 : 0)) : 0, fin, true);
+                                    fused_sort ? ((packed ? 1 : 2) | (pre512 ? 4 : 0)) : 0, fin, true,
+                                    dual && (flags & VTGS_FORWARD_SECOND_IS_DEPTH) && option(OPT_DEPTH_LITE) != 0);
   if (rc != VTGS_OK) return rc;
   // result record: assembled on the device by finalize_forward at byte 64 of the counters block
   static_assert(sizeof(VtgsForwardInfo) == 48, "VtgsForwardInfo layout is mirrored in Counters");

@@ -205,8 +205,13 @@ __device__ __forceinline__ void q_forward_step(float& T, bool& done, bool& exact
 #ifndef VTGS_Q_WAVES
 #define VTGS_Q_WAVES 4
 #endif
-template <bool DUAL>
-__global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forward_q(
+// MODE 0: one colour set + the depth image; 1: dual render (two colour sets); 2: dual render whose second set is the fused
+// caller chain's [z, 1, z^2] and whose second image is consumed as get_loss consumes it (VTGS_FORWARD_SECOND_IS_DEPTH,
+// include/vtgs.h) -- the kernel of mode 0 with z in the depth column: plane 0 = sum w z, plane 1 = 1 - T_final (= sum w up to
+// rounding), plane 2 = plane 0 squared.  Four payload columns instead of six: one matrix-instruction group per step instead
+// of two, the registers and LDS of the single render (4 wavefronts per SIMD instead of 3).
+template <int MODE>
+__global__ __launch_bounds__(256, MODE == 1 ? 3 : VTGS_Q_WAVES) void composite_forward_q(
     CamScalars cs, const float* __restrict__ bg, uint32_t nblk,
     const uint32_t* __restrict__ tile_cnt, uint32_t tile_cap, uint32_t* sorted_gid,
     const GeomRec* __restrict__ geom, const float* __restrict__ colors,
@@ -214,6 +219,7 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     const Counters* __restrict__ ctr, const float* __restrict__ colors_b, float* __restrict__ out_color_b,
     int sort_mode, const unsigned long long* __restrict__ bin_keys, const uint32_t* __restrict__ bin_vals,
     uint32_t* sorted_inst, FinalizeArgs fin, uint8_t* __restrict__ qmask, uint32_t* __restrict__ step_counters) {
+  constexpr bool DUAL = MODE == 1, ZL = MODE == 2;           // ZL: second image from the depth column
   // per wavefront: the table of the ring's entries (+ one dummy slot) and the four queues of table slots.  Queue bytes are
   // stored twice, 128 apart, so a pop reads [head & 127, head & 127 + 16) without wrapping.
   // The three tables of a wavefront are carved from one block: the counting sort of the tile's list (vtgs_sort_common.h)
@@ -359,6 +365,7 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     g0n = gp[0]; g1n = gp[1];
     c0n = colors[3 * gid]; c1n = colors[3 * gid + 1]; c2n = colors[3 * gid + 2];
     if (DUAL) { d0n = colors_b[3 * gid]; d1n = colors_b[3 * gid + 1]; d2n = colors_b[3 * gid + 2]; }
+    if (ZL) d0n = colors_b[3 * gid];
   };
   // ---- append one 64-entry chunk whose records have arrived: table, wavefront-ballot compaction into the four queues -------
   // (a macro, not a lambda: called from four places, the closure kept the ring counters in scratch memory)
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
       tile_coefficients(g0, g1, cx, cy, K);                                                                              \
       ka[slot] = make_float4(K[0], K[1], K[2], K[3]);                                                                    \
       kb[slot] = make_float2(K[4], K[5]);                                                                                \
-      pa[slot] = make_float4((FC0), (FC1), (FC2), DUAL ? (FD0) : g1.z);                                                  \
+      pa[slot] = make_float4((FC0), (FC1), (FC2), (DUAL || ZL) ? (FD0) : g1.z);                                          \
       if (DUAL) pb[slot] = make_float4((FD1), (FD2), 0.f, 0.f);                                                          \
     }                                                                                                                    \
     const bool hot = __ballot(in && g1.y > kClampGuard) != 0ull;                                                         \
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
     const float4* gp_##tag = reinterpret_cast<const float4*>(geom + gid_##tag);                             \
     const float4 g0_##tag = gp_##tag[0], g1_##tag = gp_##tag[1];                                            \
     const float c0_##tag = colors[3 * gid_##tag], c1_##tag = colors[3 * gid_##tag + 1], c2_##tag = colors[3 * gid_##tag + 2]; \
-    const float d0_##tag = DUAL ? colors_b[3 * gid_##tag] : 0.f, d1_##tag = DUAL ? colors_b[3 * gid_##tag + 1] : 0.f,         \
+    const float d0_##tag = (DUAL || ZL) ? colors_b[3 * gid_##tag] : 0.f, d1_##tag = DUAL ? colors_b[3 * gid_##tag + 1] : 0.f, \
                 d2_##tag = DUAL ? colors_b[3 * gid_##tag + 2] : 0.f;
     VTGS_Q_FETCH(a, entry(s))
     VTGS_Q_FETCH(b, gidB)
@@ -521,13 +528,19 @@ __global__ __launch_bounds__(256, DUAL ? 3 : VTGS_Q_WAVES) void composite_forwar
       out_color_b[pix] = C[3] + T * bg[0];
       out_color_b[P + pix] = C2[0] + T * bg[1];
       out_color_b[2 * P + pix] = C2[1] + T * bg[2];
+    } else if constexpr (ZL) {
+      const float D = C[3] + T * bg[0];
+      out_color_b[pix] = D;
+      out_color_b[P + pix] = (1.f - T) + T * bg[1];
+      out_color_b[2 * P + pix] = D * D;
     } else {
       out_depth[pix] = C[3];
     }
     final_T[pix] = T;
   }
 }
-template __global__ void composite_forward_q<false>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs, uint8_t*, uint32_t*);
-template __global__ void composite_forward_q<true>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs, uint8_t*, uint32_t*);
+template __global__ void composite_forward_q<0>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs, uint8_t*, uint32_t*);
+template __global__ void composite_forward_q<1>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs, uint8_t*, uint32_t*);
+template __global__ void composite_forward_q<2>(CamScalars, const float*, uint32_t, const uint32_t*, uint32_t, uint32_t*, const GeomRec*, const float*, float*, float*, float*, const Counters*, const float*, float*, int, const unsigned long long*, const uint32_t*, uint32_t*, FinalizeArgs, uint8_t*, uint32_t*);
 
 }  // namespace vtgs

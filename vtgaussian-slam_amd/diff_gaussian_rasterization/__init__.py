@@ -55,6 +55,7 @@ VTGS_OK, VTGS_ERR_INSTANCE_OVERFLOW = 0, 3
 ABI_VERSION = 15
 VTGS_FORWARD_SYNC, VTGS_FORWARD_ASYNC, VTGS_FORWARD_CHECKED = 0, 1, 2
 VTGS_FORWARD_EXPECT_SHORT_LISTS = 4        # hint: no list beyond 512 entries expected (skips the pre-sort pass for bins <= 1024)
+VTGS_FORWARD_SECOND_IS_DEPTH = 8           # dual render consumed as get_loss consumes it (include/vtgs.h): the single render's kernel
 _P, _U64, _I32, _SZ = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
 
 _SIGNATURES = {
@@ -723,7 +724,8 @@ def _scratch(nbytes: int, device) -> torch.Tensor:
     return t
 
 
-def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, want_async: bool = False, colors_b=None):
+def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, want_async: bool = False, colors_b=None,
+                 extra_flags: int = 0):
     """One forward through the C ABI.
     CHECKED (include/vtgs.h, VTGS_FORWARD_CHECKED; always in no-grad mode, and whenever the previous forward of this shape
     came within 20 % of a capacity): all kernels are enqueued, then the host waits only for the result record, which the
@@ -751,6 +753,7 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
     fs.cam, fs.n, fs.image_state, fs.key, fs.pending = cam, n, None, key, None
 
     def launch(workspace, nbytes, capacity, tile_cap, slot_ptr, flags):
+        flags |= extra_flags                       # (VTGS_FORWARD_SECOND_IS_DEPTH from the fused caller chain)
         if tile_cap & PLANNED:
             plan = _plan_for(key, device, tile_cap).data_ptr()
             if colors_b is None:

@@ -28,7 +28,7 @@ import torch
 import os
 
 from . import (_Camera, _ForwardState, _camera_for, _RADIUS_RULES, _check, _device_guard, _lib, _run_backward, _run_backward_dual,
-               _run_forward, _scratch, _scratch_instances, _settle, _stream_ptr, _I32, _P)
+               _run_forward, _scratch, _scratch_instances, _settle, _stream_ptr, _I32, _P, VTGS_FORWARD_SECOND_IS_DEPTH)
 
 _lib.vtgs_pose_partial_rows.restype, _lib.vtgs_pose_partial_rows.argtypes = ctypes.c_uint32, [_I32]
 _lib.vtgs_prepare_frame.restype, _lib.vtgs_prepare_frame.argtypes = ctypes.c_int, [_I32] + [_P] * 13
@@ -118,15 +118,16 @@ class _RenderFrame(torch.autograd.Function):
         state = None
         if dual:
             im, radii, depth_sil, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot, colors_b=dcol,
-                                                    want_async=flags != 0)
+                                                    want_async=(flags & 7) != 0,
+                                                    extra_flags=VTGS_FORWARD_SECOND_IS_DEPTH if flags & 16 else 0)
         else:
-            im, radii, _, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot, want_async=flags != 0)
+            im, radii, _, fs = _run_forward(cam, means_cam, rgb, opac, scales, rot, want_async=(flags & 7) != 0)
             H, W = cam.H, cam.W
             depth_sil, depth2, state = new(3, H, W), new(1, H, W), new(H * W)
             _check(_lib.vtgs_forward_shared(ctypes.byref(cam.c), n, dcol.data_ptr(), depth_sil.data_ptr(), depth2.data_ptr(),
                                             fs.workspace.data_ptr(), fs.workspace.numel(), fs.capacity, fs.tile_cap,
                                             state.data_ptr(), stream), "vtgs_forward_shared")
-        ctx.fs, ctx.state, ctx.flags, ctx.n, ctx.dual, ctx.owned, ctx.n_map = fs, state, flags, n, dual, owned, n_map
+        ctx.fs, ctx.state, ctx.flags, ctx.n, ctx.dual, ctx.owned, ctx.n_map = fs, state, flags & 15, n, dual, owned, n_map
         if owned is not None:                       # the radii of the map: 0 outside the list (as on any band)
             radii = torch.zeros(n_map, dtype=torch.int32, device=dev).index_copy_(0, owned.idx64, radii)
         ctx.save_for_backward(means3D, rgb, unnorm_rot, logit_op, log_scales, cam_q, cam_t, depth_w2c,
@@ -228,7 +229,8 @@ def _render_frame_ext(means3D, rgb, unnorm_rot, logit_op, log_scales, q, t, dept
     checked or run-ahead mode, the pinned result record, the retry after an overflow -- stays here, the per-call work and the
     whole backward run without the interpreter.  With the kernels of one band of the tile-row partition a rank's iteration is
     bound by this host path."""
-    from . import (PLANNED, VTGS_ERR_INSTANCE_OVERFLOW, VTGS_FORWARD_ASYNC, VTGS_FORWARD_CHECKED, _FORWARD_MODE, _async_ok,
+    from . import (PLANNED, VTGS_ERR_INSTANCE_OVERFLOW, VTGS_FORWARD_ASYNC, VTGS_FORWARD_CHECKED, VTGS_FORWARD_SECOND_IS_DEPTH,
+                   _FORWARD_MODE, _async_ok,
                    _caps_in_use, _choose_capacities, _drain, _ext, _forward_hints, _grow_after_overflow, _plan_for, _record_info,
                    _settle_after_backward, _slot_lock, _slot_pool)
     device = means3D.device
@@ -237,7 +239,7 @@ def _render_frame_ext(means3D, rgb, unnorm_rot, logit_op, log_scales, q, t, dept
     key = (device.index, n, cam.W, cam.H, cam.band)
     fs = _ForwardState()
     fs.cam, fs.n, fs.image_state, fs.key, fs.pending = cam, n, None, key, None
-    want_async = flags != 0
+    want_async = (flags & 7) != 0
     o = (None, None, None, None) if owned is None else (owned.idx, owned.idx64, owned.mask, owned.escapes)
     with _slot_lock:
         pool = _slot_pool(device, stream)
@@ -251,8 +253,8 @@ def _render_frame_ext(means3D, rgb, unnorm_rot, logit_op, log_scales, q, t, dept
             plan = _plan_for(key, device, tile_cap).data_ptr() if tile_cap & PLANNED else 0
             im, depth_sil, radii, workspace, status = _ext.render_frame(
                 means3D, rgb, unnorm_rot, logit_op, log_scales, q, t, depth_w2c, cam.bytes, cam.bg, cam.view, cam.proj, capacity,
-                tile_cap, plan, pool.ptr[slot], (VTGS_FORWARD_ASYNC if run_ahead else VTGS_FORWARD_CHECKED) | _forward_hints(key, tile_cap),
-                flags, stream, *o)
+                tile_cap, plan, pool.ptr[slot], (VTGS_FORWARD_ASYNC if run_ahead else VTGS_FORWARD_CHECKED) | _forward_hints(key, tile_cap)
+                | (VTGS_FORWARD_SECOND_IS_DEPTH if flags & 16 else 0), flags & 15, stream, *o)
             if run_ahead:
                 break
             if int(status) == VTGS_ERR_INSTANCE_OVERFLOW:     # the record says what is needed: grow whichever was short
@@ -277,7 +279,7 @@ def _render_frame_ext(means3D, rgb, unnorm_rot, logit_op, log_scales, q, t, dept
 
 def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings, first_frame_w2c: torch.Tensor,
                  gaussians_grad: bool, camera_grad: bool, radius_rule: Optional[str] = None, tile_rows=None, owned=None,
-                 depth_grad_only: bool = False):
+                 get_loss_contract: bool = False):
     """RGB render + [z,1,z^2] render of frame `time_idx` (see module docstring).  Returns (im [3,H,W],
     depth_sil [3,H,W], radii [N] int32).  `tile_rows=(begin, end)`: this rank's band of 16-pixel tile rows (multi-GPU
     partition, `partition.band_for_rank`): pixels outside the band come back as zero and the gradients are the band's
@@ -285,10 +287,13 @@ def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings
     `owned` (a `partition.OwnedSet` built for the same band): only the Gaussians of the list are transformed, projected and
     binned, and only their gradients are gathered; the set checks on the device, before every render, that no Gaussian
     outside the list could meet the band (`owned.escaped()` reads the count).
-    `depth_grad_only=True` is the caller's PROMISE that the gradient it sends back into `depth_sil` is zero in channels 1 and 2
-    (get_loss: the silhouette only feeds comparisons and z^2 a detached uncertainty, src/vtgaussian_slam.py:466-521): the
-    backward then carries four image-gradient channels instead of six (frame flag 8, include/vtgs.h) -- whatever such a
-    caller did put into those two channels would be ignored."""
+    `get_loss_contract=True` is the caller's PROMISE to treat `depth_sil` as get_loss does (src/vtgaussian_slam.py:466-521):
+    the silhouette (plane 1) only feeds comparisons, z^2 (plane 2) only the NaN test of a detached uncertainty
+    isnan(plane 2 - plane 0^2), and the gradient sent back into `depth_sil` is zero outside plane 0.  Then (include/vtgs.h:
+    VTGS_FORWARD_SECOND_IS_DEPTH, frame flag 8) the forward is the single render's kernel with z in its depth column --
+    plane 1 = 1 - T_final, which is what sum w equals up to float32 rounding, plane 2 = plane 0 squared, NaN exactly where the
+    true difference is -- and the backward carries four image-gradient channels instead of six.  A caller that reads
+    planes 1 / 2 in any other way, or differentiates through them, must leave this off."""
     dev = params["means3D"].device
     if dev.type != "cuda":
         raise RuntimeError("render_frame needs tensors on a HIP device (torch 'cuda'); no CPU path exists")
@@ -313,8 +318,8 @@ def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings
     appearance = any(params[k].requires_grad for k in ("rgb_colors", "logit_opacities", "log_scales"))
     flags = ((1 if gaussians_grad and grad_on else 0) | (2 if camera_grad and grad_on else 0)
              | (4 if appearance and grad_on else 0))
-    if depth_grad_only and flags:
-        flags |= 8
+    if get_loss_contract:                           # 8: frame flag of the backward; 16: this module's mark for the forward flag
+        flags |= 16 | (8 if flags else 0)
     if owned is not None:
         if not owned.scales_are_log:
             raise ValueError("this owned set was built for the plain operator (OwnedSet.for_operator)")

@@ -97,10 +97,11 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
                                                             gaussians_grad, camera_grad)
         variables["means2D"] = means2D                 # gradient only accumulated from the colour render (:462)
     else:
-        # (depth_grad_only: of the [z, 1, z^2] render this function differentiates z alone -- the silhouette feeds comparisons,
-        #  z^2 the detached uncertainty, :466-521 -- and the loss nodes write zeros into the other two gradient planes)
+        # (get_loss_contract: of the [z, 1, z^2] render this function differentiates z alone, compares the silhouette with
+        #  thresholds and asks of z^2 only whether the detached uncertainty is NaN, :466-521; the loss nodes write zeros into
+        #  the other two gradient planes)
         im, depth_sil, radius = render_frame(params, iter_time_idx, curr_data["cam"], curr_data["w2c"], gaussians_grad, camera_grad,
-                                             depth_grad_only=True)
+                                             get_loss_contract=True)
         variables["means2D"] = _NoScreenSpaceGradient()
     gt_im, gt_depth = curr_data["im"], curr_data["depth"]
     depth = depth_sil[0:1].detach()
