@@ -82,8 +82,8 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
     for k, v in params.items():
         params[k] = _cuda_f32(v)
     for k, v in variables.items():
-        if k != "means2D":
-            variables[k] = _cuda_f32(v)
+        if k not in ("means2D", "seen"):           # both are REPLACED below before anybody reads them: converting the bool
+            variables[k] = _cuda_f32(v)            # `seen` of the previous call to float32 was an 8 us launch per iteration
     # :428-449 -- who gets a gradient
     if tracking:
         gaussians_grad, camera_grad = False, True
