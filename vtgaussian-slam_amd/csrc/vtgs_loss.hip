@@ -19,6 +19,10 @@ constexpr int kSP = kST + 2 * kSR;      // staged patch edge (42)
 // The reference's 1-D window (utils/slam_external.py:54-56: float32(exp(-(x - 5)^2 / 4.5)) / their float32 sum), evaluated once
 // on the host.  Round 4: every thread of both kernels used to evaluate it itself -- 11 exponentials and 11 IEEE divisions, a
 // fifth of the forward kernel's instructions and over a quarter of the backward's.
+// (round 5: both SSIM kernels are bound by vector issue -- ~5300 wave-instructions per tile, 4 cycles each on a 16-lane SIMD -- so
+//  the blurs accumulate PAIRS of moments with packed v_pk_fma_f32 / v_pk_mul_f32: the same IEEE operations per component, the
+//  same bits, 5 instead of 8 instructions per tap in the row pass and 3 instead of 5 in the column pass)
+typedef float f32x2s __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gauss11(float (&w)[11]) {
   constexpr float k[11] = {0.0010283802403137088f, 0.007598758675158024f, 0.036000773310661316f, 0.1093606948852539f,
                            0.21300554275512695f,   0.2660117447376251f,   0.21300554275512695f,  0.1093606948852539f,
@@ -34,8 +38,10 @@ __global__ __launch_bounds__(256) void ssim_forward_kernel(const float* __restri
   // band form (tile-row multi-GPU partition): tiles_y tile rows starting at ty0 are launched and only the SSIM pixels of
   // rows [rb, re) are summed / get derivative maps; the staged context rows around them are read as they are (the caller
   // has put the neighbours' rows there).  Whole image: ty0 = 0, rb = 0, re >= H.
-  __shared__ float px[kSP * kSP], py[kSP * kSP];
-  __shared__ float hz[5][kSP * kST];
+  // pairs that are blurred together sit together in LDS (one ds_read_b64 = one packed operand, no register shuffling)
+  __shared__ float2 pxy[kSP * kSP];                                   // (img1, img2)
+  __shared__ float2 hzm[kSP * kST], hzs[kSP * kST];                   // row-blurred (x, y), (x^2, y^2)
+  __shared__ float hzc[kSP * kST];                                    // row-blurred x y
   __shared__ float red[4];
 #ifdef VTGS_AB_SSIM_PAD                                         // occupancy experiment
   __shared__ float ab_pad[VTGS_AB_SSIM_PAD];
@@ -44,39 +50,73 @@ __global__ __launch_bounds__(256) void ssim_forward_kernel(const float* __restri
   float w[11];
   gauss11(w);
   const int t = (int)threadIdx.x;
-  const int b = (int)blockIdx.x;
+  // Round 5: a workgroup walks tiles b = blockIdx.x, + gridDim.x, ... (the grid is what fits the chip at once, vtgs_ssim_grid) and
+  // requests the NEXT tile's patch into registers before it blurs the current one: a tile used to cost ~8 us of which the blurs
+  // were ~3 -- the rest was the wait for its own 2 x 1764 pixels with three workgroups per CU to hide it behind.  Same arithmetic
+  // per tile, same partial-sum slot per tile: bit-identical results.
+  const int ntile = C * tiles_x * tiles_y;
+  constexpr int kStage = (kSP * kSP + 255) / 256;                     // 7 staged pixels per thread and image
+  float ra[kStage], rd[kStage];
+  const int rt = t / kSP, qt = t - rt * kSP;                          // patch position of the thread's first staged pixel
+  // (the staging was a third of the kernel's vector instructions: a division, 64-bit address arithmetic and a branch per
+  //  pixel.  Now: the position advances by 256 = 6 x 42 + 4, offsets are 32-bit from a uniform plane pointer, and a pixel
+  //  outside the image is loaded from offset 0 and replaced by zero -- no branch)
+  auto fetch = [&](int bb) {
+    const int c_ = bb / (tiles_x * tiles_y), tb_ = bb - c_ * tiles_x * tiles_y;
+    const int ty_ = ty0 + tb_ / tiles_x, tx_ = tb_ - (tb_ / tiles_x) * tiles_x;
+    const int x0 = tx_ * kST - kSR, y0 = ty_ * kST - kSR;
+    const float* __restrict__ p1 = img1 + (size_t)c_ * H * W;
+    const float* __restrict__ p2 = img2 + (size_t)c_ * H * W;
+    int r = rt, q = qt;
+#pragma unroll
+    for (int k = 0; k < kStage; ++k) {
+      const int gy = y0 + r, gx = x0 + q;
+      const bool in = (k < kStage - 1 || t + 256 * k < kSP * kSP) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;   // zero padding
+      const int o = in ? gy * W + gx : 0;
+      const float a1 = p1[o], a2 = p2[o];
+      ra[k] = in ? a1 : 0.f;
+      rd[k] = in ? a2 : 0.f;
+      q += 256 - 6 * kSP; r += 6;
+      if (q >= kSP) { q -= kSP; r += 1; }
+    }
+  };
+  if ((int)blockIdx.x < ntile) fetch((int)blockIdx.x);
+  for (int b = (int)blockIdx.x; b < ntile; b += (int)gridDim.x) {
   const int c = b / (tiles_x * tiles_y), tb = b - c * tiles_x * tiles_y;
   const int ty = ty0 + tb / tiles_x, tx = tb - (tb / tiles_x) * tiles_x;
-  const int x0 = tx * kST - kSR, y0 = ty * kST - kSR;
   const size_t plane = (size_t)c * H * W;
-  for (int i = t; i < kSP * kSP; i += 256) {
-    const int r = i / kSP, q = i - r * kSP;
-    const int gy = y0 + r, gx = x0 + q;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;          // zero padding
-    const size_t o = plane + (size_t)gy * W + gx;
-    px[i] = in ? img1[o] : 0.f;
-    py[i] = in ? img2[o] : 0.f;
+#pragma unroll
+  for (int k = 0; k < kStage; ++k) {
+    const int i = t + 256 * k;
+    if (i < kSP * kSP) pxy[i] = make_float2(ra[k], rd[k]);
   }
   __syncthreads();
+  if (b + (int)gridDim.x < ntile) fetch(b + (int)gridDim.x);          // in flight during both passes
   // Both passes slide the window in registers: a work item produces FOUR adjacent outputs from 14 staged values instead of
   // 4 x 11 (the kernel was bound by its LDS reads: 86 K per workgroup).  Every output still accumulates its 11 taps in the
   // same order, so the values are the ones of the one-output-per-item form.
   for (int i = t; i < kSP * (kST / 4); i += 256) {                    // rows: 42 x 32 outputs, 4 per item
     const int r = i / (kST / 4), q = 4 * (i - r * (kST / 4));
-    float a[14], d[14];
+    f32x2s v[14], v2[14];
+    float vxy[14];
 #pragma unroll
-    for (int k = 0; k < 14; ++k) { a[k] = px[r * kSP + q + k]; d[k] = py[r * kSP + q + k]; }
+    for (int k = 0; k < 14; ++k) {                                    // squares and the product once per staged pixel, not per tap
+      const float2 pp = pxy[r * kSP + q + k];
+      v[k] = f32x2s{pp.x, pp.y}; v2[k] = v[k] * v[k]; vxy[k] = pp.x * pp.y;
+    }
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-      float m1 = 0.f, m2 = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
+      f32x2s m = {0.f, 0.f}, sq = {0.f, 0.f};
+      float xy = 0.f;
 #pragma unroll
       for (int k = 0; k < 11; ++k) {
-        const float av = a[o + k], dv = d[o + k];
-        m1 = fmaf(w[k], av, m1); m2 = fmaf(w[k], dv, m2);
-        xx = fmaf(w[k], av * av, xx); yy = fmaf(w[k], dv * dv, yy); xy = fmaf(w[k], av * dv, xy);
+        const f32x2s wk = {w[k], w[k]};
+        m = __builtin_elementwise_fma(wk, v[o + k], m);
+        sq = __builtin_elementwise_fma(wk, v2[o + k], sq);
+        xy = fmaf(w[k], vxy[o + k], xy);
       }
       const int j = r * kST + q + o;
-      hz[0][j] = m1; hz[1][j] = m2; hz[2][j] = xx; hz[3][j] = yy; hz[4][j] = xy;
+      hzm[j] = make_float2(m.x, m.y); hzs[j] = make_float2(sq.x, sq.y); hzc[j] = xy;
     }
   }
   __syncthreads();
@@ -84,35 +124,48 @@ __global__ __launch_bounds__(256) void ssim_forward_kernel(const float* __restri
   const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
   {                                                                   // columns: 32 x 32 outputs, 4 rows per item
     const int q = t & (kST - 1), r0 = 4 * (t >> 5);                   // 256 items = 8 row groups x 32 columns
-    float h[5][14];
+    f32x2s hm_[14], hs_[14];
+    float hc_[14];
 #pragma unroll
-    for (int m = 0; m < 5; ++m)
-#pragma unroll
-      for (int k = 0; k < 14; ++k) h[m][k] = hz[m][(r0 + k) * kST + q];
+    for (int k = 0; k < 14; ++k) {
+      const float2 a2 = hzm[(r0 + k) * kST + q], b2 = hzs[(r0 + k) * kST + q];
+      hm_[k] = f32x2s{a2.x, a2.y}; hs_[k] = f32x2s{b2.x, b2.y}; hc_[k] = hzc[(r0 + k) * kST + q];
+    }
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       const int r = r0 + o;
       const int gy = ty * kST + r, gx = tx * kST + q;
-      float m1 = 0.f, m2 = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
+      f32x2s mm = {0.f, 0.f}, sq = {0.f, 0.f};
+      float xy = 0.f;
 #pragma unroll
       for (int k = 0; k < 11; ++k) {
-        m1 = fmaf(w[k], h[0][o + k], m1); m2 = fmaf(w[k], h[1][o + k], m2);
-        xx = fmaf(w[k], h[2][o + k], xx); yy = fmaf(w[k], h[3][o + k], yy); xy = fmaf(w[k], h[4][o + k], xy);
+        const f32x2s wk = {w[k], w[k]};
+        mm = __builtin_elementwise_fma(wk, hm_[o + k], mm);
+        sq = __builtin_elementwise_fma(wk, hs_[o + k], sq);
+        xy = fmaf(w[k], hc_[o + k], xy);
       }
+      const float m1 = mm.x, m2 = mm.y, xx = sq.x, yy = sq.y;
       if (gy < H && gx < W && gy >= rb && gy < re) {
         const float s11 = xx - m1 * m1, s22 = yy - m2 * m2, s12 = xy - m1 * m2;
         const float a1 = 2.f * m1 * m2 + c1, a2 = 2.f * s12 + c2, b1 = m1 * m1 + m2 * m2 + c1, b2 = s11 + s22 + c2;
-        const float r1 = 1.f / b1, r2 = 1.f / b2;              // (two divisions per pixel instead of three)
+        // two reciprocals per pixel: hardware estimate + one Newton step (< 1 ulp; the IEEE division was ~10 instructions
+        // each in a kernel bound by vector issue).  b1, b2 >= c1, c2 > 0.
+        float r1 = __builtin_amdgcn_rcpf(b1), r2 = __builtin_amdgcn_rcpf(b2);
+        r1 = fmaf(r1, fmaf(-b1, r1, 1.f), r1); r2 = fmaf(r2, fmaf(-b2, r2, 1.f), r2);
         const float ib = r1 * r2;
         const float ssim = a1 * a2 * ib;
         acc += ssim;
         if (gmaps) {
           const float d_mu1 = 2.f * m2 * a2 * ib - ssim * 2.f * m1 * r1;
           const float d_s11 = -ssim * r2, d_s12 = 2.f * a1 * ib;
-          const size_t o2 = plane + (size_t)gy * W + gx, P3 = (size_t)C * H * W;
-          gmaps[o2] = d_mu1 - 2.f * m1 * d_s11 - m2 * d_s12;
-          gmaps[P3 + o2] = d_s11;
-          gmaps[2 * P3 + o2] = d_s12;
+          const size_t P3 = (size_t)C * H * W;
+          float* __restrict__ gm0 = gmaps + plane;                    // uniform bases, 32-bit offsets
+          float* __restrict__ gm1 = gm0 + P3;
+          float* __restrict__ gm2 = gm1 + P3;
+          const int o2 = gy * W + gx;
+          gm0[o2] = d_mu1 - 2.f * m1 * d_s11 - m2 * d_s12;
+          gm1[o2] = d_s11;
+          gm2[o2] = d_s12;
         }
       }
     }
@@ -121,6 +174,8 @@ __global__ __launch_bounds__(256) void ssim_forward_kernel(const float* __restri
   if ((t & 63) == 0) red[t >> 6] = acc;
   __syncthreads();
   if (t == 0) partial[b] = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();                                                    // red / hz / the patch are rewritten by the next tile
+  }
 }
 
 __global__ __launch_bounds__(256) void ssim_backward_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
@@ -131,67 +186,108 @@ __global__ __launch_bounds__(256) void ssim_backward_kernel(const float* __restr
                                                             int ty0 = 0, int rb = 0, int re = 1 << 30) {
   // band form: the derivative maps exist on rows [rb, re) only (anything else counts as zero); the gradient is written on
   // rows [rb - 5, re + 5) -- the blur carries it into the neighbours' rows -- and the L1 term belongs to rows [rb, re).
-  __shared__ float pm[3][kSP * kSP];
-  __shared__ float hz[3][kSP * kST];
+  __shared__ float2 pm01[kSP * kSP];                                  // maps A, B as a pair (see the forward), C apart
+  __shared__ float pm2[kSP * kSP];
+  __shared__ float2 hz01[kSP * kST];
+  __shared__ float hz2[kSP * kST];
   float w[11];
   gauss11(w);
   const int t = (int)threadIdx.x;
-  const int b = (int)blockIdx.x;
+  const size_t P3 = (size_t)C * H * W;
+  const int ntile = C * tiles_x * tiles_y;                            // tiles walked with the next one's patch in flight (see the forward)
+  constexpr int kStage = (kSP * kSP + 255) / 256;
+  float rm[3][kStage];
+  const int rt = t / kSP, qt = t - rt * kSP;
+  const int row_lo = rb > 0 ? rb : 0, row_hi = re < H ? re : H;       // the maps exist on these rows
+  auto fetch = [&](int bb) {                                          // (staging as in the forward: no division, no branch)
+    const int c_ = bb / (tiles_x * tiles_y), tb_ = bb - c_ * tiles_x * tiles_y;
+    const int ty_ = ty0 + tb_ / tiles_x, tx_ = tb_ - (tb_ / tiles_x) * tiles_x;
+    const int x0 = tx_ * kST - kSR, y0 = ty_ * kST - kSR;
+    const float* __restrict__ g0 = gmaps + (size_t)c_ * H * W;
+    const float* __restrict__ g1 = g0 + P3;
+    const float* __restrict__ g2 = g1 + P3;
+    int r = rt, q = qt;
+#pragma unroll
+    for (int k = 0; k < kStage; ++k) {
+      const int gy = y0 + r, gx = x0 + q;
+      const bool in = (k < kStage - 1 || t + 256 * k < kSP * kSP) && gy >= row_lo && gy < row_hi && (unsigned)gx < (unsigned)W;   // the adjoint of a zero-padded blur is the same blur
+      const int o = in ? gy * W + gx : row_lo * W;
+      const float a0 = g0[o], a1 = g1[o], a2 = g2[o];
+      rm[0][k] = in ? a0 : 0.f; rm[1][k] = in ? a1 : 0.f; rm[2][k] = in ? a2 : 0.f;
+      q += 256 - 6 * kSP; r += 6;
+      if (q >= kSP) { q -= kSP; r += 1; }
+    }
+  };
+  if ((int)blockIdx.x < ntile) fetch((int)blockIdx.x);
+  const float scale = upstream[0] * ssim_coef / (float)((size_t)C * H * W);
+  const float l1s = upstream[0] * l1_coef;
+  for (int b = (int)blockIdx.x; b < ntile; b += (int)gridDim.x) {
   const int c = b / (tiles_x * tiles_y), tb = b - c * tiles_x * tiles_y;
   const int ty = ty0 + tb / tiles_x, tx = tb - (tb / tiles_x) * tiles_x;
-  const int x0 = tx * kST - kSR, y0 = ty * kST - kSR;
-  const size_t plane = (size_t)c * H * W, P3 = (size_t)C * H * W;
-  for (int i = t; i < kSP * kSP; i += 256) {
-    const int r = i / kSP, q = i - r * kSP;
-    const int gy = y0 + r, gx = x0 + q;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W && gy >= rb && gy < re;   // the adjoint of a zero-padded blur is the same blur
-    const size_t o = plane + (size_t)gy * W + gx;
-    pm[0][i] = in ? gmaps[o] : 0.f; pm[1][i] = in ? gmaps[P3 + o] : 0.f; pm[2][i] = in ? gmaps[2 * P3 + o] : 0.f;
+  const size_t plane = (size_t)c * H * W;
+#pragma unroll
+  for (int k = 0; k < kStage; ++k) {
+    const int i = t + 256 * k;
+    if (i < kSP * kSP) { pm01[i] = make_float2(rm[0][k], rm[1][k]); pm2[i] = rm[2][k]; }
   }
   __syncthreads();
+  if (b + (int)gridDim.x < ntile) fetch(b + (int)gridDim.x);
   for (int i = t; i < kSP * (kST / 4); i += 256) {                    // rows, four outputs per item (see the forward)
     const int r = i / (kST / 4), q = 4 * (i - r * (kST / 4));
-    float v[3][14];
+    f32x2s v01[14];
+    float v2_[14];
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
-#pragma unroll
-      for (int k = 0; k < 14; ++k) v[m][k] = pm[m][r * kSP + q + k];
+    for (int k = 0; k < 14; ++k) {
+      const float2 pp = pm01[r * kSP + q + k];
+      v01[k] = f32x2s{pp.x, pp.y}; v2_[k] = pm2[r * kSP + q + k];
+    }
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+      f32x2s s01 = {0.f, 0.f};
+      float s2 = 0.f;
 #pragma unroll
       for (int k = 0; k < 11; ++k) {
-        s0 = fmaf(w[k], v[0][o + k], s0); s1 = fmaf(w[k], v[1][o + k], s1); s2 = fmaf(w[k], v[2][o + k], s2);
+        const f32x2s wk = {w[k], w[k]};
+        s01 = __builtin_elementwise_fma(wk, v01[o + k], s01);
+        s2 = fmaf(w[k], v2_[o + k], s2);
       }
       const int j = r * kST + q + o;
-      hz[0][j] = s0; hz[1][j] = s1; hz[2][j] = s2;
+      hz01[j] = make_float2(s01.x, s01.y); hz2[j] = s2;
     }
   }
   __syncthreads();
   // dL/dimg1 = upstream * ( ssim_coef * d(mean SSIM)/dimg1 + l1_coef * sign(img1 - img2) )   (plain SSIM: 1, 0)
-  const float scale = upstream[0] * ssim_coef / (float)((size_t)C * H * W);
-  const float l1s = upstream[0] * l1_coef;
   {                                                                   // columns, four rows per item
     const int q = t & (kST - 1), r0 = 4 * (t >> 5);
-    float h[3][14];
+    f32x2s h01[14];
+    float h2_[14];
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
-#pragma unroll
-      for (int k = 0; k < 14; ++k) h[m][k] = hz[m][(r0 + k) * kST + q];
+    for (int k = 0; k < 14; ++k) {
+      const float2 pp = hz01[(r0 + k) * kST + q];
+      h01[k] = f32x2s{pp.x, pp.y}; h2_[k] = hz2[(r0 + k) * kST + q];
+    }
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       const int gy = ty * kST + r0 + o, gx = tx * kST + q;
       if (gy >= H || gx >= W || gy < rb - kSR || gy >= re + kSR) continue;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+      f32x2s s01 = {0.f, 0.f};
+      float s2 = 0.f;
 #pragma unroll
       for (int k = 0; k < 11; ++k) {
-        s0 = fmaf(w[k], h[0][o + k], s0); s1 = fmaf(w[k], h[1][o + k], s1); s2 = fmaf(w[k], h[2][o + k], s2);
+        const f32x2s wk = {w[k], w[k]};
+        s01 = __builtin_elementwise_fma(wk, h01[o + k], s01);
+        s2 = fmaf(w[k], h2_[o + k], s2);
       }
-      const size_t o2 = plane + (size_t)gy * W + gx;
-      const float x = img1[o2], y = img2[o2];
-      const float lw = (gy >= rb && gy < re) ? (l1_weight ? l1s * l1_weight[o2] : l1s) : 0.f;
-      g_img1[o2] = scale * (s0 + 2.f * x * s1 + y * s2) + ((x > y) ? lw : (x < y) ? -lw : 0.f);
+      const float s0 = s01.x, s1 = s01.y;
+      // (the tile's own pixels are read here, not with the next tile's patch: eight more registers in flight across the
+      //  blurs cost the fourth wavefront per SIMD, 26 -> 29 us)
+      const int o2 = gy * W + gx;                                     // uniform bases, 32-bit offsets
+      const float x = (img1 + plane)[o2], y = (img2 + plane)[o2];
+      const float lw = (gy >= rb && gy < re) ? (l1_weight ? l1s * (l1_weight + plane)[o2] : l1s) : 0.f;
+      (g_img1 + plane)[o2] = scale * (s0 + 2.f * x * s1 + y * s2) + ((x > y) ? lw : (x < y) ? -lw : 0.f);
     }
+  }
+  __syncthreads();                                                    // hz / the patch are rewritten by the next tile
   }
 }
 
@@ -509,6 +605,15 @@ int vtgs_seen_and_max_radius(int32_t n, const int32_t* radii, float* max_2d_radi
   return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
 }
 
+// workgroups of an SSIM launch over `tiles` tiles: what the chip holds at once (256 CUs x 3 workgroups of 41 KB LDS), every
+// workgroup walking the same number of tiles when it can (ceil(tiles / rounds))
+static inline uint32_t ssim_grid(uint32_t tiles, uint32_t per_cu = 3u) {   // (the backward's 37 KB: 4 per CU)
+  const uint32_t kResident = 256u * per_cu;
+  if (tiles <= kResident) return tiles ? tiles : 1u;
+  const uint32_t rounds = (tiles + kResident - 1u) / kResident;
+  return (tiles + rounds - 1u) / rounds;
+}
+
 uint32_t vtgs_ssim_partial_rows(int32_t channels, int32_t height, int32_t width) {
   if (channels <= 0 || height <= 0 || width <= 0) return 0;
   return (uint32_t)(channels * ((height + kST - 1) / kST) * ((width + kST - 1) / kST));
@@ -518,7 +623,7 @@ int vtgs_ssim_forward(const float* img1, const float* img2, int32_t channels, in
                       float* partial_sums, float* grad_maps, void* stream) {
   if (!img1 || !img2 || !partial_sums || channels <= 0 || height <= 0 || width <= 0) return VTGS_ERR_INVALID_ARGUMENT;
   const int tx = (width + kST - 1) / kST, ty = (height + kST - 1) / kST;
-  hipLaunchKernelGGL(ssim_forward_kernel, dim3(channels * tx * ty), dim3(256), 0, (hipStream_t)stream, img1, img2, channels,
+  hipLaunchKernelGGL(ssim_forward_kernel, dim3(ssim_grid((uint32_t)(channels * tx * ty))), dim3(256), 0, (hipStream_t)stream, img1, img2, channels,
                      height, width, tx, ty, partial_sums, grad_maps);
   return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
 }
@@ -528,7 +633,7 @@ int vtgs_ssim_backward(const float* img1, const float* img2, const float* grad_m
   if (!img1 || !img2 || !grad_maps || !upstream || !grad_img1 || channels <= 0 || height <= 0 || width <= 0)
     return VTGS_ERR_INVALID_ARGUMENT;
   const int tx = (width + kST - 1) / kST, ty = (height + kST - 1) / kST;
-  hipLaunchKernelGGL(ssim_backward_kernel, dim3(channels * tx * ty), dim3(256), 0, (hipStream_t)stream, img1, img2, grad_maps,
+  hipLaunchKernelGGL(ssim_backward_kernel, dim3(ssim_grid((uint32_t)(channels * tx * ty), 4u)), dim3(256), 0, (hipStream_t)stream, img1, img2, grad_maps,
                      upstream, channels, height, width, tx, ty, grad_img1, 1.f, 0.f);
   return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
 }
@@ -554,7 +659,7 @@ int vtgs_slam_loss_forward(int32_t mode, const float* im, const float* depth_sil
   if (mode == 1) {
     const int tx = (width + kST - 1) / kST, ty = (height + kST - 1) / kST;
     ssim_rows = (uint32_t)(3 * tx * ty);
-    hipLaunchKernelGGL(ssim_forward_kernel, dim3(ssim_rows), dim3(256), 0, st, im, gt_im, 3, height, width, tx, ty,
+    hipLaunchKernelGGL(ssim_forward_kernel, dim3(ssim_grid((uint32_t)(ssim_rows))), dim3(256), 0, st, im, gt_im, 3, height, width, tx, ty,
                        ssim_partial, ssim_grad_maps);
   }
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, l1_rows, ssim_partial, ssim_rows, mode, w_im,
@@ -575,7 +680,7 @@ int vtgs_slam_loss_backward(int32_t mode, const float* im, const float* depth_si
                      gt_depth, P, sil_thres, mode, w_im, w_depth, upstream, fwd_out5, g_im, g_depth_sil, extra_mask);
   if (mode == 1) {
     const int tx = (width + kST - 1) / kST, ty = (height + kST - 1) / kST;
-    hipLaunchKernelGGL(ssim_backward_kernel, dim3(3 * tx * ty), dim3(256), 0, st, im, gt_im, ssim_grad_maps, upstream, 3,
+    hipLaunchKernelGGL(ssim_backward_kernel, dim3(ssim_grid((uint32_t)(3 * tx * ty), 4u)), dim3(256), 0, st, im, gt_im, ssim_grad_maps, upstream, 3,
                        height, width, tx, ty, g_im, -0.2f * w_im, (color_weight ? 1.0f : 0.8f) * w_im / (float)((size_t)3 * P),
                        color_weight);
   }
@@ -605,7 +710,7 @@ int vtgs_slam_loss_band_sums(int32_t mode, const float* im, const float* depth_s
   if (mode == 1) {
     const int tx = (width + kST - 1) / kST, ty0 = row_begin / kST, ty = (row_end - 1) / kST - ty0 + 1;
     ssim_rows = (uint32_t)(3 * tx * ty);
-    hipLaunchKernelGGL(ssim_forward_kernel, dim3(ssim_rows), dim3(256), 0, st, im, gt_im, 3, height, width, tx, ty,
+    hipLaunchKernelGGL(ssim_forward_kernel, dim3(ssim_grid((uint32_t)(ssim_rows))), dim3(256), 0, st, im, gt_im, 3, height, width, tx, ty,
                        ssim_partial, ssim_grad_maps, ty0, row_begin, row_end);
   }
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, l1_rows, ssim_partial, ssim_rows, mode, 0.f,
@@ -637,7 +742,7 @@ int vtgs_slam_loss_band_backward(int32_t mode, const float* im, const float* dep
   if (mode == 1) {
     const int lo = row_begin - kSR > 0 ? row_begin - kSR : 0, hi = row_end + kSR < height ? row_end + kSR : height;
     const int tx = (width + kST - 1) / kST, ty0 = lo / kST, ty = (hi - 1) / kST - ty0 + 1;
-    hipLaunchKernelGGL(ssim_backward_kernel, dim3(3 * tx * ty), dim3(256), 0, st, im, gt_im, ssim_grad_maps, upstream, 3,
+    hipLaunchKernelGGL(ssim_backward_kernel, dim3(ssim_grid((uint32_t)(3 * tx * ty), 4u)), dim3(256), 0, st, im, gt_im, ssim_grad_maps, upstream, 3,
                        height, width, tx, ty, g_im, -0.2f * w_im, (color_weight ? 1.0f : 0.8f) * w_im / (float)((size_t)3 * P),
                        color_weight, ty0, row_begin, row_end);
   }
