@@ -255,10 +255,12 @@ def run(args) -> dict:
         if esc:
             raise SystemExit(f"bench_slam.py: {esc} Gaussians escaped an owned set within one phase (margin too small)")
 
-    def render_pair(params, t_idx, gaussians_grad, camera_grad, tile_rows=None):
+    def render_pair(params, t_idx, gaussians_grad, camera_grad, tile_rows=None, contract=False):
+        # contract: the caller feeds both images to the fused tracking / mapping loss (whole frame or band), which treats the
+        # [z, 1, z^2] render as get_loss does -- fused.render_frame(get_loss_contract=True), DESIGN.md 7 row f2'
         if args.fused:
             return render_frame(params, t_idx, settings, first_w2c, gaussians_grad, camera_grad, tile_rows=tile_rows,
-                                owned=owned_for(params, t_idx) if tile_rows is not None else None)
+                                owned=owned_for(params, t_idx) if tile_rows is not None else None, get_loss_contract=contract)
         tg = sc.transform_to_frame(params, t_idx, gaussians_grad=gaussians_grad, camera_grad=camera_grad)
         rv = sc.transformed_params2rendervar(params, tg)
         dv = sc.transformed_params2depthplussilhouette(params, first_w2c, tg)
@@ -350,9 +352,9 @@ def run(args) -> dict:
     # of each phase on a throw-away copy of the parameters
     warm = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
     for _ in range(3):
-        im, depth_sil, _ = render_pair(warm, 1, gaussians_grad=False, camera_grad=True, tile_rows=band)
+        im, depth_sil, _ = render_pair(warm, 1, gaussians_grad=False, camera_grad=True, tile_rows=band, contract=True)
         track_loss(im, depth_sil, gts[1][0], gts[1][1], 0.99).backward()
-        im, depth_sil, _ = render_pair(warm, 1, gaussians_grad=True, camera_grad=False, tile_rows=band)
+        im, depth_sil, _ = render_pair(warm, 1, gaussians_grad=True, camera_grad=False, tile_rows=band, contract=True)
         map_loss(im, depth_sil, gts[1][0], gts[1][1]).backward()
     del warm
     owned_done()
@@ -401,7 +403,7 @@ def run(args) -> dict:
                     plot_dir=None, visualize_tracking_loss=False, tracking_iteration=it, dataset_name="replica",
                     presence_sil_mask_mse_ls=mse_ls, sil_thres_ls=thr_ls)
             else:
-                im, depth_sil, _ = render_pair(params, t, gaussians_grad=False, camera_grad=True, tile_rows=band)
+                im, depth_sil, _ = render_pair(params, t, gaussians_grad=False, camera_grad=True, tile_rows=band, contract=True)
                 if it == 0:
                     sil_thres = pick_threshold(im, depth_sil[1], gt_im, gt_depth)
                 loss = track_loss(im, depth_sil, gt_im, gt_depth, sil_thres)
@@ -525,7 +527,7 @@ def run(args) -> dict:
                         mapping=True, dataset_name="replica")
                     loss = loss + loss_global
             else:
-                im, depth_sil, _ = render_pair(params, kf, gaussians_grad=True, camera_grad=False, tile_rows=band)
+                im, depth_sil, _ = render_pair(params, kf, gaussians_grad=True, camera_grad=False, tile_rows=band, contract=True)
                 loss = map_loss(im, depth_sil, gt_im, gt_depth)
             loss.backward()
             if exchange is not None:               # halo gradients -> owner bands; Adam on the owned rows; updated rows -> listers
