@@ -243,7 +243,12 @@ def run(args) -> dict:
         owner_stats["phases"] += 1; owner_stats["halo_rows"] += ex.halo_rows; owner_stats["own_rows"] += int(ex.own_rows.numel())
         return ex
 
+    if world > 1:
+        dgr.defer_run_ahead_overflow(True)          # nobody raises alone: pt.phase_overflows at the end of every phase
+
     def owned_done():
+        if world > 1:
+            pt.phase_overflows(device=dev)
         if not use_owned:
             return
         esc_t = torch.zeros(1, dtype=torch.float32, device=dev)

@@ -250,6 +250,37 @@ def test_an_escape_on_one_rank_is_seen_by_every_rank(tmp_path):
         assert got["first"] == 3 and got["second"] == 0, (rank, got)
 
 
+def _overflow_worker(rank, world, port, out):
+    """A run-ahead overflow recorded on rank 1 only (deferral on): both ranks must raise, together, at the end of the phase."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization.partition import phase_overflows
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dgr.defer_run_ahead_overflow(True)
+    if rank == 1:
+        dgr._deferred_overflows.append(RuntimeError("vtgs_forward (run-ahead mode): stand-in"))
+    raised = None
+    try:
+        phase_overflows()
+    except RuntimeError as e:
+        raised = str(e)
+    clean = phase_overflows()                      # the next phase: nothing recorded anywhere
+    torch.save({"raised": raised, "clean": clean}, f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_a_run_ahead_overflow_on_one_rank_raises_on_every_rank(tmp_path):
+    """partition.phase_overflows: with defer_run_ahead_overflow(True) an overflow found inside one rank's backward
+    is recorded, not raised, and the phase-end all-reduce raises the same error on every rank -- nobody is left waiting in a
+    collective.  (The record itself comes from the pinned result record of the HIP forward: tests/test_gpu_fused_frame.py.)"""
+    out = str(tmp_path / "ovf")
+    mp.spawn(_overflow_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for rank in (0, 1):
+        got = torch.load(f"{out}.{rank}")
+        assert got["raised"] is not None and "1 run-ahead forward(s) overflowed" in got["raised"], (rank, got)
+        assert got["clean"] == 0
+
+
 def _adam_rows_cpu(p, g, m, v, rows, step, lr, eps, b1=0.9, b2=0.999):
     """torch.optim.Adam's update on the listed rows only (what vtgs_adam_step_rows does on the device)."""
     gr = g[rows]

@@ -481,3 +481,43 @@ def test_get_loss_contract_forward_against_the_full_dual_forward(gpu_device, mon
     assert (ds0[1] - ds1[1]).abs().max().item() <= 2e-6
     assert torch.equal(ds1[2], ds1[0] * ds1[0])
     assert torch.isfinite(ds0[2] - ds0[0] ** 2).all() and ds0[1].max().item() > 0.9
+
+
+def test_deferred_run_ahead_overflow_is_recorded_not_raised(gpu_device, monkeypatch):
+    """N-rank mode (`defer_run_ahead_overflow(True)`): the overflow of a run-ahead forward does not leave this rank's
+    `backward()` -- it is counted for `partition.phase_overflows`, the collective that raises on every rank at the end of the
+    phase -- and the capacities are raised as always, so the next forward of the shape is valid."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization.fused import render_frame
+    from diff_gaussian_rasterization.partition import phase_overflows
+    dev = gpu_device
+    W, H, n = 160, 96, 8001
+    base, cam = _params(dev, n, W, H, seed=5)
+    st, w2c = to_settings(cam, dev), torch.eye(4, device=dev)
+    for state in (dgr._capacity_hint, dgr._tile_cap_hint, dgr._caps_in_use, dgr._async_ok, dgr._need_hist):
+        state.clear()
+    params = {k: torch.nn.Parameter(v.detach().clone()) for k, v in base.items()}
+    dgr.deferred_overflows()
+    dgr.defer_run_ahead_overflow(True)
+    try:
+        for it in range(6):                                         # a steady loop: the later forwards run ahead
+            for v in params.values():
+                v.grad = None
+            im, ds, _ = render_frame(params, 1, st, w2c, True, True)
+            (im.sum() + ds.sum()).backward()
+        dgr.settle_pending()
+        assert dgr.deferred_overflows() == 0
+        with torch.no_grad():
+            params["log_scales"] += 2.6
+        im, ds, _ = render_frame(params, 1, st, w2c, True, True)
+        (im.sum() + ds.sum()).backward()                            # no exception on this rank
+        with pytest.raises(RuntimeError, match="redo the phase"):   # (single process: the sum over ranks is this rank's count)
+            phase_overflows(device=dev)
+        assert dgr.deferred_overflows() == 0
+        im, ds, _ = render_frame(params, 1, st, w2c, True, True)    # capacities were raised: valid now
+        (im.sum() + ds.sum()).backward()
+        assert phase_overflows(device=dev) == 0
+        assert float(im.detach().abs().max()) > 0
+    finally:
+        dgr.defer_run_ahead_overflow(False)
+        dgr.deferred_overflows()

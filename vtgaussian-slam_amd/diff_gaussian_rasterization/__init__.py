@@ -443,6 +443,26 @@ def _settle_after_backward(out: torch.Tensor, fs) -> None:
         node.register_hook(hook)
 
 
+_DEFER_OVERFLOW = [False]
+_deferred_overflows: list = []
+
+
+def defer_run_ahead_overflow(on: bool = True) -> None:
+    """N-rank loops: a rank that raised a run-ahead overflow on its own -- inside `backward()`, or at its next forward --
+    would leave the other ranks waiting in the next collective.  With deferral on, the overflow is recorded instead (the
+    capacities are raised as always; that iteration's image and gradients on this rank are those of the background), and
+    `partition.phase_overflows(group)` -- one small all-reduce at the end of a phase, like `phase_escapes` -- raises on EVERY
+    rank when any rank recorded one: redo the phase."""
+    _DEFER_OVERFLOW[0] = bool(on)
+
+
+def deferred_overflows() -> int:
+    """Number of run-ahead overflows recorded since the last call (and forgets them)."""
+    n = len(_deferred_overflows)
+    _deferred_overflows.clear()
+    return n
+
+
 def settle_pending() -> None:
     """Read the result records of ALL run-ahead forwards still outstanding (waiting for the device where needed) -- an
     overflow among them raises here.  The loops do not need to call this (every forward does it for its predecessors);
@@ -494,11 +514,15 @@ def _settle_locked(fs) -> None:
         _capacity_hint[key] = max(int(info.instances_needed), 1)
         _tile_cap_hint[key] = max(int(info.max_tile_list), 1)
         _async_ok[key] = None
-        raise RuntimeError(
+        err = RuntimeError(
             "vtgs_forward (run-ahead mode): the workspace of the previous forward overflowed -- after three forwards of this "
             "shape that needed the same, this one binned more than three times as much -- so the image it returned (the "
             "background colour) is INVALID. The capacities have been raised; redo the iteration, or set "
             "VTGS_FORWARD_MODE=checked to have every forward verified before it returns.")
+        if _DEFER_OVERFLOW[0]:                     # N ranks: nobody raises alone (partition.phase_overflows decides for all)
+            _deferred_overflows.append(err)
+            return
+        raise err
     fs._instances = int(info.instances)
     _record_info(key, n, fs.cam.W, fs.cam.H, fs.capacity, info)
 

@@ -143,6 +143,26 @@ def phase_escapes(owned_sets, group=None) -> int:
     return int(total.item())
 
 
+def phase_overflows(group=None, device=None) -> int:
+    """End of a phase on N ranks, with `diff_gaussian_rasterization.defer_run_ahead_overflow(True)`: the run-ahead overflows the
+    ranks recorded during the phase, summed over all ranks (one small all-reduce), and the SAME error on every rank when the sum is
+    not zero -- a rank raising alone, inside its `backward()`, would leave the others in the next collective.  The
+    capacities have already been raised where it happened: redo the phase."""
+    import torch
+    import torch.distributed as dist
+    import diff_gaussian_rasterization as dgr
+    dgr.settle_pending()                              # (deferred: records, does not raise)
+    total = torch.tensor([float(dgr.deferred_overflows())], dtype=torch.float32, device=device or "cpu")
+    if dist.is_available() and dist.is_initialized():
+        all_reduce_sum(total, group)
+    n = int(total.item())
+    if n:
+        raise RuntimeError(f"{n} run-ahead forward(s) overflowed their workspace on some rank during this phase: the images and "
+                           "gradients of those iterations were invalid there.  Capacities have been raised; redo the phase "
+                           "(every rank raises this together)")
+    return 0
+
+
 class OwnerExchange:
     """Mapping on N ranks without the 20 N-byte all-reduce ("reduce-scatter by Gaussian owner band ... sparse halo
     exchange with the neighbouring bands only, then each GPU runs Adam on its owned slice").
