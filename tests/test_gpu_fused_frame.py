@@ -371,11 +371,13 @@ def test_run_ahead_overflow_surfaces_inside_backward_before_the_optimizer_step(g
 
 
 @pytest.mark.parametrize("route", ["cxx", "python"])
+@pytest.mark.parametrize("scene", ["plain", "saturating"])
 @pytest.mark.parametrize("gaussians_grad,camera_grad", [(False, True), (True, False), (True, True)])
-def test_depth_only_backward_equals_the_full_dual_backward(gpu_device, monkeypatch, route, gaussians_grad, camera_grad):
+def test_depth_only_backward_equals_the_full_dual_backward(gpu_device, monkeypatch, route, scene, gaussians_grad, camera_grad):
     """render_frame(get_loss_contract=True) -- frame flag 8: four image-gradient channels, 48-byte records, the second set's colour
     sum in chain w's fourth column -- against the full dual backward (VTGS_DUAL_B1=0 makes the library ignore the flag) on a
-    gradient whose depth_sil planes 1 and 2 are zero, as get_loss sends it: the per-pair arithmetic is the same (the two
+    gradient whose depth_sil planes 1 and 2 are zero, as get_loss sends it (a plain scene and a saturating one, whose pixels
+    end inside their lists): the per-pair arithmetic is the same (the two
     dropped terms were exact zeros), so what is left is the contraction order of the compiler: 2e-6 of each tensor's largest
     gradient.  Tracking (Gaussians detached), mapping and bundle-adjustment flags, both autograd nodes."""
     import diff_gaussian_rasterization as dgr
@@ -383,6 +385,10 @@ def test_depth_only_backward_equals_the_full_dual_backward(gpu_device, monkeypat
     dev = gpu_device
     monkeypatch.setenv("VTGS_FUSED_EXT", "1" if route == "cxx" else "0")
     params, cam = _params(dev, 40000, 232, 136, seed=21)
+    if scene == "saturating":                           # opaque, 2.7 x larger splats: pixels end inside their lists (the records of
+        with torch.no_grad():                           # the entries behind are the zero-filled ones), lists of several hundred entries
+            params["logit_opacities"] += 6.0
+            params["log_scales"] += 1.0
     st = to_settings(cam, dev)
     w2c = torch.eye(4, device=dev)
     w2c[:3, 3] = torch.tensor([0.01, 0.02, -0.02], device=dev)
@@ -410,7 +416,10 @@ def test_depth_only_backward_equals_the_full_dual_backward(gpu_device, monkeypat
             scale = a.abs().max().item()
             if k == "unnorm_rotations":                   # isotropic map: float noise around an exact zero in both routes
                 scale = res[0]["log_scales"].abs().max().item() if res[0]["log_scales"] is not None else 1.0
-            assert (a - b).abs().max().item() <= 2e-6 * scale + 1e-12, (k, (a - b).abs().max().item(), scale)
+            # (saturating: the back sweep's anchor (CB - P) / T divides by a transmittance near the 1e-4 stop, which carries the
+            #  last-bit difference of the two CB expressions -- the full form adds its two zero terms -- to a few 1e-6)
+            tol = 2e-6 if scene == "plain" else 2e-5
+            assert (a - b).abs().max().item() <= tol * scale + 1e-12, (k, (a - b).abs().max().item(), scale)
     assert seen_any
 
 
