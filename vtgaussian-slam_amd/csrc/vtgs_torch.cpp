@@ -14,8 +14,11 @@
 #include <torch/extension.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 #include "../../include/vtgs.h"
 
@@ -49,6 +52,36 @@ inline int64_t counted_instances(int status, int64_t fwd_flags, int64_t slot_ptr
   if (status != VTGS_OK || (fwd_flags & VTGS_FORWARD_MODE_MASK) == VTGS_FORWARD_ASYNC || slot_ptr == 0) return 0;
   const VtgsForwardInfo* info = reinterpret_cast<const VtgsForwardInfo*>(slot_ptr);
   return (info->complete && !info->overflow) ? (int64_t)info->instances : 0;
+}
+
+// The verdict of a RUN-AHEAD forward, read at the end of the node's backward (an overflow has to leave
+// `loss.backward()`, before any optimizer step).  Round 5 first did this with a Python post-hook on the graph node (~14 us of
+// host time per iteration, the interpreter back in the backward); the pinned record is plain host memory, so the node reads it
+// itself: wait for `complete` (the device writes it right after the binning -- long before the backward was enqueued), and on
+// overflow mark the record as reported (complete = 2: the Python bookkeeping that follows at the next forward raises the
+// capacities and stays silent) and throw -- or, with deferral on (N-rank loops, partition.phase_overflows), count it.
+std::atomic<bool> g_check_in_backward{true}, g_defer_overflow{false};
+std::atomic<int64_t> g_deferred{0};
+
+void check_run_ahead(int64_t slot_ptr, int64_t fwd_flags) {
+  if (!g_check_in_backward.load() || slot_ptr == 0 || (fwd_flags & VTGS_FORWARD_MODE_MASK) != VTGS_FORWARD_ASYNC) return;
+  volatile VtgsForwardInfo* info = reinterpret_cast<volatile VtgsForwardInfo*>(slot_ptr);
+  if (!info->complete) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!info->complete) {
+      std::this_thread::yield();
+      TORCH_CHECK(std::chrono::steady_clock::now() - t0 < std::chrono::seconds(20),
+                  "vtgs_forward: timed out waiting for the result record of a run-ahead forward");
+    }
+  }
+  if (info->overflow && info->complete != 2u) {
+    info->complete = 2u;
+    if (g_defer_overflow.load()) { g_deferred.fetch_add(1); return; }
+    TORCH_CHECK(false, "vtgs_forward (run-ahead mode): the workspace of this iteration's forward overflowed -- after three "
+                "forwards of this shape that needed the same, this one binned more than three times as much -- so the image it "
+                "returned (the background colour) is INVALID, and so are these gradients. The capacities are raised at the next "
+                "forward; redo the iteration, or set VTGS_FORWARD_MODE=checked to have every forward verified before it returns.");
+  }
 }
 
 struct CamRecord {            // VtgsCamera with the three device tensors it points at kept alive
@@ -106,6 +139,8 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
                 vtgs_last_hip_error(), ")");
     ctx->save_for_backward({means3D, colors, opac, scales, rot, color, workspace, cam_bytes, bg, view, proj});
     ctx->saved_data["instances"] = counted_instances(st, flags, slot_ptr);
+    ctx->saved_data["slot_ptr"] = slot_ptr;
+    ctx->saved_data["fwd_flags"] = flags;
     ctx->saved_data["capacity"] = capacity;
     ctx->saved_data["tile_cap"] = tile_cap;
     ctx->saved_data["stream"] = stream;
@@ -163,6 +198,7 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
                                    gp[0], gp[1], gp[2], gp[3], gp[4], gp[5], reinterpret_cast<void*>(stream));
       TORCH_CHECK(st == VTGS_OK, "vtgs_backward failed: ", vtgs_strerror(st), " (", vtgs_last_hip_error(), ")");
     }
+    check_run_ahead(ctx->saved_data["slot_ptr"].toInt(), ctx->saved_data["fwd_flags"].toInt());   // (after the launches)
     at::Tensor none;
     return {g[0], g[1], g[2], g[3], g[4], g[5], none, none, none, none, none, none, none, none, none, none};
   }
@@ -253,6 +289,8 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
     ctx->save_for_backward({means3D, rgb, unnorm_rot, cam_q, cam_t, depth_w2c, vars, images, workspace, cam_bytes, bg, view, proj,
                             idx_saved});
     ctx->saved_data["instances"] = counted_instances(st, fwd_flags, slot_ptr);
+    ctx->saved_data["slot_ptr"] = slot_ptr;
+    ctx->saved_data["fwd_flags"] = fwd_flags;
     ctx->saved_data["capacity"] = capacity;
     ctx->saved_data["tile_cap"] = tile_cap;
     ctx->saved_data["stream"] = stream;
@@ -324,6 +362,7 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
       g_q = at::zeros({4}, f32); g_t = at::zeros({3}, f32);
     }
     if (n == 0 && !owned && width > 0) flat.zero_();
+    check_run_ahead(ctx->saved_data["slot_ptr"].toInt(), ctx->saved_data["fwd_flags"].toInt());   // (after the launches)
     at::Tensor none;
     return {g_means3D, g_rgb, g_ur, g_logit.defined() ? g_logit : none, g_ls.defined() ? g_ls : none, g_q, g_t,
             none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
@@ -348,4 +387,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize", &rasterize, "GaussianRasterizer forward with a C++ autograd node behind it");
   m.def("abi_version", []() { return (int64_t)vtgs_abi_version(); });
   m.def("set_poison", [](bool on) { g_poison = on; });
+  m.def("set_check_in_backward", [](bool on) { g_check_in_backward = on; });
+  m.def("set_defer_overflow", [](bool on) { g_defer_overflow = on; });
+  m.def("take_deferred_overflows", []() { return g_deferred.exchange(0); });
 }

@@ -433,9 +433,17 @@ def check_captured(fs=None) -> None:
 # does), reads the record and raises out of loss.backward(), BEFORE any optimizer step.  VTGS_SETTLE_IN_BACKWARD=0 restores
 # the late check (a caller that settles itself: settle_pending() between backward() and step()).
 _SETTLE_IN_BACKWARD = os.environ.get("VTGS_SETTLE_IN_BACKWARD", "1") != "0"
+_EXT_CHECKS_IN_BACKWARD = _ext is not None and hasattr(_ext, "set_check_in_backward")
+if _EXT_CHECKS_IN_BACKWARD:
+    _ext.set_check_in_backward(_SETTLE_IN_BACKWARD)
 
 
 def _settle_after_backward(out: torch.Tensor, fs) -> None:
+    """C++ nodes: the verdict of a run-ahead forward inside `backward()`.  The node reads the pinned record itself
+    (csrc/vtgs_torch.cpp check_run_ahead: no interpreter in the backward, ~14 us less host time per iteration than the
+    Python post-hook this function hangs on the graph node when the extension predates that)."""
+    if _EXT_CHECKS_IN_BACKWARD:
+        return
     node = out.grad_fn
     if _SETTLE_IN_BACKWARD and node is not None:
         def hook(_grad_inputs, _grad_outputs, fs=fs):
@@ -454,12 +462,16 @@ def defer_run_ahead_overflow(on: bool = True) -> None:
     `partition.phase_overflows(group)` -- one small all-reduce at the end of a phase, like `phase_escapes` -- raises on EVERY
     rank when any rank recorded one: redo the phase."""
     _DEFER_OVERFLOW[0] = bool(on)
+    if _EXT_CHECKS_IN_BACKWARD:
+        _ext.set_defer_overflow(bool(on))
 
 
 def deferred_overflows() -> int:
     """Number of run-ahead overflows recorded since the last call (and forgets them)."""
     n = len(_deferred_overflows)
     _deferred_overflows.clear()
+    if _EXT_CHECKS_IN_BACKWARD:
+        n += int(_ext.take_deferred_overflows())
     return n
 
 
@@ -514,6 +526,8 @@ def _settle_locked(fs) -> None:
         _capacity_hint[key] = max(int(info.instances_needed), 1)
         _tile_cap_hint[key] = max(int(info.max_tile_list), 1)
         _async_ok[key] = None
+        if info.complete == 2:                     # the C++ node's backward has reported this one (raised, or counted for
+            return                                 # partition.phase_overflows): the capacities above are what was left to do
         err = RuntimeError(
             "vtgs_forward (run-ahead mode): the workspace of the previous forward overflowed -- after three forwards of this "
             "shape that needed the same, this one binned more than three times as much -- so the image it returned (the "
