@@ -99,9 +99,12 @@ def test_one_dense_tile_no_longer_sizes_every_bin(gpu_device, monkeypatch):
     _same(uni, again)
 
 
-def test_fused_frame_and_shared_render_through_planned_bins(gpu_device, monkeypatch):
+@pytest.mark.parametrize("contract", [False, True])
+def test_fused_frame_and_shared_render_through_planned_bins(gpu_device, monkeypatch, contract):
     """The other consumers of the bins -- the dual render of `render_frame` with its frame-epilogue backward, and the second
-    render over the first one's bins (`render_shared`) -- read the forward's copy of the plan: identical to uniform bins."""
+    render over the first one's bins (`render_shared`) -- read the forward's copy of the plan: identical to uniform bins.
+    contract: `render_frame(get_loss_contract=True)` -- the single render's forward kernel with z in its depth column and the
+    four-channel backward -- through `vtgs_forward_dual_planned` (the gradient sent into planes 1, 2 is zero, as promised)."""
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization.fused import render_frame
     dev = gpu_device
@@ -120,8 +123,8 @@ def test_fused_frame_and_shared_render_through_planned_bins(gpu_device, monkeypa
     def run(mode):
         monkeypatch.setattr(dgr, "_BINS_MODE", mode)
         p = {k: torch.nn.Parameter(v.clone().to(dev)) for k, v in base.items()}
-        im, ds, radii = render_frame(p, 0, st, w2c, True, True)
-        ((im * g1).sum() + (ds * g2).sum()).backward()
+        im, ds, radii = render_frame(p, 0, st, w2c, True, True, get_loss_contract=contract)
+        ((im * g1).sum() + ((ds * g2)[:1] if contract else ds * g2).sum()).backward()
         out = {"im": im.detach().clone(), "ds": ds.detach().clone(), "radii": radii.clone(),
                **{"g_" + k: v.grad.clone() for k, v in p.items() if v.grad is not None}}
         leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in scene.items()}
