@@ -610,6 +610,9 @@ def main():
                             "over a 40-frame submap is 0.084).  ") +
                             ("Every ordinary frame runs the reference's densification step (forward-only render, depth_error.median(), "
                                "new Gaussians appended: N grows over the cycle).  " if world == 1 else "No densification on N > 1 ranks.  ") +
+                            "get_loss renders under its own contract (it differentiates the [z,1,z^2] image through z alone: the single render's "
+                            "forward kernel with z in the depth column, a four-channel backward -- same loss and gradients, "
+                            "tests/test_gpu_fused_frame.py).  "
                             "No dataset I/O and no keyframe-overlap selection (host / small-tensor work outside the rasterizer path)."}
         except Exception as e:                                   # (the headline line must not be lost over the second metric)
             if world == 1:
