@@ -19,7 +19,7 @@ def test_ssim_matches_reference_fixture(gpu_device):
     np.testing.assert_allclose(fused_ssim(a, b).item(), float(d["ssim"]), rtol=2e-5)
 
 
-@pytest.mark.parametrize("shape", [(3, 40, 56), (3, 97, 131), (1, 33, 31), (3, 680, 1200)])
+@pytest.mark.parametrize("shape", [(3, 40, 56), (3, 97, 131), (1, 33, 31), (3, 680, 1200), (1, 7, 5), (2, 12, 300), (3, 300, 4)])
 def test_ssim_value_and_gradient_match_conv_restatement(gpu_device, shape):
     from diff_gaussian_rasterization.losses import fused_ssim
     g = torch.Generator().manual_seed(shape[1])
