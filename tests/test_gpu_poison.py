@@ -88,8 +88,11 @@ def test_poisoned_workspaces_change_nothing(gpu_device, route, monkeypatch):
         dgr.poison_workspaces(False)
 
 
-def test_poisoned_workspaces_dual_render_and_frame_epilogue(gpu_device):
-    """The fused caller chain (dual forward, dual backward with the frame epilogue in the gather kernel) under poison."""
+@pytest.mark.parametrize("contract", [False, True])
+def test_poisoned_workspaces_dual_render_and_frame_epilogue(gpu_device, contract):
+    """The fused caller chain (dual forward, dual backward with the frame epilogue in the gather kernel) under poison.
+    contract: the get_loss forms -- the single render's forward with z in its depth column, the four-channel backward with its
+    12-float records (one pad word that nobody writes and nobody may read)."""
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import fused
     dev = gpu_device
@@ -111,8 +114,8 @@ def test_poisoned_workspaces_dual_render_and_frame_epilogue(gpu_device):
             "cam_trans": torch.tensor([0.004, -0.003, 0.002], device=dev).reshape(1, 3, 1).requires_grad_(True),
         }
         im, ds, radii = fused.render_frame(params, 0, to_settings(cam, dev), torch.eye(4, device=dev), gaussians_grad=True,
-                                           camera_grad=True)
-        ((im * g_im).sum() + (ds * g_ds).sum()).backward()
+                                           camera_grad=True, get_loss_contract=contract)
+        ((im * g_im).sum() + ((ds * g_ds)[:1] if contract else ds * g_ds).sum()).backward()
         dgr.settle_pending()
         return [im.detach().cpu(), ds.detach().cpu(), radii.cpu()] + [params[k].grad.cpu() for k in sorted(params)]
 
