@@ -23,18 +23,20 @@ def _params(dev, n, W, H, seed, T=3):
     return {k: torch.nn.Parameter(v.to(dev)) for k, v in p.items()}, cam
 
 
-def _render(params, t_idx, st, w2c, band, owned, g1, g2, gaussians_grad, camera_grad):
+def _render(params, t_idx, st, w2c, band, owned, g1, g2, gaussians_grad, camera_grad, contract=False):
     from diff_gaussian_rasterization.fused import render_frame
     for v in params.values():
         v.grad = None
-    im, ds, radii = render_frame(params, t_idx, st, w2c, gaussians_grad, camera_grad, tile_rows=band, owned=owned)
-    ((im * g1).sum() + (ds * g2).sum()).backward()
+    im, ds, radii = render_frame(params, t_idx, st, w2c, gaussians_grad, camera_grad, tile_rows=band, owned=owned,
+                                 get_loss_contract=contract)
+    ((im * g1).sum() + ((ds * g2)[:1] if contract else ds * g2).sum()).backward()     # (the contract: no gradient into planes 1, 2)
     return im.detach(), ds.detach(), radii, {k: (None if v.grad is None else v.grad.clone()) for k, v in params.items()}
 
 
+@pytest.mark.parametrize("contract", [False, True])
 @pytest.mark.parametrize("gaussians_grad,camera_grad", [(False, True), (True, True)])
 @pytest.mark.parametrize("band", [(0, 2), (3, 5), (6, 8)])
-def test_render_of_the_list_equals_the_band_render_of_the_map(gpu_device, band, gaussians_grad, camera_grad):
+def test_render_of_the_list_equals_the_band_render_of_the_map(gpu_device, band, gaussians_grad, camera_grad, contract):
     from diff_gaussian_rasterization.partition import OwnedSet
     dev = gpu_device
     W, H, n = 208, 128, 30000                              # 8 tile rows
@@ -46,8 +48,8 @@ def test_render_of_the_list_equals_the_band_render_of_the_map(gpu_device, band, 
     own = OwnedSet(params, 1, st, w2c, band, margin_px=8.0, growth=1.1)
     assert 0 < len(own) < 0.75 * n, len(own)               # a band of 2 rows of 8: most of the map is not on the list
     assert bool((own.idx[1:] > own.idx[:-1]).all())
-    im0, ds0, r0, ref = _render(params, 1, st, w2c, band, None, g1, g2, gaussians_grad, camera_grad)
-    im1, ds1, r1, got = _render(params, 1, st, w2c, band, own, g1, g2, gaussians_grad, camera_grad)
+    im0, ds0, r0, ref = _render(params, 1, st, w2c, band, None, g1, g2, gaussians_grad, camera_grad, contract)
+    im1, ds1, r1, got = _render(params, 1, st, w2c, band, own, g1, g2, gaussians_grad, camera_grad, contract)
     assert own.escaped() == 0
     assert torch.equal(im0, im1) and torch.equal(ds0, ds1) and torch.equal(r0, r1)
     assert int((r0 > 0).sum()) > 100
