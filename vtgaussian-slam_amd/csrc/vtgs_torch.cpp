@@ -44,6 +44,18 @@ bool g_poison = false;
 // partition have any length).
 inline int64_t pad4(int64_t n) { return (n + 3) & ~int64_t(3); }
 
+// Bytes to ALLOCATE for a block of `nbytes` (workspace, record scratch): from 64 MB up, the next multiple of 1/8 of the largest
+// power of two below it (<= 12.5 % more).  A SLAM map grows by a few thousand Gaussians per frame and the capacities creep
+// with it: every frame asked the caching allocator for a block slightly larger than any it had cached -- 21 GB reserved after
+// 164 frames around 2 GB in use (round 5, bench_slam.py --densify).  On the grid the sizes repeat and the blocks are reused.
+inline int64_t alloc_bytes(size_t nbytes) {
+  if (nbytes < (size_t(64) << 20)) return (int64_t)nbytes;
+  size_t p = 1;
+  while ((p << 1) <= nbytes) p <<= 1;
+  const size_t g = p >> 3;
+  return (int64_t)((nbytes + g - 1) / g * g);
+}
+
 // Instances a CHECKED (or SYNC) forward counted, read from its result record right after the call returned -- the backward's
 // scratch holds one record per instance, and the capacity policy keeps 3.6 x the last need as room for run-ahead forwards:
 // sizing the scratch by the capacity committed 3.6 x the memory (device memory is not demand-paged: ADVICE r4).  0 = not
@@ -122,7 +134,7 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     at::Tensor color = images.narrow(0, 0, 3), depth = images.narrow(0, 3, 1);
     at::Tensor radii = at::empty({n}, f32.dtype(at::kInt));
     const size_t nbytes = vtgs_workspace_bytes((int32_t)n, (int32_t)W, (int32_t)H, (uint64_t)capacity, (uint32_t)tile_cap);
-    at::Tensor workspace = at::empty({(int64_t)nbytes}, f32.dtype(at::kByte));
+    at::Tensor workspace = at::empty({alloc_bytes(nbytes)}, f32.dtype(at::kByte));
     if (g_poison) { workspace.fill_(0xFF); images.fill_(std::nanf("")); }
     // bin_plan != 0: planned bins (tile_cap carries VTGS_TILE_CAPACITY_PLANNED; the backward needs nothing else)
     const int st = bin_plan
@@ -189,7 +201,7 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
       // here; it is shared round-robin with later forwards: ADVICE r3.)
       const int64_t counted = ctx->saved_data["instances"].toInt();
       const size_t sbytes = vtgs_backward_scratch_bytes((int32_t)n, (uint64_t)(counted > 0 ? counted : capacity));
-      at::Tensor scratch = at::empty({(int64_t)sbytes}, f32.dtype(at::kByte));
+      at::Tensor scratch = at::empty({alloc_bytes(sbytes)}, f32.dtype(at::kByte));
       if (g_poison) scratch.fill_(0xFF);
       const int st = vtgs_backward(&cam.c, (int32_t)n, means3D.data_ptr<float>(), colors.data_ptr<float>(), opac.data_ptr<float>(),
                                    scales.data_ptr<float>(), rot.data_ptr<float>(), color.data_ptr<float>(),
@@ -271,7 +283,7 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
     at::Tensor im = images.narrow(0, 0, 3), depth_sil = images.narrow(0, 3, 3);
     at::Tensor radii = at::empty({n}, f32.dtype(at::kInt));
     const size_t nbytes = vtgs_workspace_bytes((int32_t)n, (int32_t)W, (int32_t)H, (uint64_t)capacity, (uint32_t)tile_cap);
-    at::Tensor workspace = at::empty({(int64_t)nbytes}, f32.dtype(at::kByte));
+    at::Tensor workspace = at::empty({alloc_bytes(nbytes)}, f32.dtype(at::kByte));
     if (g_poison) { workspace.fill_(0xFF); images.fill_(std::nanf("")); }
     const int st = bin_plan
         ? vtgs_forward_dual_planned(&cam.c, (int32_t)n, means_cam, colors_a, dcol, opac, scales, rot, im.data_ptr<float>(),
@@ -342,7 +354,7 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
       const float *means_cam = v, *opac = v + 3 * np, *scales = v + 4 * np, *rot = v + 7 * np, *dcol = v + 11 * np, *rgb_c = v + 14 * np;
       const int64_t counted = ctx->saved_data["instances"].toInt();   // (see Rasterize::backward)
       const size_t sbytes = vtgs_backward_dual_scratch_bytes((int32_t)n, (uint64_t)(counted > 0 ? counted : capacity));
-      at::Tensor scratch = at::empty({(int64_t)sbytes}, f32.dtype(at::kByte));
+      at::Tensor scratch = at::empty({alloc_bytes(sbytes)}, f32.dtype(at::kByte));
       if (g_poison) scratch.fill_(0xFF);
       const int st = vtgs_backward_dual_frame_owned(
           &cam.c, (int32_t)n, owned ? idx.data_ptr<int32_t>() : nullptr, means_cam, owned ? rgb_c : rgb.data_ptr<float>(), dcol, opac,

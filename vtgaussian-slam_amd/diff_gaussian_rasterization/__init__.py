@@ -735,10 +735,22 @@ def _workspace(n, W, H, capacity, tile_cap, device):
             f"the forward workspace would need {nbytes / 2**30:.1f} GiB (every one of the {((W + 7) // 8) * ((H + 7) // 8)} "
             f"8x8 tiles gets a bin of {tile_cap} entries, sized by the longest tile list): some tile is hit by an "
             f"extreme number of splats. Raise VTGS_MAX_WORKSPACE_GB if that is intended.")
+    nbytes = _alloc_bytes(nbytes)                   # (a few repeating sizes for the caching allocator: see _alloc_bytes)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
     if _poison:
         ws.fill_(0xFF)
     return nbytes, ws
+
+
+def _alloc_bytes(nbytes: int) -> int:
+    """Bytes to ALLOCATE for a block of `nbytes` (workspace, record scratch): from 64 MB up the next multiple of 1/8 of the
+    largest power of two below it (<= 12.5 % more; csrc/vtgs_torch.cpp alloc_bytes is the same rule).  A SLAM map grows by a few
+    thousand Gaussians per frame and the capacities creep with it, so every frame asked the caching allocator for a block
+    slightly larger than any it had cached: 21 GB reserved after 164 frames around 2 GB in use.  On the grid the sizes repeat."""
+    if nbytes < (64 << 20):
+        return nbytes
+    g = (1 << (nbytes.bit_length() - 1)) >> 3
+    return (nbytes + g - 1) // g * g
 
 
 _poison = False
@@ -756,7 +768,7 @@ def poison_workspaces(on: bool) -> None:
 
 
 def _scratch(nbytes: int, device) -> torch.Tensor:
-    t = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    t = torch.empty((_alloc_bytes(nbytes),), dtype=torch.uint8, device=device)
     if _poison:
         t.fill_(0xFF)
     return t
