@@ -200,6 +200,22 @@ def main():
     # ones at 0.369 (tools/timed_region_study.py, gpurun_out/r5/timed_region_k20.log); with 250 ms of steps first, the FIRST
     # region runs at 0.372.  A handful of warm-up steps (2-4 ms of work) does not cover the ramp, so the steady state the
     # metric is about is reached first.  (This, not a kernel, is most of the 0.3985 -> 0.36x ms between BENCH_r04 and now.)
+    # The region the driver's flags describe, taken the way rounds 1-4 took it -- --warmup steps, then --steps steps, right
+    # after the scene set-up, before any ramp -- and reported as `first_region_ms_per_step`, so that the series BENCH_r01..r04
+    # (which recorded THIS number as ms_per_step) stays comparable with the steady-state value of round 5 on
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    first_dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([first_dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        first_dt = float(tmax.item())
+    first_region_ms = first_dt / args.steps * 1e3
     ramp_steps, ramp_t0 = 0, time.perf_counter()
     if dist is not None:                       # N ranks: a step holds a collective, so every rank takes the SAME number of steps
         for _ in range(int(args.ramp_ms * 2)):
@@ -300,6 +316,13 @@ def main():
     prof = dgr.profile_collect()
     dgr.profile_enable(False)
     kern = {k: {"avg_us": v[0] / v[1] * 1e3, "launches": v[1]} for k, v in prof.items()}
+    # The bracket itself: two event records with nothing between them (libvtgs records one such pair per forward while the
+    # profile is on).  Every kernel's bracket carries about that much on top of the kernel -- in round 5 the brackets summed to
+    # MORE than the step (365 vs 359 us) -- so it is subtracted, and both figures are printed.
+    bracket_us = kern.pop("_empty_bracket", {"avg_us": 0.0})["avg_us"]
+    for v in kern.values():
+        v["raw_us"] = v["avg_us"]
+        v["avg_us"] = max(v["avg_us"] - bracket_us, 0.0)
     # rank 0's share: all N Gaussians are projected on every rank, pixels and tile instances only for its band
     if tile_rows is None:
         p_rank, r_rank = P, r16
@@ -319,15 +342,25 @@ def main():
             # HBM bytes from the committed PMC passes of the same command (profiles/pmc_traffic.json: separate --pmc FETCH_SIZE /
             # WRITE_SIZE runs, never collected inside this process): `traffic` = the DOMINANT KERNEL's bytes per launch,
             # `traffic_step_total` = all kernels of one step
+            # The file is stamped with the sha256 of the libvtgs.so it was collected on (tools/summarize_profiles.py); a different
+            # library in this process -- a kernel changed since the passes -- prints `traffic: null` and says why, instead of a
+            # stale constant.
             traffic = traffic_total = traffic_src = None
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-                if tile_rows is None and mode == "rasterize" and (N, W, H) == (1_000_000, 1200, 680) and dom in pmc:
+                lib_sha = dgr.library_sha256()
+                if not (tile_rows is None and mode == "rasterize" and (N, W, H) == (1_000_000, 1200, 680) and dom in pmc):
+                    traffic_src = "null: profiles/pmc_traffic.json holds the headline shape in rasterize mode on one GPU only"
+                elif pmc.get("_libvtgs_sha256") != lib_sha:
+                    traffic_src = (f"null: profiles/pmc_traffic.json was collected on libvtgs.so sha256 {str(pmc.get('_libvtgs_sha256'))[:12]} "
+                                   f"(round {pmc.get('_round', '?')}), this process loaded {lib_sha[:12]}: re-run tools/profile_round.sh")
+                else:
                     traffic = pmc[dom]["traffic_bytes"]
                     traffic_total = sum(v["traffic_bytes"] for k, v in pmc.items() if isinstance(v, dict) and "traffic_bytes" in v)
-                    traffic_src = f"profiles/pmc_traffic.json (round {pmc.get('_round', '?')} build, rocprofv3 --pmc passes of this command; not measured in this run)"
-            except (OSError, ValueError, KeyError):
-                pass
+                    traffic_src = (f"profiles/pmc_traffic.json (round {pmc.get('_round', '?')}, rocprofv3 --pmc passes of this command on the "
+                                   f"SAME libvtgs.so, sha256 {lib_sha[:12]}; not measured in this run)")
+            except (OSError, ValueError, KeyError) as e:
+                traffic_src = f"null: {e!r}"
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "traffic_scope": f"{dom}, per launch", "traffic_step_total": traffic_total, "traffic_source": traffic_src,
@@ -491,6 +524,15 @@ def main():
                                   "on one GPU the untimed steps then continue in chunks of 20 until two chunks agree within 3 % (<= 2 s): "
                                   "the first process on a fresh box keeps paying first-touch costs for longer"},
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["avg_us"])},
+            "kernels_us_note": {"event_bracket_us": round(bracket_us, 2),
+                                "raw_us": {k: round(v["raw_us"], 2) for k, v in kern.items()},
+                                "what": "kernels_us = HIP-event bracket around each launch minus the measured cost of an empty bracket "
+                                        "(two event records back to back, one per forward of the profiled steps); raw_us = the brackets as read"},
+            "libvtgs_sha256": dgr.library_sha256(),
+            "first_region_ms_per_step": round(first_region_ms, 4),
+            "first_region_note": "--warmup steps then --steps steps right after the scene set-up, BEFORE the clock ramp: the region "
+                                 "BENCH_r01..r04 recorded as ms_per_step (cold clocks, first-touch costs); ms_per_step / value are the "
+                                 "steady state after `clock_ramp`",
         }
         if tile_rows is not None and kern:
             # what every rank of the partition does over ALL Gaussians (projection, per-Gaussian gradient gather) beside what

@@ -366,6 +366,7 @@ def run(args) -> dict:
 
     track_ms, map_ms, errs_before, errs_after = [], [], [], []
     dens_added, dens_ms = [], []
+    redone = {"tracking": 0, "mapping": 0}           # N ranks: phases redone from their snapshot after a deferred overflow
     torch.cuda.synchronize()
     t_all = time.perf_counter()
     frame_kind, frame_s, second_frac = [], [], []
@@ -382,58 +383,70 @@ def run(args) -> dict:
             params["cam_trans"][..., t] = params["cam_trans"][..., t - 1]
         errs_before.append(pose_error(t))
         # ---- tracking
-        opt = make_adam([{"params": [v], "name": k, "lr": track_lrs[k]} for k, v in params.items()])
+        # N ranks: a run-ahead overflow is recorded, not raised (every rank must take the same decision), and the phase's
+        # optimizer keeps consuming that iteration's invalid gradients until the end of the phase: the phase is redone ONCE from
+        # a snapshot of what its optimizer moves (partition.PhaseSnapshot); the clock covers both attempts
+        snap = pt.PhaseSnapshot(params, ("cam_unnorm_rots", "cam_trans")) if world > 1 else None
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        sil_thres, best = 0.99, (float("inf"), None, None)
-        mse_ls, thr_ls = [], []
-        graph = None
-        for it in range(args.tracking_iters):
-            if args.graph and it >= 1:
-                if graph is None:                  # iteration 0 (the threshold sweep reads the device) ran eagerly; capture 1..
-                    def track_fn(it=it):
-                        return mirror_get_loss(params, curr_data(t), variables, t, {"im": 0.5, "depth": 0.025}, True, 0.99, True,
-                                               False, tracking=True, plot_dir=None, visualize_tracking_loss=False,
-                                               tracking_iteration=it, dataset_name="replica",
-                                               presence_sil_mask_mse_ls=mse_ls, sil_thres_ls=thr_ls)[0]
-                    loss = _losses = None          # (no reference to an earlier iteration's autograd graph survives)
-                    graph, loss = capture(track_fn)
-                graph.replay()
-                if it % 10 == 9 and loss.item() < best[0]:
-                    best = (loss.item(), params["cam_unnorm_rots"][..., t].clone(), params["cam_trans"][..., t].clone())
-                opt.step()                         # eager: one launch; the replay overwrites the gradients, no zero_grad
-                continue
-            if args.get_loss:                      # the call of src/vtgaussian_slam.py:1803-1806, argument for argument
-                loss, variables, _losses, mse_ls, thr_ls = mirror_get_loss(
-                    params, curr_data(t), variables, t, {"im": 0.5, "depth": 0.025}, True, 0.99, True, False, tracking=True,
-                    plot_dir=None, visualize_tracking_loss=False, tracking_iteration=it, dataset_name="replica",
-                    presence_sil_mask_mse_ls=mse_ls, sil_thres_ls=thr_ls)
-            else:
-                im, depth_sil, _ = render_pair(params, t, gaussians_grad=False, camera_grad=True, tile_rows=band, contract=True)
-                if it == 0:
-                    sil_thres = pick_threshold(im, depth_sil[1], gt_im, gt_depth)
-                loss = track_loss(im, depth_sil, gt_im, gt_depth, sil_thres)
-            loss.backward()
-            if world > 1:                          # the pose gradient of the frame = the sum over the bands (7 floats)
-                pose_grad = torch.cat([params["cam_unnorm_rots"].grad.reshape(-1), params["cam_trans"].grad.reshape(-1)])
-                pt.all_reduce_sum(pose_grad)
-                nq = params["cam_unnorm_rots"].grad.numel()
-                params["cam_unnorm_rots"].grad.copy_(pose_grad[:nq].view_as(params["cam_unnorm_rots"].grad))
-                params["cam_trans"].grad.copy_(pose_grad[nq:].view_as(params["cam_trans"].grad))
-            with torch.no_grad():
-                lv = loss.detach()
-                if it % 10 == 9 or it == 0:       # the reference keeps the best pose; checking it costs a host sync
-                    if world > 1:
-                        lv = pt.all_reduce_sum(lv.clone().reshape(1))
-                    if lv.item() < best[0]:
-                        best = (lv.item(), params["cam_unnorm_rots"][..., t].clone(), params["cam_trans"][..., t].clone())
-            opt.step(); opt.zero_grad(set_to_none=True)
-        if graph is not None:
-            torch.cuda.synchronize()
-            dgr.check_captured()
-            del graph
-            dgr.forget_captured()
-            opt.zero_grad(set_to_none=True)
-        owned_done()
+        for attempt in (0, 1):
+          opt = make_adam([{"params": [v], "name": k, "lr": track_lrs[k]} for k, v in params.items()])
+          sil_thres, best = 0.99, (float("inf"), None, None)
+          mse_ls, thr_ls = [], []
+          graph = None
+          for it in range(args.tracking_iters):
+              if args.graph and it >= 1:
+                  if graph is None:                  # iteration 0 (the threshold sweep reads the device) ran eagerly; capture 1..
+                      def track_fn(it=it):
+                          return mirror_get_loss(params, curr_data(t), variables, t, {"im": 0.5, "depth": 0.025}, True, 0.99, True,
+                                                 False, tracking=True, plot_dir=None, visualize_tracking_loss=False,
+                                                 tracking_iteration=it, dataset_name="replica",
+                                                 presence_sil_mask_mse_ls=mse_ls, sil_thres_ls=thr_ls)[0]
+                      loss = _losses = None          # (no reference to an earlier iteration's autograd graph survives)
+                      graph, loss = capture(track_fn)
+                  graph.replay()
+                  if it % 10 == 9 and loss.item() < best[0]:
+                      best = (loss.item(), params["cam_unnorm_rots"][..., t].clone(), params["cam_trans"][..., t].clone())
+                  opt.step()                         # eager: one launch; the replay overwrites the gradients, no zero_grad
+                  continue
+              if args.get_loss:                      # the call of src/vtgaussian_slam.py:1803-1806, argument for argument
+                  loss, variables, _losses, mse_ls, thr_ls = mirror_get_loss(
+                      params, curr_data(t), variables, t, {"im": 0.5, "depth": 0.025}, True, 0.99, True, False, tracking=True,
+                      plot_dir=None, visualize_tracking_loss=False, tracking_iteration=it, dataset_name="replica",
+                      presence_sil_mask_mse_ls=mse_ls, sil_thres_ls=thr_ls)
+              else:
+                  im, depth_sil, _ = render_pair(params, t, gaussians_grad=False, camera_grad=True, tile_rows=band, contract=True)
+                  if it == 0:
+                      sil_thres = pick_threshold(im, depth_sil[1], gt_im, gt_depth)
+                  loss = track_loss(im, depth_sil, gt_im, gt_depth, sil_thres)
+              loss.backward()
+              if world > 1:                          # the pose gradient of the frame = the sum over the bands (7 floats)
+                  pose_grad = torch.cat([params["cam_unnorm_rots"].grad.reshape(-1), params["cam_trans"].grad.reshape(-1)])
+                  pt.all_reduce_sum(pose_grad)
+                  nq = params["cam_unnorm_rots"].grad.numel()
+                  params["cam_unnorm_rots"].grad.copy_(pose_grad[:nq].view_as(params["cam_unnorm_rots"].grad))
+                  params["cam_trans"].grad.copy_(pose_grad[nq:].view_as(params["cam_trans"].grad))
+              with torch.no_grad():
+                  lv = loss.detach()
+                  if it % 10 == 9 or it == 0:       # the reference keeps the best pose; checking it costs a host sync
+                      if world > 1:
+                          lv = pt.all_reduce_sum(lv.clone().reshape(1))
+                      if lv.item() < best[0]:
+                          best = (lv.item(), params["cam_unnorm_rots"][..., t].clone(), params["cam_trans"][..., t].clone())
+              opt.step(); opt.zero_grad(set_to_none=True)
+          if graph is not None:
+              torch.cuda.synchronize()
+              dgr.check_captured()
+              del graph
+              dgr.forget_captured()
+              opt.zero_grad(set_to_none=True)
+          try:
+              owned_done()
+              break
+          except pt.RunAheadOverflow:
+              if attempt:
+                  raise
+              redone["tracking"] += 1
+              snap.restore()
         torch.cuda.synchronize(); track_ms.append((time.perf_counter() - t0) * 1e3 / args.tracking_iters)
         errs_after.append(pose_error(t))
         # ---- densification (the reference's add_new_gaussians_base_frame, ordinary frames only: :2366-2375)
@@ -481,7 +494,6 @@ def run(args) -> dict:
                     dens_added.append(0)
             torch.cuda.synchronize(); dens_ms.append((time.perf_counter() - td0) * 1e3)
         # ---- mapping
-        opt = make_adam([{"params": [v], "name": k, "lr": map_lrs[k]} for k, v in params.items()], lr=0.0, eps=1e-15)
         # Which view an iteration renders, and whether it makes the second call over the global set (module docstring of
         # --base-frame-every).  The draw is the reference's np.random.randint over the submap's frames so far; the same seed
         # on every rank of the N-rank loop.
@@ -492,75 +504,106 @@ def run(args) -> dict:
         rng = np.random.RandomState(1000 + t)
         frame_kind.append("base" if (is_base or E == 0) else "ordinary")
         second_calls = 0
+        snap = pt.PhaseSnapshot(params, [k for k, lr in map_lrs.items() if lr != 0.0]) if world > 1 else None
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        graph = None
-        exchange = make_exchange(params, t, window) if use_owner else None
-        owner_checked = set()
-        for it in range(args.mapping_iters):
-            if E > 0 and not is_base and args.emulate_window > 0:
-                draw = rng.randint(0, args.emulate_window)
-                kf = w0 if draw == 0 else (window[1 + (draw - 1) % (len(window) - 1)] if len(window) > 1 else w0)
-                second = bool(fixed) and kf == w0 and kf % E == 0
-            elif E > 0 and not is_base:
-                kf = window[rng.randint(0, len(window))]
-                second = bool(fixed) and kf == w0 and kf % E == 0
-            else:
-                kf, second = t, bool(fixed)
-            second_calls += int(second)
-            gt_im, gt_depth = gts[kf]
-            if args.graph:
-                if graph is None:
-                    def map_fn():
-                        loss = mirror_get_loss(params, curr_data(t), variables, t, {"im": 1.0, "depth": 1.0}, False, 0.99, True,
-                                               False, mapping=True, dataset_name="replica")[0]
-                        if fixed:
-                            loss = loss + mirror_get_loss(concat_global(), curr_data(t), variables_global, t,
-                                                          {"im": 1.0, "depth": 1.0}, False, 0.99, True, False, mapping=True,
-                                                          dataset_name="replica")[0]
-                        return loss
-                    loss = _losses = None
-                    graph, loss = capture(map_fn)
-                graph.replay()
-                opt.step()
-                continue
-            if args.get_loss:                      # (the mapping loops call it the same way, without the threshold lists)
-                loss, variables, _losses = mirror_get_loss(params, curr_data(kf), variables, kf, {"im": 1.0, "depth": 1.0}, False,
-                                                           0.99, True, False, mapping=True, dataset_name="replica")
-                if second:                         # the second call of the reference's mapping iteration (:2551-2556, :2600-2604)
-                    loss_global, variables_global, _lg = mirror_get_loss(
-                        concat_global(), curr_data(kf), variables_global, kf, {"im": 1.0, "depth": 1.0}, False, 0.99, True, False,
-                        mapping=True, dataset_name="replica")
-                    loss = loss + loss_global
-            else:
-                im, depth_sil, _ = render_pair(params, kf, gaussians_grad=True, camera_grad=False, tile_rows=band, contract=True)
-                loss = map_loss(im, depth_sil, gt_im, gt_depth)
-            loss.backward()
-            if exchange is not None:               # halo gradients -> owner bands; Adam on the owned rows; updated rows -> listers
-                if kf not in owner_checked:
-                    owner_checked.add(kf)
-                    if not exchange.covers(owned_sets[kf]):
-                        raise SystemExit(f"bench_slam.py: the list of view {kf} is not inside the phase's union list")
-                owner_stats["bytes_sent"] += exchange.reduce_grads(params)
-                opt.step(rows=exchange.update_rows)
-                owner_stats["bytes_sent"] += exchange.publish(params)
-                owner_stats["iterations"] += 1
-                opt.zero_grad(set_to_none=True)
-                continue
-            if world > 1:                          # trainable per-Gaussian gradients: one flat all-reduce, 20 B per Gaussian
-                pt.allreduce_param_grads(params)
-            opt.step(); opt.zero_grad(set_to_none=True)
-        if graph is not None:
-            torch.cuda.synchronize()
-            dgr.check_captured()
-            del graph
-            dgr.forget_captured()
-            opt.zero_grad(set_to_none=True)
-        if exchange is not None:
-            exchange.gather_all(params)            # every rank gets every owner's rows back before the next phase
-        owned_done()
+        for attempt in (0, 1):
+          opt = make_adam([{"params": [v], "name": k, "lr": map_lrs[k]} for k, v in params.items()], lr=0.0, eps=1e-15)
+          rng = np.random.RandomState(1000 + t)           # (a redone phase draws the same keyframes)
+          second_calls = 0
+          graph = None
+          exchange = make_exchange(params, t, window) if use_owner else None
+          owner_checked = set()
+          for it in range(args.mapping_iters):
+              if E > 0 and not is_base and args.emulate_window > 0:
+                  draw = rng.randint(0, args.emulate_window)
+                  kf = w0 if draw == 0 else (window[1 + (draw - 1) % (len(window) - 1)] if len(window) > 1 else w0)
+                  second = bool(fixed) and kf == w0 and kf % E == 0
+              elif E > 0 and not is_base:
+                  kf = window[rng.randint(0, len(window))]
+                  second = bool(fixed) and kf == w0 and kf % E == 0
+              else:
+                  kf, second = t, bool(fixed)
+              second_calls += int(second)
+              gt_im, gt_depth = gts[kf]
+              if args.graph:
+                  if graph is None:
+                      def map_fn():
+                          loss = mirror_get_loss(params, curr_data(t), variables, t, {"im": 1.0, "depth": 1.0}, False, 0.99, True,
+                                                 False, mapping=True, dataset_name="replica")[0]
+                          if fixed:
+                              loss = loss + mirror_get_loss(concat_global(), curr_data(t), variables_global, t,
+                                                            {"im": 1.0, "depth": 1.0}, False, 0.99, True, False, mapping=True,
+                                                            dataset_name="replica")[0]
+                          return loss
+                      loss = _losses = None
+                      graph, loss = capture(map_fn)
+                  graph.replay()
+                  opt.step()
+                  continue
+              if args.get_loss:                      # (the mapping loops call it the same way, without the threshold lists)
+                  loss, variables, _losses = mirror_get_loss(params, curr_data(kf), variables, kf, {"im": 1.0, "depth": 1.0}, False,
+                                                             0.99, True, False, mapping=True, dataset_name="replica")
+                  if second:                         # the second call of the reference's mapping iteration (:2551-2556, :2600-2604)
+                      loss_global, variables_global, _lg = mirror_get_loss(
+                          concat_global(), curr_data(kf), variables_global, kf, {"im": 1.0, "depth": 1.0}, False, 0.99, True, False,
+                          mapping=True, dataset_name="replica")
+                      loss = loss + loss_global
+              else:
+                  im, depth_sil, _ = render_pair(params, kf, gaussians_grad=True, camera_grad=False, tile_rows=band, contract=True)
+                  loss = map_loss(im, depth_sil, gt_im, gt_depth)
+              loss.backward()
+              if exchange is not None:               # halo gradients -> owner bands; Adam on the owned rows; updated rows -> listers
+                  if kf not in owner_checked:
+                      owner_checked.add(kf)
+                      if not exchange.covers(owned_sets[kf]):
+                          raise SystemExit(f"bench_slam.py: the list of view {kf} is not inside the phase's union list")
+                  owner_stats["bytes_sent"] += exchange.reduce_grads(params)
+                  opt.step(rows=exchange.update_rows)
+                  owner_stats["bytes_sent"] += exchange.publish(params)
+                  owner_stats["iterations"] += 1
+                  opt.zero_grad(set_to_none=True)
+                  continue
+              if world > 1:                          # trainable per-Gaussian gradients: one flat all-reduce, 20 B per Gaussian
+                  pt.allreduce_param_grads(params)
+              opt.step(); opt.zero_grad(set_to_none=True)
+          if graph is not None:
+              torch.cuda.synchronize()
+              dgr.check_captured()
+              del graph
+              dgr.forget_captured()
+              opt.zero_grad(set_to_none=True)
+          if exchange is not None:
+              exchange.gather_all(params)            # every rank gets every owner's rows back before the next phase
+          try:
+              owned_done()
+              break
+          except pt.RunAheadOverflow:
+              if attempt:
+                  raise
+              redone["mapping"] += 1
+              snap.restore()
         torch.cuda.synchronize(); map_ms.append((time.perf_counter() - t0) * 1e3 / args.mapping_iters)
         frame_s.append(time.perf_counter() - t_frame)
         second_frac.append(second_calls / max(args.mapping_iters, 1))
+        if os.environ.get("VTGS_SLAM_SPLAT_SIZES") and t % int(os.environ["VTGS_SLAM_SPLAT_SIZES"]) == 0:
+            # diagnostic (round 6): how many 8x8-tile instances each Gaussian has under the current view -- through the plain
+            # operator over the same bins (the fused route keeps no handle on its workspace)
+            with torch.no_grad():
+                tg = sc.transform_to_frame(params, t, gaussians_grad=False, camera_grad=False)
+                rv = sc.transformed_params2rendervar(params, tg)
+                rast = dgr.GaussianRasterizer(raster_settings=settings)
+                _c, rad, _d = rast(**rv)
+                offs, gid, _geom = dgr.debug_tile_lists(rast)
+                per = torch.bincount(gid, minlength=rad.numel())
+                edges = [0, 1, 2, 3, 5, 7, 9, 13, 17, 33, 65, 257, 1 << 30]
+                hist = {f"{a}..{b - 1}": int(((per >= a) & (per < b)).sum()) for a, b in zip(edges[:-1], edges[1:])}
+                r = rad.float().cpu()
+                sc_now = torch.exp(params["log_scales"].detach()).reshape(-1).cpu()
+                print(f"[bench_slam] frame {t}: N {rad.numel()}, instances {int(per.sum())}, per-Gaussian instance histogram {hist}; "
+                      f"radius p50 {r.quantile(0.5):.0f} p99 {r.quantile(0.99):.0f} p99.9 {r.quantile(0.999):.0f} max {r.max():.0f}; "
+                      f"scale ratio to the first frame's median: p50 {float(sc_now.median() / scene['scales'][:, 0].median()):.2f} "
+                      f"p99 {float(sc_now.quantile(0.99) / scene['scales'][:, 0].median()):.2f} max {float(sc_now.max() / scene['scales'][:, 0].median()):.2f}",
+                      file=sys.stderr, flush=True)
         if os.environ.get("VTGS_SLAM_VERBOSE"):
             print(f"[bench_slam] frame {t}: tracking {track_ms[-1]:.3f} ms/it, mapping {map_ms[-1]:.3f} ms/it, "
                   f"instances {dgr.last_forward_info().get('instances')}, longest tile list {dgr.last_forward_info().get('max_tile_list')}", file=sys.stderr, flush=True)
@@ -619,6 +662,7 @@ def run(args) -> dict:
             "ms_per_frame_mean": round(sum(dens_ms) / max(len(dens_ms), 1), 2), "gaussians_at_the_end": int(params["means3D"].shape[0]),
             "what": "forward-only render + depth_error.median() + back-projection + append, every ordinary frame "
                     "(src/vtgaussian_slam.py:732-813)"},
+        "phases_redone_after_a_run_ahead_overflow": None if world == 1 else redone,
         "owned_sets": None if not use_owned else {
             "lists_built": owned_stats["built"], "mean_listed_fraction_of_map": round(owned_stats["listed"] / max(owned_stats["built"], 1) / N, 4),
             "escapes": owned_stats["escapes"], "margin_px": 32.0, "scale_growth": 1.25, "rank": rank},

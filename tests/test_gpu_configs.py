@@ -136,9 +136,12 @@ def _hip_instance_keys(rast):
     return (tile_of << 32) | gid, offs, gid, geom
 
 
-@pytest.mark.parametrize("n,w,h,kind", [(3000, 160, 120, "tied"), (60000, 152, 104, "tied"), (5000, 200, 136, "aniso"),
-                                        (4000, 333, 201, "iso"), (1_000_000, 1200, 680, "tied")])
-def test_tile_lists_equal_the_oracle_lists(gpu_device, n, w, h, kind):
+@pytest.mark.parametrize("n,w,h,kind,rule", [(3000, 160, 120, "tied", "3sigma"), (60000, 152, 104, "tied", "3sigma"),
+                                             (5000, 200, 136, "aniso", "3sigma"), (4000, 333, 201, "iso", "3sigma"),
+                                             (1_000_000, 1200, 680, "tied", "3sigma"),
+                                             # the tile rectangles of the other radius rule
+                                             (60000, 152, 104, "tied", "opacity"), (5000, 200, 136, "aniso", "opacity")])
+def test_tile_lists_equal_the_oracle_lists(gpu_device, n, w, h, kind, rule):
     """Index parity (bit-exact work): the kernel's 8x8 lists against the oracle's 16x16 parent lists filtered by the exact
     reach predicate.  Membership: strict oracle set <= kernel set <= oracle set with twice the kernel's documented slack
     (a member of the band contributes alpha < 1/255 everywhere in the tile: output-invariant).  Order: the kernel's depth
@@ -150,13 +153,13 @@ def test_tile_lists_equal_the_oracle_lists(gpu_device, n, w, h, kind):
     else:
         scene, cam = go.random_scene(n, w, h, seed=n % 89, anisotropic=(kind == "aniso"))
     dev = gpu_device
-    rast = dgr.GaussianRasterizer(raster_settings=to_settings(cam, dev))
+    rast = dgr.GaussianRasterizer(raster_settings=to_settings(cam, dev), radius_rule=rule)
     with torch.no_grad():
         _, radii, _ = rast(**{k: v.to(dev) for k, v in scene.items()})
     hip_keys, offs, gid, geom = _hip_instance_keys(rast)
     with torch.no_grad():
         f = {k: v.double() for k, v in scene.items()}
-        sp = go.preprocess(f["means3D"], f["means2D"], f["opacities"], f["scales"], f["rotations"], cam)
+        sp = go.preprocess(f["means3D"], f["means2D"], f["opacities"], f["scales"], f["rotations"], cam, rule)
     same_rect = sp.radii == radii.cpu()               # a float32 ceil() on the other side moves the rectangle: exclude those
     assert (~same_rect).double().mean().item() <= 1e-3
     strict = oracle_instances_8x8(sp, scene["opacities"], cam)

@@ -4,7 +4,12 @@ Round 4 met a GPU memory access fault because a launcher chose the single-render
 header lets be NULL at n = 0.  Here EVERY exported render / backward / frame / pose / bookkeeping entry point is
 called with n = 0 and NULL per-Gaussian arrays, on poisoned images and workspaces: the call returns VTGS_OK, a forward writes
 the background colour into every pixel (depth 0, final transmittance 1, record: zero instances), a backward and the helpers
-touch nothing they should not, and nothing faults.  Run ONCE (a fault is a fault, not a flake)."""
+touch nothing they should not, and nothing faults.  Run ONCE (a fault is a fault, not a flake).
+
+Every call is followed by a synchronise OF ITS OWN (`_call`): the fault of an asynchronous launch surfaces at the next
+synchronise, and round 5 met an abort at a synchronise that stood behind ten entry points -- raised on a runtime thread, without
+the runtime's memory-fault line -- whose launcher could not be named afterwards.  With one synchronise per entry
+point the traceback's line IS the entry point."""
 import ctypes
 
 import pytest
@@ -15,6 +20,12 @@ from parity_util import to_settings
 
 pytestmark = pytest.mark.gpu
 NULL = None
+
+
+def _call(lib, name, *args, what=None):
+    st = getattr(lib, name)(*args)
+    assert st == 0, (name, what, lib.vtgs_strerror(st))
+    torch.cuda.synchronize()               # this entry point's launches have retired (or the process has died HERE)
 
 
 def _blocks(lib, dev, W, H, cap, tcap, dual):
@@ -89,51 +100,47 @@ def test_every_entry_point_with_an_empty_map(gpu_device, band):
     # ---- backwards: nothing to differentiate, nothing touched --------------------------------------------------------------
     g = torch.rand(3, H, W, device=dev)
     scratch = torch.full((256,), 0xFF, dtype=torch.uint8, device=dev)
-    st = lib.vtgs_backward(c, 0, NULL, NULL, NULL, NULL, NULL, kept[2].data_ptr(), g.data_ptr(), ws.data_ptr(), nbytes, cap, tcap,
-                           NULL, scratch.data_ptr(), 256, NULL, NULL, NULL, NULL, NULL, NULL, stream)
-    assert st == 0, lib.vtgs_strerror(st)
+    _call(lib, "vtgs_backward", c, 0, NULL, NULL, NULL, NULL, NULL, kept[2].data_ptr(), g.data_ptr(), ws.data_ptr(), nbytes, cap, tcap,
+          NULL, scratch.data_ptr(), 256, NULL, NULL, NULL, NULL, NULL, NULL, stream)
     nbd, wsd, ad, bd = kept_dual
-    st = lib.vtgs_backward_dual(c, 0, NULL, NULL, NULL, NULL, NULL, NULL, ad.data_ptr(), bd.data_ptr(), g.data_ptr(), g.data_ptr(),
-                                wsd.data_ptr(), nbd, cap, tcap, scratch.data_ptr(), 256, NULL, NULL, NULL, NULL, NULL, NULL, NULL, stream)
-    assert st == 0, lib.vtgs_strerror(st)
+    _call(lib, "vtgs_backward_dual", c, 0, NULL, NULL, NULL, NULL, NULL, NULL, ad.data_ptr(), bd.data_ptr(), g.data_ptr(), g.data_ptr(),
+          wsd.data_ptr(), nbd, cap, tcap, scratch.data_ptr(), 256, NULL, NULL, NULL, NULL, NULL, NULL, NULL, stream)
     q = torch.tensor([1.0, 0, 0, 0], device=dev)
     t = torch.zeros(3, device=dev)
     w2c = torch.eye(4, device=dev).reshape(-1).contiguous()
-    for flags in (1, 2, 4, 7):
-        st = lib.vtgs_backward_dual_frame(c, 0, NULL, NULL, NULL, NULL, NULL, NULL, ad.data_ptr(), bd.data_ptr(), g.data_ptr(),
-                                          g.data_ptr(), wsd.data_ptr(), nbd, cap, tcap, scratch.data_ptr(), 256, flags, NULL, NULL,
-                                          q.data_ptr(), t.data_ptr(), w2c.data_ptr(), NULL, NULL, NULL, NULL, NULL, NULL, stream)
-        assert st == 0, (flags, lib.vtgs_strerror(st))
-        st = lib.vtgs_backward_dual_frame_owned(c, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL, ad.data_ptr(), bd.data_ptr(),
-                                                g.data_ptr(), g.data_ptr(), wsd.data_ptr(), nbd, cap, tcap, scratch.data_ptr(), 256,
-                                                flags, NULL, NULL, q.data_ptr(), t.data_ptr(), w2c.data_ptr(), NULL, NULL, NULL, NULL,
-                                                NULL, NULL, stream)
-        assert st == 0, (flags, lib.vtgs_strerror(st))
+    for flags in (1, 2, 4, 7, 2 | 8, 7 | 8):
+        _call(lib, "vtgs_backward_dual_frame", c, 0, NULL, NULL, NULL, NULL, NULL, NULL, ad.data_ptr(), bd.data_ptr(), g.data_ptr(),
+              g.data_ptr(), wsd.data_ptr(), nbd, cap, tcap, scratch.data_ptr(), 256, flags, NULL, NULL,
+              q.data_ptr(), t.data_ptr(), w2c.data_ptr(), NULL, NULL, NULL, NULL, NULL, NULL, stream, what=flags)
+        _call(lib, "vtgs_backward_dual_frame_owned", c, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL, ad.data_ptr(), bd.data_ptr(),
+              g.data_ptr(), g.data_ptr(), wsd.data_ptr(), nbd, cap, tcap, scratch.data_ptr(), 256,
+              flags, NULL, NULL, q.data_ptr(), t.data_ptr(), w2c.data_ptr(), NULL, NULL, NULL, NULL,
+              NULL, NULL, stream, what=flags)
+    assert bool((scratch == 0xFF).all()), "an empty backward wrote into its scratch"
 
     # ---- the caller chain around the operator ---------------------------------------------------------------------------------
-    assert lib.vtgs_prepare_frame(0, NULL, NULL, NULL, NULL, q.data_ptr(), t.data_ptr(), w2c.data_ptr(), NULL, NULL, NULL, NULL, NULL,
-                                  stream) == 0
-    assert lib.vtgs_prepare_frame_owned(0, NULL, NULL, NULL, NULL, NULL, NULL, q.data_ptr(), t.data_ptr(), w2c.data_ptr(), NULL, NULL,
-                                        NULL, NULL, NULL, NULL, stream) == 0
-    assert lib.vtgs_prepare_frame_backward(0, 7, NULL, NULL, NULL, NULL, q.data_ptr(), t.data_ptr(), w2c.data_ptr(), *([NULL] * 14),
-                                           stream) == 0
+    _call(lib, "vtgs_prepare_frame", 0, NULL, NULL, NULL, NULL, q.data_ptr(), t.data_ptr(), w2c.data_ptr(), NULL, NULL, NULL, NULL, NULL,
+          stream)
+    _call(lib, "vtgs_prepare_frame_owned", 0, NULL, NULL, NULL, NULL, NULL, NULL, q.data_ptr(), t.data_ptr(), w2c.data_ptr(), NULL, NULL,
+          NULL, NULL, NULL, NULL, stream)
+    _call(lib, "vtgs_prepare_frame_backward", 0, 7, NULL, NULL, NULL, NULL, q.data_ptr(), t.data_ptr(), w2c.data_ptr(), *([NULL] * 14),
+          stream)
     assert lib.vtgs_pose_partial_rows(0) == 0
     gq = torch.full((4,), float("nan"), device=dev)
     gt = torch.full((3,), float("nan"), device=dev)
-    assert lib.vtgs_pose_gradient(NULL, 0, q.data_ptr(), gq.data_ptr(), gt.data_ptr(), stream) == 0
+    _call(lib, "vtgs_pose_gradient", NULL, 0, q.data_ptr(), gq.data_ptr(), gt.data_ptr(), stream)
+    assert torch.equal(gq.cpu(), torch.zeros(4)) and torch.equal(gt.cpu(), torch.zeros(3))
     out7 = torch.full((7,), float("nan"), device=dev)
-    assert lib.vtgs_pose7_reduce(0, NULL, NULL, NULL, out7.data_ptr(), stream) == 0
-    torch.cuda.synchronize()
-    assert torch.equal(gq.cpu(), torch.zeros(4)) and torch.equal(gt.cpu(), torch.zeros(3)) and torch.equal(out7.cpu(), torch.zeros(7))
-    assert lib.vtgs_mark_visible(c, 0, NULL, NULL, stream) == 0
+    _call(lib, "vtgs_pose7_reduce", 0, NULL, NULL, NULL, out7.data_ptr(), stream)
+    assert torch.equal(out7.cpu(), torch.zeros(7))
+    _call(lib, "vtgs_mark_visible", c, 0, NULL, NULL, stream)
     esc = torch.zeros(1, dtype=torch.int32, device=dev)
-    assert lib.vtgs_band_owner_mask(c, 0, NULL, NULL, 1, NULL, NULL, 32.0, 1.25, NULL, NULL, NULL, esc.data_ptr(), stream) == 0
-    assert lib.vtgs_seen_and_max_radius(0, NULL, NULL, NULL, stream) == 0
+    _call(lib, "vtgs_band_owner_mask", c, 0, NULL, NULL, 1, NULL, NULL, 32.0, 1.25, NULL, NULL, NULL, esc.data_ptr(), stream)
+    _call(lib, "vtgs_seen_and_max_radius", 0, NULL, NULL, NULL, stream)
     grp = (optim._Group * 1)()
     grp[0] = optim._Group(None, None, None, None, 0, 1e-3, 1e-15)
-    assert lib.vtgs_adam_step(grp, 1, 1, 0.9, 0.999, stream) == 0
-    assert lib.vtgs_adam_step_rows(grp, 1, 1, 0.9, 0.999, NULL, 0, 1, stream) == 0
-    torch.cuda.synchronize()
+    _call(lib, "vtgs_adam_step", grp, 1, 1, 0.9, 0.999, stream)
+    _call(lib, "vtgs_adam_step_rows", grp, 1, 1, 0.9, 0.999, NULL, 0, 1, stream)
     assert int(esc.item()) == 0
 
 

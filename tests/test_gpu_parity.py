@@ -111,6 +111,35 @@ def test_forward_backward_parity(gpu_device, name):
     _check_grads(ref_g, got_g, taint)
 
 
+@pytest.mark.parametrize("name", ["view_tied_dense", "random_aniso"])
+@pytest.mark.parametrize("rule,mod", [("opacity", 1.0), ("3sigma", 0.7), ("opacity", 1.6)])
+def test_parity_under_the_radius_rule_switch_and_a_scale_modifier(gpu_device, name, rule, mod):
+    """The two exported switches of VtgsCamera that no reference config moves, on the device against the oracle under the SAME
+    switch: `radius_rule="opacity"` -- the only stand-in for the fork's unreadable "smallerGSradii"
+    (/root/reference/requirements.txt:19): radius = min(ceil(3 sqrt(lambda)), ceil(sqrt(2 ln(255 o) lambda))) -- and
+    `scale_modifier != 1` (/root/reference/utils/recon_helpers.py:19 always passes 1.0; the operator multiplies every scale by
+    it and dL/dscales carries the factor).  Images, radii and all six gradients, same criteria as
+    test_forward_backward_parity."""
+    scene, cam = SCENES[name]()
+    cam = cam._replace(scale_modifier=mod)
+    g = torch.Generator().manual_seed(77)
+    grad_color = torch.rand(3, cam.image_height, cam.image_width, generator=g) * 2 - 1
+    ref_c, ref_r, ref_d, ref_g, aux = run_oracle(scene, cam, grad_color, radius_rule=rule)
+    got_c, got_r, got_d, got_g = run_hip(scene, cam, gpu_device, grad_color, radius_rule=rule)
+    if rule == "opacity":           # the switch is live: some radii are below the 3-sigma ones (else this test checks nothing)
+        r3 = run_oracle(scene, cam, radius_rule="3sigma")[1]
+        assert int((ref_r < r3).sum()) > 0.05 * int((r3 > 0).sum()), "the opacity rule changed (almost) no radius in this scene"
+    if mod != 1.0:                  # ... and so is the modifier: the radii of the unmodified camera differ
+        r1 = run_oracle(scene, cam._replace(scale_modifier=1.0), radius_rule=rule)[1]
+        assert int((ref_r != r1).sum()) > 0.05 * int((r1 > 0).sum())
+    diff = (ref_r != got_r)        # float32 log / sqrt / ceil on the other side of an integer
+    assert diff.double().mean().item() <= 2e-3, f"radii differ for {diff.sum().item()} splats"
+    assert ((ref_r > 0) != (got_r > 0)).sum().item() <= 2
+    taint = _check_images(ref_c, ref_d, got_c, got_d, audit=(aux, scene["opacities"], cam))
+    taint |= tainted_gaussians(aux, tiles_of(aux, diff, cam), diff.numel())
+    _check_grads(ref_g, got_g, taint)
+
+
 def test_a_frame_smaller_than_one_tile(gpu_device):
     """5 x 3 pixels: one 8x8 tile with 15 live lanes, three of a workgroup's four wavefronts without a tile.  Images as
     everywhere; the gradients against the largest element of their tensor (fifteen pixels under 25 anisotropic splats: the

@@ -17,10 +17,11 @@
 #          stamps:<lib>     tools/forward_stamps.py with a -DVTGS_Q_STAMPS build
 #          slam:<args>      python bench_slam.py <args>
 #          py:<file>[:args] python <file> <args>
+#          sh:<script>[:args] bash <script> <args>     (commas for spaces: sh:tools/trace_slam_late.sh:a,22,--densify)
 #          profile          tools/profile_round.sh <tag>
 set -o pipefail
 TAG=$1; shift
-ROUND=${VTGS_ROUND:-r4}
+ROUND=${VTGS_ROUND:-r6}; export VTGS_ROUND=$ROUND
 R=$PWD; O=$R/gpurun_out/$ROUND; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 LIMIT=${VTGS_STEP_TIMEOUT:-900}
@@ -53,6 +54,7 @@ for step in "$@"; do
     stamps)  VTGS_LIBRARY=$R/vtgaussian-slam_amd/lib/$arg VTGS_TAIL=40 run $O/stamps_${TAG}.log python tools/forward_stamps.py ;;
     slam)    run $O/slam_$TAG.log python bench_slam.py ${arg//,/ } ;;
     py)      f=${arg%%:*}; a=""; [ "$arg" != "$f" ] && a=${arg#*:}; VTGS_TAIL=${VTGS_TAIL:-30} run $O/py_${TAG}_$(basename $f .py).log python $f ${a//,/ } ;;
+    sh)      f=${arg%%:*}; a=""; [ "$arg" != "$f" ] && a=${arg#*:}; VTGS_TAIL=${VTGS_TAIL:-60} run $O/sh_${TAG}_$(basename $f .sh).log bash $f ${a//,/ } ;;
     profile) run $O/profile_$TAG.log bash tools/profile_round.sh $TAG ;;
     *) echo "unknown step $step"; exit 64 ;;
   esac

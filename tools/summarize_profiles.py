@@ -46,7 +46,10 @@ for fused in ("sort_tiles", "finalize_forward"):      # done inside the forward 
 w = pmc(find("pmc_write", "counter_collection.csv"), "WRITE_SIZE")
 out = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 5 --warmup 2 "
                 "--no-cpu-baseline`; traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE "
-                "correction of MI355X_MICROARCH.md); workload N=1M, 1200x680", "_round": tag}
+                "correction of MI355X_MICROARCH.md); workload N=1M, 1200x680", "_round": tag,
+       # the build the passes ran on (the bench line of the same script run carries it): bench.py quotes these bytes only for
+       # a process that loaded the same library
+       "_libvtgs_sha256": b.get("libvtgs_sha256")}
 for k in alg:
     if k in f and k in w:
         out[k] = {"fetch_kb": round(f[k][0]), "write_kb": round(w[k][0]),

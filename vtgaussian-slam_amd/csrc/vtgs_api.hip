@@ -306,6 +306,10 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
     cs.bin_plan = (const uint32_t*)(ws + L.plan); cs.bin_limit = L.tiles8 * L.tile_cap;
   }
 
+  // (per-kernel profiling only) an EMPTY bracket: what two event records cost with nothing between them -- every kernel's bracket
+  // is inflated by about that much (the brackets of round 5 summed to more than the step); vtgs_profile_collect reports it as
+  // "_empty_bracket" and bench.py subtracts it
+  { ProfScope ps__("_empty_bracket", st); }
   // counters + per-tile list lengths in one fill (adjacent in the layout, padded to 256 B).  (Round 5, measured and dropped:
   // clearing inside project_and_bin under a token costs +27 us -- the check sits on every workgroup's latency chain -- and a
   // clear kernel of this library takes the same 4.6-5 us as the runtime's fill; profiles/r5_negative_results.md)

@@ -75,8 +75,19 @@ inline int64_t counted_instances(int status, int64_t fwd_flags, int64_t slot_ptr
 std::atomic<bool> g_check_in_backward{true}, g_defer_overflow{false};
 std::atomic<int64_t> g_deferred{0};
 
-void check_run_ahead(int64_t slot_ptr, int64_t fwd_flags) {
+// The records are handed out round-robin (64 per device and stream) and a record is settled and handed on 64 forwards later: a
+// backward that runs that late (a retained graph, many evaluation renders in between) would read ANOTHER forward's record --
+// spin on its complete = 0, report its overflow as this one's, or mark it reported so that its own backward stays silent
+// (ADVICE r5).  The host keeps a generation number in the spare bytes of the 64-byte slot (bytes 48..55, which the device
+// never writes; the Python pool bumps it whenever the slot changes hands); the node remembers the generation it was given and
+// skips the check when the slot has moved on -- the pool settled this forward's verdict before it handed the slot on.
+inline int64_t slot_generation(int64_t slot_ptr) {
+  return slot_ptr ? (int64_t)*reinterpret_cast<volatile uint64_t*>(slot_ptr + (int64_t)sizeof(VtgsForwardInfo)) : 0;
+}
+
+void check_run_ahead(int64_t slot_ptr, int64_t fwd_flags, int64_t generation) {
   if (!g_check_in_backward.load() || slot_ptr == 0 || (fwd_flags & VTGS_FORWARD_MODE_MASK) != VTGS_FORWARD_ASYNC) return;
+  if (slot_generation(slot_ptr) != generation) return;          // the slot belongs to a later forward now
   volatile VtgsForwardInfo* info = reinterpret_cast<volatile VtgsForwardInfo*>(slot_ptr);
   if (!info->complete) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -152,6 +163,7 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     ctx->save_for_backward({means3D, colors, opac, scales, rot, color, workspace, cam_bytes, bg, view, proj});
     ctx->saved_data["instances"] = counted_instances(st, flags, slot_ptr);
     ctx->saved_data["slot_ptr"] = slot_ptr;
+    ctx->saved_data["slot_gen"] = slot_generation(slot_ptr);
     ctx->saved_data["fwd_flags"] = flags;
     ctx->saved_data["capacity"] = capacity;
     ctx->saved_data["tile_cap"] = tile_cap;
@@ -210,7 +222,7 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
                                    gp[0], gp[1], gp[2], gp[3], gp[4], gp[5], reinterpret_cast<void*>(stream));
       TORCH_CHECK(st == VTGS_OK, "vtgs_backward failed: ", vtgs_strerror(st), " (", vtgs_last_hip_error(), ")");
     }
-    check_run_ahead(ctx->saved_data["slot_ptr"].toInt(), ctx->saved_data["fwd_flags"].toInt());   // (after the launches)
+    check_run_ahead(ctx->saved_data["slot_ptr"].toInt(), ctx->saved_data["fwd_flags"].toInt(), ctx->saved_data["slot_gen"].toInt());   // (after the launches)
     at::Tensor none;
     return {g[0], g[1], g[2], g[3], g[4], g[5], none, none, none, none, none, none, none, none, none, none};
   }
@@ -302,6 +314,7 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
                             idx_saved});
     ctx->saved_data["instances"] = counted_instances(st, fwd_flags, slot_ptr);
     ctx->saved_data["slot_ptr"] = slot_ptr;
+    ctx->saved_data["slot_gen"] = slot_generation(slot_ptr);
     ctx->saved_data["fwd_flags"] = fwd_flags;
     ctx->saved_data["capacity"] = capacity;
     ctx->saved_data["tile_cap"] = tile_cap;
@@ -374,7 +387,7 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
       g_q = at::zeros({4}, f32); g_t = at::zeros({3}, f32);
     }
     if (n == 0 && !owned && width > 0) flat.zero_();
-    check_run_ahead(ctx->saved_data["slot_ptr"].toInt(), ctx->saved_data["fwd_flags"].toInt());   // (after the launches)
+    check_run_ahead(ctx->saved_data["slot_ptr"].toInt(), ctx->saved_data["fwd_flags"].toInt(), ctx->saved_data["slot_gen"].toInt());   // (after the launches)
     at::Tensor none;
     return {g_means3D, g_rgb, g_ur, g_logit.defined() ? g_logit : none, g_ls.defined() ? g_ls : none, g_q, g_t,
             none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};

@@ -197,6 +197,20 @@ def last_forward_info() -> dict:
     return dict(_last_info)
 
 
+_lib_sha = None
+
+
+def library_sha256() -> str:
+    """sha256 of the libvtgs.so this process loaded: measurements kept in files (profiles/pmc_traffic.json) name the build they
+    were taken on, and bench.py refuses to quote them for another one."""
+    global _lib_sha
+    if _lib_sha is None:
+        import hashlib
+        with open(os.path.abspath(_LIB_PATH), "rb") as f:
+            _lib_sha = hashlib.sha256(f.read()).hexdigest()
+    return _lib_sha
+
+
 def profile_enable(on: bool) -> None:
     """Bracket every kernel launch of the library with HIP events on its stream (measurement phases only)."""
     _check(_lib.vtgs_profile_enable(1 if on else 0), "vtgs_profile_enable")
@@ -347,6 +361,9 @@ class _SlotPool:
         self.ptr = [base + 64 * i for i in range(total)]
         self.info = [_VtgsForwardInfo.from_address(a) for a in self.ptr]
         self.owner = [None] * self.SLOTS           # the _ForwardState whose record is still unread
+        # bytes 48..55 of a slot (the device writes the 48-byte record only): the slot's GENERATION, bumped whenever it changes
+        # hands -- the C++ nodes remember the one they were given and leave a slot that has moved on alone
+        self.gen = [ctypes.c_uint64.from_address(a + 48) for a in self.ptr]
         self.next = 0
         self.next_graph = self.SLOTS
         self.pending = collections.deque()         # run-ahead forwards whose record has not been read, oldest first
@@ -355,6 +372,7 @@ class _SlotPool:
         if self.next_graph >= self.SLOTS + self.GRAPH_SLOTS:
             raise RuntimeError("too many forwards captured into graphs on this stream (64 result records)")
         self.next_graph += 1
+        self.gen[self.next_graph - 1].value += 1
         return self.next_graph - 1
 
     def take(self, fs):
@@ -364,6 +382,7 @@ class _SlotPool:
         if prev is not None:                       # 64 forwards later: its record has long landed
             _settle(prev)
         self.owner[i] = fs
+        self.gen[i].value += 1
         return i
 
 
@@ -620,10 +639,11 @@ def _choose_capacities(key, n):
         seed = _last_shape.get(view)
         if seed is not None and seed[0] > 0 and n > 0 and seed[0] != n:      # (the same n again: its tables were cleared on purpose)
             scale = max(1.0, n / float(seed[0]))
+            if len(_capacity_hint) >= _POLICY_KEYS_MAX:            # a seeded shape is a new key like any other
+                _evict_policy_keys()
             _capacity_hint[key] = need_i = int(seed[1] * scale) + 1
             _tile_cap_hint[key] = need_t = int(seed[2] * min(scale, 2.0)) + 1
-            if seed[3]:
-                _slots_hint[key] = int(seed[3] * scale) + 1
+            _slots_hint[key] = max(int(seed[3] * scale), 0) + 1     # (always present: _record_info stores `need_s or 1` too)
         else:
             return 8 * n + 65536, (PLANNED | 512) if _BINS_MODE == "planned" else 512
     cap, tcap = _caps_in_use.get(key, (0, 0))
@@ -632,7 +652,7 @@ def _choose_capacities(key, n):
     if need_i * _RUN_AHEAD_HEADROOM > cap or need_i * 12 < cap:
         cap = max(int(need_i * (_RUN_AHEAD_HEADROOM * 1.2)) + 4096, 4 * n + 4096)
     if _wants_planned(key, _tile_capacity_for(need_t)):
-        tiles, need_s = _tiles8(key[2], key[3]), _slots_hint[key]
+        tiles, need_s = _tiles8(key[2], key[3]), _slots_hint.get(key, 1)
         have = (tcap & ~PLANNED) * tiles if tcap & PLANNED else 0
         if need_s * 1.1 > have or need_s * 4 < have:
             tcap = _planned_capacity(key, need_s)

@@ -143,23 +143,62 @@ def phase_escapes(owned_sets, group=None) -> int:
     return int(total.item())
 
 
+class PhaseSnapshot:
+    """What "redo the phase" needs.  With deferred run-ahead overflows the iteration that overflowed still ran to its
+    end on every rank: the overflowing rank rendered the BACKGROUND for its band, its gradients went into the collectives, and
+    `optimizer.step()` applied them -- and so did every later iteration of the phase, until `phase_overflows` raises.  Redoing the
+    phase is only correct from the state BEFORE it: take a snapshot of every tensor the phase's optimizer moves (and nothing
+    else: the tracking phase moves the two camera tensors, 7 T floats; the mapping phase the trainable Gaussian groups), run the
+    phase, and on the error `restore()` and build a fresh optimizer (its moments belong to the discarded steps).
+
+        snap = PhaseSnapshot(params, ("cam_unnorm_rots", "cam_trans"))
+        try:
+            run_the_phase(); partition.phase_overflows()
+        except partition.RunAheadOverflow:
+            snap.restore(); optimizer = make_optimizer(); run_the_phase(); partition.phase_overflows()
+
+    bench_slam.py's N-rank loop does exactly this (one redo: the capacities were raised where it happened)."""
+
+    def __init__(self, params, keys):
+        self.params, self.saved = params, {k: params[k].detach().clone() for k in keys}
+
+    def restore(self) -> None:
+        import torch
+        with torch.no_grad():
+            for k, v in self.saved.items():
+                self.params[k].copy_(v)
+                self.params[k].grad = None
+
+
+class RunAheadOverflow(RuntimeError):
+    """Raised by `phase_overflows` on EVERY rank together."""
+
+
 def phase_overflows(group=None, device=None) -> int:
     """End of a phase on N ranks, with `diff_gaussian_rasterization.defer_run_ahead_overflow(True)`: the run-ahead overflows the
-    ranks recorded during the phase, summed over all ranks (one small all-reduce), and the SAME error on every rank when the sum is
-    not zero -- a rank raising alone, inside its `backward()`, would leave the others in the next collective.  The
-    capacities have already been raised where it happened: redo the phase."""
+    ranks recorded during the phase, summed over all ranks (one small all-reduce), and the SAME error (`RunAheadOverflow`) on
+    every rank when the sum is not zero -- a rank raising alone, inside its `backward()`, would leave the others in the next
+    collective.  The capacities have already been raised where it happened; the parameters and the optimizer
+    state are those of a phase that consumed invalid gradients: restore them (`PhaseSnapshot`) and redo the phase.
+    `device`: where the one-float count lives for the all-reduce; default: the current HIP device when the group's backend
+    reduces device tensors (RCCL), the host otherwise (gloo)."""
     import torch
     import torch.distributed as dist
     import diff_gaussian_rasterization as dgr
     dgr.settle_pending()                              # (deferred: records, does not raise)
-    total = torch.tensor([float(dgr.deferred_overflows())], dtype=torch.float32, device=device or "cpu")
+    if device is None:
+        device = "cpu"
+        if dist.is_available() and dist.is_initialized() and not _host_staged(group) and torch.cuda.is_available():
+            device = torch.device("cuda", torch.cuda.current_device())
+    total = torch.tensor([float(dgr.deferred_overflows())], dtype=torch.float32, device=device)
     if dist.is_available() and dist.is_initialized():
         all_reduce_sum(total, group)
     n = int(total.item())
     if n:
-        raise RuntimeError(f"{n} run-ahead forward(s) overflowed their workspace on some rank during this phase: the images and "
-                           "gradients of those iterations were invalid there.  Capacities have been raised; redo the phase "
-                           "(every rank raises this together)")
+        raise RunAheadOverflow(f"{n} run-ahead forward(s) overflowed their workspace on some rank during this phase: the images and "
+                               "gradients of those iterations were invalid there and the optimizer has consumed them.  Capacities "
+                               "have been raised; restore the phase's parameters (partition.PhaseSnapshot) and redo the phase "
+                               "(every rank raises this together)")
     return 0
 
 
