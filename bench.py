@@ -132,7 +132,7 @@ def main():
 
     import diff_gaussian_rasterization as dgr
     from oracle import gs_oracle as go           # scene generator + CPU baseline (checker side only)
-    from parity_util import to_settings
+    from parity_util import HIP_CENTRE_ERR_PX, to_settings
 
     N, W, H = args.n, args.width, args.height
     P = W * H
@@ -435,8 +435,8 @@ def main():
         hc = torch.where(mask[None, :, None], got_c, ref_c)          # outside the rows the oracle image is just the background
         hd = torch.where(mask[None, :, None], got_d, ref_d)
         sub_op = scene["opacities"][idx]
-        a_c = audit_outliers(ref_c, hc, aux, sub_op, cam, 1e-4)
-        a_d = audit_outliers(ref_d, hd, aux, sub_op, cam, 1e-4)
+        a_c = audit_outliers(ref_c, hc, aux, sub_op, cam, 1e-4, centre_err_px=HIP_CENTRE_ERR_PX)
+        a_d = audit_outliers(ref_d, hd, aux, sub_op, cam, 1e-4, centre_err_px=HIP_CENTRE_ERR_PX)
         taint = tainted_gaussians(aux, a_c["tiles"] | a_d["tiles"], idx.numel())
         rdiff = ref_r != radii.cpu()                                 # float32 ceil() on the other side moves a tile rectangle
         taint_full = torch.zeros(N, dtype=torch.bool)

@@ -161,19 +161,51 @@ def oracle_instances_8x8(sp, opacities, cam, rel_slack=0.0, abs_slack=0.0, rows8
 # discrete decision of the composite -- a pair whose alpha is within float32 rounding of 1/255 (counted or skipped), or a
 # transmittance within rounding of the 1e-4 stop -- as seen in the ORACLE's own per-pair values.  Anything else fails.
 # ---------------------------------------------------------------------------------------------------------------
-# |ln alpha - ln(1/255)| a float32 implementation cannot resolve: 5e-5 for the exponent arithmetic itself (DESIGN.md 2,
-# deviation 3) plus the float32 representation of the splat centre -- u, v are O(W) pixels, so they carry an absolute
-# error of a few half-ulps of max(W, H) (6e-5 px at 1024, the published CUDA operator has the same), which moves the
-# exponent by |grad_centre q| times that: up to ~3 per pixel at the rim of a sigma ~ 1 px splat.
+# The margins are BOUNDS derived from float32 rounding, not tuned values ("audit margins"):
+#
+# LN_ALPHA_MARGIN -- |ln alpha(float32) - ln alpha(exact)| from the exponent arithmetic alone.  The kernels form
+#   log2 alpha = sum_m K_m Phi_m  (csrc/vtgs_composite_common.h::tile_coefficients + six MFMA steps): 7 roundings in K_0
+#   (three products, three fma, the log2 of the opacity), 3 each in K_1, K_2, 6 in the MFMA chain -- 19 roundings, each at most
+#   a relative half-ulp (2^-24) of a partial result that is itself at most M = the sum of the absolute values of the terms
+#   (|q_a| s_x^2 + |q_b s_x s_y| + |q_c| s_y^2 + |log2 o| + |K_1 X| + |K_2 Y| + |q_a| X^2 + |q_b X Y| + |q_c| Y^2, s = splat centre -
+#   tile centre, (X, Y) = pixel - tile centre).  For a pair near the threshold of a sigma ~ 1 px splat M stays below 64
+#   (|log2(1/255)| = 8, the quadratic terms of a centre up to 7.5 px from the tile centre: < 56), which gives
+#   19 x 2^-24 x 64 x ln 2 = 5.0e-5; the audit evaluates M for every pair and scales the margin by max(1, M / 64), so the
+#   bound also holds for the sharp or distant splats of the anisotropic scenes.  (v_exp_f32 / v_log_f32: one ulp of the RESULT
+#   each, 1.2e-7 relative -- nothing.  A float32 implementation that evaluates the quadratic form directly from the pixel offset
+#   -- the CPU oracle in float32, the published CUDA operator -- makes ~8 roundings of smaller partials: inside the same bound.)
+# centre error -- what the implementation's pixel-centre arithmetic loses, in pixels; it moves ln alpha by |d ln alpha / d centre|
+#   (`gq` below, up to ~3 per pixel at the rim of a sigma ~ 1 px splat) times that.
+#   * an implementation that forms the centre in float32 (the CPU oracle in float32, the published operator):
+#     u = ((ndc + 1) W - 1) / 2 rounds at the divide, at ndc + 1, at the product (magnitude W) and again in u - pixel:
+#     CENTRE_HALF_ULPS = 4 half-ulps of max(W, H), 4 x 2^-24 x max(W, H) px (2.9e-4 px at 1200).
+#   * the HIP kernels since round 5: the centre travels as a float32 PAIR (error 2^-45 relative) and the only rounding left is
+#     (u - tile centre) + lo at magnitude < 16 px: HIP_CENTRE_ERR_PX = 2^-20 px.
+# T stop -- |T (1 - alpha) / 1e-4 - 1|, T a product of (1 - alpha_k): d ln(1 - alpha_k) = alpha_k / (1 - alpha_k) x d ln alpha_k, so the
+#   relative error of the product at list position j is bounded PER PIXEL by
+#       sum_{k <= j, counted} alpha_k / (1 - alpha_k) x (LN_ALPHA_MARGIN + gq_k x centre error)  +  2 j x 2^-24
+#   (a clamped alpha = 0.99 carries no exponent error; the second term: one rounding each of 1 - alpha and of the running
+#   product).  T_STOP_MARGIN = 1e-3 is what that bound comes to for a stack that reaches T = 1e-4 through alphas <= 0.5
+#   (sum alpha / (1 - alpha) <= 2 sum alpha <= 2 x 9.2) and stays as the documented typical value; the audit uses the
+#   per-pixel bound.
+# tests/test_audit_margins.py (CPU): the float32 CPU oracle against the float64 one needs exactly these margins -- every outlier
+# it produces is explained by them, and with the margins at zero the same outliers are NOT explained.
 LN_ALPHA_MARGIN = 5e-5
 CENTRE_HALF_ULPS = 4.0
-T_STOP_MARGIN = 1e-3        # |T (1 - alpha) / 1e-4 - 1|: a product of up to ~100 float32 factors, each with the above
+HIP_CENTRE_ERR_PX = 2.0 ** -20
+T_STOP_MARGIN = 1e-3
 
 
-def audit_outliers(ref, got, aux, opacities, cam, tol=1e-4, max_report=5000):
+def float32_centre_err_px(cam) -> float:
+    return CENTRE_HALF_ULPS * 2.0 ** -24 * max(int(cam.image_width), int(cam.image_height))
+
+
+def audit_outliers(ref, got, aux, opacities, cam, tol=1e-4, max_report=5000, centre_err_px=None, ln_alpha_margin=LN_ALPHA_MARGIN):
     """ref/got: [C,H,W] images (any number of channels).  aux: oracle aux (float64 render) whose `splats`, `sorted_gid`,
-    `tile_offsets` describe the scene `opacities` belongs to.  Returns dict(outliers, explained, unexplained [(y,x)...],
-    max_rel, tiles) -- `tiles` = set of 16x16 tile ids that hold an outlier pixel."""
+    `tile_offsets` describe the scene `opacities` belongs to.  `centre_err_px`: what the audited implementation's centre
+    arithmetic loses (default: a float32 centre, float32_centre_err_px; the HIP kernels: HIP_CENTRE_ERR_PX).  Returns
+    dict(outliers, explained, unexplained [(y,x)...], max_rel, tiles) -- `tiles` = set of 16x16 tile ids that hold an outlier
+    pixel."""
     ref, got = ref.double(), got.double()
     scale = ref.abs().max().item() + 1e-12
     err = ((ref - got).abs() / scale).amax(dim=0)
@@ -187,7 +219,7 @@ def audit_outliers(ref, got, aux, opacities, cam, tol=1e-4, max_report=5000):
     gx = (int(cam.image_width) + 15) // 16
     op_all = opacities.reshape(-1).double()
     ln_min = float(torch.log(torch.tensor(go.ALPHA_MIN, dtype=torch.float64)))
-    delta = CENTRE_HALF_ULPS * 2.0 ** -24 * max(int(cam.image_width), int(cam.image_height))
+    delta = float32_centre_err_px(cam) if centre_err_px is None else float(centre_err_px)
     for y, x in zip(ys.tolist(), xs.tolist()):
         t = (y // 16) * gx + x // 16
         out["tiles"].add(t)
@@ -204,9 +236,21 @@ def audit_outliers(ref, got, aux, opacities, cam, tol=1e-4, max_report=5000):
         reach = ~torch.cat([torch.zeros(1, dtype=torch.bool), stopped[:-1]])      # pairs the pixel still looks at
         ln_a = torch.log(torch.clamp(a_raw, min=1e-300))
         gq = torch.sqrt((con[:, 0] * dx + con[:, 1] * dy) ** 2 + (con[:, 2] * dy + con[:, 1] * dx) ** 2)   # |d power / d centre|
-        m_alpha = ((ln_a - ln_min).abs() - gq * delta)[reach & (power <= 0)]
-        m_T = (Tcum / go.T_STOP - 1.0).abs()[reach & valid]
-        ok = (m_alpha.numel() and float(m_alpha.min()) <= LN_ALPHA_MARGIN) or (m_T.numel() and float(m_T.min()) <= T_STOP_MARGIN)
+        # M of every pair (comment above), in log2 units, around the centre of the pixel's 8x8 tile
+        l2e = 1.4426950408889634
+        sx, sy = xy[:, 0] - (8 * (x // 8) + 3.5), xy[:, 1] - (8 * (y // 8) + 3.5)
+        X, Y = x - (8 * (x // 8) + 3.5), y - (8 * (y // 8) + 3.5)
+        qa, qb, qc = 0.5 * l2e * con[:, 0].abs(), l2e * con[:, 1].abs(), 0.5 * l2e * con[:, 2].abs()
+        M = (qa * sx * sx + qb * (sx * sy).abs() + qc * sy * sy + torch.log2(torch.clamp(op, min=1e-300)).abs()
+             + (2 * qa * sx.abs() + qb * sy.abs()) * abs(X) + (2 * qc * sy.abs() + qb * sx.abs()) * abs(Y)
+             + qa * X * X + qb * abs(X * Y) + qc * Y * Y)
+        ln_m = ln_alpha_margin * torch.clamp(M / 64.0, min=1.0)
+        m_alpha = ((ln_a - ln_min).abs() - gq * delta - ln_m)[reach & (power <= 0)]
+        # the per-pixel bound on the relative error of T (1 - alpha) at every list position (comment above)
+        d_ln = torch.where(valid & (a_raw < go.ALPHA_MAX), a_eff / (1.0 - a_eff) * (ln_m + gq * delta), torch.zeros_like(a_eff))
+        t_bound = torch.cumsum(d_ln, 0) + 2.0 * torch.cumsum(valid.double(), 0) * 2.0 ** -24
+        m_T = ((Tcum / go.T_STOP - 1.0).abs() - t_bound)[reach & valid]
+        ok = (m_alpha.numel() and float(m_alpha.min()) <= 0.0) or (m_T.numel() and float(m_T.min()) <= 0.0)
         if ok:
             out["explained"] += 1
         else:

@@ -15,7 +15,7 @@ import pytest
 import torch
 
 from oracle import gs_oracle as go
-from parity_util import (GRAD_KEYS, audit_outliers, grad_error, oracle_instances_8x8, oracle_rows, rows_mask, run_hip,
+from parity_util import (HIP_CENTRE_ERR_PX, GRAD_KEYS, audit_outliers, grad_error, oracle_instances_8x8, oracle_rows, rows_mask, run_hip,
                          tainted_gaussians, to_settings)
 
 pytestmark = pytest.mark.gpu
@@ -72,8 +72,8 @@ def test_config_rows_radii_and_properties(gpu_device, name):
     sub_op = scene["opacities"][idx]
     hc = torch.where(mask[None, :, None], got_c.double(), ref_c)        # outside the rows the oracle image is just bg
     hd = torch.where(mask[None, :, None], got_d.double(), ref_d)
-    a_c = audit_outliers(ref_c, hc, aux, sub_op, cam, IMG_TOL)
-    a_d = audit_outliers(ref_d, hd, aux, sub_op, cam, IMG_TOL)
+    a_c = audit_outliers(ref_c, hc, aux, sub_op, cam, IMG_TOL, centre_err_px=HIP_CENTRE_ERR_PX)
+    a_d = audit_outliers(ref_d, hd, aux, sub_op, cam, IMG_TOL, centre_err_px=HIP_CENTRE_ERR_PX)
     n_px = int(mask.sum()) * W
     for label, a in (("colour", a_c), ("depth", a_d)):
         assert not a["unexplained"], f"{name} {label}: pixels above {IMG_TOL} not on a discrete decision: {a['unexplained'][:5]}"
@@ -205,8 +205,8 @@ def test_dual_render_against_two_oracle_renders(gpu_device):
     grads = dgr._run_backward_dual(fs, t["means3D"], col_a, col_b, t["opacities"], t["scales"], t["rotations"], im_a, im_b,
                                    g_a.to(dev), g_b.to(dev))
     g_means3D, g_means2D, g_ca, g_op, g_sc, g_rot, g_cb = [x.cpu() for x in grads]
-    a1 = audit_outliers(ref_a[0], im_a.cpu(), ref_a[4], scene["opacities"], cam, IMG_TOL)
-    a2 = audit_outliers(ref_b[0], im_b.cpu(), ref_b[4], scene["opacities"], cam, IMG_TOL)
+    a1 = audit_outliers(ref_a[0], im_a.cpu(), ref_a[4], scene["opacities"], cam, IMG_TOL, centre_err_px=HIP_CENTRE_ERR_PX)
+    a2 = audit_outliers(ref_b[0], im_b.cpu(), ref_b[4], scene["opacities"], cam, IMG_TOL, centre_err_px=HIP_CENTRE_ERR_PX)
     for a in (a1, a2):
         assert not a["unexplained"] and a["max_rel"] <= 8e-3 and a["frac"] <= 1e-3, a
     taint = tainted_gaussians(ref_a[4], a1["tiles"] | a2["tiles"], z.shape[0])

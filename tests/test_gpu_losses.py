@@ -21,14 +21,21 @@ def test_ssim_matches_reference_fixture(gpu_device):
 
 @pytest.mark.parametrize("shape", [(3, 40, 56), (3, 97, 131), (1, 33, 31), (3, 680, 1200), (1, 7, 5), (2, 12, 300), (3, 300, 4)])
 def test_ssim_value_and_gradient_match_conv_restatement(gpu_device, shape):
+    # The comparator runs on the CPU, in float64.  Until round 6 it ran on the device (torch's conv2d -> MIOpen -> a Tensile GEMM),
+    # and at shape (1, 33, 31) THAT kernel reads past the end of its operand: harmless while the next bytes are mapped, a
+    # "Memory access fault by GPU node" -- at a 2 MB-aligned address -- when the allocator happens to put the tensor at the end
+    # of a segment (three runs in a row after the round's new tests had shifted the layout; gpurun_out/r6/tests_f.log shows
+    # the Tensile kernels being loaded and the fault inside `ref.backward()`, with none of this library's kernels in flight).
     from diff_gaussian_rasterization.losses import fused_ssim
     g = torch.Generator().manual_seed(shape[1])
-    a = torch.rand(*shape, generator=g).to(gpu_device).requires_grad_(True)
-    b = (a.detach() + 0.1 * torch.randn(*shape, generator=g).to(gpu_device)).clamp(0, 1)
-    ref = sc.calc_ssim(a, b)
+    a_cpu = torch.rand(*shape, generator=g)
+    b_cpu = (a_cpu + 0.1 * torch.randn(*shape, generator=g)).clamp(0, 1)
+    ar = a_cpu.double().requires_grad_(True)
+    ref = sc.calc_ssim(ar, b_cpu.double())
     ref.backward()
-    gref = a.grad.clone()
-    a.grad = None
+    gref = ar.grad.float().to(gpu_device)
+    a = a_cpu.to(gpu_device).requires_grad_(True)
+    b = b_cpu.to(gpu_device)
     out = fused_ssim(a, b)
     (out * 1.0).backward()
     assert abs(out.item() - ref.item()) <= 2e-5 * abs(ref.item())
@@ -53,15 +60,16 @@ def test_fused_slam_losses_match_the_restatement(gpu_device, mode):
     gt_depth = (z + 0.2 * torch.randn(H, W, generator=g))[None].clone()
     gt_depth[0, :4, :] = 0
     gt_depth = gt_depth.to(dev)
+    # (the restatement runs on CPU copies: its SSIM term is torch's conv2d, see the note in the test above)
+    im_c, ds_c = im.detach().cpu().requires_grad_(True), ds.detach().cpu().requires_grad_(True)
     if mode == "tracking":
-        ref = sc.tracking_loss(im, ds, gt_im, gt_depth, 0.95)
+        ref = sc.tracking_loss(im_c, ds_c, gt_im.cpu(), gt_depth.cpu(), 0.95)
         fn = lambda: losses.tracking_loss(im, ds, gt_im, gt_depth, 0.95)
     else:
-        ref = sc.mapping_loss(im, ds, gt_im, gt_depth)
+        ref = sc.mapping_loss(im_c, ds_c, gt_im.cpu(), gt_depth.cpu())
         fn = lambda: losses.mapping_loss(im, ds, gt_im, gt_depth)
     (ref * 2.5).backward()                                # an upstream gradient other than 1 (read on the device)
-    r_im, r_ds = im.grad.clone(), torch.nan_to_num(ds.grad.clone())
-    im.grad = None; ds.grad = None
+    r_im, r_ds = im_c.grad.to(dev), torch.nan_to_num(ds_c.grad).to(dev)
     out = fn()
     (out * 2.5).backward()
     assert abs(out.item() - ref.item()) <= 2e-5 * abs(ref.item())

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from oracle import gs_oracle as go
-from parity_util import (GRAD_KEYS, audit_outliers, grad_error, image_error, run_hip, run_oracle, tainted_gaussians,
+from parity_util import (HIP_CENTRE_ERR_PX, GRAD_KEYS, audit_outliers, grad_error, image_error, run_hip, run_oracle, tainted_gaussians,
                          tiles_of)
 
 pytestmark = pytest.mark.gpu
@@ -53,7 +53,7 @@ def _check_images(ref_c, ref_d, got_c, got_d, audit=None):
     aux, opacities, cam = audit
     tiles = set()
     for name, r, g in (("color", ref_c, got_c), ("depth", ref_d, got_d)):
-        a = audit_outliers(r, g, aux, opacities, cam, IMG_TOL)
+        a = audit_outliers(r, g, aux, opacities, cam, IMG_TOL, centre_err_px=HIP_CENTRE_ERR_PX)
         assert not a["unexplained"], f"{name}: pixels above {IMG_TOL} that sit on no discrete decision: {a['unexplained'][:5]}"
         assert a["frac"] <= 1e-3 and a["max_rel"] <= 8e-3, f"{name}: {a['outliers']} outliers, max {a['max_rel']:.2e}"
         tiles |= a["tiles"]

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import gs_oracle as go
-from parity_util import audit_outliers, grad_error, tainted_gaussians, to_settings
+from parity_util import HIP_CENTRE_ERR_PX, audit_outliers, grad_error, tainted_gaussians, to_settings
 
 pytestmark = pytest.mark.gpu
 
@@ -83,7 +83,7 @@ def test_cov3d_precomp_against_the_oracle(gpu_device, band):
     assert diff.double().mean().item() <= 2e-3
     taint = torch.zeros(3000, dtype=torch.bool)
     for r_img, g_img in ((ref_c, color), (ref_d, depth)):
-        a = audit_outliers(r_img, g_img.detach().cpu(), aux, scene["opacities"], cam, 1e-4)
+        a = audit_outliers(r_img, g_img.detach().cpu(), aux, scene["opacities"], cam, 1e-4, centre_err_px=HIP_CENTRE_ERR_PX)
         assert not a["unexplained"] and a["max_rel"] <= 8e-3, a
         taint |= tainted_gaussians(aux, a["tiles"], 3000)
     for name, r, h in (("means3D", L["means3D"].grad, D["means3D"].grad), ("means2D", L["means2D"].grad, D["means2D"].grad),
@@ -124,7 +124,7 @@ def test_render_with_shs_through_the_operator(gpu_device):
     color, radii, depth = rast(means3D=D["means3D"], means2D=D["means2D"], opacities=D["opacities"], shs=sd, scales=D["scales"],
                                rotations=D["rotations"])
     (color * grad_color.to(dev)).sum().backward()
-    a = audit_outliers(ref_c, color.detach().cpu(), aux, scene["opacities"], cam, 1e-4)
+    a = audit_outliers(ref_c, color.detach().cpu(), aux, scene["opacities"], cam, 1e-4, centre_err_px=HIP_CENTRE_ERR_PX)
     assert not a["unexplained"] and a["max_rel"] <= 8e-3
     taint = tainted_gaussians(aux, a["tiles"], 6000)
     for name, r, h in (("shs", s64.grad, sd.grad), ("means3D", L["means3D"].grad, D["means3D"].grad),

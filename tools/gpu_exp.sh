@@ -47,7 +47,12 @@ run() {   # run <log> <command...>
 for step in "$@"; do
   name=${step%%:*}; arg=""; [ "$step" != "$name" ] && arg=${step#*:}
   case $name in
-    tests)   if [ -n "$arg" ]; then run $O/tests_$TAG.log python -m pytest tests/ -x -q -m gpu -k "$arg"; else run $O/tests_$TAG.log python -m pytest tests/ -x -q -m gpu; fi ;;
+    tests)
+             # --capture=sys: pytest's default capture redirects FILE DESCRIPTOR 2 into a temporary file for the duration of a test and
+             # shows it only for a failed one -- when the process ABORTS the file is lost with it, which is why the two aborts above left
+             # nothing but faulthandler's dump (it writes to a duplicate of the original descriptor): whatever the runtime printed
+             # (a memory-fault line, a queue error) went into the capture.  Capturing sys.stdout / sys.stderr only lets it through.
+             if [ -n "$arg" ]; then run $O/tests_$TAG.log python -m pytest tests/ -x -q -m gpu --capture=sys -k "$arg"; else run $O/tests_$TAG.log python -m pytest tests/ -x -q -m gpu --capture=sys; fi ;;
     smoke)   run $O/smoke_$TAG.log python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench)   run $O/bench_$TAG.log python bench.py ${arg//,/ } ;;
     timing)  if [ -n "$arg" ]; then VTGS_LIBRARY=$R/vtgaussian-slam_amd/lib/$arg ABL_TAG=$arg run $O/timing_${TAG}_${arg%.so}.log python tools/kernel_timing.py; else ABL_TAG=shipped run $O/timing_$TAG.log python tools/kernel_timing.py; fi ;;

@@ -4,7 +4,7 @@ import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "vtgaussian-slam_amd"), os.path.join(ROOT, "tests")]
 from oracle import gs_oracle as go
-from parity_util import GRAD_KEYS, audit_outliers, oracle_rows, rows_mask, tainted_gaussians, to_settings
+from parity_util import HIP_CENTRE_ERR_PX, GRAD_KEYS, audit_outliers, oracle_rows, rows_mask, tainted_gaussians, to_settings
 import diff_gaussian_rasterization as dgr
 dev = torch.device("cuda:0")
 N, W, H = 1_000_000, 1200, 680
@@ -23,7 +23,7 @@ color.backward(gsel.to(dev))
 got_c, got_d = color.detach().cpu().double(), depth.detach().cpu().double()
 hc = torch.where(mask[None, :, None], got_c, ref_c); hd = torch.where(mask[None, :, None], got_d, ref_d)
 sub_op = scene["opacities"][idx]
-a_c = audit_outliers(ref_c, hc, aux, sub_op, cam, 1e-4); a_d = audit_outliers(ref_d, hd, aux, sub_op, cam, 1e-4)
+a_c = audit_outliers(ref_c, hc, aux, sub_op, cam, 1e-4, centre_err_px=HIP_CENTRE_ERR_PX); a_d = audit_outliers(ref_d, hd, aux, sub_op, cam, 1e-4, centre_err_px=HIP_CENTRE_ERR_PX)
 taint = tainted_gaussians(aux, a_c["tiles"] | a_d["tiles"], idx.numel())
 tf = torch.zeros(N, dtype=torch.bool); tf[idx[taint]] = True; tf |= (ref_r != radii.cpu())
 gy16 = (H + 15) // 16

@@ -13,6 +13,14 @@ dev=torch.device('cuda:0')
 N=int(os.environ.get('ABL_N','1000000'))
 W=int(os.environ.get('ABL_W','1200')); H=int(os.environ.get('ABL_H','680'))
 scene,cam=go.view_tied_scene(N,W,H,seed=0)
+if os.environ.get('ABL_TAIL','0')!='0':
+    # a map AFTER some frames of mapping (round 6): the optimiser has grown a heavy tail of splat sizes -- at frame 21 of the synthetic
+    # Replica sequence 6 % of the Gaussians have 5-6 instances, 8 % have 7..64, 0.1 % hundreds (gpurun_out/r6/slam_c.log).  Here:
+    # 14 % of the scales x exp(U(0.3, 1.6)), 1 % x exp(U(1.6, 3)), 0.03 % x exp(U(3, 4.3))
+    gt=torch.Generator().manual_seed(5); u=torch.rand(N,generator=gt); f=torch.ones(N)
+    r=torch.rand(N,generator=gt)
+    f=torch.where(u<0.14, torch.exp(0.3+1.3*r), f); f=torch.where(u<0.01, torch.exp(1.6+1.4*r), f); f=torch.where(u<0.0003, torch.exp(3.0+1.3*r), f)
+    scene['scales']=scene['scales']*f[:,None]
 if 'ABL_OPACITY' in os.environ: scene['opacities']=torch.full_like(scene['opacities'], float(os.environ['ABL_OPACITY']))   # saturating scenes
 leaves={k:v.to(dev).requires_grad_(True) for k,v in scene.items()}
 band=None
@@ -35,4 +43,8 @@ torch.cuda.synchronize(); t=time.time()
 dgr.profile_enable(False)
 for it in range(20): step()
 torch.cuda.synchronize(); dt=(time.time()-t)/20*1e3
+if os.environ.get('ABL_TAIL','0')!='0':
+    offs,gid,_=dgr.debug_tile_lists(rast); per=torch.bincount(gid,minlength=N)
+    edges=[0,1,2,3,5,7,9,13,17,33,65,257,1<<30]
+    print('instances',int(per.sum()),{f"{a}..{b-1}":int(((per>=a)&(per<b)).sum()) for a,b in zip(edges[:-1],edges[1:])}, flush=True)
 print(os.environ.get('ABL_TAG',''), 'step %.3f ms'%dt, {k:round(v[0]/v[1]*1e3,1) for k,v in p.items()}, flush=True)

@@ -358,16 +358,19 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
                          (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), ctr,                            \
                          (BlockStats*)(ws + L.block_stats), (unsigned long long)instance_capacity, L.tile_cap)
       // (LDS: 0 = run-aggregated global atomics, 1 = the band's whole tile table in LDS, 2 = a window of kWinEntries tiles)
+      // (every form gets at least kDeferLds bytes of dynamic LDS: the end phase keeps the workgroup's deferred-splat lists there)
+      constexpr size_t kDeferLds = 1024 * 2 + 1024 * 4;
+      const size_t table_lds = table_bytes > kDeferLds ? table_bytes : kDeferLds;
       if (lds_bins) {
 #define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin<LDS, MODE>
-        if (mode == 0) VTGS_LAUNCH_PROJECT(1, 0, table_bytes);
+        if (mode == 0) VTGS_LAUNCH_PROJECT(1, 0, table_lds);
 #undef VTGS_PROJECT_KERNEL
 #define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin_capped<LDS, MODE>
-        else if (mode == 1) VTGS_LAUNCH_PROJECT(1, 1, table_bytes);
-        else if (mode == 2) VTGS_LAUNCH_PROJECT(1, 2, table_bytes);
-        else if (mode == 4) VTGS_LAUNCH_PROJECT(1, 4, table_bytes);
-        else if (mode == 5) VTGS_LAUNCH_PROJECT(1, 5, table_bytes);
-        else VTGS_LAUNCH_PROJECT(1, 3, table_bytes);
+        else if (mode == 1) VTGS_LAUNCH_PROJECT(1, 1, table_lds);
+        else if (mode == 2) VTGS_LAUNCH_PROJECT(1, 2, table_lds);
+        else if (mode == 4) VTGS_LAUNCH_PROJECT(1, 4, table_lds);
+        else if (mode == 5) VTGS_LAUNCH_PROJECT(1, 5, table_lds);
+        else VTGS_LAUNCH_PROJECT(1, 3, table_lds);
       } else if (win_bins) {
 #undef VTGS_PROJECT_KERNEL
 #define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin<LDS, MODE>
@@ -380,14 +383,14 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
       } else {
 #undef VTGS_PROJECT_KERNEL
 #define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin<LDS, MODE>
-        if (mode == 0) VTGS_LAUNCH_PROJECT(0, 0, 0);
+        if (mode == 0) VTGS_LAUNCH_PROJECT(0, 0, kDeferLds);
 #undef VTGS_PROJECT_KERNEL
 #define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin_capped<LDS, MODE>
-        else if (mode == 1) VTGS_LAUNCH_PROJECT(0, 1, 0);
-        else if (mode == 2) VTGS_LAUNCH_PROJECT(0, 2, 0);
-        else if (mode == 4) VTGS_LAUNCH_PROJECT(0, 4, 0);
-        else if (mode == 5) VTGS_LAUNCH_PROJECT(0, 5, 0);
-        else VTGS_LAUNCH_PROJECT(0, 3, 0);
+        else if (mode == 1) VTGS_LAUNCH_PROJECT(0, 1, kDeferLds);
+        else if (mode == 2) VTGS_LAUNCH_PROJECT(0, 2, kDeferLds);
+        else if (mode == 4) VTGS_LAUNCH_PROJECT(0, 4, kDeferLds);
+        else if (mode == 5) VTGS_LAUNCH_PROJECT(0, 5, kDeferLds);
+        else VTGS_LAUNCH_PROJECT(0, 3, kDeferLds);
       }
 #undef VTGS_PROJECT_KERNEL
 #undef VTGS_LAUNCH_PROJECT

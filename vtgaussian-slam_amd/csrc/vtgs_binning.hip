@@ -106,29 +106,75 @@ __device__ __forceinline__ void store_geom(GeomRec* __restrict__ rec, const Spla
 constexpr int kProjBlock = 1024;     // threads per workgroup: one allocation atomic per 1024 Gaussians
 constexpr uint32_t kWinEntries = 16384;  // windowed LDS tile table (LDSBINS == 2): 64 KB, two workgroups per CU
 
-// A Gaussian whose candidate walk exceeds kBigArea tiles (a splat that has grown over a hole of the map can cover
-// thousands) is not walked by its own lane -- one thread iterating over 3,000 tiles held project_and_bin for up to 2 ms in
-// a long mapping run -- but by the whole wavefront, 64 tiles at a time, at the END of the kernel: it takes its instance ids
-// with an atomic of its own and its bin slots straight from the global per-tile counters, so the common path above does
-// not know it exists (inlined between the two passes, the mere presence of these loops cost the common path 13 us).
-// Same tiles, instances in raster order of the walk, same results.
-constexpr int kBigArea = 64;
+// A Gaussian whose candidate walk exceeds kDeferArea tiles is DEFERRED: its own lane does not walk it.  (Rounds 2-5: only walks
+// of more than 64 tiles were taken away from their lane, by the lane's wavefront at the end of the kernel, each with an atomic of
+// its own.  But every lane of a wavefront waits for the longest walk among the 64, and an optimised SLAM map has a heavy tail
+// of splat sizes: after 20 frames of mapping 8 % of the Gaussians of the synthetic Replica sequence cover 7 .. 64 tiles, so
+// nearly every wavefront held one and ran 16 .. 64 trips of both passes where a fresh view-tied map runs 4 -- project_and_bin
+// 160 us against 46 us, gpurun_out/r6/slamlate_b_dens.txt.)  The deferred splats of a WORKGROUP are processed at the end of
+// the kernel, balanced over all of its lanes:
+//   * up to kGroupArea candidate tiles: one 16-lane group per splat (64 groups per workgroup), 16 tiles per step;
+//   * more: the whole workgroup per splat, 1,024 tiles per step (a splat grown over a hole of the map covers thousands);
+// first a counting round, then ONE instance-range atomic for all of them, then the binning round (slots straight from the global
+// per-tile counters).  Instance ids of a splat follow the raster order of its walk, as everywhere.  The common path does not
+// know any of this exists: lanes with a deferred splat walk nothing, and a workgroup without one leaves before the end phase.
+#ifndef VTGS_DEFER_AREA
+#define VTGS_DEFER_AREA 9
+#endif
+constexpr int kDeferArea = VTGS_DEFER_AREA;      // candidate tiles a lane walks itself (3 x 3: what a few-pixel splat can straddle)
+constexpr int kGroupArea = 64;                   // deferred splats up to this many candidates: a 16-lane group each
+static_assert(kDeferArea >= 1 && kDeferArea <= 64, "the reach mask of the common path holds 64 candidates");
 
-struct BigWalk {            // wave-uniform copy of one lane's walk and reach test
-  TileWalk w; Splat sp; ReachForm rf; float tau; int area;
-};
-__device__ __forceinline__ BigWalk broadcast_walk(const TileWalk& w, const Splat& sp, const ReachForm& rf, float tau, int area,
-                                                  int src) {
-  BigWalk b;
-  auto bi = [&](int v) { return __builtin_amdgcn_readlane(v, src); };
-  auto bf = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
-  b.w.cx0 = bi(w.cx0); b.w.cy0 = bi(w.cy0); b.w.cw = bi(w.cw); b.w.ch = bi(w.ch);
-  b.sp = Splat{};
-  b.sp.u = bf(sp.u); b.sp.v = bf(sp.v); b.sp.A = bf(sp.A); b.sp.B = bf(sp.B); b.sp.C = bf(sp.C);
-  b.rf.hA = bf(rf.hA); b.rf.B = bf(rf.B); b.rf.hC = bf(rf.hC); b.rf.kx = bf(rf.kx); b.rf.ky = bf(rf.ky);
-  b.rf.regular = bi(rf.regular ? 1 : 0) != 0;
-  b.tau = bf(tau); b.area = bi(area);
-  return b;
+// What the walk of one splat needs besides the splat: the reach threshold, the hoisted reach form, the candidate rectangle
+// (shrunk to the bounding box of the alpha >= 1/255 ellipse).  One function for the common path and for the end phase, which
+// rebuilds it from the stored geometry record: the same floats through the same operations.
+struct WalkSetup { TileWalk w; ReachForm rf; float tau; int area; };
+
+__device__ __forceinline__ WalkSetup setup_walk(const CamParams& cam, const Splat& sp, float op, bool vis) {
+  WalkSetup ws;
+  // alpha = o*G >= 1/255 somewhere  <=>  q <= ln(255 o); slack keeps the test conservative
+  ws.tau = -1.f;
+  if (vis && op * 255.f >= 1.f) { ws.tau = __log2f(255.f * op) * 0.69314718f; ws.tau += 1e-4f * ws.tau + 1e-4f; }   // (v_log_f32: 1 ulp, inside the slack)
+  const bool reach = vis && ws.tau >= 0.f;
+  ws.rf = make_reach_form(sp);
+  ws.w = make_walk(cam, sp, reach);
+  if (reach && ws.rf.regular) {
+    // shrink the walk to the tiles under the bounding box of the alpha >= 1/255 ellipse (half-widths sqrt(2 tau C / det),
+    // sqrt(2 tau A / det); tau carries the slack): a few-pixel splat then tests ~4 candidates instead of the 16 under its
+    // 16x16-tile rectangle.  The exact test still decides; the box only removes tiles it cannot pass.
+    // (hardware reciprocal / square root as in composite_forward_q's quadrant box, with the same 2e-6 relative + 1e-5 px of
+    //  slack: the IEEE forms are ~35 instructions per Gaussian and the box only has to be conservative)
+    const float idet = __builtin_amdgcn_rcpf(fmaxf(sp.A * sp.C - sp.B * sp.B, 1e-30f));
+    const float k2 = 2.f * ws.tau * idet;
+    const float hx = __builtin_amdgcn_sqrtf(k2 * sp.C) * 1.000002f + 1e-5f, hy = __builtin_amdgcn_sqrtf(k2 * sp.A) * 1.000002f + 1e-5f;
+    const float inv8 = 1.f / (float)kSubTile;
+    const int bx0 = (int)ceilf((sp.u - hx - (float)(kSubTile - 1)) * inv8), bx1 = (int)floorf((sp.u + hx) * inv8);
+    const int by0 = (int)ceilf((sp.v - hy - (float)(kSubTile - 1)) * inv8), by1 = (int)floorf((sp.v + hy) * inv8);
+    const int x0 = max(ws.w.cx0, bx0), x1 = min(ws.w.cx0 + ws.w.cw, bx1 + 1);
+    const int y0 = max(ws.w.cy0, by0), y1 = min(ws.w.cy0 + ws.w.ch, by1 + 1);
+    if (x1 > x0 && y1 > y0) { ws.w.cx0 = x0; ws.w.cy0 = y0; ws.w.cw = x1 - x0; ws.w.ch = y1 - y0; }
+    else { ws.w.cw = 0; ws.w.ch = 0; }
+  }
+  ws.area = ws.w.cw * ws.w.ch;
+  return ws;
+}
+
+// A deferred splat, rebuilt from what the common path stored for it (geometry record + radius)
+struct DeferredSplat { Splat sp; float op; WalkSetup ws; unsigned long long key; };
+
+__device__ __forceinline__ DeferredSplat load_deferred(const CamParams& cam, const GeomRec* __restrict__ geom,
+                                                       const int32_t* __restrict__ radii, int gid) {
+  DeferredSplat d;
+  const float4* gp = reinterpret_cast<const float4*>(geom + gid);
+  const float4 g0 = gp[0], g1 = gp[1];
+  d.sp = Splat{};
+  d.sp.u = g0.x; d.sp.v = g0.y; d.sp.A = g0.z; d.sp.B = g0.w; d.sp.C = g1.x; d.sp.depth = g1.z;
+  d.op = g1.y;
+  d.sp.radius = radii[gid];
+  tile_rect(cam, d.sp.u, d.sp.v, d.sp.radius, d.sp.x0, d.sp.y0, d.sp.x1, d.sp.y1);
+  d.ws = setup_walk(cam, d.sp, d.op, true);
+  d.key = ((unsigned long long)__float_as_uint(d.sp.depth) << 32) | (unsigned long long)(uint32_t)gid;
+  return d;
 }
 
 // LDSBINS (tile count fits the LDS table): the workgroup first histograms its instances per tile in LDS, then takes ONE
@@ -221,32 +267,14 @@ __device__ __forceinline__ void project_and_bin_body(
       return;
     }
   }
-  // alpha = o*G >= 1/255 somewhere  <=>  q <= ln(255 o); slack keeps the test conservative
-  float tau = -1.f;
-  if (vis && op * 255.f >= 1.f) { tau = __log2f(255.f * op) * 0.69314718f; tau += 1e-4f * tau + 1e-4f; }   // (v_log_f32: 1 ulp, inside the slack)
-  const bool reach = vis && tau >= 0.f;
-  const ReachForm rf = make_reach_form(sp);
-  TileWalk w = make_walk(cam, sp, reach);
-  if (reach && rf.regular) {
-    // shrink the walk to the tiles under the bounding box of the alpha >= 1/255 ellipse (half-widths sqrt(2 tau C / det),
-    // sqrt(2 tau A / det); tau carries the slack): a few-pixel splat then tests ~4 candidates instead of the 16 under its
-    // 16x16-tile rectangle.  The exact test below still decides; the box only removes tiles it cannot pass.
-    // (hardware reciprocal / square root as in composite_forward_q's quadrant box, with the same 2e-6 relative + 1e-5 px of
-    //  slack: the IEEE forms are ~35 instructions per Gaussian and the box only has to be conservative)
-    const float idet = __builtin_amdgcn_rcpf(fmaxf(sp.A * sp.C - sp.B * sp.B, 1e-30f));
-    const float k2 = 2.f * tau * idet;
-    const float hx = __builtin_amdgcn_sqrtf(k2 * sp.C) * 1.000002f + 1e-5f, hy = __builtin_amdgcn_sqrtf(k2 * sp.A) * 1.000002f + 1e-5f;
-    const float inv8 = 1.f / (float)kSubTile;
-    const int bx0 = (int)ceilf((sp.u - hx - (float)(kSubTile - 1)) * inv8), bx1 = (int)floorf((sp.u + hx) * inv8);
-    const int by0 = (int)ceilf((sp.v - hy - (float)(kSubTile - 1)) * inv8), by1 = (int)floorf((sp.v + hy) * inv8);
-    const int x0 = max(w.cx0, bx0), x1 = min(w.cx0 + w.cw, bx1 + 1);
-    const int y0 = max(w.cy0, by0), y1 = min(w.cy0 + w.ch, by1 + 1);
-    if (x1 > x0 && y1 > y0) { w.cx0 = x0; w.cy0 = y0; w.cw = x1 - x0; w.ch = y1 - y0; }
-    else { w.cw = 0; w.ch = 0; }
-  }
+  const WalkSetup wsu = setup_walk(cam, sp, op, vis);
+  const TileWalk w = wsu.w;
+  const ReachForm rf = wsu.rf;
+  const float tau = wsu.tau;
   VTGS_P_STAMP(1)                                                // inputs arrived, projection + walk set up
-  const int area_all = w.cw * w.ch;
-  const bool big = area_all > kBigArea;                        // left to the wavefront, at the end of the kernel
+  const int area_all = wsu.area;
+  const bool big = area_all > kDeferArea;                      // deferred: left to the workgroup, at the end of the kernel
+  const bool large = area_all > kGroupArea;                    // ... and there to the whole workgroup, not to a 16-lane group
   const int area = big ? 0 : area_all;
 
   // the per-tile table is cleared only now: the input loads above are in flight while it happens, and the workgroups of a
@@ -261,7 +289,7 @@ __device__ __forceinline__ void project_and_bin_body(
   for (int i = 0, tx = 0, ty = 0; i < area; ++i) {
     const bool hit = tile_reached(cam, sp, rf, tau, w.cx0 + tx, w.cy0 + ty);
     cnt += hit ? 1u : 0u;
-    if (i < 64 && hit) reach_mask |= 1ull << i;
+    if (hit) reach_mask |= 1ull << i;                           // (area <= kDeferArea <= 64)
     if constexpr (LDSBINS == 1) { if (hit) atomicAdd(&lds_tile[(w.cy0 + ty) * cam.gx8 + w.cx0 + tx - tile0], 1u); }
     if (++tx == w.cw) { tx = 0; ++ty; }
   }
@@ -270,16 +298,22 @@ __device__ __forceinline__ void project_and_bin_body(
   // global counter: same-address atomics serialise at the memory side (~14 ns each measured), so per-wavefront
   // atomics on one cache line cost more than the whole projection.
   __shared__ uint32_t s_wave_cnt[kWaves], s_wave_vis[kWaves], s_wave_r16[kWaves], s_block_base;
+  __shared__ uint32_t s_wave_small[kWaves], s_wave_large[kWaves], s_n_small, s_n_large;   // deferred splats of the workgroup
   const int wv = (int)(threadIdx.x >> 6);
   const uint32_t incl = wave_incl_scan(cnt);
   const uint32_t r16 = vis ? (uint32_t)((sp.x1 - sp.x0) * (sp.y1 - sp.y0)) : 0u;
   const uint32_t r16_incl = wave_incl_scan(r16);
   const unsigned long long vb = __ballot(vis);
-  if (l == 63) { s_wave_cnt[wv] = incl; s_wave_vis[wv] = (uint32_t)__popcll(vb); s_wave_r16[wv] = r16_incl; }
+  const unsigned long long small_b = __ballot(big && !large), large_b = __ballot(large);
+  if (l == 63) {
+    s_wave_cnt[wv] = incl; s_wave_vis[wv] = (uint32_t)__popcll(vb); s_wave_r16[wv] = r16_incl;
+    s_wave_small[wv] = (uint32_t)__popcll(small_b); s_wave_large[wv] = (uint32_t)__popcll(large_b);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t tot = 0, v = 0; unsigned long long r = 0;
-    for (int k = 0; k < kWaves; ++k) { tot += s_wave_cnt[k]; v += s_wave_vis[k]; r += s_wave_r16[k]; }
+    uint32_t tot = 0, v = 0, ns = 0, nl = 0; unsigned long long r = 0;
+    for (int k = 0; k < kWaves; ++k) { tot += s_wave_cnt[k]; v += s_wave_vis[k]; r += s_wave_r16[k]; ns += s_wave_small[k]; nl += s_wave_large[k]; }
+    s_n_small = ns; s_n_large = nl;
     s_block_base = tot ? atomicAdd(&ctr->inst_total, tot) : 0u;
     BlockStats bs;
     bs.visible = v; bs.pad = 0; bs.r16 = r;
@@ -361,7 +395,7 @@ __device__ __forceinline__ void project_and_bin_body(
     // pass 2, LDS form: every lane walks its own reached tiles; the slot comes from the LDS table
     for (int i = 0, tx = 0, ty = 0; i < area; ++i) {
       const int ttx = w.cx0 + tx, tty = w.cy0 + ty;
-      const bool hit = (i < 64) ? ((reach_mask >> i) & 1ull) != 0ull : tile_reached(cam, sp, rf, tau, ttx, tty);
+      const bool hit = ((reach_mask >> i) & 1ull) != 0ull;
       if (hit) {
         const int tile = tty * cam.gx8 + ttx;
         const uint32_t slot = atomicAdd(&lds_tile[tile - tile0], 1u);
@@ -392,9 +426,8 @@ __device__ __forceinline__ void project_and_bin_body(
       ++ord;
     }
   };
-  const int max_area = wave_max_i(area);
-  if (max_area <= 64) {
-    // common case: step k handles every lane's k-th REACHED tile (k-th set bit of its mask).  Raster-ordered
+  {
+    // step k handles every lane's k-th REACHED tile (k-th set bit of its mask).  Raster-ordered
     // neighbours have near-identical masks, so runs still form, and there are ~3 steps instead of ~16.
     const int steps = wave_max_i((int)cnt);
     unsigned long long m = reach_mask;
@@ -412,21 +445,6 @@ __device__ __forceinline__ void project_and_bin_body(
       consume(pend);
       pend = cur;
     }
-  } else {
-    // a splat of this wavefront covers more than 64 candidate tiles: walk all candidates in lock-step
-    for (int i = 0, tx = 0, ty = 0; i <= max_area; ++i) {
-      Reservation cur;
-      cur.base = 0; cur.head_lane = 0; cur.rank = 0; cur.act = false; cur.tile = -1;
-      if (i < max_area) {                                    // wave-uniform
-        const bool in = i < area;
-        const int ttx = w.cx0 + tx, tty = w.cy0 + ty;
-        const bool act = in && ((i < 64) ? ((reach_mask >> i) & 1ull) != 0ull : tile_reached(cam, sp, rf, tau, ttx, tty));
-        cur = reserve_issue(tile_cnt, act ? (tty * cam.gx8 + ttx) : -1, act);
-        if (in && ++tx == w.cw) { tx = 0; ++ty; }
-      }
-      consume(pend);
-      pend = cur;
-    }
   }
   }  // (global-atomic form)
 
@@ -439,48 +457,117 @@ __device__ __forceinline__ void project_and_bin_body(
     o[5] = (uint32_t)prt0; o[6] = (uint32_t)__builtin_amdgcn_s_memrealtime(); o[7] = (uint32_t)area_all;
   }
 #endif
-  // ---- the big splats of this wavefront, one after the other, every lane a tile --------------------------------------------
-  for (unsigned long long rest = __ballot(big); rest; rest &= rest - 1ull) {      // wave-uniform
-    const int src = __builtin_ctzll(rest);
-    const BigWalk b = broadcast_walk(w, sp, rf, tau, area_all, src);
-    uint32_t total = 0;
-    for (int i0 = 0; i0 < b.area; i0 += 64) {
-      const int i = i0 + l;
-      const int ty = i / b.w.cw, tx = i - ty * b.w.cw;
-      const bool hit = i < b.area && tile_reached(cam, b.sp, b.rf, b.tau, b.w.cx0 + tx, b.w.cy0 + ty);
-      total += (uint32_t)__builtin_popcountll(__ballot(hit));
+  // ---- end phase: the deferred splats of this workgroup (see kDeferArea) -----------------------------------------------------
+  const uint32_t n_small = s_n_small, n_large = s_n_large;       // (written before the barrier behind the instance-range atomic)
+  if (n_small + n_large == 0u) return;                           // workgroup-uniform: the common case leaves here
+  __syncthreads();                                               // the LDS tile table is dead from here on: the lists live in it
+  // lists in the dynamic LDS block (the launcher gives it at least kDeferLdsBytes): local thread index of every deferred
+  // splat -- the small ones from the front, the large ones from the back, both in thread order -- and their counts / bases
+  uint16_t* __restrict__ s_def = reinterpret_cast<uint16_t*>(lds_tile);                       // [kProjBlock]
+  uint32_t* __restrict__ s_val = lds_tile + kProjBlock / 2;                                   // [kProjBlock]
+  {
+    uint32_t ps = 0, pl = 0;
+    for (int k = 0; k < wv; ++k) { ps += s_wave_small[k]; pl += s_wave_large[k]; }
+    const unsigned long long below = (1ull << l) - 1ull;
+    if (big && !large) s_def[ps + (uint32_t)__popcll(small_b & below)] = (uint16_t)threadIdx.x;
+    if (large) s_def[(uint32_t)kProjBlock - 1u - (pl + (uint32_t)__popcll(large_b & below))] = (uint16_t)threadIdx.x;
+  }
+  __syncthreads();
+  const int gid0 = (int)(blockIdx.x * (uint32_t)kProjBlock);
+  const int grp = (int)(threadIdx.x >> 4), sub = l & 15, gsh = l & 48;  // 16-lane group of the workgroup, lane in it, its bit offset
+  // round A: how many tiles does each deferred splat reach
+  for (uint32_t e = (uint32_t)grp; e < n_small; e += (uint32_t)(kProjBlock / 16)) {
+    const DeferredSplat d = load_deferred(cam, geom, radii, gid0 + (int)s_def[e]);
+    uint32_t c = 0;
+    for (int i0 = 0; i0 < d.ws.area; i0 += 16) {
+      const int i = i0 + sub;
+      const int ty = i / d.ws.w.cw, tx = i - ty * d.ws.w.cw;
+      const bool hit = i < d.ws.area && tile_reached(cam, d.sp, d.ws.rf, d.ws.tau, d.ws.w.cx0 + tx, d.ws.w.cy0 + ty);
+      c += (uint32_t)__popcll((__ballot(hit) >> gsh) & 0xFFFFull);
     }
-    uint32_t base = 0;
-    if (l == src && total) base = atomicAdd(&ctr->inst_total, total);
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, src);
-    const unsigned long long key_src = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), src) << 32) |
-                                       (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, src);
+    if (sub == 0) s_val[e] = c;
+  }
+  for (uint32_t e = 0; e < n_large; ++e) {                       // workgroup-uniform
+    const uint32_t slot_e = (uint32_t)kProjBlock - 1u - e;
+    const DeferredSplat d = load_deferred(cam, geom, radii, gid0 + (int)s_def[slot_e]);
+    if (threadIdx.x == 0) s_val[slot_e] = 0u;
+    __syncthreads();
+    uint32_t c = 0;
+    for (int i0 = 0; i0 < d.ws.area; i0 += kProjBlock) {
+      const int i = i0 + (int)threadIdx.x;
+      const int ty = i / d.ws.w.cw, tx = i - ty * d.ws.w.cw;
+      const bool hit = i < d.ws.area && tile_reached(cam, d.sp, d.ws.rf, d.ws.tau, d.ws.w.cx0 + tx, d.ws.w.cy0 + ty);
+      c += (uint32_t)__popcll(__ballot(hit));
+    }
+    if (l == 0 && c) atomicAdd(&s_val[slot_e], c);               // (integer: the order does not matter)
+  }
+  __syncthreads();
+  // one instance range for all of them: entry t of the list belongs to thread t of this scan
+  {
+    const bool mine = threadIdx.x < n_small || threadIdx.x >= (uint32_t)kProjBlock - n_large;
+    const uint32_t v = mine ? s_val[threadIdx.x] : 0u;
+    const uint32_t inc = wave_incl_scan(v);
+    if (l == 63) s_wave_cnt[wv] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t tot = 0;
+      for (int k = 0; k < kWaves; ++k) tot += s_wave_cnt[k];
+      s_block_base = tot ? atomicAdd(&ctr->inst_total, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_block_base;
+    for (int k = 0; k < wv; ++k) base += s_wave_cnt[k];
+    base += inc - v;
+    if (mine) {
+      s_val[threadIdx.x] = base;
+      gaux[gid0 + (int)s_def[threadIdx.x]] = GaussAux{base, v};
+    }
+  }
+  __syncthreads();
+  // round B: slots from the global per-tile counters, keys and instance ids into the bins
+  auto emit = [&](const DeferredSplat& d, int tile, unsigned long long id) {
+    const uint32_t slot = atomicAdd(&tile_cnt[tile], 1u);
+    const BinRange br = planned ? bin_range(cs, (uint32_t)tile, tile_cap) : BinRange{(uint32_t)tile * tile_cap, tile_cap};
+    if (id < capacity && slot < br.cap) {                        // an overflowing bin / id is dropped and flagged later
+      const size_t pos = (size_t)br.s + slot;
+      keys[pos] = d.key;
+      vals[pos] = (uint32_t)id;
+    }
+  };
+  for (uint32_t e = (uint32_t)grp; e < n_small; e += (uint32_t)(kProjBlock / 16)) {
+    const DeferredSplat d = load_deferred(cam, geom, radii, gid0 + (int)s_def[e]);
+    const uint32_t base = s_val[e];
     uint32_t done = 0;
-    for (int i0 = 0; i0 < b.area; i0 += 64) {
-      const int i = i0 + l;
-      const int ty = i / b.w.cw, tx = i - ty * b.w.cw;
-      const bool hit = i < b.area && tile_reached(cam, b.sp, b.rf, b.tau, b.w.cx0 + tx, b.w.cy0 + ty);
-      const unsigned long long hb = __ballot(hit);
-      if (hit) {
-        const int tile = (b.w.cy0 + ty) * cam.gx8 + b.w.cx0 + tx;
-        const uint32_t slot = atomicAdd(&tile_cnt[tile], 1u);
-        const uint32_t rank = (uint32_t)__builtin_popcountll(hb & ((1ull << l) - 1ull));
-        const unsigned long long id = (unsigned long long)base + done + rank;            // raster order of the walk
-        const BinRange br = planned ? bin_range(cs, (uint32_t)tile, tile_cap) : BinRange{(uint32_t)tile * tile_cap, tile_cap};
-        if (id < capacity && slot < br.cap) {
-          const size_t pos = (size_t)br.s + slot;
-          keys[pos] = key_src;
-          vals[pos] = (uint32_t)id;
-        }
-      }
-      done += (uint32_t)__builtin_popcountll(hb);
+    for (int i0 = 0; i0 < d.ws.area; i0 += 16) {
+      const int i = i0 + sub;
+      const int ty = i / d.ws.w.cw, tx = i - ty * d.ws.w.cw;
+      const bool hit = i < d.ws.area && tile_reached(cam, d.sp, d.ws.rf, d.ws.tau, d.ws.w.cx0 + tx, d.ws.w.cy0 + ty);
+      const uint32_t hb = (uint32_t)((__ballot(hit) >> gsh) & 0xFFFFull);
+      if (hit) emit(d, (d.ws.w.cy0 + ty) * cam.gx8 + d.ws.w.cx0 + tx, (unsigned long long)base + done + (uint32_t)__popc(hb & ((1u << sub) - 1u)));
+      done += (uint32_t)__popc(hb);
     }
-    if (l == src) {
-      gaux[gid] = GaussAux{base, total};
+  }
+  for (uint32_t e = 0; e < n_large; ++e) {                       // workgroup-uniform
+    const uint32_t slot_e = (uint32_t)kProjBlock - 1u - e;
+    const DeferredSplat d = load_deferred(cam, geom, radii, gid0 + (int)s_def[slot_e]);
+    const uint32_t base = s_val[slot_e];
+    uint32_t done = 0;
+    for (int i0 = 0; i0 < d.ws.area; i0 += kProjBlock) {
+      const int i = i0 + (int)threadIdx.x;
+      const int ty = i / d.ws.w.cw, tx = i - ty * d.ws.w.cw;
+      const bool hit = i < d.ws.area && tile_reached(cam, d.sp, d.ws.rf, d.ws.tau, d.ws.w.cx0 + tx, d.ws.w.cy0 + ty);
+      const unsigned long long hb = __ballot(hit);
+      __syncthreads();                                           // (the previous step's readers of s_wave_cnt are through)
+      if (l == 0) s_wave_cnt[wv] = (uint32_t)__popcll(hb);
+      __syncthreads();
+      uint32_t before = 0, step_total = 0;
+      for (int k = 0; k < kWaves; ++k) { const uint32_t c = s_wave_cnt[k]; before += k < wv ? c : 0u; step_total += c; }
+      if (hit) emit(d, (d.ws.w.cy0 + ty) * cam.gx8 + d.ws.w.cx0 + tx,
+                    (unsigned long long)base + done + before + (uint32_t)__popcll(hb & ((1ull << l) - 1ull)));   // raster order of the walk
+      done += step_total;
     }
   }
 }
-
 
 
 // The kernels proper.  MODE 0 (whole frame, uniform bins) compiles to 79 scalar registers by itself; the other modes need 82-90,

@@ -1277,10 +1277,19 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
   for (int i = 0; i < 3; ++i) { g.mean3D[i] = g.mean2D[i] = g.color[i] = g.scale[i] = 0.f; }
   g.opacity = 0.f; g.rot[0] = g.rot[1] = g.rot[2] = g.rot[3] = 0.f;
   float cb0 = 0.f, cb1 = 0.f, cb2 = 0.f;         // dual: dL/d(second render's colours)
+  // ---- the gradient records of the wavefront's 64 splats -----------------------------------------------------------------
+  // Round 6.  Until round 5 every lane walked ITS OWN records in a loop (the first four requested ahead, the rest one
+  // dependent load after the other): a wavefront took as long as its largest splat, and an optimised SLAM map has a heavy tail
+  // -- after 20 frames of mapping 8 % of the Gaussians of the synthetic Replica sequence have 7 .. 64 instances, so nearly every
+  // wavefront holds one and ran 16 .. 64 serial trips to memory (152 us against 54 us on the fresh map,
+  // gpurun_out/r6/slamlate_b_dens.txt).  Now the wavefront reads the records of ALL its splats as one list, 64 records per
+  // step, every lane one record: position j of the list belongs to the last lane whose first position V is <= j (six-step
+  // search over the lanes' scan with ds_bpermute); the lane re-centres its record with the owner's centre and parks the ten
+  // sums in a 3 KB LDS window; then every owner adds ITS rows of the window, in index order -- the order the per-lane loop had,
+  // so the sums are the same bits -- from LDS, not from memory.  No float atomics, no cross-lane float reduction.
   // A Gaussian with more than kBigInst instances (a splat grown over a hole of the map has thousands) is summed by the whole
-  // wavefront, 64 records at a time, instead of by its own lane in a loop that held this kernel for up to 1 ms.
-  constexpr uint32_t kBigInst = 32;
-  constexpr uint32_t kGatherAhead = 4;
+  // wavefront instead, 64 records at a time with a butterfly at the end (its own fixed order).
+  constexpr uint32_t kBigInst = 64;
   const bool big = ga.inst_cnt > kBigInst;
   // dual: 14 floats = seven float2 (56-byte stride); single render: 10 floats = five float2 (40-byte stride)
   auto load_record = [&](uint32_t inst, float4& a, float4& b, float4& c, float4& d) {
@@ -1329,14 +1338,38 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
   SplatMoments mo;
   for (int k = 0; k < 9; ++k) mo.m[k] = 0.f;
   bool ok = false;
-  if (ga.inst_cnt) {
-    // The records are read with everything else: their addresses only need gaux, so the first kGatherAhead of them (a
-    // splat has 3.5 on average at the headline shape) are in flight together with the inputs of the projection instead
-    // of behind its arithmetic -- this kernel is bound by how many loads it keeps outstanding at 3 waves per SIMD.
-    float4 pa[kGatherAhead], pb[kGatherAhead], pc[kGatherAhead], pd[kGatherAhead];
+  // the wavefront's list: lane l's records sit at positions [V, V + my_cnt) (wave-level scan; a big splat is not in it)
+  constexpr int kRow = 12;                                          // floats per parked record: 9 sums + up to 3 second-set colours
+  __shared__ __attribute__((aligned(16))) float lds_rows[4][64 * kRow];
+  float* __restrict__ rows = lds_rows[threadIdx.x >> 6];
+  const int ln = lane_id();
+  const uint32_t my_cnt = (live && !big) ? ga.inst_cnt : 0u;
+  const uint32_t incl_cnt = wave_incl_scan(my_cnt);
+  const uint32_t V = incl_cnt - my_cnt;
+  const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl_cnt, 63);
+  auto owner_of = [&](uint32_t j) {                                 // last lane whose V <= j (j < T: that lane holds position j)
+    int lo = 0, hi = 63;
 #pragma unroll
-    for (uint32_t i = 0; i < kGatherAhead; ++i)            // past the end: the last record again (a cache hit), unused
-      load_record(ga.inst_base + min(i, ga.inst_cnt - 1u), pa[i], pb[i], pc[i], pd[i]);
+    for (int it = 0; it < 6; ++it) {
+      const int mid = (lo + hi + 1) >> 1;
+      const uint32_t vm = (uint32_t)__builtin_amdgcn_ds_bpermute(mid << 2, (int)V);
+      const bool le = vm <= j;
+      lo = le ? mid : lo; hi = le ? hi : mid - 1;
+    }
+    return lo;
+  };
+  // the first window's records are requested with everything else: their addresses only need gaux, so they are in flight
+  // together with the inputs of the projection instead of behind its arithmetic
+  float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, rd = ra;
+  int own = 0;
+  bool have = (uint32_t)ln < T;
+  {
+    own = owner_of(have ? (uint32_t)ln : 0u);                       // (every lane takes part in the permutes)
+    const uint32_t ob = (uint32_t)__builtin_amdgcn_ds_bpermute(own << 2, (int)ga.inst_base);
+    const uint32_t ov = (uint32_t)__builtin_amdgcn_ds_bpermute(own << 2, (int)V);
+    if (have) load_record(ob + ((uint32_t)ln - ov), ra, rb, rc, rd);
+  }
+  if (ga.inst_cnt) {
     const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
     if constexpr (COV3D) {
       for (int i = 0; i < 6; ++i) c6[i] = scales[6 * gid + i];
@@ -1347,16 +1380,48 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     }
     op = opacities[gid];
     ok = project_splat(cam, mean, sc, q, op, sp, aux, COV3D ? c6 : nullptr);
-    if (ok && !big) {
-#pragma unroll
-      for (uint32_t i = 0; i < kGatherAhead; ++i)
-        if (i < ga.inst_cnt) add_record(mo, cb0, cb1, cb2, pa[i], pb[i], pc[i], pd[i], sp.u, sp.v, sp.ulo, sp.vlo);
-      for (uint32_t i = kGatherAhead; i < ga.inst_cnt; ++i) {
-        float4 a, b, c, d;
-        load_record(ga.inst_base + i, a, b, c, d);
-        add_record(mo, cb0, cb1, cb2, a, b, c, d, sp.u, sp.v, sp.ulo, sp.vlo);
-      }
+  }
+  for (uint32_t j0 = 0; j0 < T; j0 += 64u) {                        // wave-uniform
+    {
+      // my record of this window, re-centred with ITS owner's centre, parked in row `ln`
+      const float ou = __int_as_float(__builtin_amdgcn_ds_bpermute(own << 2, __float_as_int(sp.u)));
+      const float ovv = __int_as_float(__builtin_amdgcn_ds_bpermute(own << 2, __float_as_int(sp.v)));
+      const float oul = __int_as_float(__builtin_amdgcn_ds_bpermute(own << 2, __float_as_int(sp.ulo)));
+      const float ovl = __int_as_float(__builtin_amdgcn_ds_bpermute(own << 2, __float_as_int(sp.vlo)));
+      SplatMoments one;
+      for (int k = 0; k < 9; ++k) one.m[k] = 0.f;
+      float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+      if (have) add_record(one, o0, o1, o2, ra, rb, rc, rd, ou, ovv, oul, ovl);
+      float4* row = reinterpret_cast<float4*>(rows + ln * kRow);
+      row[0] = make_float4(one.m[0], one.m[1], one.m[2], one.m[3]);
+      row[1] = make_float4(one.m[4], one.m[5], one.m[6], one.m[7]);
+      row[2] = make_float4(one.m[8], o0, o1, o2);
     }
+    // the next window's records go out before this window's rows are added up
+    const uint32_t jn = j0 + 64u + (uint32_t)ln;
+    const bool have_n = jn < T;
+    if (j0 + 64u < T) {                                             // wave-uniform
+      own = owner_of(have_n ? jn : 0u);
+      const uint32_t ob = (uint32_t)__builtin_amdgcn_ds_bpermute(own << 2, (int)ga.inst_base);
+      const uint32_t ov = (uint32_t)__builtin_amdgcn_ds_bpermute(own << 2, (int)V);
+      if (have_n) load_record(ob + (jn - ov), ra, rb, rc, rd);
+    }
+    have = have_n;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the rows are written (one wavefront: LDS runs in order) ...
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ... and every owner adds its rows of the window, in index order
+    const uint32_t r0 = V > j0 ? V - j0 : 0u, r1 = min(V + my_cnt, j0 + 64u);
+    for (uint32_t r = r0; r + j0 < r1 && my_cnt; ++r) {
+      const float4* row = reinterpret_cast<const float4*>(rows + r * kRow);
+      const float4 x0 = row[0], x1 = row[1], x2 = row[2];
+      mo.m[0] += x0.x; mo.m[1] += x0.y; mo.m[2] += x0.z; mo.m[3] += x0.w;
+      mo.m[4] += x1.x; mo.m[5] += x1.y; mo.m[6] += x1.z; mo.m[7] += x1.w;
+      mo.m[8] += x2.x; cb0 += x2.y;
+      if constexpr (DUAL && !B1) { cb1 += x2.z; cb2 += x2.w; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // (the next window overwrites the rows)
+    __builtin_amdgcn_wave_barrier();
   }
   for (unsigned long long rest = __ballot(ok && big); rest; rest &= rest - 1ull) {     // wave-uniform
     const int src = __builtin_ctzll(rest);

@@ -106,6 +106,18 @@ VTGS_HD void ewa_M(const CamParams& cam, float tx, float ty, float tz, float M[6
   }
 }
 
+// The half-open rectangle of 16x16 tiles under a splat's centre and radius (with the lattice epsilon
+// of kRectEps).  project_splat calls it; so does the end phase of project_and_bin, which rebuilds the rectangle of a deferred
+// splat from its stored centre and radius -- the same floats through the same operations, hence the same rectangle.
+VTGS_HD void tile_rect(const CamParams& cam, float u, float v, int radius, int& x0, int& y0, int& x1, int& y1) {
+  const float rf = (float)radius;
+  const float it = 1.f / (float)kBinTile;
+  x0 = clampi((int)floorf((u - rf) * it + kRectEps), 0, cam.gx16);
+  x1 = clampi((int)floorf((u + rf + (float)(kBinTile - 1)) * it + kRectEps), 0, cam.gx16);
+  y0 = clampi((int)floorf((v - rf) * it + kRectEps), 0, cam.gy16);
+  y1 = clampi((int)floorf((v + rf + (float)(kBinTile - 1)) * it + kRectEps), 0, cam.gy16);
+}
+
 // Forward projection of one Gaussian.  Returns false when culled (radius = 0).
 // cov_precomp != NULL: the caller gives the 3-D covariance itself (xx xy xz yy yz zz -- the operator's `cov3D_precomp`, used as
 // it is: no scale modifier) instead of scale + rotation; every existing caller passes the default and pays nothing.
@@ -184,11 +196,7 @@ VTGS_HD bool project_splat(const CamParams& cam, const float mean[3], const floa
   const int radius = splat_radius(lam, opacity, cam.radius_rule);
   const float rf = (float)radius;
   if (!(fabsf(out.u) < 1e9f) || !(fabsf(out.v) < 1e9f) || !(rf < 1e9f)) return false;
-  const float it = 1.f / (float)kBinTile;
-  out.x0 = clampi((int)floorf((out.u - rf) * it + kRectEps), 0, cam.gx16);
-  out.x1 = clampi((int)floorf((out.u + rf + (float)(kBinTile - 1)) * it + kRectEps), 0, cam.gx16);
-  out.y0 = clampi((int)floorf((out.v - rf) * it + kRectEps), 0, cam.gy16);
-  out.y1 = clampi((int)floorf((out.v + rf + (float)(kBinTile - 1)) * it + kRectEps), 0, cam.gy16);
+  tile_rect(cam, out.u, out.v, radius, out.x0, out.y0, out.x1, out.y1);
   if ((out.x1 - out.x0) * (out.y1 - out.y0) <= 0) return false;
   out.radius = radius;
   return true;
