@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VTGS_ABI_VERSION 15
+#define VTGS_ABI_VERSION 16
 
 typedef enum VtgsStatus {
   VTGS_OK = 0,
@@ -70,8 +70,12 @@ typedef struct VtgsCamera {
 
 /* Result record of a forward.  Assembled on the device and copied to `info` (host). */
 typedef struct VtgsForwardInfo {
-  uint64_t instances;        /* (Gaussian, 8x8 tile) instances binned by this call (0 on overflow)    */
-  uint64_t instances_needed; /* == instances, or the count that did not fit on overflow              */
+  uint64_t instances;        /* (Gaussian, 8x8 tile) instances binned by this call = entries of all   */
+                             /* tile lists (0 on overflow)                                            */
+  uint64_t instances_needed; /* instance IDS handed out: what instance_capacity and the backward's    */
+                             /* scratch must hold.  >= instances: a splat of more than nine candidate */
+                             /* tiles holds one id per CANDIDATE tile, and the ids of the candidates  */
+                             /* it does not reach stay unused (ABI 16).  On overflow: what did not fit */
   uint64_t tiles16_touched;  /* R of SURVEY 8(d): sum over Gaussians of 16x16 tiles in their rect    */
   uint32_t visible;          /* Gaussians with radii > 0                                             */
   uint32_t max_tile_list;    /* longest per-tile list                                                */
@@ -196,7 +200,8 @@ int vtgs_forward_shared(const VtgsCamera* cam, int32_t n, const float* colors,
  *   workspace / instance_capacity / tile_capacity: exactly what the forward was given (they fix the layout).
  *   image_state: NULL to use the state stored in the workspace by vtgs_forward, or the buffer a
  *   vtgs_forward_shared call filled.
- *   scratch: vtgs_backward_scratch_bytes(n, info.instances) bytes, contents undefined on entry and exit.
+ *   scratch: vtgs_backward_scratch_bytes(n, info.instances_needed) bytes (records are addressed by instance id), contents
+ *            undefined on entry and exit.
  *   In band mode (tile_row_begin/end) the gradients are this band's partial sums; pixels outside the
  *   band are written as zero by the forward and ignored by the backward.
  *   g_means2D[N,3] holds the NDC-scaled screen-space gradient in [:, :2] (what means2D.grad shows at
@@ -288,6 +293,18 @@ int vtgs_mark_visible(const VtgsCamera* cam, int32_t n, const float* means3D,
  * takes the 12 -> 7 step through the quaternion.  No atomics: results are bitwise reproducible.  The four *_b inputs
  * may all be NULL (after vtgs_backward_dual the *_a set already holds the sum over both renders).                       */
 uint32_t vtgs_pose_partial_rows(int32_t n);
+/* Round 6 (ABI 16): the two slot helpers below folded into their neighbours, for callers that hold the reference's camera
+ * tensors [1,4,T] / [1,3,T] (contiguous):
+ *   vtgs_prepare_frame_slot   = vtgs_pose_slot_gather + vtgs_prepare_frame in ONE launch: the pose is read in place (column t)
+ *                               and out_pose7 (device, 7 floats: q, t) receives it contiguous for the backward's entry points;
+ *   vtgs_pose_gradient_slot   = vtgs_pose_gradient + vtgs_pose_slot_scatter in ONE launch: writes the FULL-SIZE gradients
+ *                               (4 T and 3 T floats, zero except column t); cam_q = the contiguous q of out_pose7.             */
+int vtgs_prepare_frame_slot(int32_t n, const float* means3D, const float* logit_opacities, const float* log_scales,
+                            const float* unnorm_rotations, const float* cam_unnorm_rots, const float* cam_trans, int32_t frames,
+                            int32_t t, const float* depth_w2c, float* out_means_cam, float* out_opacities, float* out_scales,
+                            float* out_rotations, float* out_depth_colors, float* out_pose7, void* stream);
+int vtgs_pose_gradient_slot(const float* pose_partials, uint32_t rows, const float* cam_q, int32_t frames, int32_t t,
+                            float* g_cam_unnorm_rots, float* g_cam_trans, void* stream);
 /* The pose of frame t out of the reference's camera tensors, cam_unnorm_rots [1,4,frames] and cam_trans [1,3,frames]
  * (src/vtgaussian_slam.py:160-167), as seven contiguous floats (q[4], t[3]); and its adjoint: full-size gradients that are zero
  * except column t.  One launch each -- tensor indexing costs ten (two strided copies, four zero-fills, four slice copies). */
@@ -431,6 +448,13 @@ int vtgs_slam_loss_forward(int32_t mode, const float* im, const float* depth_sil
                            int32_t height, int32_t width, float sil_thres, float w_im, float w_depth, float* scratch,
                            float* ssim_grad_maps, float* out8, const float* extra_mask, const float* color_weight,
                            void* stream);
+/* The same, with get_loss's bookkeeping of the render it belongs to (src/vtgaussian_slam.py:681-689: seen = radius > 0, the
+ * running maximum of the screen-space radius) in the SAME launch as the loss's last step -- vtgs_seen_and_max_radius folded in:
+ * one launch less per iteration.  n = 0: exactly vtgs_slam_loss_forward.  radii / max_2d_radius 16-byte aligned.  (ABI 16) */
+int vtgs_slam_loss_forward_seen(int32_t mode, const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth,
+                                int32_t height, int32_t width, float sil_thres, float w_im, float w_depth, float* scratch,
+                                float* ssim_grad_maps, float* out8, const float* extra_mask, const float* color_weight,
+                                int32_t n, const int32_t* radii, float* max_2d_radius, uint8_t* seen, void* stream);
 int vtgs_slam_loss_backward(int32_t mode, const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth,
                             int32_t height, int32_t width, float sil_thres, float w_im, float w_depth,
                             const float* ssim_grad_maps, const float* fwd_out8, const float* upstream, float* g_im,

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_version_strings_and_sizes(lib):
     lib.vtgs_abi_version.restype = ctypes.c_uint32
-    assert lib.vtgs_abi_version() == 15
+    assert lib.vtgs_abi_version() == 16
     lib.vtgs_strerror.restype = ctypes.c_char_p
     assert lib.vtgs_strerror(0) == b"ok" and b"instance" in lib.vtgs_strerror(3)
     lib.vtgs_workspace_bytes.restype = ctypes.c_size_t
@@ -132,7 +132,7 @@ def test_header_is_plain_c99_and_links(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src),
                     "-L", lib_dir, "-lvtgs", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert out[0] == "15"
+    assert out[0] == "16"
     # the ctypes mirrors of the package describe the same records as the header
     import diff_gaussian_rasterization as dgr
     assert [int(x) for x in out[1:4]] == [ctypes.sizeof(dgr._VtgsForwardInfo), ctypes.sizeof(dgr._VtgsCamera),

@@ -271,7 +271,8 @@ def test_capacity_overflow_is_answered_inside_the_forward(gpu_device):
     assert info["instances"] > 8 * n + 65536 or info["instances"] > 4 * n + 4096
     _check_images(ref_c, ref_d, c.detach().cpu(), d.detach().cpu())
     key = next(iter(dgr._capacity_hint))
-    real = (info["instances"], info["max_tile_list"])
+    real = (info["instances_needed"], info["max_tile_list"])        # (the instance IDS handed out: what the capacity must hold)
+    assert info["instances_needed"] >= info["instances"]
 
     def poison(which):                         # stale hints -> capacities far too small for the instance total / a tile list
         dgr._capacity_hint[key] = 1 if which & 1 else real[0]

@@ -259,3 +259,44 @@ def test_alternating_views_never_raise(gpu_device):
     finally:
         dgr._FORWARD_MODE = os.environ.get("VTGS_FORWARD_MODE", "auto")
 
+
+
+def test_a_scratch_smaller_than_the_instance_ids_gives_wrong_numbers_not_a_fault(gpu_device, monkeypatch):
+    """the backward's scratch is sized from the instance count of the forward's record; nothing on the device used to tie
+    the ids in the tile lists to that size, so a wrong or stale count was an out-of-bounds write (composite) and read (gather).
+    Now both kernels know how many records the scratch holds (CamScalars::scratch_records): an id at or beyond it is neither
+    written nor read, and the Gaussians whose records would lie there get a ZERO gradient.  Here the scratch is cut to a
+    third of the ids on purpose -- on poisoned memory, so that a read past it would be a NaN or a fault."""
+    import diff_gaussian_rasterization as dgr
+    monkeypatch.setattr(dgr, "_ext", None)                        # (the Python node sizes the scratch through _scratch_instances)
+    dev = gpu_device
+    scene, cam = go.view_tied_scene(20000, 200, 136, seed=9)
+    leaves = {k: v.to(dev).requires_grad_(True) for k, v in scene.items()}
+    g = torch.Generator().manual_seed(2)
+    grad_color = (torch.rand(3, 136, 200, generator=g) * 2 - 1).to(dev)
+    _clear_policy(dgr)
+    dgr.poison_workspaces(True)
+    try:
+        c, r, d = dgr.GaussianRasterizer(raster_settings=to_settings(cam, dev))(**leaves)
+        full = {}
+        (c * grad_color).sum().backward(retain_graph=True)
+        torch.cuda.synchronize()
+        full = {k: leaves[k].grad.clone() for k in GRAD_KEYS}
+        ids = dgr.last_forward_info()["instances_needed"]
+        for t in leaves.values():
+            t.grad = None
+        real = dgr._scratch_instances
+        monkeypatch.setattr(dgr, "_scratch_instances", lambda fs: max(real(fs) // 3, 1))
+        (c * grad_color).sum().backward()
+        torch.cuda.synchronize()                                  # a fault would surface here
+    finally:
+        dgr.poison_workspaces(False)
+    cut = {k: leaves[k].grad for k in GRAD_KEYS}
+    same = zero = 0
+    for k in ("means3D", "opacities", "colors_precomp"):
+        assert bool(torch.isfinite(cut[k]).all()), k
+        eq = (cut[k] == full[k]).reshape(cut[k].shape[0], -1).all(dim=1)
+        zr = (cut[k] == 0).reshape(cut[k].shape[0], -1).all(dim=1)
+        assert bool((eq | zr).all()), f"{k}: a Gaussian has a gradient that is neither the full one nor zero"
+        same, zero = int(eq.sum()), int((zr & ~eq).sum())
+    assert ids > 3 and zero > 0 and same > 0, (ids, same, zero)    # some Gaussians kept their records, some lost them

@@ -38,6 +38,16 @@ run() {   # run <log> <command...>
   fi
   if grep -q -E "Memory access fault|Fatal Python error|Segmentation fault|core dumped|HSA_STATUS_ERROR" $log; then
     echo "GPU FAULT / ABORT in $log:"; grep -E "Memory access fault|Fatal Python error|Segmentation fault|core dumped|HSA_STATUS_ERROR" $log | head -5
+    # the runtime leaves a GPU core file (gpucore.<pid>) in the working directory: the waves in flight, their kernel and their
+    # program counters name the faulting kernel -- the fault line itself only has an address (round 6)
+    for c in $(ls -t gpucore.* 2>/dev/null | head -1); do
+      echo "== rocgdb on $c (summary in ${log%.log}.gpucore.txt)"
+      timeout -k 5 240 /opt/rocm/bin/rocgdb -batch -ex "set pagination off" -ex "info agents" -ex "info threads" -ex "thread apply all bt 3" \
+        $(command -v python3) $c 2>&1 | head -c 4000000 > ${log%.log}.gpucore.txt
+      grep -E "fault|SIGSEGV|SIGBUS|exception|stopped|Memory" ${log%.log}.gpucore.txt | sort | uniq -c | sort -rn | head -8
+      grep -o -E "in [A-Za-z_0-9:<>, ]+\(" ${log%.log}.gpucore.txt | sort | uniq -c | sort -rn | head -8
+      rm -f $c
+    done
     fail=2; return 2
   fi
   if [ $rc -ne 0 ]; then echo "step failed (rc $rc): $*"; tail -25 $log | cut -c1-300; fail=1; return 1; fi

@@ -10,6 +10,7 @@ from oracle import gs_oracle as go
 from parity_util import to_settings
 import diff_gaussian_rasterization as dgr
 dev=torch.device('cuda:0')
+if os.environ.get('ABL_POISON','0')=='1': dgr.poison_workspaces(True)   # every workspace / scratch starts as 0xFF bytes: a kernel that reads a slot nobody wrote shows up
 N=int(os.environ.get('ABL_N','1000000'))
 W=int(os.environ.get('ABL_W','1200')); H=int(os.environ.get('ABL_H','680'))
 scene,cam=go.view_tied_scene(N,W,H,seed=0)

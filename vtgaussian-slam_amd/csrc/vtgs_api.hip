@@ -14,11 +14,14 @@ namespace vtgs {
 template <int LDSBINS, int MODE>
 __global__ void project_and_bin(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
                                 const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*,
-                                Counters*, BlockStats*, unsigned long long, uint32_t);
+                                Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
 template <int LDSBINS, int MODE>
 __global__ void project_and_bin_capped(CamScalars, const float*, const float*, int, const float*, const float*, const float*,
                                 const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*,
-                                Counters*, BlockStats*, unsigned long long, uint32_t);
+                                Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+template <bool PLANNED>
+__global__ void bin_deferred_splats(CamScalars, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, const DeferRec*,
+                                    unsigned long long, uint32_t);
 __global__ void finalize_forward(const uint32_t*, uint32_t, Counters*, unsigned long long, uint32_t, const BlockStats*,
                                  uint32_t, VtgsForwardInfo*, const uint32_t*, uint32_t*);
 template <bool WIDE>
@@ -102,9 +105,18 @@ static bool g_prof_on = false;
 static ProfSlot g_prof[8192];
 static int g_prof_n = 0, g_prof_created = 0;
 
+// VTGS_DEBUG_SYNC=1 (environment, read once): every bracketed kernel is followed by a stream synchronise and a line on stderr --
+// a GPU fault then names the kernel that was in flight instead of surfacing at some later call (round 6: a fault in a new kernel
+// showed up as "Memory access fault" with nothing to say which of seven launches it belonged to)
+static int g_debug_sync = -1;
+static bool debug_sync() {
+  if (g_debug_sync < 0) { const char* v = getenv("VTGS_DEBUG_SYNC"); g_debug_sync = (v && v[0] == '1') ? 1 : 0; }
+  return g_debug_sync == 1;
+}
+
 struct ProfScope {
-  hipStream_t st; int idx;
-  ProfScope(const char* name, hipStream_t s) : st(s), idx(-1) {
+  hipStream_t st; int idx; const char* nm;
+  ProfScope(const char* name, hipStream_t s) : st(s), idx(-1), nm(name) {
     if (!g_prof_on || g_prof_n >= 8192) return;
     idx = g_prof_n++;
     if (idx >= g_prof_created) {
@@ -114,7 +126,14 @@ struct ProfScope {
     g_prof[idx].name = name;
     (void)hipEventRecord(g_prof[idx].a, st);
   }
-  ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, st); }
+  ~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, st);
+    if (debug_sync()) {
+      const hipError_t e = hipStreamSynchronize(st);
+      fprintf(stderr, "[vtgs] %s: %s\n", nm, e == hipSuccess ? "done" : hipGetErrorString(e));
+      fflush(stderr);
+    }
+  }
 };
 
 static bool band_of(const VtgsCamera* cam, int* row8_begin, int* row8_end, int* rows16, int* row16_0) {
@@ -144,6 +163,7 @@ static CamScalars scalars_of(const VtgsCamera* cam, int row8_begin, int row8_end
   cs.row8_begin = row8_begin; cs.row8_end = row8_end;
   cs.bin_plan = nullptr; cs.bin_limit = 0u;                  // planned bins: set by the caller once the workspace layout is known
   cs.bwd_flags = 0u;
+  cs.scratch_records = 0xFFFFFFFFu;
 #ifdef VTGS_Q_STAMPS
   cs.dbg_proj = nullptr;
 #endif
@@ -356,21 +376,19 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
                          cam->viewmatrix, cam->projmatrix, n, means3D, opacities, scales, rotations, out_radii,         \
                          (GeomRec*)(ws + L.geom), (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt),              \
                          (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), ctr,                            \
-                         (BlockStats*)(ws + L.block_stats), (unsigned long long)instance_capacity, L.tile_cap)
+                         (BlockStats*)(ws + L.block_stats), (unsigned long long)instance_capacity, L.tile_cap,            \
+                         (DeferRec*)(ws + L.defer_list))
       // (LDS: 0 = run-aggregated global atomics, 1 = the band's whole tile table in LDS, 2 = a window of kWinEntries tiles)
-      // (every form gets at least kDeferLds bytes of dynamic LDS: the end phase keeps the workgroup's deferred-splat lists there)
-      constexpr size_t kDeferLds = 1024 * 2 + 1024 * 4;
-      const size_t table_lds = table_bytes > kDeferLds ? table_bytes : kDeferLds;
       if (lds_bins) {
 #define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin<LDS, MODE>
-        if (mode == 0) VTGS_LAUNCH_PROJECT(1, 0, table_lds);
+        if (mode == 0) VTGS_LAUNCH_PROJECT(1, 0, table_bytes);
 #undef VTGS_PROJECT_KERNEL
 #define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin_capped<LDS, MODE>
-        else if (mode == 1) VTGS_LAUNCH_PROJECT(1, 1, table_lds);
-        else if (mode == 2) VTGS_LAUNCH_PROJECT(1, 2, table_lds);
-        else if (mode == 4) VTGS_LAUNCH_PROJECT(1, 4, table_lds);
-        else if (mode == 5) VTGS_LAUNCH_PROJECT(1, 5, table_lds);
-        else VTGS_LAUNCH_PROJECT(1, 3, table_lds);
+        else if (mode == 1) VTGS_LAUNCH_PROJECT(1, 1, table_bytes);
+        else if (mode == 2) VTGS_LAUNCH_PROJECT(1, 2, table_bytes);
+        else if (mode == 4) VTGS_LAUNCH_PROJECT(1, 4, table_bytes);
+        else if (mode == 5) VTGS_LAUNCH_PROJECT(1, 5, table_bytes);
+        else VTGS_LAUNCH_PROJECT(1, 3, table_bytes);
       } else if (win_bins) {
 #undef VTGS_PROJECT_KERNEL
 #define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin<LDS, MODE>
@@ -383,17 +401,33 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
       } else {
 #undef VTGS_PROJECT_KERNEL
 #define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin<LDS, MODE>
-        if (mode == 0) VTGS_LAUNCH_PROJECT(0, 0, kDeferLds);
+        if (mode == 0) VTGS_LAUNCH_PROJECT(0, 0, 0);
 #undef VTGS_PROJECT_KERNEL
 #define VTGS_PROJECT_KERNEL(LDS, MODE) project_and_bin_capped<LDS, MODE>
-        else if (mode == 1) VTGS_LAUNCH_PROJECT(0, 1, kDeferLds);
-        else if (mode == 2) VTGS_LAUNCH_PROJECT(0, 2, kDeferLds);
-        else if (mode == 4) VTGS_LAUNCH_PROJECT(0, 4, kDeferLds);
-        else if (mode == 5) VTGS_LAUNCH_PROJECT(0, 5, kDeferLds);
-        else VTGS_LAUNCH_PROJECT(0, 3, kDeferLds);
+        else if (mode == 1) VTGS_LAUNCH_PROJECT(0, 1, 0);
+        else if (mode == 2) VTGS_LAUNCH_PROJECT(0, 2, 0);
+        else if (mode == 4) VTGS_LAUNCH_PROJECT(0, 4, 0);
+        else if (mode == 5) VTGS_LAUNCH_PROJECT(0, 5, 0);
+        else VTGS_LAUNCH_PROJECT(0, 3, 0);
       }
 #undef VTGS_PROJECT_KERNEL
 #undef VTGS_LAUNCH_PROJECT
+    }
+    VTGS_HIP(hipGetLastError());
+    {
+      // the splats project_and_bin left aside (more than kDeferArea candidate tiles): binned here, 64 list entries per workgroup
+      // and round; the list's length is on the device, so the grid is what a list of N / 8 entries needs (longer lists: more
+      // rounds per workgroup) and, with an empty list, every workgroup leaves after one load
+      ProfScope ps__("bin_deferred_splats", st);
+      const uint32_t dgrid = (uint32_t)min((long long)4096, max((long long)64, ((long long)n / 8 + 63) / 64));
+      if (L.planned)
+        hipLaunchKernelGGL((bin_deferred_splats<true>), dim3(dgrid), dim3(256), 0, st, cs, (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt),
+                           (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), ctr, (const DeferRec*)(ws + L.defer_list),
+                           (unsigned long long)instance_capacity, L.tile_cap);
+      else
+        hipLaunchKernelGGL((bin_deferred_splats<false>), dim3(dgrid), dim3(256), 0, st, cs, (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt),
+                           (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), ctr, (const DeferRec*)(ws + L.defer_list),
+                           (unsigned long long)instance_capacity, L.tile_cap);
     }
     VTGS_HIP(hipGetLastError());
   }
@@ -613,6 +647,11 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
   // FrameEpilogue flag 8 (the caller's promise: grad_color_b is zero outside its first channel -- get_loss, whose loss reaches
   // the [z, 1, z^2] render through z alone): four gradient channels instead of six, three contraction chains, 48-byte records
   const bool b1 = dual && frame && (frame->flags & 8u) && bwd_impl == 2 && option(OPT_DUAL_B1) != 0;
+  {
+    const size_t rec_bytes = (size_t)(b1 ? kGradRecDual1 : (dual ? kGradRecDual : kGradRec)) * sizeof(float);
+    const size_t recs = scratch_bytes / rec_bytes;
+    cs.scratch_records = recs > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)recs;
+  }
   {
     ProfScope ps__(dual ? "composite_backward_dual" : "composite_backward", st);
     if (b1)

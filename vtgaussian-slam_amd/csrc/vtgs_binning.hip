@@ -111,18 +111,25 @@ constexpr uint32_t kWinEntries = 16384;  // windowed LDS tile table (LDSBINS == 
 // its own.  But every lane of a wavefront waits for the longest walk among the 64, and an optimised SLAM map has a heavy tail
 // of splat sizes: after 20 frames of mapping 8 % of the Gaussians of the synthetic Replica sequence cover 7 .. 64 tiles, so
 // nearly every wavefront held one and ran 16 .. 64 trips of both passes where a fresh view-tied map runs 4 -- project_and_bin
-// 160 us against 46 us, gpurun_out/r6/slamlate_b_dens.txt.)  The deferred splats of a WORKGROUP are processed at the end of
-// the kernel, balanced over all of its lanes:
-//   * up to kGroupArea candidate tiles: one 16-lane group per splat (64 groups per workgroup), 16 tiles per step;
-//   * more: the whole workgroup per splat, 1,024 tiles per step (a splat grown over a hole of the map covers thousands);
-// first a counting round, then ONE instance-range atomic for all of them, then the binning round (slots straight from the global
-// per-tile counters).  Instance ids of a splat follow the raster order of its walk, as everywhere.  The common path does not
-// know any of this exists: lanes with a deferred splat walk nothing, and a workgroup without one leaves before the end phase.
+// 160 us against 46 us, gpurun_out/r6/slamlate_b_dens.txt.)  project_and_bin only LISTS them -- 48-byte records in ONE list for the
+// forward; a workgroup takes its stretch of the list with the atomic that takes its instance range -- and a second kernel,
+// bin_deferred_splats, bins them balanced over its lanes, 256 list entries per workgroup and round:
+//   * up to kGroupArea candidate tiles: one 16-lane group per splat, 16 tiles per step;
+//   * up to kWaveArea: one wavefront per splat, 64 tiles per step;
+//   * more: the whole workgroup, 256 tiles per step (a splat grown over a hole of the map covers thousands);
+// first a counting round, then ONE instance-range atomic for the round's splats, then the binning round (slots straight from the
+// global per-tile counters).  Instance ids of a splat follow the raster order of its walk, as everywhere.
+// A kernel of its own because inlined at the end of project_and_bin the same code kept twenty more scalar registers alive
+// through the common path (88 against 68), which that kernel answers with s_load re-materialisation inside its loops: 62 us
+// against 52 us at the headline shape (gpurun_out/r6/timing_g_head*.log); as a called function it dragged its registers and a
+// scratch frame into the caller (120 VGPRs).  With an empty list every workgroup of the second kernel leaves after one load.
 #ifndef VTGS_DEFER_AREA
 #define VTGS_DEFER_AREA 9
 #endif
 constexpr int kDeferArea = VTGS_DEFER_AREA;      // candidate tiles a lane walks itself (3 x 3: what a few-pixel splat can straddle)
 constexpr int kGroupArea = 64;                   // deferred splats up to this many candidates: a 16-lane group each
+constexpr int kDeferBlock = 256;                 // threads per workgroup of bin_deferred_splats
+constexpr int kWaveArea = 512;                   // ... larger ones up to this many: one WAVEFRONT each, 64 tiles per step; beyond: the workgroup
 static_assert(kDeferArea >= 1 && kDeferArea <= 64, "the reach mask of the common path holds 64 candidates");
 
 // What the walk of one splat needs besides the splat: the reach threshold, the hoisted reach form, the candidate rectangle
@@ -159,23 +166,7 @@ __device__ __forceinline__ WalkSetup setup_walk(const CamParams& cam, const Spla
   return ws;
 }
 
-// A deferred splat, rebuilt from what the common path stored for it (geometry record + radius)
-struct DeferredSplat { Splat sp; float op; WalkSetup ws; unsigned long long key; };
-
-__device__ __forceinline__ DeferredSplat load_deferred(const CamParams& cam, const GeomRec* __restrict__ geom,
-                                                       const int32_t* __restrict__ radii, int gid) {
-  DeferredSplat d;
-  const float4* gp = reinterpret_cast<const float4*>(geom + gid);
-  const float4 g0 = gp[0], g1 = gp[1];
-  d.sp = Splat{};
-  d.sp.u = g0.x; d.sp.v = g0.y; d.sp.A = g0.z; d.sp.B = g0.w; d.sp.C = g1.x; d.sp.depth = g1.z;
-  d.op = g1.y;
-  d.sp.radius = radii[gid];
-  tile_rect(cam, d.sp.u, d.sp.v, d.sp.radius, d.sp.x0, d.sp.y0, d.sp.x1, d.sp.y1);
-  d.ws = setup_walk(cam, d.sp, d.op, true);
-  d.key = ((unsigned long long)__float_as_uint(d.sp.depth) << 32) | (unsigned long long)(uint32_t)gid;
-  return d;
-}
+constexpr int kBigArea = kDeferArea;          // (the name the body of project_and_bin uses)
 
 // LDSBINS (tile count fits the LDS table): the workgroup first histograms its instances per tile in LDS, then takes ONE
 // global slot range per touched tile -- all those device-scope atomics are in flight together, so their round trip
@@ -192,7 +183,8 @@ __device__ __forceinline__ void project_and_bin_body(
     const float* __restrict__ scales, const float* __restrict__ rotations,
     int32_t* __restrict__ radii, GeomRec* __restrict__ geom, GaussAux* __restrict__ gaux,
     uint32_t* __restrict__ tile_cnt, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
-    Counters* __restrict__ ctr, BlockStats* __restrict__ block_stats, unsigned long long capacity, uint32_t tile_cap) {
+    Counters* __restrict__ ctr, BlockStats* __restrict__ block_stats, unsigned long long capacity, uint32_t tile_cap,
+    DeferRec* __restrict__ defer_list) {
   constexpr int kWaves = kProjBlock / 64;
   extern __shared__ uint32_t lds_tile[];                         // LDSBINS: one entry per 8x8 tile of this call's band
 #ifdef VTGS_Q_STAMPS
@@ -267,14 +259,32 @@ __device__ __forceinline__ void project_and_bin_body(
       return;
     }
   }
-  const WalkSetup wsu = setup_walk(cam, sp, op, vis);
-  const TileWalk w = wsu.w;
-  const ReachForm rf = wsu.rf;
-  const float tau = wsu.tau;
+  // alpha = o*G >= 1/255 somewhere  <=>  q <= ln(255 o); slack keeps the test conservative
+  float tau = -1.f;
+  if (vis && op * 255.f >= 1.f) { tau = __log2f(255.f * op) * 0.69314718f; tau += 1e-4f * tau + 1e-4f; }   // (v_log_f32: 1 ulp, inside the slack)
+  const bool reach = vis && tau >= 0.f;
+  const ReachForm rf = make_reach_form(sp);
+  TileWalk w = make_walk(cam, sp, reach);
+  if (reach && rf.regular) {
+    // shrink the walk to the tiles under the bounding box of the alpha >= 1/255 ellipse (half-widths sqrt(2 tau C / det),
+    // sqrt(2 tau A / det); tau carries the slack): a few-pixel splat then tests ~4 candidates instead of the 16 under its
+    // 16x16-tile rectangle.  The exact test below still decides; the box only removes tiles it cannot pass.
+    // (hardware reciprocal / square root as in composite_forward_q's quadrant box, with the same 2e-6 relative + 1e-5 px of
+    //  slack: the IEEE forms are ~35 instructions per Gaussian and the box only has to be conservative)
+    const float idet = __builtin_amdgcn_rcpf(fmaxf(sp.A * sp.C - sp.B * sp.B, 1e-30f));
+    const float k2 = 2.f * tau * idet;
+    const float hx = __builtin_amdgcn_sqrtf(k2 * sp.C) * 1.000002f + 1e-5f, hy = __builtin_amdgcn_sqrtf(k2 * sp.A) * 1.000002f + 1e-5f;
+    const float inv8 = 1.f / (float)kSubTile;
+    const int bx0 = (int)ceilf((sp.u - hx - (float)(kSubTile - 1)) * inv8), bx1 = (int)floorf((sp.u + hx) * inv8);
+    const int by0 = (int)ceilf((sp.v - hy - (float)(kSubTile - 1)) * inv8), by1 = (int)floorf((sp.v + hy) * inv8);
+    const int x0 = max(w.cx0, bx0), x1 = min(w.cx0 + w.cw, bx1 + 1);
+    const int y0 = max(w.cy0, by0), y1 = min(w.cy0 + w.ch, by1 + 1);
+    if (x1 > x0 && y1 > y0) { w.cx0 = x0; w.cy0 = y0; w.cw = x1 - x0; w.ch = y1 - y0; }
+    else { w.cw = 0; w.ch = 0; }
+  }
   VTGS_P_STAMP(1)                                                // inputs arrived, projection + walk set up
-  const int area_all = wsu.area;
-  const bool big = area_all > kDeferArea;                      // deferred: left to the workgroup, at the end of the kernel
-  const bool large = area_all > kGroupArea;                    // ... and there to the whole workgroup, not to a 16-lane group
+  const int area_all = w.cw * w.ch;
+  const bool big = area_all > kBigArea;                        // deferred: listed for bin_deferred_splats, not walked here
   const int area = big ? 0 : area_all;
 
   // the per-tile table is cleared only now: the input loads above are in flight while it happens, and the workgroups of a
@@ -289,7 +299,7 @@ __device__ __forceinline__ void project_and_bin_body(
   for (int i = 0, tx = 0, ty = 0; i < area; ++i) {
     const bool hit = tile_reached(cam, sp, rf, tau, w.cx0 + tx, w.cy0 + ty);
     cnt += hit ? 1u : 0u;
-    if (hit) reach_mask |= 1ull << i;                           // (area <= kDeferArea <= 64)
+    if (i < 64 && hit) reach_mask |= 1ull << i;
     if constexpr (LDSBINS == 1) { if (hit) atomicAdd(&lds_tile[(w.cy0 + ty) * cam.gx8 + w.cx0 + tx - tile0], 1u); }
     if (++tx == w.cw) { tx = 0; ++ty; }
   }
@@ -298,23 +308,29 @@ __device__ __forceinline__ void project_and_bin_body(
   // global counter: same-address atomics serialise at the memory side (~14 ns each measured), so per-wavefront
   // atomics on one cache line cost more than the whole projection.
   __shared__ uint32_t s_wave_cnt[kWaves], s_wave_vis[kWaves], s_wave_r16[kWaves], s_block_base;
-  __shared__ uint32_t s_wave_small[kWaves], s_wave_large[kWaves], s_n_small, s_n_large;   // deferred splats of the workgroup
+  __shared__ uint32_t s_wave_def[kWaves], s_def_base;              // deferred splats of the workgroup, per wavefront; its stretch of the list
   const int wv = (int)(threadIdx.x >> 6);
-  const uint32_t incl = wave_incl_scan(cnt);
+  // a deferred splat takes its instance ids here too: one per candidate tile, an upper bound (DeferRec::inst_base)
+  const uint32_t cnt_ids = big ? (uint32_t)area_all : cnt;
+  const uint32_t incl = wave_incl_scan(cnt_ids);
   const uint32_t r16 = vis ? (uint32_t)((sp.x1 - sp.x0) * (sp.y1 - sp.y0)) : 0u;
   const uint32_t r16_incl = wave_incl_scan(r16);
   const unsigned long long vb = __ballot(vis);
-  const unsigned long long small_b = __ballot(big && !large), large_b = __ballot(large);
+  const unsigned long long def_b = __ballot(big);
   if (l == 63) {
     s_wave_cnt[wv] = incl; s_wave_vis[wv] = (uint32_t)__popcll(vb); s_wave_r16[wv] = r16_incl;
-    s_wave_small[wv] = (uint32_t)__popcll(small_b); s_wave_large[wv] = (uint32_t)__popcll(large_b);
+    s_wave_def[wv] = (uint32_t)__popcll(def_b);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t tot = 0, v = 0, ns = 0, nl = 0; unsigned long long r = 0;
-    for (int k = 0; k < kWaves; ++k) { tot += s_wave_cnt[k]; v += s_wave_vis[k]; r += s_wave_r16[k]; ns += s_wave_small[k]; nl += s_wave_large[k]; }
-    s_n_small = ns; s_n_large = nl;
-    s_block_base = tot ? atomicAdd(&ctr->inst_total, tot) : 0u;
+    uint32_t tot = 0, v = 0, nd = 0; unsigned long long r = 0;
+    // (unrolled sixteen times the compiler requests all 80 partials at once and the KERNEL's register count follows: 94 VGPRs,
+    //  the second workgroup per CU gone -- with three arrays, until round 5, the same loop just fitted under 64)
+#pragma unroll 4
+    for (int k = 0; k < kWaves; ++k) { tot += s_wave_cnt[k]; v += s_wave_vis[k]; r += s_wave_r16[k]; nd += s_wave_def[k]; }
+    // the instance range and the stretch of the deferred list with ONE atomic (Counters: the 64-bit pair)
+    const unsigned long long old = (tot | nd) ? atomicAdd(reinterpret_cast<unsigned long long*>(ctr), ((unsigned long long)tot << 32) | (unsigned long long)nd) : 0ull;
+    s_block_base = (uint32_t)(old >> 32); s_def_base = (uint32_t)old;
     BlockStats bs;
     bs.visible = v; bs.pad = 0; bs.r16 = r;
     block_stats[blockIdx.x] = bs;
@@ -330,7 +346,18 @@ __device__ __forceinline__ void project_and_bin_body(
   VTGS_P_STAMP(3)                                                // scans, the instance-range atomic, per-tile global reservations
   uint32_t wave_base = s_block_base;
   for (int k = 0; k < wv; ++k) wave_base += s_wave_cnt[k];
-  const uint32_t inst_base = wave_base + incl - cnt;
+  const uint32_t inst_base = wave_base + incl - cnt_ids;
+
+  if (big) {
+    // listed for bin_deferred_splats, with everything it needs (DeferRec).  HERE, between the passes: the splat is still in registers.
+    uint32_t pos = s_def_base + (uint32_t)__popcll(def_b & ((1ull << l) - 1ull));
+    for (int k = 0; k < wv; ++k) pos += s_wave_def[k];
+    float4* __restrict__ rec = reinterpret_cast<float4*>(defer_list + pos);
+    rec[0] = make_float4(sp.u, sp.v, sp.A, sp.B);
+    rec[1] = make_float4(sp.C, tau, sp.depth, __uint_as_float((uint32_t)gid));
+    rec[2] = make_float4(__uint_as_float((uint32_t)w.cx0 | ((uint32_t)w.cy0 << 16)), __int_as_float(w.cw), __int_as_float(w.ch),
+                         __uint_as_float(inst_base));
+  }
 
   if (valid && !big) {
     // the geometry record is only ever reached through a tile list: a splat without instances (culled, or outside this
@@ -395,7 +422,7 @@ __device__ __forceinline__ void project_and_bin_body(
     // pass 2, LDS form: every lane walks its own reached tiles; the slot comes from the LDS table
     for (int i = 0, tx = 0, ty = 0; i < area; ++i) {
       const int ttx = w.cx0 + tx, tty = w.cy0 + ty;
-      const bool hit = ((reach_mask >> i) & 1ull) != 0ull;
+      const bool hit = (i < 64) ? ((reach_mask >> i) & 1ull) != 0ull : tile_reached(cam, sp, rf, tau, ttx, tty);
       if (hit) {
         const int tile = tty * cam.gx8 + ttx;
         const uint32_t slot = atomicAdd(&lds_tile[tile - tile0], 1u);
@@ -426,8 +453,9 @@ __device__ __forceinline__ void project_and_bin_body(
       ++ord;
     }
   };
-  {
-    // step k handles every lane's k-th REACHED tile (k-th set bit of its mask).  Raster-ordered
+  const int max_area = wave_max_i(area);
+  if (max_area <= 64) {
+    // common case: step k handles every lane's k-th REACHED tile (k-th set bit of its mask).  Raster-ordered
     // neighbours have near-identical masks, so runs still form, and there are ~3 steps instead of ~16.
     const int steps = wave_max_i((int)cnt);
     unsigned long long m = reach_mask;
@@ -445,6 +473,21 @@ __device__ __forceinline__ void project_and_bin_body(
       consume(pend);
       pend = cur;
     }
+  } else {
+    // a splat of this wavefront covers more than 64 candidate tiles: walk all candidates in lock-step
+    for (int i = 0, tx = 0, ty = 0; i <= max_area; ++i) {
+      Reservation cur;
+      cur.base = 0; cur.head_lane = 0; cur.rank = 0; cur.act = false; cur.tile = -1;
+      if (i < max_area) {                                    // wave-uniform
+        const bool in = i < area;
+        const int ttx = w.cx0 + tx, tty = w.cy0 + ty;
+        const bool act = in && ((i < 64) ? ((reach_mask >> i) & 1ull) != 0ull : tile_reached(cam, sp, rf, tau, ttx, tty));
+        cur = reserve_issue(tile_cnt, act ? (tty * cam.gx8 + ttx) : -1, act);
+        if (in && ++tx == w.cw) { tx = 0; ++ty; }
+      }
+      consume(pend);
+      pend = cur;
+    }
   }
   }  // (global-atomic form)
 
@@ -457,116 +500,6 @@ __device__ __forceinline__ void project_and_bin_body(
     o[5] = (uint32_t)prt0; o[6] = (uint32_t)__builtin_amdgcn_s_memrealtime(); o[7] = (uint32_t)area_all;
   }
 #endif
-  // ---- end phase: the deferred splats of this workgroup (see kDeferArea) -----------------------------------------------------
-  const uint32_t n_small = s_n_small, n_large = s_n_large;       // (written before the barrier behind the instance-range atomic)
-  if (n_small + n_large == 0u) return;                           // workgroup-uniform: the common case leaves here
-  __syncthreads();                                               // the LDS tile table is dead from here on: the lists live in it
-  // lists in the dynamic LDS block (the launcher gives it at least kDeferLdsBytes): local thread index of every deferred
-  // splat -- the small ones from the front, the large ones from the back, both in thread order -- and their counts / bases
-  uint16_t* __restrict__ s_def = reinterpret_cast<uint16_t*>(lds_tile);                       // [kProjBlock]
-  uint32_t* __restrict__ s_val = lds_tile + kProjBlock / 2;                                   // [kProjBlock]
-  {
-    uint32_t ps = 0, pl = 0;
-    for (int k = 0; k < wv; ++k) { ps += s_wave_small[k]; pl += s_wave_large[k]; }
-    const unsigned long long below = (1ull << l) - 1ull;
-    if (big && !large) s_def[ps + (uint32_t)__popcll(small_b & below)] = (uint16_t)threadIdx.x;
-    if (large) s_def[(uint32_t)kProjBlock - 1u - (pl + (uint32_t)__popcll(large_b & below))] = (uint16_t)threadIdx.x;
-  }
-  __syncthreads();
-  const int gid0 = (int)(blockIdx.x * (uint32_t)kProjBlock);
-  const int grp = (int)(threadIdx.x >> 4), sub = l & 15, gsh = l & 48;  // 16-lane group of the workgroup, lane in it, its bit offset
-  // round A: how many tiles does each deferred splat reach
-  for (uint32_t e = (uint32_t)grp; e < n_small; e += (uint32_t)(kProjBlock / 16)) {
-    const DeferredSplat d = load_deferred(cam, geom, radii, gid0 + (int)s_def[e]);
-    uint32_t c = 0;
-    for (int i0 = 0; i0 < d.ws.area; i0 += 16) {
-      const int i = i0 + sub;
-      const int ty = i / d.ws.w.cw, tx = i - ty * d.ws.w.cw;
-      const bool hit = i < d.ws.area && tile_reached(cam, d.sp, d.ws.rf, d.ws.tau, d.ws.w.cx0 + tx, d.ws.w.cy0 + ty);
-      c += (uint32_t)__popcll((__ballot(hit) >> gsh) & 0xFFFFull);
-    }
-    if (sub == 0) s_val[e] = c;
-  }
-  for (uint32_t e = 0; e < n_large; ++e) {                       // workgroup-uniform
-    const uint32_t slot_e = (uint32_t)kProjBlock - 1u - e;
-    const DeferredSplat d = load_deferred(cam, geom, radii, gid0 + (int)s_def[slot_e]);
-    if (threadIdx.x == 0) s_val[slot_e] = 0u;
-    __syncthreads();
-    uint32_t c = 0;
-    for (int i0 = 0; i0 < d.ws.area; i0 += kProjBlock) {
-      const int i = i0 + (int)threadIdx.x;
-      const int ty = i / d.ws.w.cw, tx = i - ty * d.ws.w.cw;
-      const bool hit = i < d.ws.area && tile_reached(cam, d.sp, d.ws.rf, d.ws.tau, d.ws.w.cx0 + tx, d.ws.w.cy0 + ty);
-      c += (uint32_t)__popcll(__ballot(hit));
-    }
-    if (l == 0 && c) atomicAdd(&s_val[slot_e], c);               // (integer: the order does not matter)
-  }
-  __syncthreads();
-  // one instance range for all of them: entry t of the list belongs to thread t of this scan
-  {
-    const bool mine = threadIdx.x < n_small || threadIdx.x >= (uint32_t)kProjBlock - n_large;
-    const uint32_t v = mine ? s_val[threadIdx.x] : 0u;
-    const uint32_t inc = wave_incl_scan(v);
-    if (l == 63) s_wave_cnt[wv] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t tot = 0;
-      for (int k = 0; k < kWaves; ++k) tot += s_wave_cnt[k];
-      s_block_base = tot ? atomicAdd(&ctr->inst_total, tot) : 0u;
-    }
-    __syncthreads();
-    uint32_t base = s_block_base;
-    for (int k = 0; k < wv; ++k) base += s_wave_cnt[k];
-    base += inc - v;
-    if (mine) {
-      s_val[threadIdx.x] = base;
-      gaux[gid0 + (int)s_def[threadIdx.x]] = GaussAux{base, v};
-    }
-  }
-  __syncthreads();
-  // round B: slots from the global per-tile counters, keys and instance ids into the bins
-  auto emit = [&](const DeferredSplat& d, int tile, unsigned long long id) {
-    const uint32_t slot = atomicAdd(&tile_cnt[tile], 1u);
-    const BinRange br = planned ? bin_range(cs, (uint32_t)tile, tile_cap) : BinRange{(uint32_t)tile * tile_cap, tile_cap};
-    if (id < capacity && slot < br.cap) {                        // an overflowing bin / id is dropped and flagged later
-      const size_t pos = (size_t)br.s + slot;
-      keys[pos] = d.key;
-      vals[pos] = (uint32_t)id;
-    }
-  };
-  for (uint32_t e = (uint32_t)grp; e < n_small; e += (uint32_t)(kProjBlock / 16)) {
-    const DeferredSplat d = load_deferred(cam, geom, radii, gid0 + (int)s_def[e]);
-    const uint32_t base = s_val[e];
-    uint32_t done = 0;
-    for (int i0 = 0; i0 < d.ws.area; i0 += 16) {
-      const int i = i0 + sub;
-      const int ty = i / d.ws.w.cw, tx = i - ty * d.ws.w.cw;
-      const bool hit = i < d.ws.area && tile_reached(cam, d.sp, d.ws.rf, d.ws.tau, d.ws.w.cx0 + tx, d.ws.w.cy0 + ty);
-      const uint32_t hb = (uint32_t)((__ballot(hit) >> gsh) & 0xFFFFull);
-      if (hit) emit(d, (d.ws.w.cy0 + ty) * cam.gx8 + d.ws.w.cx0 + tx, (unsigned long long)base + done + (uint32_t)__popc(hb & ((1u << sub) - 1u)));
-      done += (uint32_t)__popc(hb);
-    }
-  }
-  for (uint32_t e = 0; e < n_large; ++e) {                       // workgroup-uniform
-    const uint32_t slot_e = (uint32_t)kProjBlock - 1u - e;
-    const DeferredSplat d = load_deferred(cam, geom, radii, gid0 + (int)s_def[slot_e]);
-    const uint32_t base = s_val[slot_e];
-    uint32_t done = 0;
-    for (int i0 = 0; i0 < d.ws.area; i0 += kProjBlock) {
-      const int i = i0 + (int)threadIdx.x;
-      const int ty = i / d.ws.w.cw, tx = i - ty * d.ws.w.cw;
-      const bool hit = i < d.ws.area && tile_reached(cam, d.sp, d.ws.rf, d.ws.tau, d.ws.w.cx0 + tx, d.ws.w.cy0 + ty);
-      const unsigned long long hb = __ballot(hit);
-      __syncthreads();                                           // (the previous step's readers of s_wave_cnt are through)
-      if (l == 0) s_wave_cnt[wv] = (uint32_t)__popcll(hb);
-      __syncthreads();
-      uint32_t before = 0, step_total = 0;
-      for (int k = 0; k < kWaves; ++k) { const uint32_t c = s_wave_cnt[k]; before += k < wv ? c : 0u; step_total += c; }
-      if (hit) emit(d, (d.ws.w.cy0 + ty) * cam.gx8 + d.ws.w.cx0 + tx,
-                    (unsigned long long)base + done + before + (uint32_t)__popcll(hb & ((1ull << l) - 1ull)));   // raster order of the walk
-      done += step_total;
-    }
-  }
 }
 
 
@@ -581,8 +514,9 @@ __global__ __launch_bounds__(kProjBlock) void project_and_bin(
     const float* __restrict__ scales, const float* __restrict__ rotations,
     int32_t* __restrict__ radii, GeomRec* __restrict__ geom, GaussAux* __restrict__ gaux,
     uint32_t* __restrict__ tile_cnt, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
-    Counters* __restrict__ ctr, BlockStats* __restrict__ block_stats, unsigned long long capacity, uint32_t tile_cap) {
-  project_and_bin_body<LDSBINS, MODE>(cs, Vp, PVp, n, means3D, opacities, scales, rotations, radii, geom, gaux, tile_cnt, keys, vals, ctr, block_stats, capacity, tile_cap);
+    Counters* __restrict__ ctr, BlockStats* __restrict__ block_stats, unsigned long long capacity, uint32_t tile_cap,
+    DeferRec* __restrict__ defer_list) {
+  project_and_bin_body<LDSBINS, MODE>(cs, Vp, PVp, n, means3D, opacities, scales, rotations, radii, geom, gaux, tile_cnt, keys, vals, ctr, block_stats, capacity, tile_cap, defer_list);
 }
 template <int LDSBINS, int MODE>
 __global__ __launch_bounds__(kProjBlock) __attribute__((amdgpu_num_sgpr(80))) void project_and_bin_capped(
@@ -591,25 +525,237 @@ __global__ __launch_bounds__(kProjBlock) __attribute__((amdgpu_num_sgpr(80))) vo
     const float* __restrict__ scales, const float* __restrict__ rotations,
     int32_t* __restrict__ radii, GeomRec* __restrict__ geom, GaussAux* __restrict__ gaux,
     uint32_t* __restrict__ tile_cnt, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
-    Counters* __restrict__ ctr, BlockStats* __restrict__ block_stats, unsigned long long capacity, uint32_t tile_cap) {
-  project_and_bin_body<LDSBINS, MODE>(cs, Vp, PVp, n, means3D, opacities, scales, rotations, radii, geom, gaux, tile_cnt, keys, vals, ctr, block_stats, capacity, tile_cap);
+    Counters* __restrict__ ctr, BlockStats* __restrict__ block_stats, unsigned long long capacity, uint32_t tile_cap,
+    DeferRec* __restrict__ defer_list) {
+  project_and_bin_body<LDSBINS, MODE>(cs, Vp, PVp, n, means3D, opacities, scales, rotations, radii, geom, gaux, tile_cnt, keys, vals, ctr, block_stats, capacity, tile_cap, defer_list);
 }
-template __global__ void project_and_bin<0, 0>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin<1, 0>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin<2, 0>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<2, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<2, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<2, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<0, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<0, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<0, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<1, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<1, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<1, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<0, 4>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<0, 5>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<1, 4>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
-template __global__ void project_and_bin_capped<1, 5>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t);
+template __global__ void project_and_bin<0, 0>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+template __global__ void project_and_bin<1, 0>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+template __global__ void project_and_bin<2, 0>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+template __global__ void project_and_bin_capped<2, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+template __global__ void project_and_bin_capped<2, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+template __global__ void project_and_bin_capped<2, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+template __global__ void project_and_bin_capped<0, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+template __global__ void project_and_bin_capped<0, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+template __global__ void project_and_bin_capped<0, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+template __global__ void project_and_bin_capped<1, 1>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+template __global__ void project_and_bin_capped<1, 2>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+template __global__ void project_and_bin_capped<1, 3>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+template __global__ void project_and_bin_capped<0, 4>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+template __global__ void project_and_bin_capped<0, 5>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+template __global__ void project_and_bin_capped<1, 4>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+template __global__ void project_and_bin_capped<1, 5>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
+
+// The deferred splats of a forward (see kDeferArea), kDeferChunk list entries per workgroup and round -- the list is one for the
+// whole forward, so the work spreads evenly however the large splats cluster in the map (with one list per projection workgroup
+// the densified end of a SLAM map kept a few workgroups busy for 98 us, gpurun_out/r6/slamlate_j_dens.txt).  Every entry brings its
+// instance range along (DeferRec::inst_base), so there is no counter, no scan and no barrier between the entries:
+//   * up to kGroupArea candidates: a 16-lane group forms the reach mask, writes (first id, count) into gaux and bins the
+//     mask's bits -- the slot atomics of ALL the group's entries of the round go out before anything is stored: the round trip of
+//     those atomics (~1.5 us) is what bounds this kernel, and with one waited for after the other the same work took 105 us
+//     (gpurun_out/r6/timing_k_tail.log);
+//   * up to kWaveArea: a wavefront walks the candidates 64 at a time, keeps the hit ballots, then bins with four steps' atomics
+//     in flight;
+//   * beyond (a splat grown over a hole of the map: thousands of tiles): the whole workgroup, 256 candidates per step; the
+//     per-step, per-wavefront counts go through LDS once, then the steps are binned without a barrier.
+// Everything a splat needs arrives in its 48-byte DeferRec: no dependent loads.
+constexpr int kDeferChunk = 64;                  // list entries per workgroup and round: four per 16-lane group
+constexpr int kWaveSteps = kWaveArea / 64;
+constexpr int kMaxHugeSteps = 512;               // 131,072 candidate tiles (a 2896 x 2896-pixel splat on an 8-pixel grid) per huge splat and pass
+template <bool PLANNED>
+__global__ __launch_bounds__(kDeferBlock) void bin_deferred_splats(
+    CamScalars cs, GaussAux* __restrict__ gaux, uint32_t* __restrict__ tile_cnt,
+    unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, Counters* __restrict__ ctr,
+    const DeferRec* __restrict__ list, unsigned long long capacity, uint32_t tile_cap) {
+  constexpr int kWaves = kDeferBlock / 64, kGroups = kDeferBlock / 16, kPerGroup = kDeferChunk / kGroups, kSteps = kGroupArea / 16;
+  static_assert(kPerGroup * kGroups == kDeferChunk, "whole groups");
+  constexpr bool planned = PLANNED;
+  const uint32_t total = ctr->defer_total;                       // (complete: project_and_bin has retired)
+  if (blockIdx.x * (uint32_t)kDeferChunk >= total) return;       // workgroup-uniform: nothing (left) for this workgroup
+  __shared__ uint32_t s_large[kDeferChunk], s_nlarge;            // the round's entries beyond kGroupArea (local indices)
+  __shared__ uint32_t s_cnt[kMaxHugeSteps][kWaves];              // huge splats: hits per step and wavefront
+  // camera scalars the walk needs (no matrices: the projection is done)
+  CamParams cam{};
+  cam.W = cs.W; cam.H = cs.H;
+  cam.gx8 = (cs.W + kSubTile - 1) / kSubTile; cam.gy8 = (cs.H + kSubTile - 1) / kSubTile;
+  const int l = lane_id(), wv = (int)(threadIdx.x >> 6);
+  const int grp = (int)(threadIdx.x >> 4), sub = l & 15, gsh = l & 48;  // 16-lane group of the workgroup, lane in it, its bit offset
+  struct Rec { float4 a, b, c; };
+  auto splat_of = [&](const Rec& r, Splat& sp, ReachForm& rf) {
+    sp = Splat{};
+    sp.u = r.a.x; sp.v = r.a.y; sp.A = r.a.z; sp.B = r.a.w; sp.C = r.b.x;
+    rf = make_reach_form(sp);
+  };
+  auto put = [&](int tile, uint32_t slot, unsigned long long key, unsigned long long id) {
+    const BinRange br = planned ? bin_range(cs, (uint32_t)tile, tile_cap) : BinRange{(uint32_t)tile * tile_cap, tile_cap};
+    if (id < capacity && slot < br.cap) {                        // an overflowing bin / id is dropped and flagged later
+      const size_t pos = (size_t)br.s + slot;
+      keys[pos] = key;
+      vals[pos] = (uint32_t)id;
+    }
+  };
+  for (uint32_t c0 = blockIdx.x * (uint32_t)kDeferChunk; c0 < total; c0 += gridDim.x * (uint32_t)kDeferChunk) {   // workgroup-uniform
+    const uint32_t ne = min((uint32_t)kDeferChunk, total - c0);
+    auto load_rec = [&](uint32_t e) { const float4* p = reinterpret_cast<const float4*>(list + c0 + e); return Rec{p[0], p[1], p[2]}; };
+    if (threadIdx.x == 0) s_nlarge = 0u;
+    __syncthreads();
+    // ---- the groups: all records requested first; masks; gaux; all slot atomics; the bin entries
+    {
+      Rec rs[kPerGroup];
+      unsigned long long ms[kPerGroup];
+#pragma unroll
+      for (int j = 0; j < kPerGroup; ++j) {
+        const uint32_t e = (uint32_t)(grp + kGroups * j);
+        rs[j] = load_rec(e < ne ? e : 0u);
+      }
+#pragma unroll
+      for (int j = 0; j < kPerGroup; ++j) {
+        const uint32_t e = (uint32_t)(grp + kGroups * j);
+        ms[j] = 0ull;
+        if (e >= ne) continue;                                   // (group-uniform)
+        const Rec& r = rs[j];
+        const uint32_t cxy = __float_as_uint(r.c.x);
+        const int cx0 = (int)(cxy & 0xFFFFu), cy0 = (int)(cxy >> 16), cw = __float_as_int(r.c.y), ch = __float_as_int(r.c.z);
+        const int area = cw * ch;
+        if (area > kGroupArea) {                                  // (group-uniform) a larger splat: listed for the wavefronts
+          if (sub == 0) s_large[atomicAdd(&s_nlarge, 1u)] = e;
+          continue;
+        }
+        Splat sp; ReachForm rf;
+        splat_of(r, sp, rf);
+        unsigned long long m = 0ull;
+        for (int i0 = 0; i0 < area; i0 += 16) {                  // (area <= kGroupArea: at most four steps)
+          const int i = i0 + sub;
+          const int ty = i / cw, tx = i - ty * cw;
+          const bool hit = i < area && tile_reached(cam, sp, rf, r.b.y, cx0 + tx, cy0 + ty);
+          m |= ((__ballot(hit) >> gsh) & 0xFFFFull) << i0;
+        }
+        ms[j] = m;
+        if (sub == 0) gaux[__float_as_uint(r.b.w)] = GaussAux{__float_as_uint(r.c.w), (uint32_t)__popcll(m)};
+      }
+      uint32_t slot[kPerGroup][kSteps];
+#pragma unroll
+      for (int j = 0; j < kPerGroup; ++j) {
+        const uint32_t cxy = __float_as_uint(rs[j].c.x);
+        const int cx0 = (int)(cxy & 0xFFFFu), cy0 = (int)(cxy >> 16), cw = __float_as_int(rs[j].c.y);
+#pragma unroll
+        for (int k = 0; k < kSteps; ++k) {
+          const int i = 16 * k + sub;
+          slot[j][k] = 0u;
+          if ((ms[j] >> i) & 1ull) {
+            const int ty = i / cw, tx = i - ty * cw;
+            slot[j][k] = atomicAdd(&tile_cnt[(cy0 + ty) * cam.gx8 + cx0 + tx], 1u);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kPerGroup; ++j) {
+        const unsigned long long m = ms[j];
+        if (m == 0ull) continue;
+        const uint32_t cxy = __float_as_uint(rs[j].c.x);
+        const int cx0 = (int)(cxy & 0xFFFFu), cy0 = (int)(cxy >> 16), cw = __float_as_int(rs[j].c.y);
+        const uint32_t base = __float_as_uint(rs[j].c.w);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(rs[j].b.z) << 32) | (unsigned long long)__float_as_uint(rs[j].b.w);
+#pragma unroll
+        for (int k = 0; k < kSteps; ++k) {
+          const int i = 16 * k + sub;
+          if ((m >> i) & 1ull) {
+            const int ty = i / cw, tx = i - ty * cw;
+            put((cy0 + ty) * cam.gx8 + cx0 + tx, slot[j][k], key, (unsigned long long)base + (uint32_t)__popcll(m & ((1ull << i) - 1ull)));   // raster order of the walk
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t nl = s_nlarge;
+    // ---- larger splats, one wavefront each (up to kWaveArea candidates)
+    for (uint32_t k = (uint32_t)wv; k < nl; k += (uint32_t)kWaves) {                       // wave-uniform
+      const Rec r = load_rec(s_large[k]);
+      const uint32_t cxy = __float_as_uint(r.c.x);
+      const int cx0 = (int)(cxy & 0xFFFFu), cy0 = (int)(cxy >> 16), cw = __float_as_int(r.c.y), ch = __float_as_int(r.c.z);
+      const int area = cw * ch;
+      if (area > kWaveArea) continue;
+      Splat sp; ReachForm rf;
+      splat_of(r, sp, rf);
+      const uint32_t base = __float_as_uint(r.c.w);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(r.b.z) << 32) | (unsigned long long)__float_as_uint(r.b.w);
+      unsigned long long hb[kWaveSteps];                        // the hit ballots of all steps (wave-uniform: scalar registers)
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int st = 0; st < kWaveSteps; ++st) {
+        hb[st] = 0ull;
+        if (64 * st < area) {                                    // wave-uniform
+          const int i = 64 * st + l;
+          const int ty = i / cw, tx = i - ty * cw;
+          hb[st] = __ballot(i < area && tile_reached(cam, sp, rf, r.b.y, cx0 + tx, cy0 + ty));
+          cnt += (uint32_t)__popcll(hb[st]);
+        }
+      }
+      if (l == 0) gaux[__float_as_uint(r.b.w)] = GaussAux{base, cnt};
+      uint32_t done = 0;
+#pragma unroll
+      for (int s4 = 0; s4 < kWaveSteps; s4 += 4) {
+        if (64 * s4 >= area) break;                              // wave-uniform
+        uint32_t slot4[4]; int tile4[4]; uint32_t rank4[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const unsigned long long b = hb[s4 + h];
+          const int i = 64 * (s4 + h) + l;
+          const int ty = i / cw, tx = i - ty * cw;
+          tile4[h] = (cy0 + ty) * cam.gx8 + cx0 + tx;
+          rank4[h] = done + (uint32_t)__popcll(b & ((1ull << l) - 1ull));
+          done += (uint32_t)__popcll(b);
+          slot4[h] = ((b >> l) & 1ull) ? atomicAdd(&tile_cnt[tile4[h]], 1u) : 0u;
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+          if ((hb[s4 + h] >> l) & 1ull) put(tile4[h], slot4[h], key, (unsigned long long)base + rank4[h]);
+      }
+    }
+    // ---- huge splats: the workgroup
+    for (uint32_t k = 0; k < nl; ++k) {                                                    // workgroup-uniform
+      const Rec r = load_rec(s_large[k]);
+      const uint32_t cxy = __float_as_uint(r.c.x);
+      const int cx0 = (int)(cxy & 0xFFFFu), cy0 = (int)(cxy >> 16), cw = __float_as_int(r.c.y), ch = __float_as_int(r.c.z);
+      const int area = cw * ch;
+      if (area <= kWaveArea) continue;
+      Splat sp; ReachForm rf;
+      splat_of(r, sp, rf);
+      const uint32_t base = __float_as_uint(r.c.w);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(r.b.z) << 32) | (unsigned long long)__float_as_uint(r.b.w);
+      uint32_t done = 0;                                         // ids handed out by the passes before this one
+      for (int p0 = 0; p0 < area; p0 += kMaxHugeSteps * kDeferBlock) {                     // (one pass unless the splat covers > 131,072 tiles)
+        const int pend = min(area, p0 + kMaxHugeSteps * kDeferBlock);
+        __syncthreads();                                         // (the previous user of s_cnt is through)
+        for (int i0 = p0, st = 0; i0 < pend; i0 += kDeferBlock, ++st) {
+          const int i = i0 + (int)threadIdx.x;
+          const int ty = i / cw, tx = i - ty * cw;
+          const bool hit = i < pend && tile_reached(cam, sp, rf, r.b.y, cx0 + tx, cy0 + ty);
+          const uint32_t c = (uint32_t)__popcll(__ballot(hit));
+          if (l == 0) s_cnt[st][wv] = c;
+        }
+        __syncthreads();
+        for (int i0 = p0, st = 0; i0 < pend; i0 += kDeferBlock, ++st) {
+          const int i = i0 + (int)threadIdx.x;
+          const int ty = i / cw, tx = i - ty * cw;
+          const bool hit = i < pend && tile_reached(cam, sp, rf, r.b.y, cx0 + tx, cy0 + ty);
+          const unsigned long long b = __ballot(hit);
+          uint32_t before = 0, step_total = 0;
+          for (int kk = 0; kk < kWaves; ++kk) { const uint32_t c = s_cnt[st][kk]; before += kk < wv ? c : 0u; step_total += c; }
+          if (hit) {
+            const int tile = (cy0 + ty) * cam.gx8 + cx0 + tx;
+            put(tile, atomicAdd(&tile_cnt[tile], 1u), key, (unsigned long long)base + done + before + (uint32_t)__popcll(b & ((1ull << l) - 1ull)));
+          }
+          done += step_total;
+        }
+      }
+      if (threadIdx.x == 0) gaux[__float_as_uint(r.b.w)] = GaussAux{base, done};
+    }
+    __syncthreads();                                             // the next round reuses the lists
+  }
+}
+template __global__ void bin_deferred_splats<false>(CamScalars, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, const DeferRec*, unsigned long long, uint32_t);
+template __global__ void bin_deferred_splats<true>(CamScalars, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, const DeferRec*, unsigned long long, uint32_t);
 
 // One workgroup right after the binning: longest tile list, statistics, overflow flags and the image of the
 // host-visible VtgsForwardInfo (finalize_block, vtgs_internal.h; the quadrant-queue forward runs it in its first workgroup

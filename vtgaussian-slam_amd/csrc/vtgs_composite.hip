@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
       const float Fw2 = DUAL6 ? quarter_sum(Pw2) : 0.f;          // cross-lane: must run with all lanes active
       const int srow = (l & 12) + (l >> 4);                     // 4 sg + rho
       const uint32_t inst = (uint32_t)__shfl((int)my_inst, 16 * b + srow, 64);
-      if (srow < nb) {
+      if (srow < nb && inst < cs.scratch_records) {
         float* __restrict__ rec = grad_inst + (size_t)inst * REC;
         rec[cj] = Fa;
         if (b_live) rec[col_b] = Fb;
@@ -1178,8 +1178,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) void composite_backward_mx(
   }
   for (; base < e; base += 64u) {
     const int n = (int)min(64u, e - base);
-    if (l < n) {
-      const uint32_t inst = sorted_inst[base + (uint32_t)l];
+    const uint32_t inst = (l < n) ? sorted_inst[base + (uint32_t)l] : 0xFFFFFFFFu;
+    if (l < n && inst < cs.scratch_records) {
       if constexpr (B1) {
         float4* p = reinterpret_cast<float4*>(grad_inst + (size_t)inst * REC);
         p[0] = p[1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1234,7 +1234,12 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_colors,
     float* __restrict__ g_opacities, float* __restrict__ g_scales, float* __restrict__ g_rotations,
     const Counters* __restrict__ ctr, float* __restrict__ g_colors_b, FrameEpilogue fe = FrameEpilogue{}) {
-  const int gid = (int)(blockIdx.x * 256u + threadIdx.x);
+  // Workgroups walk the map from its END: a SLAM map is appended to (densification, new submaps), and the appended Gaussians
+  // are the ones the optimiser has grown the most -- the workgroups with the most records.  Started last they were the kernel's
+  // tail; started first, the light workgroups fill in behind them.  (The per-workgroup pose partials keep their row: the
+  // block index below is only the position in the map.)
+  const uint32_t blk = gridDim.x - 1u - blockIdx.x;
+  const int gid = (int)(blk * 256u + threadIdx.x);
   if (ctr->overflow) {
     // The forward did not complete: nothing valid to differentiate.  The Python layer never gets here (its checked forward
     // answers an overflow before it returns); a bare C-ABI caller that ignored the overflow of an asynchronous forward
@@ -1264,7 +1269,7 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
       }
     }
     if constexpr (FRAME) {
-      if ((fe.flags & 2u) && threadIdx.x < 12) fe.pose_partials[(size_t)blockIdx.x * 12 + threadIdx.x] = 0.f;
+      if ((fe.flags & 2u) && threadIdx.x < 12) fe.pose_partials[(size_t)blk * 12 + threadIdx.x] = 0.f;
     }
     return;
   }
@@ -1272,7 +1277,8 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
   const bool live = gid < n;                     // nobody leaves: the wavefront sums the records of its big splats together
   // (an early exit for wavefronts without any instance -- 7/8 of them on a rank of an 8-way partition -- was measured and
   //  dropped: it puts the camera's scalar loads behind the gaux load for the wavefronts that stay, +2 us whole frame, +1 in a band)
-  const GaussAux ga = live ? gaux[gid] : GaussAux{0u, 0u};
+  GaussAux ga = live ? gaux[gid] : GaussAux{0u, 0u};
+  if ((unsigned long long)ga.inst_base + ga.inst_cnt > (unsigned long long)cs.scratch_records) ga.inst_cnt = 0u;   // (CamScalars::scratch_records)
   SplatGrads g;
   for (int i = 0; i < 3; ++i) { g.mean3D[i] = g.mean2D[i] = g.color[i] = g.scale[i] = 0.f; }
   g.opacity = 0.f; g.rot[0] = g.rot[1] = g.rot[2] = g.rot[3] = 0.f;
@@ -1282,11 +1288,13 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
   // dependent load after the other): a wavefront took as long as its largest splat, and an optimised SLAM map has a heavy tail
   // -- after 20 frames of mapping 8 % of the Gaussians of the synthetic Replica sequence have 7 .. 64 instances, so nearly every
   // wavefront holds one and ran 16 .. 64 serial trips to memory (152 us against 54 us on the fresh map,
-  // gpurun_out/r6/slamlate_b_dens.txt).  Now the wavefront reads the records of ALL its splats as one list, 64 records per
-  // step, every lane one record: position j of the list belongs to the last lane whose first position V is <= j (six-step
-  // search over the lanes' scan with ds_bpermute); the lane re-centres its record with the owner's centre and parks the ten
-  // sums in a 3 KB LDS window; then every owner adds ITS rows of the window, in index order -- the order the per-lane loop had,
-  // so the sums are the same bits -- from LDS, not from memory.  No float atomics, no cross-lane float reduction.
+  // gpurun_out/r6/slamlate_b_dens.txt).  Now: the first kGatherAhead records of every lane as before (in flight with the
+  // projection's inputs; 93 % of the splats of a fresh map have no more) and the EXCESS records of the wavefront's splats as one
+  // list, 64 records per step, every lane one record: position j of the list belongs to the last lane whose first position V is
+  // <= j (six-step search over the lanes' scan with ds_bpermute); the lane re-centres its record with the owner's centre and
+  // parks the ten sums in a 3 KB LDS window; then every owner adds ITS rows of the window, in index order -- the order the
+  // per-lane loop had -- from LDS, not from memory.  No float atomics, no cross-lane float reduction.  (The list for ALL records
+  // cost the fresh map 9 us: three windows where four loads in flight did, gpurun_out/r6/timing_g_head.log.)
   // A Gaussian with more than kBigInst instances (a splat grown over a hole of the map has thousands) is summed by the whole
   // wavefront instead, 64 records at a time with a butterfly at the end (its own fixed order).
   constexpr uint32_t kBigInst = 64;
@@ -1338,12 +1346,13 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
   SplatMoments mo;
   for (int k = 0; k < 9; ++k) mo.m[k] = 0.f;
   bool ok = false;
-  // the wavefront's list: lane l's records sit at positions [V, V + my_cnt) (wave-level scan; a big splat is not in it)
+  constexpr uint32_t kGatherAhead = 4;
+  // the wavefront's list of EXCESS records: lane l's sit at positions [V, V + my_cnt) (wave-level scan; a big splat is not in it)
   constexpr int kRow = 12;                                          // floats per parked record: 9 sums + up to 3 second-set colours
   __shared__ __attribute__((aligned(16))) float lds_rows[4][64 * kRow];
   float* __restrict__ rows = lds_rows[threadIdx.x >> 6];
   const int ln = lane_id();
-  const uint32_t my_cnt = (live && !big) ? ga.inst_cnt : 0u;
+  const uint32_t my_cnt = (live && !big && ga.inst_cnt > kGatherAhead) ? ga.inst_cnt - kGatherAhead : 0u;
   const uint32_t incl_cnt = wave_incl_scan(my_cnt);
   const uint32_t V = incl_cnt - my_cnt;
   const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl_cnt, 63);
@@ -1358,19 +1367,19 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     }
     return lo;
   };
-  // the first window's records are requested with everything else: their addresses only need gaux, so they are in flight
-  // together with the inputs of the projection instead of behind its arithmetic
-  float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, rd = ra;
-  int own = 0;
-  bool have = (uint32_t)ln < T;
-  {
-    own = owner_of(have ? (uint32_t)ln : 0u);                       // (every lane takes part in the permutes)
-    const uint32_t ob = (uint32_t)__builtin_amdgcn_ds_bpermute(own << 2, (int)ga.inst_base);
-    const uint32_t ov = (uint32_t)__builtin_amdgcn_ds_bpermute(own << 2, (int)V);
-    if (have) load_record(ob + ((uint32_t)ln - ov), ra, rb, rc, rd);
+  // the lane's first records are requested up front: their addresses only need gaux, so they are in flight together with the
+  // inputs of the projection instead of behind its arithmetic
+  float4 pa[kGatherAhead], pb[kGatherAhead], pc[kGatherAhead], pd[kGatherAhead];
+  if (ga.inst_cnt && !big) {
+#pragma unroll
+    for (uint32_t i = 0; i < kGatherAhead; ++i)            // past the end: the last record again (a cache hit), unused
+      load_record(ga.inst_base + min(i, ga.inst_cnt - 1u), pa[i], pb[i], pc[i], pd[i]);
   }
+  // inputs of the projection; of the projection itself only the pixel centre is formed before the records are summed -- the
+  // rest (and with it ~25 live registers: the backward's intermediates) follows behind the record phase
+  float mean[3] = {0.f, 0.f, 0.f}, cu = 0.f, cv = 0.f, culo = 0.f, cvlo = 0.f;
   if (ga.inst_cnt) {
-    const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
+    mean[0] = means3D[3 * gid]; mean[1] = means3D[3 * gid + 1]; mean[2] = means3D[3 * gid + 2];
     if constexpr (COV3D) {
       for (int i = 0; i < 6; ++i) c6[i] = scales[6 * gid + i];
     } else {
@@ -1379,15 +1388,31 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
       q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
     }
     op = opacities[gid];
-    ok = project_splat(cam, mean, sc, q, op, sp, aux, COV3D ? c6 : nullptr);
+    pixel_centre(cam, mean[0], mean[1], mean[2], cu, cv, culo, cvlo);
+    if (!big) {
+#pragma unroll
+      for (uint32_t i = 0; i < kGatherAhead; ++i)
+        if (i < ga.inst_cnt) add_record(mo, cb0, cb1, cb2, pa[i], pb[i], pc[i], pd[i], cu, cv, culo, cvlo);
+    }
+  }
+  // (the list's first window goes out here, behind the lanes' own records: requested with them it kept sixteen more registers
+  //  alive through the projection -- 144-158 VGPRs, three wavefronts per SIMD instead of four)
+  float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, rd = ra;
+  int own = 0;
+  bool have = (uint32_t)ln < T;
+  if (T) {                                                          // wave-uniform
+    own = owner_of(have ? (uint32_t)ln : 0u);                       // (every lane takes part in the permutes)
+    const uint32_t ob = (uint32_t)__builtin_amdgcn_ds_bpermute(own << 2, (int)ga.inst_base);
+    const uint32_t ov = (uint32_t)__builtin_amdgcn_ds_bpermute(own << 2, (int)V);
+    if (have) load_record(ob + kGatherAhead + ((uint32_t)ln - ov), ra, rb, rc, rd);
   }
   for (uint32_t j0 = 0; j0 < T; j0 += 64u) {                        // wave-uniform
     {
       // my record of this window, re-centred with ITS owner's centre, parked in row `ln`
-      const float ou = __int_as_float(__builtin_amdgcn_ds_bpermute(own << 2, __float_as_int(sp.u)));
-      const float ovv = __int_as_float(__builtin_amdgcn_ds_bpermute(own << 2, __float_as_int(sp.v)));
-      const float oul = __int_as_float(__builtin_amdgcn_ds_bpermute(own << 2, __float_as_int(sp.ulo)));
-      const float ovl = __int_as_float(__builtin_amdgcn_ds_bpermute(own << 2, __float_as_int(sp.vlo)));
+      const float ou = __int_as_float(__builtin_amdgcn_ds_bpermute(own << 2, __float_as_int(cu)));
+      const float ovv = __int_as_float(__builtin_amdgcn_ds_bpermute(own << 2, __float_as_int(cv)));
+      const float oul = __int_as_float(__builtin_amdgcn_ds_bpermute(own << 2, __float_as_int(culo)));
+      const float ovl = __int_as_float(__builtin_amdgcn_ds_bpermute(own << 2, __float_as_int(cvlo)));
       SplatMoments one;
       for (int k = 0; k < 9; ++k) one.m[k] = 0.f;
       float o0 = 0.f, o1 = 0.f, o2 = 0.f;
@@ -1404,7 +1429,7 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
       own = owner_of(have_n ? jn : 0u);
       const uint32_t ob = (uint32_t)__builtin_amdgcn_ds_bpermute(own << 2, (int)ga.inst_base);
       const uint32_t ov = (uint32_t)__builtin_amdgcn_ds_bpermute(own << 2, (int)V);
-      if (have_n) load_record(ob + (jn - ov), ra, rb, rc, rd);
+      if (have_n) load_record(ob + kGatherAhead + (jn - ov), ra, rb, rc, rd);
     }
     have = have_n;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the rows are written (one wavefront: LDS runs in order) ...
@@ -1423,14 +1448,14 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // (the next window overwrites the rows)
     __builtin_amdgcn_wave_barrier();
   }
-  for (unsigned long long rest = __ballot(ok && big); rest; rest &= rest - 1ull) {     // wave-uniform
+  for (unsigned long long rest = __ballot(big); rest; rest &= rest - 1ull) {     // wave-uniform
     const int src = __builtin_ctzll(rest);
     const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)ga.inst_base, src);
     const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)ga.inst_cnt, src);
-    const float u = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sp.u), src));
-    const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sp.v), src));
-    const float ulo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sp.ulo), src));
-    const float vlo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sp.vlo), src));
+    const float u = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cu), src));
+    const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), src));
+    const float ulo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(culo), src));
+    const float vlo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cvlo), src));
     SplatMoments part;
     for (int k = 0; k < 9; ++k) part.m[k] = 0.f;
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
@@ -1443,6 +1468,10 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     for (int k = 0; k < 9; ++k) part.m[k] = wave_sum(part.m[k]);
     if constexpr (DUAL) { p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2); }
     if (lane_id() == src) { mo = part; cb0 = p0; cb1 = p1; cb2 = p2; }
+  }
+  if (ga.inst_cnt) {
+    const float centre4[4] = {cu, cv, culo, cvlo};                                            // (formed above: not computed twice)
+    ok = project_splat(cam, mean, sc, q, op, sp, aux, COV3D ? c6 : nullptr, centre4);
   }
   if (ok) {
     if (moments_scaled_by_opacity) {        // the matrix-core backward accumulates u' = o*u
@@ -1497,7 +1526,7 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
       if (l == 0)
         for (int k = 0; k < 12; ++k) red[wv][k] = acc[k];
       __syncthreads();
-      if (threadIdx.x < 12) fe.pose_partials[(size_t)blockIdx.x * 12 + threadIdx.x] =
+      if (threadIdx.x < 12) fe.pose_partials[(size_t)blk * 12 + threadIdx.x] =
           red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     }
     return;

@@ -18,8 +18,15 @@ __global__ __launch_bounds__(256) void prepare_frame_kernel(
     const float* __restrict__ log_scales, const float* __restrict__ unnorm_rot, const float* __restrict__ rgb,
     const float* __restrict__ cam_q, const float* __restrict__ cam_t,
     const float* __restrict__ depth_w2c, float* __restrict__ means_cam, float* __restrict__ opac,
-    float* __restrict__ scales, float* __restrict__ rot, float* __restrict__ dcol, float* __restrict__ rgb_out) {
-  const FramePose P = load_pose(cam_q, cam_t, depth_w2c);
+    float* __restrict__ scales, float* __restrict__ rot, float* __restrict__ dcol, float* __restrict__ rgb_out,
+    int pose_stride = 1, float* __restrict__ pose7_out = nullptr) {
+  // pose_stride / pose7_out (round 6, vtgs_prepare_frame_slot): the pose is column t of the reference's [1,4,T] / [1,3,T] camera
+  // tensors -- element k of q sits at cam_q[k * T] -- read in place, and workgroup 0 leaves the seven floats contiguous for the
+  // backward: the slot-gather launch of round 5 is gone
+  const float qs[4] = {cam_q[0], cam_q[pose_stride], cam_q[2 * pose_stride], cam_q[3 * pose_stride]};
+  const float ts[3] = {cam_t[0], cam_t[pose_stride], cam_t[2 * pose_stride]};
+  const FramePose P = load_pose(qs, ts, depth_w2c);
+  if (pose7_out && blockIdx.x == 0 && threadIdx.x < 7) pose7_out[threadIdx.x] = threadIdx.x < 4 ? qs[threadIdx.x] : ts[threadIdx.x - 4];
   const int i = (int)(blockIdx.x * 256u + threadIdx.x);
   if (i >= n) return;
   const int row = idx ? idx[i] : i;
@@ -154,8 +161,12 @@ __global__ __launch_bounds__(256) void prepare_frame_backward_kernel(
 // dL/dt = sum[0..2];  dL/dq = J_norm^T ( dR/dq_hat : dL/dR )  with q_hat = q/|q|  (utils/slam_external.py:25-42).
 __global__ __launch_bounds__(256) void pose_gradient_kernel(const float* __restrict__ partials, uint32_t rows,
                                                             const float* __restrict__ cam_q, float* __restrict__ g_q,
-                                                            float* __restrict__ g_t) {
+                                                            float* __restrict__ g_t, int frames = 0, int slot = 0,
+                                                            float* __restrict__ g_rots = nullptr, float* __restrict__ g_trans = nullptr) {
+  // frames > 0 (round 6, vtgs_pose_gradient_slot): the seven floats go straight into the FULL-SIZE gradients of the reference's
+  // [1,4,T] / [1,3,T] camera tensors -- zero except column `slot` -- in this launch: the slot-scatter launch of round 5 is gone
   __shared__ float red[4][12];
+  __shared__ float s_g7[7];
   float acc[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) acc[k] = 0.f;
@@ -170,7 +181,6 @@ __global__ __launch_bounds__(256) void pose_gradient_kernel(const float* __restr
   if (threadIdx.x == 0) {
     float s[12];
     for (int k = 0; k < 12; ++k) s[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
-    g_t[0] = s[0]; g_t[1] = s[1]; g_t[2] = s[2];
     const float* dR = s + 3;                                     // row-major dL/dR
     const float n2 = cam_q[0] * cam_q[0] + cam_q[1] * cam_q[1] + cam_q[2] * cam_q[2] + cam_q[3] * cam_q[3];
     const float inv = rsqrtf(n2);
@@ -182,7 +192,20 @@ __global__ __launch_bounds__(256) void pose_gradient_kernel(const float* __restr
     gh[3] = 2.f * (-2.f * qz * dR[0] - qr * dR[1] + qx * dR[2] + qr * dR[3] - 2.f * qz * dR[4] + qy * dR[5] + qx * dR[6] + qy * dR[7]);
     const float qh[4] = {qr, qx, qy, qz};
     const float dot = qh[0] * gh[0] + qh[1] * gh[1] + qh[2] * gh[2] + qh[3] * gh[3];
-    for (int k = 0; k < 4; ++k) g_q[k] = (gh[k] - qh[k] * dot) * inv;   // through q_hat = q / |q|
+    for (int k = 0; k < 4; ++k) {
+      const float gk = (gh[k] - qh[k] * dot) * inv;                       // through q_hat = q / |q|
+      if (g_q) g_q[k] = gk;
+      s_g7[k] = gk;
+    }
+    if (g_t) { g_t[0] = s[0]; g_t[1] = s[1]; g_t[2] = s[2]; }
+    s_g7[4] = s[0]; s_g7[5] = s[1]; s_g7[6] = s[2];
+  }
+  if (frames > 0) {
+    __syncthreads();
+    for (int i = (int)threadIdx.x; i < 7 * frames; i += 256) {
+      if (i < 4 * frames) { const int r = i / frames, c = i - r * frames; g_rots[i] = (c == slot) ? s_g7[r] : 0.f; }
+      else { const int k = i - 4 * frames, r = k / frames, c = k - r * frames; g_trans[k] = (c == slot) ? s_g7[4 + r] : 0.f; }
+    }
   }
 }
 
@@ -269,7 +292,34 @@ int vtgs_pose_gradient(const float* pose_partials, uint32_t rows, const float* c
   return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
 }
 
+int vtgs_pose_gradient_slot(const float* pose_partials, uint32_t rows, const float* cam_q, int32_t frames, int32_t t,
+                            float* g_cam_unnorm_rots, float* g_cam_trans, void* stream) {
+  if ((rows > 0 && !pose_partials) || !cam_q || !g_cam_unnorm_rots || !g_cam_trans || frames <= 0 || t < 0 || t >= frames)
+    return VTGS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(pose_gradient_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pose_partials, rows, cam_q, (float*)nullptr,
+                     (float*)nullptr, (int)frames, (int)t, g_cam_unnorm_rots, g_cam_trans);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
+
 uint32_t vtgs_pose_partial_rows(int32_t n) { return n > 0 ? (uint32_t)((n + 255) / 256) : 0u; }
+
+int vtgs_prepare_frame_slot(int32_t n, const float* means3D, const float* logit_opacities, const float* log_scales,
+                            const float* unnorm_rotations, const float* cam_unnorm_rots, const float* cam_trans, int32_t frames,
+                            int32_t t, const float* depth_w2c, float* out_means_cam, float* out_opacities, float* out_scales,
+                            float* out_rotations, float* out_depth_colors, float* out_pose7, void* stream) {
+  if (n < 0 || !cam_unnorm_rots || !cam_trans || !depth_w2c || !out_pose7 || frames <= 0 || t < 0 || t >= frames)
+    return VTGS_ERR_INVALID_ARGUMENT;
+  if (n == 0)                                                  // an empty map: the pose still has to reach the caller's seven floats
+    return vtgs_pose_slot_gather(cam_unnorm_rots, cam_trans, frames, t, out_pose7, stream);
+  if (!means3D || !logit_opacities || !log_scales || !unnorm_rotations || !out_means_cam || !out_opacities || !out_scales ||
+      !out_rotations || !out_depth_colors)
+    return VTGS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(prepare_frame_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, (const int32_t*)nullptr,
+                     means3D, logit_opacities, log_scales, unnorm_rotations, (const float*)nullptr, cam_unnorm_rots + t, cam_trans + t,
+                     depth_w2c, out_means_cam, out_opacities, out_scales, out_rotations, out_depth_colors, (float*)nullptr,
+                     (int)frames, out_pose7);
+  return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+}
 
 int vtgs_prepare_frame(int32_t n, const float* means3D, const float* logit_opacities, const float* log_scales,
                        const float* unnorm_rotations, const float* cam_q, const float* cam_t, const float* depth_w2c,

@@ -23,23 +23,28 @@ namespace vtgs {
 //   sorted_inst  T8 x cap_t x 4   per-tile instance ids (address of the per-instance gradient record)
 //   final_T      P x 4     per-pixel transmittance after the last contributor
 //   qmask        T8 x cap_t x 1   which 4x4 quadrants of its tile a sorted list entry can reach (quadrant-queue composites)
+//   defer_list   N x 48    the splats project_and_bin left to bin_deferred_splats (round 6): first Counters::defer_total entries
 // Every tile owns a fixed-capacity bin (cap_t, a caller hint like the instance capacity), so binning is one
 // pass: no prefix scan over tiles and no scatter pass.  finalize_forward raises the overflow flags right after the
 // binning (a dropped instance leaves an unwritten bin slot, so sort and composite bail on the flag) and the caller
 // re-runs with the sizes reported in the result record.
 // ------------------------------------------------------------------------------------------------
 struct Counters {
+  // the first two words are ONE 64-bit counter for project_and_bin: a workgroup takes its instance range and its stretch of the
+  // deferred-splat list with a single atomic (the deferred count in the LOW word, so that an instance count running past 2^32 --
+  // it keeps counting past the capacity -- carries out of the top and not into its neighbour)
+  uint32_t defer_total;     // splats project_and_bin left to bin_deferred_splats (entries of the deferred list)
   uint32_t inst_total;      // instances requested (keeps counting past capacity)
   uint32_t overflow;        // bit 0: inst_total > instance capacity, bit 1: a tile list > tile capacity (finalize_forward)
   uint32_t qmask_valid;     // composite_forward_q wrote the quadrant masks of this forward's lists (composite_backward_q reads them)
-  uint32_t pad[13];
+  uint32_t pad[12];
   // byte 64: image of the public VtgsForwardInfo, written by finalize_forward, copied to the host by vtgs_forward
   unsigned long long info_instances, info_needed, info_r16;
   uint32_t info_visible, info_max_list, info_overflow, info_complete;
   unsigned long long info_slots;
 };
 static_assert(sizeof(Counters) <= 256, "counters block");
-static_assert(offsetof(Counters, info_instances) == 64, "Counters layout");
+static_assert(offsetof(Counters, info_instances) == 64 && offsetof(Counters, defer_total) == 0 && offsetof(Counters, inst_total) == 4, "Counters layout");
 
 struct alignas(16) GeomRec {   // 32 bytes
   float u, v;                  // pixel centre (float32)
@@ -61,6 +66,20 @@ struct alignas(8) GaussAux { uint32_t inst_base, inst_cnt; };
 
 struct alignas(16) BlockStats { uint32_t visible, pad; unsigned long long r16; };
 
+// What bin_deferred_splats needs of a splat that project_and_bin left aside (more than kDeferArea candidate tiles): written by the
+// splat's own lane into the forward's deferred list, read back 16 lanes (a wavefront, a workgroup) at a time -- no dependent look-ups.
+struct alignas(16) DeferRec {   // 48 bytes
+  float u, v, A, B;             // centre (float32 part: the reach test is conservative by 1e-4 anyway), conic
+  float C, tau, depth;          // tau = ln(255 o) with its slack; depth bits = the sort key's high word
+  uint32_t gid;                 // the Gaussian
+  uint32_t cxy;                 // candidate walk (8x8 tiles), already shrunk to the ellipse's bounding box: cx0 | cy0 << 16,
+  int32_t cw, ch;               // ... width, height
+  uint32_t inst_base;           // first instance id of the splat: project_and_bin reserved cw * ch ids for it (an upper bound --
+                                // the ids behind the tiles it turns out to reach stay unused -- so that bin_deferred_splats needs
+                                // no counter of its own: same-address atomics retire one per ~14 ns)
+};
+static_assert(sizeof(DeferRec) == 48, "DeferRec layout");
+
 constexpr int kGradRec = 10;       // floats per instance gradient record: 6 moments, 3 colour sums, tile id (40-byte stride, float2 access)
 constexpr int kGradRecDual = 14;   // dual render: 6 moments + 6 colour sums + tile id + one pad word (56-byte stride, float2 access)
 constexpr int kGradRecDual1 = 12;  // dual render, second image differentiated through its first channel only: 6 moments + 3 + 1
@@ -69,7 +88,7 @@ constexpr int kGradRecDual1 = 12;  // dual render, second image differentiated t
 constexpr int kStampWords = 12;    // -DVTGS_Q_STAMPS: words per tile in the debug region (8 phase stamps, start / end in 10 ns units of
                                    // the chip-wide constant clock, HW_ID, XCC_ID)
 struct WsLayout {
-  size_t counters, geom, gaux, block_stats, tile_cnt, keys, vals, sorted_gid, sorted_inst, final_T, qmask, dbg, plan, total;
+  size_t counters, geom, gaux, block_stats, tile_cnt, keys, vals, sorted_gid, sorted_inst, final_T, qmask, dbg, plan, defer_list, total;
   uint32_t tiles8, tile_cap;      // tile_cap: slots per bin (uniform bins) or the average over the bins (planned bins)
   bool planned;                   // VTGS_TILE_CAPACITY_PLANNED: bin t = [plan[t], plan[t+1]) instead of [t * tile_cap, (t+1) * tile_cap)
 };
@@ -104,6 +123,7 @@ inline WsLayout make_layout(int32_t n, int32_t w, int32_t h, uint64_t cap, uint3
   L.dbg = o;         o += 256;                           // 64 step counters (measurement only, VTGS_COUNT_STEPS)
 #endif
   L.plan = o;        o += align256(((size_t)L.tiles8 + 1) * 4);   // planned bins: this forward's copy of the caller's plan
+  L.defer_list = o;  o += align256(((size_t)n + 1) * sizeof(DeferRec));   // the deferred splats of this forward, in no particular order
   L.total = o;
   return L;
 }
@@ -119,6 +139,9 @@ struct CamScalars {
   uint32_t bin_limit;             // ... and the slots the workspace holds: no bin reaches past it, whatever the plan says
   uint32_t bwd_flags;             // composite_backward_mx: bit 0 = nobody wants dL/d(first colour set) -- the tracking loop detaches
                                   // the Gaussians, and the pose gradient does not need it: that contraction chain is skipped
+  uint32_t scratch_records;       // backward: gradient records the caller's scratch holds.  An instance id at or beyond it is
+                                  // neither written (composite) nor read (gather: that Gaussian's gradient is zero): a scratch
+                                  // sized from a wrong or stale count gives wrong numbers, not an out-of-bounds access
 #ifdef VTGS_Q_STAMPS
   uint32_t* dbg_proj;             // diagnostic build: 8 words of stamps per workgroup of project_and_bin
 #endif
@@ -262,12 +285,14 @@ __device__ __forceinline__ void finalize_block(const uint32_t* __restrict__ tile
                                                uint32_t* __restrict__ plan_next = nullptr) {
   constexpr int kW = THREADS / 64;
   __shared__ uint32_t wmax[kW], svis[kW], sover[kW], swsum[kW], sslots[kW];
-  __shared__ unsigned long long sr16[kW];
+  __shared__ unsigned long long sr16[kW], slisted[kW];
   const uint32_t t = threadIdx.x;
   uint32_t mx = 0, over = 0, slots = 0;
+  unsigned long long listed = 0;                                 // entries of all lists = the instances actually binned
   for (uint32_t i = t; i < tiles; i += (uint32_t)THREADS) {
     const uint32_t c = tile_cnt[i];
     mx = max(mx, c);
+    listed += c;
     slots += planned_bin_capacity(c);                            // what bins sized to these lists take in total
     if (plan) {                                                  // planned bins: every bin against its own capacity
       const uint32_t limit = tiles * tile_cap, a = min(plan[i], limit), b = min(plan[i + 1], limit);
@@ -282,6 +307,7 @@ __device__ __forceinline__ void finalize_block(const uint32_t* __restrict__ tile
     vis += (uint32_t)__shfl_xor((int)vis, m, 64);
     r16 += (unsigned long long)__shfl_xor((long long)r16, m, 64);
     slots += (uint32_t)__shfl_xor((int)slots, m, 64);
+    listed += (unsigned long long)__shfl_xor((long long)listed, m, 64);
   }
   // planned bins: the NEXT plan from this forward's list lengths (the caller's persistent buffer; this forward and its
   // backward read the workspace copy).  Wavefront w owns a contiguous run of tiles, walked 64 at a time (coalesced) with a
@@ -294,7 +320,7 @@ __device__ __forceinline__ void finalize_block(const uint32_t* __restrict__ tile
     for (uint32_t i = lo + ln; i < hi; i += 64u) run_total += planned_bin_capacity(tile_cnt[i]);
     for (int m = 1; m < 64; m <<= 1) run_total += (uint32_t)__shfl_xor((int)run_total, m, 64);
   }
-  if (ln == 0) { wmax[wv] = mx; svis[wv] = vis; sr16[wv] = r16; sover[wv] = over; swsum[wv] = run_total; sslots[wv] = slots; }
+  if (ln == 0) { wmax[wv] = mx; svis[wv] = vis; sr16[wv] = r16; sover[wv] = over; swsum[wv] = run_total; sslots[wv] = slots; slisted[wv] = listed; }
   __syncthreads();
   unsigned long long slots_next = 0;
   for (int i = 0; i < kW; ++i) slots_next += sslots[i];
@@ -311,18 +337,20 @@ __device__ __forceinline__ void finalize_block(const uint32_t* __restrict__ tile
     if (t == 0) plan_next[tiles] = (uint32_t)slots_next;
   }
   if (t == 0) {
-    uint32_t m = 0, v = 0, ov = 0; unsigned long long r = 0;
-    for (int i = 0; i < kW; ++i) { m = max(m, wmax[i]); v += svis[i]; r += sr16[i]; ov |= sover[i]; }
+    uint32_t m = 0, v = 0, ov = 0; unsigned long long r = 0, binned = 0;
+    for (int i = 0; i < kW; ++i) { m = max(m, wmax[i]); v += svis[i]; r += sr16[i]; ov |= sover[i]; binned += slisted[i]; }
+    // instance IDS handed out: what the capacity and the backward's scratch must hold.  >= the instances binned: a splat binned
+    // by bin_deferred_splats holds one id per CANDIDATE tile (DeferRec::inst_base)
     const uint32_t total = ctr->inst_total;
     const bool bin_over = plan ? (ov != 0u) : (m > tile_cap);
     const uint32_t ovf = (((unsigned long long)total > capacity) ? 1u : 0u) | (bin_over ? 2u : 0u);
     const unsigned long long slots = slots_next;     // what bins sized to this forward's lists take in total (planned bins)
     ctr->overflow = ovf;
-    ctr->info_instances = ovf ? 0ull : (unsigned long long)total;
+    ctr->info_instances = ovf ? 0ull : binned;
     ctr->info_needed = total; ctr->info_r16 = r;
     ctr->info_visible = v; ctr->info_max_list = m; ctr->info_overflow = ovf; ctr->info_slots = slots; ctr->info_complete = 1u;
     if (host_record) {                         // the caller's pinned record, device-addressable
-      host_record->instances = ovf ? 0ull : (unsigned long long)total;
+      host_record->instances = ovf ? 0ull : binned;
       host_record->instances_needed = total; host_record->tiles16_touched = r;
       host_record->visible = v; host_record->max_tile_list = m; host_record->overflow = ovf;
       host_record->bin_slots_needed = slots;

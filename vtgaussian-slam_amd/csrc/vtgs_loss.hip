@@ -475,9 +475,9 @@ __global__ __launch_bounds__(256) void adam_step_rows_kernel(AdamLaunch a, AdamR
 }
 
 // seen = radius > 0 and the running maximum of the screen-space radius (src/vtgaussian_slam.py:681-689): four Gaussians per thread
-__global__ __launch_bounds__(256) void seen_and_max_radius_kernel(int n, const int32_t* __restrict__ radii, float* __restrict__ mx,
-                                                                  uint8_t* __restrict__ seen) {
-  const int i0 = (int)(blockIdx.x * 1024u + threadIdx.x * 4u);
+__device__ __forceinline__ void seen_and_max_radius_block(uint32_t block, int n, const int32_t* __restrict__ radii, float* __restrict__ mx,
+                                                          uint8_t* __restrict__ seen) {
+  const int i0 = (int)(block * 1024u + threadIdx.x * 4u);
   if (i0 + 3 < n) {
     const int4 r = *reinterpret_cast<const int4*>(radii + i0);
     float4 m = *reinterpret_cast<const float4*>(mx + i0);
@@ -485,8 +485,12 @@ __global__ __launch_bounds__(256) void seen_and_max_radius_kernel(int n, const i
     *reinterpret_cast<float4*>(mx + i0) = m;
     *reinterpret_cast<uint32_t*>(seen + i0) = (r.x > 0 ? 1u : 0u) | (r.y > 0 ? 0x100u : 0u) | (r.z > 0 ? 0x10000u : 0u) | (r.w > 0 ? 0x1000000u : 0u);
   } else {
-    for (int i = i0; i < n; ++i) { mx[i] = fmaxf(mx[i], (float)radii[i]); seen[i] = radii[i] > 0 ? 1 : 0; }
+    for (int i = i0; i < min(n, i0 + 4); ++i) { mx[i] = fmaxf(mx[i], (float)radii[i]); seen[i] = radii[i] > 0 ? 1 : 0; }
   }
+}
+__global__ __launch_bounds__(256) void seen_and_max_radius_kernel(int n, const int32_t* __restrict__ radii, float* __restrict__ mx,
+                                                                  uint8_t* __restrict__ seen) {
+  seen_and_max_radius_block(blockIdx.x, n, radii, mx, seen);
 }
 
 // ---- whole loss of get_loss in a handful of launches (src/vtgaussian_slam.py:519-608, 678-679) ----------------------------
@@ -499,7 +503,12 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
                                                             const float* __restrict__ ssim_partial, uint32_t ssim_rows,
                                                             int mode, float w_im, float w_depth, float numel_im,
                                                             float* __restrict__ out, float l1_coef = 0.8f,
-                                                            int raw = 0) {
+                                                            int raw = 0, int n_seen = 0, const int32_t* __restrict__ radii = nullptr,
+                                                            float* __restrict__ max_radius = nullptr, uint8_t* __restrict__ seen = nullptr) {
+  // Round 6: get_loss's bookkeeping (seen = radius > 0, the running maximum of the radius, src/vtgaussian_slam.py:681-689) rides in
+  // this launch -- workgroups 1 .. ceil(n / 1024) -- instead of in one of its own: both depend on the render alone, and a
+  // launch of a few microseconds of work costs ~5 us on this runtime (gpurun_out/r6/slamlate_b_dens.txt).
+  if (blockIdx.x > 0) { seen_and_max_radius_block(blockIdx.x - 1u, n_seen, radii, max_radius, seen); return; }
   __shared__ float red[4][4];
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   for (uint32_t r = threadIdx.x; r < l1_rows; r += 256u) { a0 += l1_partial[3 * r]; a1 += l1_partial[3 * r + 1]; a2 += l1_partial[3 * r + 2]; }
@@ -735,8 +744,18 @@ int vtgs_slam_loss_forward(int32_t mode, const float* im, const float* depth_sil
                            int32_t height, int32_t width, float sil_thres, float w_im, float w_depth, float* scratch,
                            float* ssim_grad_maps, float* out5, const float* extra_mask, const float* color_weight,
                            void* stream) {
+  return vtgs_slam_loss_forward_seen(mode, im, depth_sil, gt_im, gt_depth, height, width, sil_thres, w_im, w_depth, scratch,
+                                     ssim_grad_maps, out5, extra_mask, color_weight, 0, nullptr, nullptr, nullptr, stream);
+}
+
+int vtgs_slam_loss_forward_seen(int32_t mode, const float* im, const float* depth_sil, const float* gt_im, const float* gt_depth,
+                                int32_t height, int32_t width, float sil_thres, float w_im, float w_depth, float* scratch,
+                                float* ssim_grad_maps, float* out5, const float* extra_mask, const float* color_weight,
+                                int32_t n, const int32_t* radii, float* max_2d_radius, uint8_t* seen, void* stream) {
   if ((mode < 0 || mode > 2) || !im || !depth_sil || !gt_im || !gt_depth || !scratch || !out5 || height <= 0 || width <= 0)
     return VTGS_ERR_INVALID_ARGUMENT;
+  if (n < 0 || (n > 0 && (!radii || !max_2d_radius || !seen))) return VTGS_ERR_INVALID_ARGUMENT;
+  if (n > 0 && (((uintptr_t)radii | (uintptr_t)max_2d_radius) & 15u)) return VTGS_ERR_INVALID_ARGUMENT;   // (read as int4 / float4)
   const int32_t P = height * width;
   const uint32_t l1_rows = vtgs_masked_l1_partial_rows(P);
   float* ssim_partial = scratch + (size_t)l1_rows * 3;
@@ -750,8 +769,9 @@ int vtgs_slam_loss_forward(int32_t mode, const float* im, const float* depth_sil
     hipLaunchKernelGGL(ssim_forward_kernel, dim3(ssim_grid((uint32_t)(ssim_rows))), dim3(256), 0, st, im, gt_im, 3, height, width, tx, ty,
                        ssim_partial, ssim_grad_maps);
   }
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, l1_rows, ssim_partial, ssim_rows, mode, w_im,
-                     w_depth, (float)((size_t)3 * P), out5, (mode == 1 && color_weight) ? 1.0f : 0.8f);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1u + (uint32_t)((n + 1023) / 1024)), dim3(256), 0, st, scratch, l1_rows, ssim_partial,
+                     ssim_rows, mode, w_im, w_depth, (float)((size_t)3 * P), out5, (mode == 1 && color_weight) ? 1.0f : 0.8f, 0,
+                     (int)n, radii, max_2d_radius, seen);
   return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
 }
 

@@ -118,11 +118,38 @@ VTGS_HD void tile_rect(const CamParams& cam, float u, float v, int radius, int& 
   y1 = clampi((int)floorf((v + rf + (float)(kBinTile - 1)) * it + kRectEps), 0, cam.gy16);
 }
 
+// Pixel centre.  A float32 centre at |u| ~ 1000 px carries ~6e-5 px of rounding -- against exponent slopes of a few per
+// pixel that is the 3e-4 relative noise on every alpha that put the 99.9th percentile of the gradient error at 1.4e-3 of
+// the float64 oracle at 1200x680 (CPU study: the float32 oracle itself drops from 2e-3 to 1.5e-5 when
+// only the centre OFFSETS are exact).  The homogeneous coordinates and the divide are therefore carried in double (a
+// dozen half-rate instructions per Gaussian), and the centre leaves as a float32 pair: the consumers form
+// (u - tile centre) + ulo, whose first term is exact.  (A function of its own since round 6: gather_splat_grads needs the
+// centre, and nothing else of the projection, while it sums the records.)
+VTGS_HD void pixel_centre(const CamParams& cam, float x, float y, float z, float& u, float& v, float& ulo, float& vlo) {
+  const float* P = cam.PV;
+  const double xd = (double)x, yd = (double)y, zd = (double)z;
+  const double hxd = (double)P[0] * xd + ((double)P[4] * yd + ((double)P[8] * zd + (double)P[12]));
+  const double hyd = (double)P[1] * xd + ((double)P[5] * yd + ((double)P[9] * zd + (double)P[13]));
+  const double hwd = (double)P[3] * xd + ((double)P[7] * yd + ((double)P[11] * zd + (double)P[15])) + 1e-7;
+  // quotient: the float32 one, then one Newton step in double (relative error ~2^-45)
+  const float inv = 1.f / (float)hwd;
+  double qx = (double)((float)hxd * inv), qy = (double)((float)hyd * inv);
+  qx += (hxd - qx * hwd) * (double)inv;
+  qy += (hyd - qy * hwd) * (double)inv;
+  const double hwid = 0.5 * (double)cam.W, hhd = 0.5 * (double)cam.H;            // ((q + 1) W - 1) / 2 = q W/2 + (W - 1)/2
+  const double ud = qx * hwid + (hwid - 0.5), vd = qy * hhd + (hhd - 0.5);
+  u = (float)ud; v = (float)vd;
+  ulo = (float)(ud - (double)u); vlo = (float)(vd - (double)v);
+}
+
 // Forward projection of one Gaussian.  Returns false when culled (radius = 0).
 // cov_precomp != NULL: the caller gives the 3-D covariance itself (xx xy xz yy yz zz -- the operator's `cov3D_precomp`, used as
 // it is: no scale modifier) instead of scale + rotation; every existing caller passes the default and pays nothing.
+// centre4 != NULL: (u, v, ulo, vlo) as pixel_centre returned them for this mean -- the caller formed the centre ahead of the
+// rest (gather_splat_grads) and the double-precision chain is not run a second time.
 VTGS_HD bool project_splat(const CamParams& cam, const float mean[3], const float scale[3],
-                           const float quat[4], float opacity, Splat& out, SplatAux& aux, const float* cov_precomp = nullptr) {
+                           const float quat[4], float opacity, Splat& out, SplatAux& aux, const float* cov_precomp = nullptr,
+                           const float* centre4 = nullptr) {
   out.radius = 0; out.x0 = out.y0 = out.x1 = out.y1 = 0;
   const float x = mean[0], y = mean[1], z = mean[2];
   const float* V = cam.V;
@@ -138,27 +165,8 @@ VTGS_HD bool project_splat(const CamParams& cam, const float mean[3], const floa
   const float hw = fmaf(P[3], x, fmaf(P[7], y, fmaf(P[11], z, P[15])));
   const float hw_inv = 1.f / (hw + 1e-7f);
   aux.hw_inv = hw_inv; aux.hx = hx; aux.hy = hy;
-  // Pixel centre.  A float32 centre at |u| ~ 1000 px carries ~6e-5 px of rounding -- against exponent slopes of a few per
-  // pixel that is the 3e-4 relative noise on every alpha that put the 99.9th percentile of the gradient error at 1.4e-3 of
-  // the float64 oracle at 1200x680 (CPU study: the float32 oracle itself drops from 2e-3 to 1.5e-5 when
-  // only the centre OFFSETS are exact).  The homogeneous coordinates and the divide are therefore carried in double (a
-  // dozen half-rate instructions per Gaussian), and the centre leaves as a float32 pair: the consumers form
-  // (u - tile centre) + ulo, whose first term is exact.
-  {
-    const double xd = (double)x, yd = (double)y, zd = (double)z;
-    const double hxd = (double)P[0] * xd + ((double)P[4] * yd + ((double)P[8] * zd + (double)P[12]));
-    const double hyd = (double)P[1] * xd + ((double)P[5] * yd + ((double)P[9] * zd + (double)P[13]));
-    const double hwd = (double)P[3] * xd + ((double)P[7] * yd + ((double)P[11] * zd + (double)P[15])) + 1e-7;
-    // quotient: the float32 one, then one Newton step in double (relative error ~2^-45)
-    const float inv = 1.f / (float)hwd;
-    double qx = (double)((float)hxd * inv), qy = (double)((float)hyd * inv);
-    qx += (hxd - qx * hwd) * (double)inv;
-    qy += (hyd - qy * hwd) * (double)inv;
-    const double hwid = 0.5 * (double)cam.W, hhd = 0.5 * (double)cam.H;            // ((q + 1) W - 1) / 2 = q W/2 + (W - 1)/2
-    const double ud = qx * hwid + (hwid - 0.5), vd = qy * hhd + (hhd - 0.5);
-    out.u = (float)ud; out.v = (float)vd;
-    out.ulo = (float)(ud - (double)out.u); out.vlo = (float)(vd - (double)out.v);
-  }
+  if (centre4) { out.u = centre4[0]; out.v = centre4[1]; out.ulo = centre4[2]; out.vlo = centre4[3]; }
+  else pixel_centre(cam, x, y, z, out.u, out.v, out.ulo, out.vlo);
 
   if (cov_precomp) {
     for (int i = 0; i < 6; ++i) aux.cov3[i] = cov_precomp[i];

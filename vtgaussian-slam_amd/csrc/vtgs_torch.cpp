@@ -63,7 +63,7 @@ inline int64_t alloc_bytes(size_t nbytes) {
 inline int64_t counted_instances(int status, int64_t fwd_flags, int64_t slot_ptr) {
   if (status != VTGS_OK || (fwd_flags & VTGS_FORWARD_MODE_MASK) == VTGS_FORWARD_ASYNC || slot_ptr == 0) return 0;
   const VtgsForwardInfo* info = reinterpret_cast<const VtgsForwardInfo*>(slot_ptr);
-  return (info->complete && !info->overflow) ? (int64_t)info->instances : 0;
+  return (info->complete && !info->overflow) ? (int64_t)info->instances_needed : 0;   // (instance IDS handed out: >= the instances binned)
 }
 
 // The verdict of a RUN-AHEAD forward, read at the end of the node's backward (an overflow has to leave
@@ -244,7 +244,8 @@ std::vector<at::Tensor> rasterize(at::Tensor means3D, at::Tensor means2D, at::Te
 // forward returns {im, depth_sil, radii, workspace, status}.
 struct RenderFrame : public torch::autograd::Function<RenderFrame> {
   static variable_list forward(AutogradContext* ctx, at::Tensor means3D, at::Tensor rgb, at::Tensor unnorm_rot, at::Tensor logit_op,
-                               at::Tensor log_scales, at::Tensor cam_q, at::Tensor cam_t, at::Tensor depth_w2c, at::Tensor cam_bytes,
+                               at::Tensor log_scales, at::Tensor cam_rots, at::Tensor cam_trans, int64_t t_idx, at::Tensor depth_w2c,
+                               at::Tensor cam_bytes,
                                at::Tensor bg, at::Tensor view, at::Tensor proj, int64_t capacity, int64_t tile_cap, int64_t bin_plan,
                                int64_t slot_ptr, int64_t fwd_flags, int64_t frame_flags, int64_t stream,
                                c10::optional<at::Tensor> owned_idx, c10::optional<at::Tensor> owned_idx64,
@@ -260,8 +261,15 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
     unnorm_rot = need(unnorm_rot, "unnorm_rotations", 4, n_map, dev);
     logit_op = need(logit_op, "logit_opacities", 1, n_map, dev);
     log_scales = need(log_scales, "log_scales", 1, n_map, dev);
-    cam_q = need(cam_q, "camera rotation", 4, 1, dev);
-    cam_t = need(cam_t, "camera translation", 3, 1, dev);
+    // The pose: column t_idx of the reference's camera tensors [1,4,T] / [1,3,T] (src/vtgaussian_slam.py:160-167), read IN PLACE
+    // by vtgs_prepare_frame_slot, which also leaves it as seven contiguous floats for the backward; the gradient goes back
+    // full-size from vtgs_pose_gradient_slot (round 6: the two slot launches of round 5 folded into their neighbours)
+    TORCH_CHECK(cam_rots.dim() == 3 && cam_trans.dim() == 3 && cam_rots.size(0) == 1 && cam_trans.size(0) == 1 && cam_rots.size(1) == 4 &&
+                cam_trans.size(1) == 3 && cam_rots.size(2) == cam_trans.size(2) && t_idx >= 0 && t_idx < cam_rots.size(2),
+                "camera tensors [1,4,T] / [1,3,T] and a frame index inside them");
+    const int64_t frames = cam_rots.size(2);
+    cam_rots = need(cam_rots.reshape({4 * frames}), "cam_unnorm_rots", 4 * frames, 1, dev);
+    cam_trans = need(cam_trans.reshape({3 * frames}), "cam_trans", 3 * frames, 1, dev);
     depth_w2c = need(depth_w2c, "first-frame w2c", 16, 1, dev);
     CamRecord cam = camera_from(cam_bytes, bg, view, proj);
     const int64_t H = cam.c.image_height, W = cam.c.image_width;
@@ -272,8 +280,13 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
     at::Tensor vars = at::empty({std::max<int64_t>(np, 4) * (owned ? 17 : 14)}, f32);
     float* v = vars.data_ptr<float>();
     float *means_cam = v, *opac = v + 3 * np, *scales = v + 4 * np, *rot = v + 7 * np, *dcol = v + 11 * np, *rgb_c = v + 14 * np;
+    at::Tensor pose7 = at::empty({7}, f32);
+    at::Tensor cam_q = pose7.narrow(0, 0, 4), cam_t = pose7.narrow(0, 4, 3);
     int rc;
     if (owned) {
+      rc = vtgs_pose_slot_gather(cam_rots.data_ptr<float>(), cam_trans.data_ptr<float>(), (int32_t)frames, (int32_t)t_idx,
+                                 pose7.data_ptr<float>(), st_);     // (the band test below wants the pose ahead of the transform)
+      TORCH_CHECK(rc == VTGS_OK, "vtgs_pose_slot_gather failed: ", vtgs_strerror(rc));
       TORCH_CHECK(owned_idx->scalar_type() == at::kInt && owned_idx->is_contiguous() && owned_idx->device() == dev &&
                   owned_idx64.has_value() && owned_mask.has_value() && owned_escapes.has_value(), "owned set: int32 index list on the device");
       rc = vtgs_band_owner_mask(&cam.c, (int32_t)n_map, means3D.data_ptr<float>(), log_scales.data_ptr<float>(), 1,
@@ -285,9 +298,10 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
                                     cam_q.data_ptr<float>(), cam_t.data_ptr<float>(), depth_w2c.data_ptr<float>(), means_cam, opac,
                                     scales, rot, dcol, rgb_c, st_);
     } else {
-      rc = vtgs_prepare_frame((int32_t)n, means3D.data_ptr<float>(), logit_op.data_ptr<float>(), log_scales.data_ptr<float>(),
-                              unnorm_rot.data_ptr<float>(), cam_q.data_ptr<float>(), cam_t.data_ptr<float>(),
-                              depth_w2c.data_ptr<float>(), means_cam, opac, scales, rot, dcol, st_);
+      rc = vtgs_prepare_frame_slot((int32_t)n, means3D.data_ptr<float>(), logit_op.data_ptr<float>(), log_scales.data_ptr<float>(),
+                                   unnorm_rot.data_ptr<float>(), cam_rots.data_ptr<float>(), cam_trans.data_ptr<float>(),
+                                   (int32_t)frames, (int32_t)t_idx, depth_w2c.data_ptr<float>(), means_cam, opac, scales, rot, dcol,
+                                   pose7.data_ptr<float>(), st_);
     }
     TORCH_CHECK(rc == VTGS_OK, "vtgs_prepare_frame failed: ", vtgs_strerror(rc), " (", vtgs_last_hip_error(), ")");
     const float* colors_a = owned ? rgb_c : rgb.data_ptr<float>();
@@ -322,6 +336,8 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
     ctx->saved_data["n"] = n;
     ctx->saved_data["n_map"] = n_map;
     ctx->saved_data["frame_flags"] = frame_flags;
+    ctx->saved_data["frames"] = frames;
+    ctx->saved_data["t_idx"] = t_idx;
     ctx->set_materialize_grads(false);
     at::Tensor status = at::empty({}, at::TensorOptions().dtype(at::kLong));
     status.fill_((int64_t)st);
@@ -338,7 +354,8 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
     CamRecord cam = camera_from(saved[9], saved[10], saved[11], saved[12]);
     const int64_t n = ctx->saved_data["n"].toInt(), n_map = ctx->saved_data["n_map"].toInt(),
                   capacity = ctx->saved_data["capacity"].toInt(), tile_cap = ctx->saved_data["tile_cap"].toInt(),
-                  stream = ctx->saved_data["stream"].toInt(), flags = ctx->saved_data["frame_flags"].toInt();
+                  stream = ctx->saved_data["stream"].toInt(), flags = ctx->saved_data["frame_flags"].toInt(),
+                  frames = ctx->saved_data["frames"].toInt(), t_idx = ctx->saved_data["t_idx"].toInt();
     const bool owned = idx.defined();
     void* st_ = reinterpret_cast<void*>(stream);
     const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
@@ -377,30 +394,30 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
           depth_w2c.data_ptr<float>(), ptr(g_rgb), ptr(g_means3D), ptr(g_logit), ptr(g_ls), ptr(g_ur), ptr(partials), st_);
       TORCH_CHECK(st == VTGS_OK, "vtgs_backward_dual_frame failed: ", vtgs_strerror(st), " (", vtgs_last_hip_error(), ")");
       if (want_p) {
-        at::Tensor qt = at::empty({7}, f32);
-        g_q = qt.narrow(0, 0, 4); g_t = qt.narrow(0, 4, 3);
-        const int sp = vtgs_pose_gradient(partials.data_ptr<float>(), rows, cam_q.data_ptr<float>(), g_q.data_ptr<float>(),
-                                          g_t.data_ptr<float>(), st_);
-        TORCH_CHECK(sp == VTGS_OK, "vtgs_pose_gradient failed: ", vtgs_strerror(sp));
+        at::Tensor qt = at::empty({7 * frames}, f32);
+        g_q = qt.narrow(0, 0, 4 * frames).view({1, 4, frames}); g_t = qt.narrow(0, 4 * frames, 3 * frames).view({1, 3, frames});
+        const int sp = vtgs_pose_gradient_slot(partials.data_ptr<float>(), rows, cam_q.data_ptr<float>(), (int32_t)frames, (int32_t)t_idx,
+                                               g_q.data_ptr<float>(), g_t.data_ptr<float>(), st_);
+        TORCH_CHECK(sp == VTGS_OK, "vtgs_pose_gradient_slot failed: ", vtgs_strerror(sp));
       }
     } else if (want_p) {                                           // nothing rendered: zero pose gradient, no launch
-      g_q = at::zeros({4}, f32); g_t = at::zeros({3}, f32);
+      g_q = at::zeros({1, 4, frames}, f32); g_t = at::zeros({1, 3, frames}, f32);
     }
     if (n == 0 && !owned && width > 0) flat.zero_();
     check_run_ahead(ctx->saved_data["slot_ptr"].toInt(), ctx->saved_data["fwd_flags"].toInt(), ctx->saved_data["slot_gen"].toInt());   // (after the launches)
     at::Tensor none;
-    return {g_means3D, g_rgb, g_ur, g_logit.defined() ? g_logit : none, g_ls.defined() ? g_ls : none, g_q, g_t,
+    return {g_means3D, g_rgb, g_ur, g_logit.defined() ? g_logit : none, g_ls.defined() ? g_ls : none, g_q, g_t, none,
             none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
   }
 };
 
 std::vector<at::Tensor> render_frame(at::Tensor means3D, at::Tensor rgb, at::Tensor unnorm_rot, at::Tensor logit_op, at::Tensor log_scales,
-                                     at::Tensor cam_q, at::Tensor cam_t, at::Tensor depth_w2c, at::Tensor cam_bytes, at::Tensor bg,
+                                     at::Tensor cam_rots, at::Tensor cam_trans, int64_t t_idx, at::Tensor depth_w2c, at::Tensor cam_bytes, at::Tensor bg,
                                      at::Tensor view, at::Tensor proj, int64_t capacity, int64_t tile_cap, int64_t bin_plan,
                                      int64_t slot_ptr, int64_t fwd_flags, int64_t frame_flags, int64_t stream,
                                      c10::optional<at::Tensor> owned_idx, c10::optional<at::Tensor> owned_idx64,
                                      c10::optional<at::Tensor> owned_mask, c10::optional<at::Tensor> owned_escapes) {
-  return RenderFrame::apply(means3D, rgb, unnorm_rot, logit_op, log_scales, cam_q, cam_t, depth_w2c, cam_bytes, bg, view, proj, capacity,
+  return RenderFrame::apply(means3D, rgb, unnorm_rot, logit_op, log_scales, cam_rots, cam_trans, t_idx, depth_w2c, cam_bytes, bg, view, proj, capacity,
                             tile_cap, bin_plan, slot_ptr, fwd_flags, frame_flags, stream, owned_idx, owned_idx64, owned_mask,
                             owned_escapes);
 }

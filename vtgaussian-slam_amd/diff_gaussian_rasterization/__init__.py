@@ -52,7 +52,7 @@ class _VtgsProfileEntry(ctypes.Structure):
 
 
 VTGS_OK, VTGS_ERR_INSTANCE_OVERFLOW = 0, 3
-ABI_VERSION = 15
+ABI_VERSION = 16
 VTGS_FORWARD_SYNC, VTGS_FORWARD_ASYNC, VTGS_FORWARD_CHECKED = 0, 1, 2
 VTGS_FORWARD_EXPECT_SHORT_LISTS = 4        # hint: no list beyond 512 entries expected (skips the pre-sort pass for bins <= 1024)
 VTGS_FORWARD_SECOND_IS_DEPTH = 8           # dual render consumed as get_loss consumes it (include/vtgs.h): the single render's kernel
@@ -192,8 +192,8 @@ def last_forward_info() -> dict:
     run-ahead forwards that are still outstanding first."""
     settle_pending()
     if _last_raw is not None:
-        _last_info.update(zip(("instances", "tiles16_touched", "visible", "max_tile_list", "n", "width", "height", "capacity"),
-                              _last_raw))
+        _last_info.update(zip(("instances", "tiles16_touched", "visible", "max_tile_list", "n", "width", "height", "capacity",
+                               "instances_needed"), _last_raw))
     return dict(_last_info)
 
 
@@ -556,7 +556,7 @@ def _settle_locked(fs) -> None:
             _deferred_overflows.append(err)
             return
         raise err
-    fs._instances = int(info.instances)
+    fs._instances = int(info.instances_needed)
     _record_info(key, n, fs.cam.W, fs.cam.H, fs.capacity, info)
 
 
@@ -739,7 +739,7 @@ def _record_info(key, n, W, H, capacity, info):
     roomy = bool(cap and tcap and need_i * _RUN_AHEAD_HEADROOM <= cap and bins_roomy)
     _async_ok[key] = (cap, tcap) if (roomy and steady) else None   # ... are the only ones the next forward may run ahead with
     global _last_raw
-    _last_raw = (int(info.instances), int(info.tiles16_touched), int(info.visible), need_t, n, W, H, int(capacity))
+    _last_raw = (int(info.instances), int(info.tiles16_touched), int(info.visible), need_t, n, W, H, int(capacity), need_i)
 
 
 _last_raw = None
@@ -898,7 +898,7 @@ def _run_forward(cam: _Camera, means3D, colors, opacities, scales, rotations, wa
         pool.owner[slot] = None
         _caps_in_use.setdefault(key, (capacity, tile_cap))
         _record_info(key, n, W, H, capacity, info)
-        fs.workspace, fs.capacity, fs.tile_cap, fs._instances = workspace, capacity, tile_cap, int(info.instances)
+        fs.workspace, fs.capacity, fs.tile_cap, fs._instances = workspace, capacity, tile_cap, int(info.instances_needed)
     return color, radii, depth, fs
 
 
@@ -945,7 +945,7 @@ def _forward_ext(cam: _Camera, means3D, means2D, colors, opacities, scales, rota
             pool.owner[slot] = None
             _caps_in_use.setdefault(key, (capacity, tile_cap))
             _record_info(key, n, cam.W, cam.H, capacity, info)
-            fs._instances = int(info.instances)
+            fs._instances = int(info.instances_needed)
     return color, radii, depth, fs
 
 

@@ -224,7 +224,21 @@ def _backward_fused(ctx, g_im, g_ds):
 _RenderFrame._backward_fused = staticmethod(_backward_fused)
 
 
-def _render_frame_ext(means3D, rgb, unnorm_rot, logit_op, log_scales, q, t, depth_w2c, cam: _Camera, flags: int, owned):
+def _pose_tensors(params, time_idx: int, camera_grad: bool):
+    """(cam_unnorm_rots [1,4,T], cam_trans [1,3,T], frame index) for the C++ node, which reads column `time_idx` in place and
+    returns full-size gradients (round 6: no slot-gather / slot-scatter launches).  Any other layout: the pose as [1,4,1] /
+    [1,3,1] tensors taken with plain indexing, frame index 0."""
+    rots, trans = params["cam_unnorm_rots"], params["cam_trans"]
+    if (rots.dim() == 3 and trans.dim() == 3 and rots.shape[0] == 1 and trans.shape[0] == 1 and rots.shape[1] == 4 and trans.shape[1] == 3
+            and rots.shape[2] == trans.shape[2] and rots.dtype is torch.float32 and trans.dtype is torch.float32
+            and rots.is_contiguous() and trans.is_contiguous() and rots.is_cuda and 0 <= int(time_idx) < rots.shape[2]):
+        return (rots, trans, int(time_idx)) if camera_grad else (rots.detach(), trans.detach(), int(time_idx))
+    q, t = rots[0, :, time_idx].reshape(1, 4, 1), trans[0, :, time_idx].reshape(1, 3, 1)
+    q, t = q.to(torch.float32).contiguous(), t.to(torch.float32).contiguous()
+    return (q, t, 0) if camera_grad else (q.detach(), t.detach(), 0)
+
+
+def _render_frame_ext(means3D, rgb, unnorm_rot, logit_op, log_scales, pose, depth_w2c, cam: _Camera, flags: int, owned):
     """The same render through the C++ autograd node (csrc/vtgs_torch.cpp `RenderFrame`): the policy of `_run_forward` -- capacities,
     checked or run-ahead mode, the pinned result record, the retry after an overflow -- stays here, the per-call work and the
     whole backward run without the interpreter.  With the kernels of one band of the tile-row partition a rank's iteration is
@@ -252,7 +266,7 @@ def _render_frame_ext(means3D, rgb, unnorm_rot, logit_op, log_scales, q, t, dept
             info.complete = 0
             plan = _plan_for(key, device, tile_cap).data_ptr() if tile_cap & PLANNED else 0
             im, depth_sil, radii, workspace, status = _ext.render_frame(
-                means3D, rgb, unnorm_rot, logit_op, log_scales, q, t, depth_w2c, cam.bytes, cam.bg, cam.view, cam.proj, capacity,
+                means3D, rgb, unnorm_rot, logit_op, log_scales, pose[0], pose[1], pose[2], depth_w2c, cam.bytes, cam.bg, cam.view, cam.proj, capacity,
                 tile_cap, plan, pool.ptr[slot], (VTGS_FORWARD_ASYNC if run_ahead else VTGS_FORWARD_CHECKED) | _forward_hints(key, tile_cap)
                 | (VTGS_FORWARD_SECOND_IS_DEPTH if flags & 16 else 0), flags & 15, stream, *o)
             if run_ahead:
@@ -273,7 +287,7 @@ def _render_frame_ext(means3D, rgb, unnorm_rot, logit_op, log_scales, q, t, dept
             pool.owner[slot] = None
             _caps_in_use.setdefault(key, (capacity, tile_cap))
             _record_info(key, n, cam.W, cam.H, capacity, info)
-            fs._instances = int(info.instances)
+            fs._instances = int(info.instances_needed)
     return im, depth_sil, radii
 
 
@@ -310,7 +324,6 @@ def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings
     import os
     rule = _RADIUS_RULES[radius_rule or os.environ.get("VTGS_RADIUS_RULE", "3sigma")]
     cam = _camera_for(raster_settings, dev, rule, None if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1])))
-    q, t = _pose_of_frame(params, time_idx, camera_grad)
     # like the reference, gaussians_grad=False detaches only the geometry (means3D, unnorm_rotations); colours,
     # opacities and scales keep their gradient whenever they require one (utils/slam_helpers.py:362-367, 152-159)
     g = lambda x: x if gaussians_grad else x.detach()
@@ -329,7 +342,9 @@ def render_frame(params: Dict[str, torch.Tensor], time_idx: int, raster_settings
             and os.environ.get("VTGS_FRAME_EPILOGUE", "1") != "0" and os.environ.get("VTGS_FUSED_EXT", "1") != "0"
             and not torch.cuda.is_current_stream_capturing()):
         return _render_frame_ext(g(params["means3D"]), params["rgb_colors"], g(params["unnorm_rotations"]), params["logit_opacities"],
-                                 params["log_scales"], q, t, first_frame_w2c.to(dev), cam, flags, owned)
+                                 params["log_scales"], _pose_tensors(params, time_idx, camera_grad), first_frame_w2c.to(dev), cam, flags,
+                                 owned)
+    q, t = _pose_of_frame(params, time_idx, camera_grad)
     return _RenderFrame.apply(g(params["means3D"]), params["rgb_colors"], g(params["unnorm_rotations"]),
                               params["logit_opacities"], params["log_scales"], q, t,
                               first_frame_w2c.to(dev), cam, flags, owned)

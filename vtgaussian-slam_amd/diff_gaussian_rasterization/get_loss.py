@@ -138,30 +138,32 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
     for m in masks:
         extra = m if extra is None else (extra & m)
 
+    # :681-689 -- bookkeeping, decided here because it rides in the loss's last launch when it can:
+    # max_2D_radius[seen] = max(radius[seen], max_2D_radius[seen]) without the boolean-mask gathers (each of them waits for
+    # the device to count its elements -- 0.3 - 1.2 ms per iteration at 1 M Gaussians): a culled Gaussian has radius 0 and
+    # the running maximum is never negative, so the element-wise maximum over ALL Gaussians is the same in-place update
+    mx = variables["max_2D_radius"]
+    fast_bk = (mx.dtype == torch.float32 and mx.is_contiguous() and radius.dtype == torch.int32 and radius.is_contiguous()
+               and mx.data_ptr() % 16 == 0 and radius.data_ptr() % 16 == 0 and mx.numel() == radius.numel() and radius.numel() > 0)
+    seen = torch.empty(radius.shape, dtype=torch.bool, device=radius.device) if fast_bk else None
+    bk = (radius, mx, seen) if fast_bk else None
+
     # :590-611 -- the loss
     w_im = float(loss_weights["im"])
     w_depth = float(loss_weights["depth"]) if use_l1 else 0.0   # use_l1 = False: no depth term at all (:591-596)
     if tracking:
         loss, terms = _l.tracking_loss(im, depth_sil, gt_im, gt_depth, thr if use_sil_for_loss else float("-inf"),
                                        w_im=w_im, w_depth=w_depth, extra_mask=extra, return_terms=True,
-                                       colour_over_all_pixels=not (use_sil_for_loss or ignore_outlier_depth_loss))
+                                       colour_over_all_pixels=not (use_sil_for_loss or ignore_outlier_depth_loss), bookkeeping=bk)
     else:
         loss, terms = _l.mapping_loss(im, depth_sil, gt_im, gt_depth, w_im=w_im, w_depth=w_depth, extra_mask=extra,
-                                      additional_mask=additional_mask, return_terms=True)
+                                      additional_mask=additional_mask, return_terms=True, bookkeeping=bk)
     weighted_losses = {"im": terms[5]}                          # formed by the loss kernel: no element-wise launches here
     if use_l1:
         weighted_losses["depth"] = terms[6]
 
-    # :681-689 -- bookkeeping
-    # max_2D_radius[seen] = max(radius[seen], max_2D_radius[seen]) without the boolean-mask gathers (each of them waits for
-    # the device to count its elements -- 0.3 - 1.2 ms per iteration at 1 M Gaussians): a culled Gaussian has radius 0 and
-    # the running maximum is never negative, so the element-wise maximum over ALL Gaussians is the same in-place update
-    mx = variables["max_2D_radius"]
-    if mx.dtype == torch.float32 and mx.is_contiguous() and radius.dtype == torch.int32 and radius.is_contiguous() \
-            and mx.data_ptr() % 16 == 0 and radius.data_ptr() % 16 == 0:
-        seen = torch.empty(radius.shape, dtype=torch.bool, device=radius.device)         # one launch: vtgs_seen_and_max_radius
-        _l.seen_and_max_radius(radius, mx, seen)
-    else:
+    # :681-689 -- bookkeeping: done inside the loss's last launch (above) or, for other tensor layouts, with torch
+    if not fast_bk:
         seen = radius > 0
         torch.maximum(mx, radius.to(mx.dtype), out=mx)
     variables["seen"] = seen

@@ -105,6 +105,9 @@ _lib.vtgs_slam_loss_forward.argtypes = [_I32, _P, _P, _P, _P, _I32, _I32, ctypes
 _lib.vtgs_slam_loss_backward.restype = ctypes.c_int
 _lib.vtgs_slam_loss_backward.argtypes = [_I32, _P, _P, _P, _P, _I32, _I32, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P,
                                          _P, _P, _P, _P, _P]
+_lib.vtgs_slam_loss_forward_seen.restype = ctypes.c_int
+_lib.vtgs_slam_loss_forward_seen.argtypes = [_I32, _P, _P, _P, _P, _I32, _I32, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P,
+                                             _P, _P, _I32, _P, _P, _P, _P]
 
 
 class _SlamLoss(torch.autograd.Function):
@@ -113,7 +116,9 @@ class _SlamLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, im, depth_sil, gt_im, gt_depth, mode: int, sil_thres: float, w_im: float, w_depth: float,
-                extra_mask=None, color_weight=None):
+                extra_mask=None, color_weight=None, bookkeeping=None):
+        # bookkeeping = (radius int32 [N], max_2D_radius float32 [N], seen bool [N]) of the render this loss belongs to: get_loss's
+        # `seen` / running-maximum update (src/vtgaussian_slam.py:681-689) rides in the loss's last launch (round 6)
         if not im.is_cuda:
             raise RuntimeError("the fused losses need tensors on a HIP device (torch 'cuda'); no CPU path exists")
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
@@ -129,11 +134,12 @@ class _SlamLoss(torch.autograd.Function):
         scratch = torch.empty(int(_lib.vtgs_loss_scratch_floats(H, W)), dtype=torch.float32, device=a.device)
         gmaps = torch.empty((3, 3, H, W), dtype=torch.float32, device=a.device) if (mode == 1 and need) else None
         out = torch.empty(8, dtype=torch.float32, device=a.device)
-        _check(_lib.vtgs_slam_loss_forward(mode, a.data_ptr(), d.data_ptr(), ga.data_ptr(), gd.data_ptr(), H, W,
-                                           float(sil_thres), float(w_im), float(w_depth), scratch.data_ptr(),
-                                           None if gmaps is None else gmaps.data_ptr(), out.data_ptr(),
-                                           None if em is None else em.data_ptr(), None if cw is None else cw.data_ptr(),
-                                           _stream_ptr(a.device)), "vtgs_slam_loss_forward")
+        n_bk, bk = (0, (None, None, None)) if bookkeeping is None else (int(bookkeeping[0].numel()), [t.data_ptr() for t in bookkeeping])
+        _check(_lib.vtgs_slam_loss_forward_seen(mode, a.data_ptr(), d.data_ptr(), ga.data_ptr(), gd.data_ptr(), H, W,
+                                                float(sil_thres), float(w_im), float(w_depth), scratch.data_ptr(),
+                                                None if gmaps is None else gmaps.data_ptr(), out.data_ptr(),
+                                                None if em is None else em.data_ptr(), None if cw is None else cw.data_ptr(),
+                                                n_bk, bk[0], bk[1], bk[2], _stream_ptr(a.device)), "vtgs_slam_loss_forward_seen")
         ctx.em, ctx.cw = em, cw
         ctx.save_for_backward(a, d, ga, gd, out, gmaps if gmaps is not None else out)
         ctx.cfg = (mode, float(sil_thres), float(w_im), float(w_depth), need, gmaps is not None)
@@ -146,7 +152,7 @@ class _SlamLoss(torch.autograd.Function):
     def backward(ctx, g, _g_terms=None):
         mode, sil_thres, w_im, w_depth, need, has_maps = ctx.cfg
         if g is None or not need:
-            return (None,) * 10
+            return (None,) * 11
         a, d, ga, gd, out, gmaps = ctx.saved_tensors
         H, W = a.shape[-2], a.shape[-1]
         up = g.detach().to(torch.float32).reshape(1).contiguous()
@@ -157,11 +163,11 @@ class _SlamLoss(torch.autograd.Function):
                                             None if ctx.em is None else ctx.em.data_ptr(),
                                             None if ctx.cw is None else ctx.cw.data_ptr(), _stream_ptr(a.device)),
                "vtgs_slam_loss_backward")
-        return g_im, g_ds, None, None, None, None, None, None, None, None
+        return g_im, g_ds, None, None, None, None, None, None, None, None, None
 
 
 def tracking_loss(im, depth_sil, gt_im, gt_depth, sil_thres: float, w_im: float = 0.5, w_depth: float = 0.025,
-                  extra_mask=None, return_terms: bool = False, colour_over_all_pixels: bool = False):
+                  extra_mask=None, return_terms: bool = False, colour_over_all_pixels: bool = False, bookkeeping=None):
     """Tracking loss of get_loss (src/vtgaussian_slam.py:519-605): w_im * masked L1 SUM of colour + w_depth * masked L1
     SUM of depth over gt_depth > 0 & finite & silhouette > sil_thres [& extra_mask].  `extra_mask` [H,W] / [1,H,W]
     (bool or float, detached) carries the masks of the TUM / ScanNet / ScanNet++ branches -- build it with
@@ -170,17 +176,17 @@ def tracking_loss(im, depth_sil, gt_im, gt_depth, sil_thres: float, w_im: float 
     w_depth * depth term, 0}.  colour_over_all_pixels: the branch with neither use_sil_for_loss nor
     ignore_outlier_depth_loss (:601-602) -- the colour sum ignores the mask; w_depth = 0: use_l1 = False (:591-596)."""
     loss, terms = _SlamLoss.apply(im, depth_sil, gt_im, gt_depth, 2 if colour_over_all_pixels else 0, sil_thres, w_im, w_depth,
-                                  extra_mask, None)
+                                  extra_mask, None, bookkeeping)
     return (loss, terms) if return_terms else loss
 
 
 def mapping_loss(im, depth_sil, gt_im, gt_depth, w_im: float = 1.0, w_depth: float = 1.0, extra_mask=None,
-                 additional_mask=None, return_terms: bool = False):
+                 additional_mask=None, return_terms: bool = False, bookkeeping=None):
     """Mapping loss (src/vtgaussian_slam.py:592-611): w_depth * masked L1 MEAN of depth + w_im * (0.8 * L1 mean + 0.2 *
     (1 - SSIM)) of colour; with `additional_mask` the colour L1 becomes mean(|im - gt| * (10 * additional_mask + 0.8))
     (l1_loss_v1_mask, utils/slam_helpers.py:8-9).  `extra_mask`: the outlier-depth mask when ignore_outlier_depth_loss."""
     cw = None if additional_mask is None else 10.0 * additional_mask.to(torch.float32) + 0.8
-    loss, terms = _SlamLoss.apply(im, depth_sil, gt_im, gt_depth, 1, 0.0, w_im, w_depth, extra_mask, cw)
+    loss, terms = _SlamLoss.apply(im, depth_sil, gt_im, gt_depth, 1, 0.0, w_im, w_depth, extra_mask, cw, bookkeeping)
     return (loss, terms) if return_terms else loss
 
 

@@ -106,7 +106,7 @@ class _RasterizeCov3D(torch.autograd.Function):
                 raise RuntimeError("vtgs_forward_cov3d: instance capacity kept overflowing")
             pool.owner[slot] = None
             fs.cam, fs.n, fs.workspace, fs.capacity, fs.tile_cap, fs.image_state, fs.key, fs.pending = cam, n, ws, capacity, tile_cap, None, None, None
-            fs._instances = int(info.instances)
+            fs._instances = int(info.instances_needed)
         ctx.fs = fs
         ctx.save_for_backward(means3D, colors, opac, cov, color)
         ctx.set_materialize_grads(False)
