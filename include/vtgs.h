@@ -289,7 +289,8 @@ int vtgs_mark_visible(const VtgsCamera* cam, int32_t n, const float* means3D,
  * pass): it takes the two sets of operator gradients plus dL/d(depth colours) and writes (flags bit 0) the gradients of
  * means3D / unnorm_rotations, (flags bit 2) those of logit_opacities / log_scales -- the reference's gaussians_grad=False
  * detaches only the former pair -- and (flags bit 1) per-workgroup partial sums of
- * [dL/dt (3) | dL/dR (9, row-major)] into pose_partials[vtgs_pose_partial_rows(n)][12]; the caller sums the rows and
+ * [dL/dt (3) | dL/dR (9, row-major)] into pose_partials[vtgs_pose_partial_rows(n)][12] (16-byte aligned: the reduction reads
+ * a row as three 16-byte words; otherwise VTGS_ERR_INVALID_ARGUMENT); the caller sums the rows and
  * takes the 12 -> 7 step through the quaternion.  No atomics: results are bitwise reproducible.  The four *_b inputs
  * may all be NULL (after vtgs_backward_dual the *_a set already holds the sum over both renders).                       */
 uint32_t vtgs_pose_partial_rows(int32_t n);

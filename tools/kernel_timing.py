@@ -40,10 +40,15 @@ torch.cuda.synchronize()
 dgr.profile_enable(True)
 for it in range(20): step()
 p=dgr.profile_collect()
-torch.cuda.synchronize(); t=time.time()
+torch.cuda.synchronize()
 dgr.profile_enable(False)
+for it in range(10): step()
+torch.cuda.synchronize(); t=time.time()
+e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True); e0.record()
 for it in range(20): step()
-torch.cuda.synchronize(); dt=(time.time()-t)/20*1e3
+e1.record(); torch.cuda.synchronize(); dt=(time.time()-t)/20*1e3
+print('policy: run-ahead', [bool(v) for v in dgr._async_ok.values()], 'capacities', list(dgr._caps_in_use.values()), 'info', dgr.last_forward_info(),
+      'events %.3f ms per step'%(e0.elapsed_time(e1)/20), flush=True)
 if os.environ.get('ABL_TAIL','0')!='0':
     offs,gid,_=dgr.debug_tile_lists(rast); per=torch.bincount(gid,minlength=N)
     edges=[0,1,2,3,5,7,9,13,17,33,65,257,1<<30]

@@ -21,7 +21,7 @@ __global__ void project_and_bin_capped(CamScalars, const float*, const float*, i
                                 Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
 template <bool PLANNED>
 __global__ void bin_deferred_splats(CamScalars, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, const DeferRec*,
-                                    unsigned long long, uint32_t);
+                                    uint32_t, unsigned long long, uint32_t, uint32_t);
 __global__ void finalize_forward(const uint32_t*, uint32_t, Counters*, unsigned long long, uint32_t, const BlockStats*,
                                  uint32_t, VtgsForwardInfo*, const uint32_t*, uint32_t*);
 template <bool WIDE>
@@ -415,19 +415,20 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
     }
     VTGS_HIP(hipGetLastError());
     {
-      // the splats project_and_bin left aside (more than kDeferArea candidate tiles): binned here, 64 list entries per workgroup
-      // and round; the list's length is on the device, so the grid is what a list of N / 8 entries needs (longer lists: more
-      // rounds per workgroup) and, with an empty list, every workgroup leaves after one load
+      // the splats project_and_bin left aside (more than kDeferArea candidate tiles): binned here.  The lists' lengths are on the
+      // device, so the grid is what lists of N / 8 small and N / 256 large entries need (longer lists: more rounds per
+      // workgroup); with empty lists every workgroup leaves after one load.  The large list's workgroups come first.
       ProfScope ps__("bin_deferred_splats", st);
-      const uint32_t dgrid = (uint32_t)min((long long)4096, max((long long)64, ((long long)n / 8 + 63) / 64));
+      const uint32_t lgrid = (uint32_t)min((long long)1024, max((long long)16, (long long)n / 1024));
+      const uint32_t dgrid = lgrid + (uint32_t)min((long long)4096, max((long long)64, ((long long)n / 8 + 63) / 64));
       if (L.planned)
         hipLaunchKernelGGL((bin_deferred_splats<true>), dim3(dgrid), dim3(256), 0, st, cs, (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt),
                            (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), ctr, (const DeferRec*)(ws + L.defer_list),
-                           (unsigned long long)instance_capacity, L.tile_cap);
+                           (uint32_t)n, (unsigned long long)instance_capacity, L.tile_cap, lgrid);
       else
         hipLaunchKernelGGL((bin_deferred_splats<false>), dim3(dgrid), dim3(256), 0, st, cs, (GaussAux*)(ws + L.gaux), (uint32_t*)(ws + L.tile_cnt),
                            (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.vals), ctr, (const DeferRec*)(ws + L.defer_list),
-                           (unsigned long long)instance_capacity, L.tile_cap);
+                           (uint32_t)n, (unsigned long long)instance_capacity, L.tile_cap, lgrid);
     }
     VTGS_HIP(hipGetLastError());
   }

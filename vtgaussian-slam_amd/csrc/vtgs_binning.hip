@@ -111,14 +111,15 @@ constexpr uint32_t kWinEntries = 16384;  // windowed LDS tile table (LDSBINS == 
 // its own.  But every lane of a wavefront waits for the longest walk among the 64, and an optimised SLAM map has a heavy tail
 // of splat sizes: after 20 frames of mapping 8 % of the Gaussians of the synthetic Replica sequence cover 7 .. 64 tiles, so
 // nearly every wavefront held one and ran 16 .. 64 trips of both passes where a fresh view-tied map runs 4 -- project_and_bin
-// 160 us against 46 us, gpurun_out/r6/slamlate_b_dens.txt.)  project_and_bin only LISTS them -- 48-byte records in ONE list for the
-// forward; a workgroup takes its stretch of the list with the atomic that takes its instance range -- and a second kernel,
-// bin_deferred_splats, bins them balanced over its lanes, 256 list entries per workgroup and round:
+// 160 us against 46 us, gpurun_out/r6/slamlate_b_dens.txt.)  project_and_bin only LISTS them -- 48-byte records, one list for the
+// forward from the front of an array (up to kGroupArea candidates) and one from its end (larger); a workgroup takes its stretches
+// with the atomic that takes its instance range -- and a second kernel, bin_deferred_splats, bins them balanced over its lanes:
 //   * up to kGroupArea candidate tiles: one 16-lane group per splat, 16 tiles per step;
 //   * up to kWaveArea: one wavefront per splat, 64 tiles per step;
-//   * more: the whole workgroup, 256 tiles per step (a splat grown over a hole of the map covers thousands);
-// first a counting round, then ONE instance-range atomic for the round's splats, then the binning round (slots straight from the
-// global per-tile counters).  Instance ids of a splat follow the raster order of its walk, as everywhere.
+//   * more: the whole workgroup, 256 tiles per step (a splat grown over a hole of the map covers thousands).
+// A deferred splat's instance ids are reserved by project_and_bin, one per CANDIDATE tile (an upper bound: the ids behind the
+// tiles it does not reach stay unused), so the second kernel needs no counter of its own.  Instance ids of a splat follow the
+// raster order of its walk, as everywhere.
 // A kernel of its own because inlined at the end of project_and_bin the same code kept twenty more scalar registers alive
 // through the common path (88 against 68), which that kernel answers with s_load re-materialisation inside its loops: 62 us
 // against 52 us at the headline shape (gpurun_out/r6/timing_g_head*.log); as a called function it dragged its registers and a
@@ -309,6 +310,7 @@ __device__ __forceinline__ void project_and_bin_body(
   // atomics on one cache line cost more than the whole projection.
   __shared__ uint32_t s_wave_cnt[kWaves], s_wave_vis[kWaves], s_wave_r16[kWaves], s_block_base;
   __shared__ uint32_t s_wave_def[kWaves], s_def_base;              // deferred splats of the workgroup, per wavefront; its stretch of the list
+  __shared__ uint32_t s_wave_lrg[kWaves], s_lrg_base;              // ... those beyond kGroupArea candidates: the list's other end
   const int wv = (int)(threadIdx.x >> 6);
   // a deferred splat takes its instance ids here too: one per candidate tile, an upper bound (DeferRec::inst_base)
   const uint32_t cnt_ids = big ? (uint32_t)area_all : cnt;
@@ -316,21 +318,25 @@ __device__ __forceinline__ void project_and_bin_body(
   const uint32_t r16 = vis ? (uint32_t)((sp.x1 - sp.x0) * (sp.y1 - sp.y0)) : 0u;
   const uint32_t r16_incl = wave_incl_scan(r16);
   const unsigned long long vb = __ballot(vis);
-  const unsigned long long def_b = __ballot(big);
+  const bool large = area_all > kGroupArea;                        // (implies big)
+  const unsigned long long def_b = __ballot(big && !large), lrg_b = __ballot(large);
   if (l == 63) {
     s_wave_cnt[wv] = incl; s_wave_vis[wv] = (uint32_t)__popcll(vb); s_wave_r16[wv] = r16_incl;
-    s_wave_def[wv] = (uint32_t)__popcll(def_b);
+    s_wave_def[wv] = (uint32_t)__popcll(def_b); s_wave_lrg[wv] = (uint32_t)__popcll(lrg_b);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t tot = 0, v = 0, nd = 0; unsigned long long r = 0;
+    uint32_t tot = 0, v = 0, nd = 0, nl = 0; unsigned long long r = 0;
     // (unrolled sixteen times the compiler requests all 80 partials at once and the KERNEL's register count follows: 94 VGPRs,
     //  the second workgroup per CU gone -- with three arrays, until round 5, the same loop just fitted under 64)
 #pragma unroll 4
-    for (int k = 0; k < kWaves; ++k) { tot += s_wave_cnt[k]; v += s_wave_vis[k]; r += s_wave_r16[k]; nd += s_wave_def[k]; }
+    for (int k = 0; k < kWaves; ++k) { tot += s_wave_cnt[k]; v += s_wave_vis[k]; r += s_wave_r16[k]; nd += s_wave_def[k]; nl += s_wave_lrg[k]; }
     // the instance range and the stretch of the deferred list with ONE atomic (Counters: the 64-bit pair)
     const unsigned long long old = (tot | nd) ? atomicAdd(reinterpret_cast<unsigned long long*>(ctr), ((unsigned long long)tot << 32) | (unsigned long long)nd) : 0ull;
-    s_block_base = (uint32_t)(old >> 32); s_def_base = (uint32_t)old;
+    // (the large ones are rare -- none in a fresh view-tied map: their counter is touched only by the workgroups that hold one;
+    //  both atomics are in flight together)
+    const uint32_t oldl = nl ? atomicAdd(&ctr->defer_large, nl) : 0u;
+    s_block_base = (uint32_t)(old >> 32); s_def_base = (uint32_t)old; s_lrg_base = oldl;
     BlockStats bs;
     bs.visible = v; bs.pad = 0; bs.r16 = r;
     block_stats[blockIdx.x] = bs;
@@ -350,8 +356,10 @@ __device__ __forceinline__ void project_and_bin_body(
 
   if (big) {
     // listed for bin_deferred_splats, with everything it needs (DeferRec).  HERE, between the passes: the splat is still in registers.
-    uint32_t pos = s_def_base + (uint32_t)__popcll(def_b & ((1ull << l) - 1ull));
-    for (int k = 0; k < wv; ++k) pos += s_wave_def[k];
+    // (up to kGroupArea candidates: from the front of the list; larger: from its end, position n - 1 - index)
+    uint32_t pos = (large ? s_lrg_base : s_def_base) + (uint32_t)__popcll((large ? lrg_b : def_b) & ((1ull << l) - 1ull));
+    for (int k = 0; k < wv; ++k) pos += large ? s_wave_lrg[k] : s_wave_def[k];
+    if (large) pos = (uint32_t)n - 1u - pos;
     float4* __restrict__ rec = reinterpret_cast<float4*>(defer_list + pos);
     rec[0] = make_float4(sp.u, sp.v, sp.A, sp.B);
     rec[1] = make_float4(sp.C, tau, sp.depth, __uint_as_float((uint32_t)gid));
@@ -546,40 +554,48 @@ template __global__ void project_and_bin_capped<0, 5>(CamScalars, const float*, 
 template __global__ void project_and_bin_capped<1, 4>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
 template __global__ void project_and_bin_capped<1, 5>(CamScalars, const float*, const float*, int, const float*, const float*, const float*, const float*, int32_t*, GeomRec*, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, BlockStats*, unsigned long long, uint32_t, DeferRec*);
 
-// The deferred splats of a forward (see kDeferArea), kDeferChunk list entries per workgroup and round -- the list is one for the
-// whole forward, so the work spreads evenly however the large splats cluster in the map (with one list per projection workgroup
-// the densified end of a SLAM map kept a few workgroups busy for 98 us, gpurun_out/r6/slamlate_j_dens.txt).  Every entry brings its
-// instance range along (DeferRec::inst_base), so there is no counter, no scan and no barrier between the entries:
-//   * up to kGroupArea candidates: a 16-lane group forms the reach mask, writes (first id, count) into gaux and bins the
-//     mask's bits -- the slot atomics of ALL the group's entries of the round go out before anything is stored: the round trip of
-//     those atomics (~1.5 us) is what bounds this kernel, and with one waited for after the other the same work took 105 us
+// The deferred splats of a forward (see kDeferArea).  project_and_bin leaves TWO lists in one array: splats of up to kGroupArea
+// candidate tiles from the front (Counters::defer_total), larger ones from the end (Counters::defer_large) -- one list for the
+// whole forward each, so the work spreads evenly however the large splats cluster in the map (with one list per projection
+// workgroup the densified end of a SLAM map kept a few workgroups busy for 98 us, gpurun_out/r6/slamlate_j_dens.txt).  Every
+// entry brings its instance range along (DeferRec::inst_base), so there is no counter, no scan and no barrier between entries.
+// The first `large_grid` workgroups take the large list (they are dispatched first: theirs are the long chains), the others
+// the small one -- until run r of round 6 one workgroup did both for its 64 entries, one tier after the other behind a
+// barrier: 55 us for the 150 K entries of the heavy-tailed test map, of which the waiting for atomics is 19.
+//   * small (<= kGroupArea candidates): a 16-lane group forms the reach mask, writes (first id, count) into gaux and bins the
+//     mask's bits -- the slot atomics of ALL the group's four entries of the round go out before anything is stored: the round
+//     trip of those atomics (~1.5 us) is what bounds this part, and with one waited for after the other the same work took 105 us
 //     (gpurun_out/r6/timing_k_tail.log);
-//   * up to kWaveArea: a wavefront walks the candidates 64 at a time, keeps the hit ballots, then bins with four steps' atomics
-//     in flight;
+//   * large, up to kWaveArea: a wavefront walks the candidates 64 at a time, keeps the hit ballots, then bins with four steps'
+//     atomics in flight;
 //   * beyond (a splat grown over a hole of the map: thousands of tiles): the whole workgroup, 256 candidates per step; the
-//     per-step, per-wavefront counts go through LDS once, then the steps are binned without a barrier.
+//     per-step, per-wavefront counts go through LDS once, then the steps are binned four at a time without a barrier.
 // Everything a splat needs arrives in its 48-byte DeferRec: no dependent loads.
-constexpr int kDeferChunk = 64;                  // list entries per workgroup and round: four per 16-lane group
+constexpr int kDeferChunk = 64;                  // small-list entries per workgroup and round: four per 16-lane group
 constexpr int kWaveSteps = kWaveArea / 64;
 constexpr int kMaxHugeSteps = 512;               // 131,072 candidate tiles (a 2896 x 2896-pixel splat on an 8-pixel grid) per huge splat and pass
+// diagnostic builds only (-DVTGS_EXP_DEFER=1: no slot atomics, 2: no bin stores): where this kernel's time goes
+#ifndef VTGS_EXP_DEFER
+#define VTGS_EXP_DEFER 0
+#endif
+#define DEFER_SLOT(p) ((VTGS_EXP_DEFER & 1) ? 0u : atomicAdd((p), 1u))
 template <bool PLANNED>
 __global__ __launch_bounds__(kDeferBlock) void bin_deferred_splats(
     CamScalars cs, GaussAux* __restrict__ gaux, uint32_t* __restrict__ tile_cnt,
     unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, Counters* __restrict__ ctr,
-    const DeferRec* __restrict__ list, unsigned long long capacity, uint32_t tile_cap) {
+    const DeferRec* __restrict__ list, uint32_t n, unsigned long long capacity, uint32_t tile_cap, uint32_t large_grid) {
   constexpr int kWaves = kDeferBlock / 64, kGroups = kDeferBlock / 16, kPerGroup = kDeferChunk / kGroups, kSteps = kGroupArea / 16;
   static_assert(kPerGroup * kGroups == kDeferChunk, "whole groups");
   constexpr bool planned = PLANNED;
-  const uint32_t total = ctr->defer_total;                       // (complete: project_and_bin has retired)
-  if (blockIdx.x * (uint32_t)kDeferChunk >= total) return;       // workgroup-uniform: nothing (left) for this workgroup
-  __shared__ uint32_t s_large[kDeferChunk], s_nlarge;            // the round's entries beyond kGroupArea (local indices)
-  __shared__ uint32_t s_cnt[kMaxHugeSteps][kWaves];              // huge splats: hits per step and wavefront
+  const bool large_role = blockIdx.x < large_grid;                // workgroup-uniform
+  const uint32_t total = large_role ? ctr->defer_large : ctr->defer_total;   // (complete: project_and_bin has retired)
+  const uint32_t blk = large_role ? blockIdx.x : blockIdx.x - large_grid, nblk = large_role ? large_grid : gridDim.x - large_grid;
+  if (blk * (uint32_t)(large_role ? kWaves : kDeferChunk) >= total) return;  // workgroup-uniform: nothing (left) for this workgroup
   // camera scalars the walk needs (no matrices: the projection is done)
   CamParams cam{};
   cam.W = cs.W; cam.H = cs.H;
   cam.gx8 = (cs.W + kSubTile - 1) / kSubTile; cam.gy8 = (cs.H + kSubTile - 1) / kSubTile;
   const int l = lane_id(), wv = (int)(threadIdx.x >> 6);
-  const int grp = (int)(threadIdx.x >> 4), sub = l & 15, gsh = l & 48;  // 16-lane group of the workgroup, lane in it, its bit offset
   struct Rec { float4 a, b, c; };
   auto splat_of = [&](const Rec& r, Splat& sp, ReachForm& rf) {
     sp = Splat{};
@@ -588,43 +604,38 @@ __global__ __launch_bounds__(kDeferBlock) void bin_deferred_splats(
   };
   auto put = [&](int tile, uint32_t slot, unsigned long long key, unsigned long long id) {
     const BinRange br = planned ? bin_range(cs, (uint32_t)tile, tile_cap) : BinRange{(uint32_t)tile * tile_cap, tile_cap};
-    if (id < capacity && slot < br.cap) {                        // an overflowing bin / id is dropped and flagged later
+    if ((VTGS_EXP_DEFER & 2) == 0 && id < capacity && slot < br.cap) {   // an overflowing bin / id is dropped and flagged later
       const size_t pos = (size_t)br.s + slot;
       keys[pos] = key;
       vals[pos] = (uint32_t)id;
     }
   };
-  for (uint32_t c0 = blockIdx.x * (uint32_t)kDeferChunk; c0 < total; c0 += gridDim.x * (uint32_t)kDeferChunk) {   // workgroup-uniform
-    const uint32_t ne = min((uint32_t)kDeferChunk, total - c0);
-    auto load_rec = [&](uint32_t e) { const float4* p = reinterpret_cast<const float4*>(list + c0 + e); return Rec{p[0], p[1], p[2]}; };
-    if (threadIdx.x == 0) s_nlarge = 0u;
-    __syncthreads();
-    // ---- the groups: all records requested first; masks; gaux; all slot atomics; the bin entries
-    {
+  if (!large_role) {
+    // ---- the small list: no LDS, no barrier
+    const int grp = (int)(threadIdx.x >> 4), sub = l & 15, gsh = l & 48;  // 16-lane group of the workgroup, lane in it, its bit offset
+    for (uint32_t c0 = blk * (uint32_t)kDeferChunk; c0 < total; c0 += nblk * (uint32_t)kDeferChunk) {   // workgroup-uniform
+      const uint32_t ne = min((uint32_t)kDeferChunk, total - c0);
       Rec rs[kPerGroup];
       unsigned long long ms[kPerGroup];
 #pragma unroll
-      for (int j = 0; j < kPerGroup; ++j) {
+      for (int j = 0; j < kPerGroup; ++j) {                        // all records requested first
         const uint32_t e = (uint32_t)(grp + kGroups * j);
-        rs[j] = load_rec(e < ne ? e : 0u);
+        const float4* p = reinterpret_cast<const float4*>(list + c0 + (e < ne ? e : 0u));
+        rs[j] = Rec{p[0], p[1], p[2]};
       }
 #pragma unroll
       for (int j = 0; j < kPerGroup; ++j) {
         const uint32_t e = (uint32_t)(grp + kGroups * j);
         ms[j] = 0ull;
-        if (e >= ne) continue;                                   // (group-uniform)
+        if (e >= ne) continue;                                     // (group-uniform)
         const Rec& r = rs[j];
         const uint32_t cxy = __float_as_uint(r.c.x);
         const int cx0 = (int)(cxy & 0xFFFFu), cy0 = (int)(cxy >> 16), cw = __float_as_int(r.c.y), ch = __float_as_int(r.c.z);
-        const int area = cw * ch;
-        if (area > kGroupArea) {                                  // (group-uniform) a larger splat: listed for the wavefronts
-          if (sub == 0) s_large[atomicAdd(&s_nlarge, 1u)] = e;
-          continue;
-        }
+        const int area = min(cw * ch, kGroupArea);                 // (<= kGroupArea by construction of the list)
         Splat sp; ReachForm rf;
         splat_of(r, sp, rf);
         unsigned long long m = 0ull;
-        for (int i0 = 0; i0 < area; i0 += 16) {                  // (area <= kGroupArea: at most four steps)
+        for (int i0 = 0; i0 < area; i0 += 16) {                    // at most four steps
           const int i = i0 + sub;
           const int ty = i / cw, tx = i - ty * cw;
           const bool hit = i < area && tile_reached(cam, sp, rf, r.b.y, cx0 + tx, cy0 + ty);
@@ -635,7 +646,7 @@ __global__ __launch_bounds__(kDeferBlock) void bin_deferred_splats(
       }
       uint32_t slot[kPerGroup][kSteps];
 #pragma unroll
-      for (int j = 0; j < kPerGroup; ++j) {
+      for (int j = 0; j < kPerGroup; ++j) {                        // all slot atomics of the round
         const uint32_t cxy = __float_as_uint(rs[j].c.x);
         const int cx0 = (int)(cxy & 0xFFFFu), cy0 = (int)(cxy >> 16), cw = __float_as_int(rs[j].c.y);
 #pragma unroll
@@ -644,12 +655,12 @@ __global__ __launch_bounds__(kDeferBlock) void bin_deferred_splats(
           slot[j][k] = 0u;
           if ((ms[j] >> i) & 1ull) {
             const int ty = i / cw, tx = i - ty * cw;
-            slot[j][k] = atomicAdd(&tile_cnt[(cy0 + ty) * cam.gx8 + cx0 + tx], 1u);
+            slot[j][k] = DEFER_SLOT(&tile_cnt[(cy0 + ty) * cam.gx8 + cx0 + tx]);
           }
         }
       }
 #pragma unroll
-      for (int j = 0; j < kPerGroup; ++j) {
+      for (int j = 0; j < kPerGroup; ++j) {                        // the bin entries
         const unsigned long long m = ms[j];
         if (m == 0ull) continue;
         const uint32_t cxy = __float_as_uint(rs[j].c.x);
@@ -666,67 +677,78 @@ __global__ __launch_bounds__(kDeferBlock) void bin_deferred_splats(
         }
       }
     }
+    return;
+  }
+  // ---- the large list (entry e sits at list[n - 1 - e]): one entry per wavefront and round; what is beyond kWaveArea waits in
+  // s_huge for the whole workgroup
+  __shared__ uint32_t s_huge[kWaves], s_nhuge;
+  __shared__ uint32_t s_cnt[kMaxHugeSteps][kWaves];                // huge splats: hits per step and wavefront
+  auto load_large = [&](uint32_t e) { const float4* p = reinterpret_cast<const float4*>(list + (n - 1u - e)); return Rec{p[0], p[1], p[2]}; };
+  for (uint32_t c0 = blk * (uint32_t)kWaves; c0 < total; c0 += nblk * (uint32_t)kWaves) {               // workgroup-uniform
+    if (threadIdx.x == 0) s_nhuge = 0u;
     __syncthreads();
-    const uint32_t nl = s_nlarge;
-    // ---- larger splats, one wavefront each (up to kWaveArea candidates)
-    for (uint32_t k = (uint32_t)wv; k < nl; k += (uint32_t)kWaves) {                       // wave-uniform
-      const Rec r = load_rec(s_large[k]);
+    const uint32_t e = c0 + (uint32_t)wv;
+    if (e < total) {                                                                                  // wave-uniform
+      const Rec r = load_large(e);
       const uint32_t cxy = __float_as_uint(r.c.x);
       const int cx0 = (int)(cxy & 0xFFFFu), cy0 = (int)(cxy >> 16), cw = __float_as_int(r.c.y), ch = __float_as_int(r.c.z);
       const int area = cw * ch;
-      if (area > kWaveArea) continue;
-      Splat sp; ReachForm rf;
-      splat_of(r, sp, rf);
-      const uint32_t base = __float_as_uint(r.c.w);
-      const unsigned long long key = ((unsigned long long)__float_as_uint(r.b.z) << 32) | (unsigned long long)__float_as_uint(r.b.w);
-      unsigned long long hb[kWaveSteps];                        // the hit ballots of all steps (wave-uniform: scalar registers)
-      uint32_t cnt = 0;
+      if (area > kWaveArea) {
+        if (l == 0) s_huge[atomicAdd(&s_nhuge, 1u)] = e;
+      } else {
+        Splat sp; ReachForm rf;
+        splat_of(r, sp, rf);
+        const uint32_t base = __float_as_uint(r.c.w);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(r.b.z) << 32) | (unsigned long long)__float_as_uint(r.b.w);
+        unsigned long long hb[kWaveSteps];                        // the hit ballots of all steps (wave-uniform: scalar registers)
+        uint32_t cnt = 0;
 #pragma unroll
-      for (int st = 0; st < kWaveSteps; ++st) {
-        hb[st] = 0ull;
-        if (64 * st < area) {                                    // wave-uniform
-          const int i = 64 * st + l;
-          const int ty = i / cw, tx = i - ty * cw;
-          hb[st] = __ballot(i < area && tile_reached(cam, sp, rf, r.b.y, cx0 + tx, cy0 + ty));
-          cnt += (uint32_t)__popcll(hb[st]);
+        for (int st = 0; st < kWaveSteps; ++st) {
+          hb[st] = 0ull;
+          if (64 * st < area) {                                    // wave-uniform
+            const int i = 64 * st + l;
+            const int ty = i / cw, tx = i - ty * cw;
+            hb[st] = __ballot(i < area && tile_reached(cam, sp, rf, r.b.y, cx0 + tx, cy0 + ty));
+            cnt += (uint32_t)__popcll(hb[st]);
+          }
         }
-      }
-      if (l == 0) gaux[__float_as_uint(r.b.w)] = GaussAux{base, cnt};
-      uint32_t done = 0;
+        if (l == 0) gaux[__float_as_uint(r.b.w)] = GaussAux{base, cnt};
+        uint32_t done = 0;
 #pragma unroll
-      for (int s4 = 0; s4 < kWaveSteps; s4 += 4) {
-        if (64 * s4 >= area) break;                              // wave-uniform
-        uint32_t slot4[4]; int tile4[4]; uint32_t rank4[4];
+        for (int s4 = 0; s4 < kWaveSteps; s4 += 4) {
+          if (64 * s4 >= area) break;                              // wave-uniform
+          uint32_t slot4[4]; int tile4[4]; uint32_t rank4[4];
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-          const unsigned long long b = hb[s4 + h];
-          const int i = 64 * (s4 + h) + l;
-          const int ty = i / cw, tx = i - ty * cw;
-          tile4[h] = (cy0 + ty) * cam.gx8 + cx0 + tx;
-          rank4[h] = done + (uint32_t)__popcll(b & ((1ull << l) - 1ull));
-          done += (uint32_t)__popcll(b);
-          slot4[h] = ((b >> l) & 1ull) ? atomicAdd(&tile_cnt[tile4[h]], 1u) : 0u;
+          for (int h = 0; h < 4; ++h) {
+            const unsigned long long b = hb[s4 + h];
+            const int i = 64 * (s4 + h) + l;
+            const int ty = i / cw, tx = i - ty * cw;
+            tile4[h] = (cy0 + ty) * cam.gx8 + cx0 + tx;
+            rank4[h] = done + (uint32_t)__popcll(b & ((1ull << l) - 1ull));
+            done += (uint32_t)__popcll(b);
+            slot4[h] = ((b >> l) & 1ull) ? DEFER_SLOT(&tile_cnt[tile4[h]]) : 0u;
+          }
+#pragma unroll
+          for (int h = 0; h < 4; ++h)
+            if ((hb[s4 + h] >> l) & 1ull) put(tile4[h], slot4[h], key, (unsigned long long)base + rank4[h]);
         }
-#pragma unroll
-        for (int h = 0; h < 4; ++h)
-          if ((hb[s4 + h] >> l) & 1ull) put(tile4[h], slot4[h], key, (unsigned long long)base + rank4[h]);
       }
     }
-    // ---- huge splats: the workgroup
-    for (uint32_t k = 0; k < nl; ++k) {                                                    // workgroup-uniform
-      const Rec r = load_rec(s_large[k]);
+    __syncthreads();
+    const uint32_t nh = s_nhuge;
+    for (uint32_t k = 0; k < nh; ++k) {                                                                // workgroup-uniform
+      const Rec r = load_large(s_huge[k]);
       const uint32_t cxy = __float_as_uint(r.c.x);
       const int cx0 = (int)(cxy & 0xFFFFu), cy0 = (int)(cxy >> 16), cw = __float_as_int(r.c.y), ch = __float_as_int(r.c.z);
       const int area = cw * ch;
-      if (area <= kWaveArea) continue;
       Splat sp; ReachForm rf;
       splat_of(r, sp, rf);
       const uint32_t base = __float_as_uint(r.c.w);
       const unsigned long long key = ((unsigned long long)__float_as_uint(r.b.z) << 32) | (unsigned long long)__float_as_uint(r.b.w);
-      uint32_t done = 0;                                         // ids handed out by the passes before this one
-      for (int p0 = 0; p0 < area; p0 += kMaxHugeSteps * kDeferBlock) {                     // (one pass unless the splat covers > 131,072 tiles)
+      uint32_t done = 0;                                           // ids handed out so far
+      for (int p0 = 0; p0 < area; p0 += kMaxHugeSteps * kDeferBlock) {                                 // (one pass unless the splat covers > 131,072 tiles)
         const int pend = min(area, p0 + kMaxHugeSteps * kDeferBlock);
-        __syncthreads();                                         // (the previous user of s_cnt is through)
+        __syncthreads();                                           // (the previous user of s_cnt is through)
         for (int i0 = p0, st = 0; i0 < pend; i0 += kDeferBlock, ++st) {
           const int i = i0 + (int)threadIdx.x;
           const int ty = i / cw, tx = i - ty * cw;
@@ -735,27 +757,35 @@ __global__ __launch_bounds__(kDeferBlock) void bin_deferred_splats(
           if (l == 0) s_cnt[st][wv] = c;
         }
         __syncthreads();
-        for (int i0 = p0, st = 0; i0 < pend; i0 += kDeferBlock, ++st) {
-          const int i = i0 + (int)threadIdx.x;
-          const int ty = i / cw, tx = i - ty * cw;
-          const bool hit = i < pend && tile_reached(cam, sp, rf, r.b.y, cx0 + tx, cy0 + ty);
-          const unsigned long long b = __ballot(hit);
-          uint32_t before = 0, step_total = 0;
-          for (int kk = 0; kk < kWaves; ++kk) { const uint32_t c = s_cnt[st][kk]; before += kk < wv ? c : 0u; step_total += c; }
-          if (hit) {
-            const int tile = (cy0 + ty) * cam.gx8 + cx0 + tx;
-            put(tile, atomicAdd(&tile_cnt[tile], 1u), key, (unsigned long long)base + done + before + (uint32_t)__popcll(b & ((1ull << l) - 1ull)));
+        for (int i0 = p0, st = 0; i0 < pend; i0 += 4 * kDeferBlock, st += 4) {                         // four steps' atomics in flight
+          uint32_t slot4[4]; int tile4[4]; uint32_t rank4[4]; bool hit4[4];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const int i = i0 + h * kDeferBlock + (int)threadIdx.x;
+            const int ty = i / cw, tx = i - ty * cw;
+            hit4[h] = i < pend && tile_reached(cam, sp, rf, r.b.y, cx0 + tx, cy0 + ty);
+            const unsigned long long b = __ballot(hit4[h]);
+            uint32_t before = 0, step_total = 0;
+            if (i0 + h * kDeferBlock < pend) {                     // workgroup-uniform (s_cnt holds this pass's steps only)
+              for (int kk = 0; kk < kWaves; ++kk) { const uint32_t c = s_cnt[st + h][kk]; before += kk < wv ? c : 0u; step_total += c; }
+            }
+            tile4[h] = (cy0 + ty) * cam.gx8 + cx0 + tx;
+            rank4[h] = done + before + (uint32_t)__popcll(b & ((1ull << l) - 1ull));
+            done += step_total;
+            slot4[h] = hit4[h] ? DEFER_SLOT(&tile_cnt[tile4[h]]) : 0u;
           }
-          done += step_total;
+#pragma unroll
+          for (int h = 0; h < 4; ++h)
+            if (hit4[h]) put(tile4[h], slot4[h], key, (unsigned long long)base + rank4[h]);
         }
       }
       if (threadIdx.x == 0) gaux[__float_as_uint(r.b.w)] = GaussAux{base, done};
     }
-    __syncthreads();                                             // the next round reuses the lists
+    // (the next round's first barrier separates this round's readers of s_huge / s_cnt from its writers)
   }
 }
-template __global__ void bin_deferred_splats<false>(CamScalars, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, const DeferRec*, unsigned long long, uint32_t);
-template __global__ void bin_deferred_splats<true>(CamScalars, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, const DeferRec*, unsigned long long, uint32_t);
+template __global__ void bin_deferred_splats<false>(CamScalars, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, const DeferRec*, uint32_t, unsigned long long, uint32_t, uint32_t);
+template __global__ void bin_deferred_splats<true>(CamScalars, GaussAux*, uint32_t*, unsigned long long*, uint32_t*, Counters*, const DeferRec*, uint32_t, unsigned long long, uint32_t, uint32_t);
 
 // One workgroup right after the binning: longest tile list, statistics, overflow flags and the image of the
 // host-visible VtgsForwardInfo (finalize_block, vtgs_internal.h; the quadrant-queue forward runs it in its first workgroup

@@ -23,7 +23,8 @@ namespace vtgs {
 //   sorted_inst  T8 x cap_t x 4   per-tile instance ids (address of the per-instance gradient record)
 //   final_T      P x 4     per-pixel transmittance after the last contributor
 //   qmask        T8 x cap_t x 1   which 4x4 quadrants of its tile a sorted list entry can reach (quadrant-queue composites)
-//   defer_list   N x 48    the splats project_and_bin left to bin_deferred_splats (round 6): first Counters::defer_total entries
+//   defer_list   N x 48    the splats project_and_bin left to bin_deferred_splats (round 6): the first Counters::defer_total entries
+//                          (up to 64 candidate tiles each) and, from the END, Counters::defer_large entries (larger splats)
 // Every tile owns a fixed-capacity bin (cap_t, a caller hint like the instance capacity), so binning is one
 // pass: no prefix scan over tiles and no scatter pass.  finalize_forward raises the overflow flags right after the
 // binning (a dropped instance leaves an unwritten bin slot, so sort and composite bail on the flag) and the caller
@@ -37,7 +38,8 @@ struct Counters {
   uint32_t inst_total;      // instances requested (keeps counting past capacity)
   uint32_t overflow;        // bit 0: inst_total > instance capacity, bit 1: a tile list > tile capacity (finalize_forward)
   uint32_t qmask_valid;     // composite_forward_q wrote the quadrant masks of this forward's lists (composite_backward_q reads them)
-  uint32_t pad[12];
+  uint32_t defer_large;     // deferred splats beyond kGroupArea candidate tiles: listed from the END of the deferred list
+  uint32_t pad[11];
   // byte 64: image of the public VtgsForwardInfo, written by finalize_forward, copied to the host by vtgs_forward
   unsigned long long info_instances, info_needed, info_r16;
   uint32_t info_visible, info_max_list, info_overflow, info_complete;

@@ -184,6 +184,12 @@ if _FORWARD_MODE not in ("auto", "checked"):
     raise ImportError("VTGS_FORWARD_MODE must be auto or checked")
 _RUN_AHEAD_HEADROOM = 3.0
 _RUN_AHEAD_MAX_BIN = 1024        # uniform bins up to this many slots can be sorted inside the forward composite (no pre-sort pass)
+# Round 6: a STEADY loop gets that room in larger bins too (up to this many slots, i.e. a longest list of ~1,100): until then a
+# view whose longest list passed 284 entries (3.6 x 284 > 1,024) stayed in the checked mode for good -- every frame of the SLAM
+# block after the first few: the host waited for the record in every tracking iteration and the GPU then waited ~40 us for
+# the host in front of loss_backward_kernel (gpurun_out/r6/slamapi_s.txt).  Bins beyond 1,024 slots bring the pre-sort
+# passes (~7 us each when no list needs them) and 21 bytes per slot of workspace (1 GB at 1200x680): cheap against the bubble.
+_RUN_AHEAD_BIN_LIMIT = int(os.environ.get("VTGS_RUN_AHEAD_BIN_LIMIT", "4096"))
 _SHORT_LIST_HINT = 400           # longest list of the last forward up to which the next one is launched with EXPECT_SHORT_LISTS
 
 
@@ -663,10 +669,24 @@ def _choose_capacities(key, n):
         if roomy_cap <= _RUN_AHEAD_MAX_BIN:
             if tcap & PLANNED or need_t * _RUN_AHEAD_HEADROOM > tcap or tcap > _RUN_AHEAD_MAX_BIN or need_t * 12 < tcap:
                 tcap = max(64, roomy_cap)
+        elif roomy_cap <= _RUN_AHEAD_BIN_LIMIT and _looks_steady(key):
+            # (only for a loop that can use the room: one whose views differ stays checked whatever its bins hold)
+            if tcap & PLANNED or need_t * _RUN_AHEAD_HEADROOM > tcap or tcap > _RUN_AHEAD_BIN_LIMIT or need_t * 12 < tcap:
+                tcap = roomy_cap
         elif tcap & PLANNED or need_t * 1.1 > tcap or need_t * 4 < tcap:
             tcap = _tile_capacity_for(need_t)
     _caps_in_use[key] = (cap, tcap)
     return cap, tcap
+
+
+def _looks_steady(key) -> bool:
+    """The needs of the last (up to three) forwards of this shape agree within 10 % (what _record_info asks of a run-ahead loop)."""
+    hist = _need_hist.get(key)
+    if not hist:
+        return True                        # a new shape (a densified map: the seed came from a loop that was steady or not -- try)
+    a = [h[0] for h in hist]
+    b = [h[1] for h in hist]
+    return max(a) <= 1.1 * max(1, min(a)) and max(b) <= 1.1 * max(1, min(b))
 
 
 def _forward_hints(key, tile_cap: int) -> int:
