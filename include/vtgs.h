@@ -132,6 +132,13 @@ int vtgs_bin_plan_uniform(int32_t width, int32_t height, uint32_t slots_per_bin,
                                 /* rounding) and plane 2 = plane 0 squared (NaN exactly where the true difference is) come    */
                                 /* from the single render's kernel with z in its depth column.  VTGS_DEPTH_LITE=0 /           */
                                 /* vtgs_set_option ignores the bit.                                                           */
+#define VTGS_FORWARD_RAW_ACTIVATIONS 16u /* vtgs_forward_dual*, OR-ed to one of the modes (round 6): the map is ISOTROPIC and its    */
+                                /* activations are applied by the projection itself -- `opacities` holds the LOGITS [N],           */
+                                /* `scales` the LOG-scales [N] (one per Gaussian: exp(.) on all three axes), `rotations` is     */
+                                /* not read (may be NULL: the covariance of an isotropic Gaussian does not depend on it).  What  */
+                                /* vtgs_prepare_frame_slot then still has to write is means_cam and the depth colours          */
+                                /* (its other three outputs NULL): 36 instead of 92 bytes per Gaussian and iteration.          */
+                                /* The matching backward is vtgs_backward_dual_frame with flags bit 4 (16).                     */
 #define VTGS_FORWARD_MODE_MASK 3u
 
 uint32_t    vtgs_abi_version(void);
@@ -298,6 +305,8 @@ uint32_t vtgs_pose_partial_rows(int32_t n);
  * tensors [1,4,T] / [1,3,T] (contiguous):
  *   vtgs_prepare_frame_slot   = vtgs_pose_slot_gather + vtgs_prepare_frame in ONE launch: the pose is read in place (column t)
  *                               and out_pose7 (device, 7 floats: q, t) receives it contiguous for the backward's entry points;
+ *                               out_opacities, out_scales and out_rotations may be NULL TOGETHER (the caller renders with
+ *                               VTGS_FORWARD_RAW_ACTIVATIONS): only means_cam and the depth colours are written;
  *   vtgs_pose_gradient_slot   = vtgs_pose_gradient + vtgs_pose_slot_scatter in ONE launch: writes the FULL-SIZE gradients
  *                               (4 T and 3 T floats, zero except column t); cam_q = the contiguous q of out_pose7.             */
 int vtgs_prepare_frame_slot(int32_t n, const float* means3D, const float* logit_opacities, const float* log_scales,
@@ -344,7 +353,10 @@ int vtgs_prepare_frame_backward(int32_t n, uint32_t flags, const float* means3D,
  * [z, 1, z^2] render through z alone: the silhouette only feeds comparisons, z^2 a detached uncertainty,
  * src/vtgaussian_slam.py:466-521).  Planes 1 and 2 of grad_color_b are then not read: four image-gradient channels instead of
  * six, one colour of the second set per splat, 48-byte instead of 56-byte gradient records.  Results equal those without the
- * bit whenever the promise holds (tests/test_gpu_fused_frame.py).  VTGS_DUAL_B1=0 / vtgs_set_option ignores the bit.  */
+ * bit whenever the promise holds (tests/test_gpu_fused_frame.py).  VTGS_DUAL_B1=0 / vtgs_set_option ignores the bit.
+ * flags bit 4 (16), round 6: the forward ran with VTGS_FORWARD_RAW_ACTIVATIONS -- `opacities` = logit_opacities [N], `scales` =
+ * log_scales [N], `rotations` not read (may be NULL); the rotation of a Gaussian (unnorm_rotations, normalised) is read only when
+ * bit 0 asks for its gradient.  Not with an owned list (owned_idx must be NULL: the compact arrays are prepared in full).     */
 int vtgs_backward_dual_frame(const VtgsCamera* cam, int32_t n, const float* means_cam, const float* colors_a, const float* colors_b,
                              const float* opacities, const float* scales, const float* rotations, const float* out_color_a,
                              const float* out_color_b, const float* grad_color_a, const float* grad_color_b,

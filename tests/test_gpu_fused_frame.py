@@ -206,6 +206,66 @@ def test_frame_epilogue_in_the_gather_kernel_matches_the_two_kernel_route(gpu_de
             assert (a - b).abs().max().item() <= 4e-6 * scale + 1e-12, (k, (a - b).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("gaussians_grad,camera_grad,contract,band", [(False, True, True, None), (True, False, True, None),
+                                                                      (True, True, False, None), (False, True, True, (2, 6))])
+def test_raw_activations_in_the_render_kernels_match_the_full_prepare(gpu_device, gaussians_grad, camera_grad, contract, band):
+    """Round 6, VTGS_FORWARD_RAW_ACTIVATIONS (default of the C++ node without an owned list): project_and_bin and
+    gather_splat_grads read logits / log-scales and apply sigmoid / exp themselves, the rotation of the isotropic map is not read
+    (identity in the forward, the normalised parameter in the backward only when its gradient is wanted), and
+    vtgs_prepare_frame_slot writes the camera-frame means and the depth colours only -- against set_frame_raw(False), the
+    full prepare step.  Same formulas on the same float32 inputs: images within 2e-6 of the image maximum (the covariance
+    s^2 R R^T of a unit quaternion is s^2 I up to rounding), radii equal, gradients within 1e-5 of each tensor's largest."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization.fused import render_frame
+    if dgr._ext is None or not hasattr(dgr._ext, "set_frame_raw"):
+        pytest.skip("the C++ node is not built")
+    dev = gpu_device
+    W, H = 200, 136
+    params, cam = _params(dev, 30000, W, H, seed=13)
+    st = to_settings(cam, dev, bg=torch.tensor([0.2, 0.4, 0.1]))
+    w2c = torch.eye(4, device=dev)
+    w2c[:3, 3] = torch.tensor([0.02, -0.01, 0.03], device=dev)
+    g = torch.Generator().manual_seed(8)
+    g1 = (torch.rand(3, H, W, generator=g) * 2 - 1).to(dev)
+    g2 = (torch.rand(3, H, W, generator=g) * 2 - 1).to(dev)
+    if contract:
+        g2[1:] = 0                                        # the promise: the second image is differentiated through z alone
+    res = {}
+    try:
+        for raw in (False, True):
+            dgr.set_frame_raw(raw)
+            for v in params.values():
+                v.grad = None
+            im, ds, radii = render_frame(params, 1, st, w2c, gaussians_grad, camera_grad, tile_rows=band, get_loss_contract=contract)
+            ((im * g1).sum() + (ds[:1] * g2[:1]).sum() if contract else (im * g1).sum() + (ds * g2).sum()).backward()
+            torch.cuda.synchronize()
+            res[raw] = (im.detach().clone(), ds.detach().clone(), radii.clone(),
+                        {k: (None if v.grad is None else v.grad.clone()) for k, v in params.items()})
+    finally:
+        dgr.set_frame_raw(True)
+    # (identity against a normalised quaternion: the covariance differs in the last bit, so a radius that sits on an integer
+    #  and a pair on the 1/255 threshold may fall on the other side -- _images_agree bounds both)
+    dr = (res[False][2] - res[True][2]).abs()
+    assert int((dr > 0).sum()) <= 3 and int(dr.max()) <= 1, (int((dr > 0).sum()), int(dr.max()))
+    for i in (0, 1):
+        a, b = res[False][i], res[True][i]
+        if contract and i == 1:
+            a, b = a[:1], b[:1]                           # (planes 1, 2: compared with thresholds / isnan only)
+        _images_agree(a, b, tol=2e-6)
+    seen = 0
+    for k in params:
+        a, b = res[False][3][k], res[True][3][k]
+        assert (a is None) == (b is None), k
+        if a is None:
+            continue
+        seen += 1
+        scale = a.abs().max().item()
+        if k == "unnorm_rotations":                       # isotropic map: float noise around an exact zero in both routes
+            scale = max(v.abs().max().item() for kk, v in res[False][3].items() if v is not None and kk != "unnorm_rotations")
+        assert (a - b).abs().max().item() <= 1e-5 * scale + 1e-12, (k, (a - b).abs().max().item(), scale)
+    assert seen >= 2
+
+
 def test_render_frame_bands_add_up_to_the_full_frame(gpu_device):
     """Tile-row partition of the fused operator: the band images tile the frame bit-exactly and the band
     gradients -- pose gradient and appearance gradients -- sum to the full-frame ones (float32 summation order)."""

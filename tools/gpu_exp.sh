@@ -8,7 +8,7 @@
 # segmentation fault -- an experiment script of round 3 exited 0 through such a fault.
 #
 # steps:   tests            the whole -m gpu suite, one process
-#          tests:<expr>     pytest -k <expr> of the -m gpu suite
+#          tests:<expr>     pytest -k <expr> of the -m gpu suite (commas for spaces: tests:fused_frame,or,poison)
 #          smoke            __graft_entry__.smoke()
 #          bench            python bench.py (default arguments)
 #          bench:<args>     python bench.py <args>   (commas for spaces: bench:--steps,50,--mode,tracking)
@@ -62,7 +62,7 @@ for step in "$@"; do
              # shows it only for a failed one -- when the process ABORTS the file is lost with it, which is why the two aborts above left
              # nothing but faulthandler's dump (it writes to a duplicate of the original descriptor): whatever the runtime printed
              # (a memory-fault line, a queue error) went into the capture.  Capturing sys.stdout / sys.stderr only lets it through.
-             if [ -n "$arg" ]; then run $O/tests_$TAG.log python -m pytest tests/ -x -q -m gpu --capture=sys -k "$arg"; else run $O/tests_$TAG.log python -m pytest tests/ -x -q -m gpu --capture=sys; fi ;;
+             if [ -n "$arg" ]; then run $O/tests_$TAG.log python -m pytest tests/ -x -q -m gpu --capture=sys -k "${arg//,/ }"; else run $O/tests_$TAG.log python -m pytest tests/ -x -q -m gpu --capture=sys; fi ;;
     smoke)   run $O/smoke_$TAG.log python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench)   run $O/bench_$TAG.log python bench.py ${arg//,/ } ;;
     timing)  if [ -n "$arg" ]; then VTGS_LIBRARY=$R/vtgaussian-slam_amd/lib/$arg ABL_TAG=$arg run $O/timing_${TAG}_${arg%.so}.log python tools/kernel_timing.py; else ABL_TAG=shipped run $O/timing_$TAG.log python tools/kernel_timing.py; fi ;;

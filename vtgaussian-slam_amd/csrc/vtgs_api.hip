@@ -164,6 +164,7 @@ static CamScalars scalars_of(const VtgsCamera* cam, int row8_begin, int row8_end
   cs.bin_plan = nullptr; cs.bin_limit = 0u;                  // planned bins: set by the caller once the workspace layout is known
   cs.bwd_flags = 0u;
   cs.scratch_records = 0xFFFFFFFFu;
+  cs.raw_act = 0u;
 #ifdef VTGS_Q_STAMPS
   cs.dbg_proj = nullptr;
 #endif
@@ -304,7 +305,9 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
       instance_capacity > 0xFFFFFFFFull || (tile_capacity & ~VTGS_TILE_CAPACITY_PLANNED) == 0 ||
       ((tile_capacity & VTGS_TILE_CAPACITY_PLANNED) != 0) != (bin_plan != nullptr) || (cov3d && (dual || bin_plan)))
     return VTGS_ERR_INVALID_ARGUMENT;
-  if (n > 0 && (!means3D || !colors || (dual && !colors_b) || !opacities || !scales || (!rotations && !cov3d) || !out_radii))
+  const bool raw_act = (flags & VTGS_FORWARD_RAW_ACTIVATIONS) != 0u;      // logits / log-scales in, rotations not read (dual render only)
+  if (raw_act && (!dual || cov3d)) return VTGS_ERR_INVALID_ARGUMENT;
+  if (n > 0 && (!means3D || !colors || (dual && !colors_b) || !opacities || !scales || (!rotations && !cov3d && !raw_act) || !out_radii))
     return VTGS_ERR_INVALID_ARGUMENT;
   int r8b, r8e, rows16, row16_0;
   if (!band_of(cam, &r8b, &r8e, &rows16, &row16_0)) return VTGS_ERR_INVALID_ARGUMENT;
@@ -314,6 +317,7 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
   CamScalars cs = scalars_of(cam, r8b, r8e);
+  cs.raw_act = raw_act ? 1u : 0u;
   Counters* ctr = (Counters*)(ws + L.counters);
 #ifdef VTGS_Q_STAMPS
   cs.dbg_proj = (uint32_t*)(ws + L.dbg + align256(256 + (size_t)L.tiles8 * kStampWords * 4));
@@ -611,7 +615,9 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
   if (!cam_ok(cam) || n < 0 || !out_color || !grad_color || !workspace || !scratch || instance_capacity == 0 ||
       instance_capacity > 0xFFFFFFFFull || (tile_capacity & ~VTGS_TILE_CAPACITY_PLANNED) == 0 || (dual && (!out_color_b || !grad_color_b)) || (frame && !dual))
     return VTGS_ERR_INVALID_ARGUMENT;
-  if (n > 0 && (!means3D || !colors || !opacities || !scales || (!rotations && !cov3d) || (dual && !colors_b)))
+  const bool raw_act = frame && (frame->flags & 16u) != 0u;                // the forward's VTGS_FORWARD_RAW_ACTIVATIONS
+  if (raw_act && frame->idx) return VTGS_ERR_INVALID_ARGUMENT;             // (an owned list renders from fully prepared compact arrays)
+  if (n > 0 && (!means3D || !colors || !opacities || !scales || (!rotations && !cov3d && !raw_act) || (dual && !colors_b)))
     return VTGS_ERR_INVALID_ARGUMENT;
   if (cov3d && (dual || frame)) return VTGS_ERR_INVALID_ARGUMENT;
   // any output may be NULL (a gradient nobody asked for -- the tracking loop detaches the Gaussians,
@@ -643,6 +649,7 @@ static int backward_impl(const VtgsCamera* cam, int32_t n, const float* means3D,
   // dL/d(first colour set) not asked for (tracking: the Gaussians are detached, src/vtgaussian_slam.py:428-449, and the pose
   // gradient flows through means3D and the SECOND set's [z, 1, z^2] only): the lane = pixel backward skips that contraction chain
   if (frame ? !(frame->flags & 4u) : !g_colors) cs.bwd_flags |= 1u;
+  cs.raw_act = raw_act ? 1u : 0u;
   if (dual && bwd_impl == 0) bwd_impl = 1;                   // 0 = scalar kernel (single render only); read per call
   if (dual && bwd_impl == 3) bwd_impl = 2;                   // 3 = quadrant queues (single render only so far)
   // FrameEpilogue flag 8 (the caller's promise: grad_color_b is zero outside its first channel -- get_loss, whose loss reaches

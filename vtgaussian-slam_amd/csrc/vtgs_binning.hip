@@ -177,6 +177,24 @@ constexpr int kBigArea = kDeferArea;          // (the name the body of project_a
 // budget: either feature alone cost that case 13 us of 54 through s_load re-materialisation, batch P of round 3):
 //   bit 0  a band of the tile-row partition (row cull before the projection, early exit of workgroups with nothing in the band)
 //   bit 1  planned bins (bin t = [plan[t], plan[t+1]), include/vtgs.h)
+// The per-Gaussian inputs of the projection besides the mean.  raw (CamScalars::raw_act, kernel-uniform): the fused caller chain's
+// isotropic map as its PARAMETERS -- logit, log-scale -- with the activations of utils/slam_helpers.py:127-160 applied here
+// (sigmoid, exp on all three axes) and the rotation left at the identity: the covariance s^2 I does not depend on it.
+__device__ __forceinline__ void load_activations(bool raw, int gid, const float* __restrict__ opacities, const float* __restrict__ scales,
+                                                 const float* __restrict__ rotations, float& op, float (&sc)[3], float (&q)[4]) {
+  if (raw) {
+    const float lo = opacities[gid], ls = scales[gid];
+    op = 1.f / (1.f + __expf(-lo));
+    sc[0] = sc[1] = sc[2] = __expf(ls);
+    q[0] = 1.f; q[1] = q[2] = q[3] = 0.f;
+  } else {
+    sc[0] = scales[3 * gid]; sc[1] = scales[3 * gid + 1]; sc[2] = scales[3 * gid + 2];
+    const float4 q4 = reinterpret_cast<const float4*>(rotations)[gid];
+    q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+    op = opacities[gid];
+  }
+}
+
 template <int LDSBINS, int MODE>
 __device__ __forceinline__ void project_and_bin_body(
     CamScalars cs, const float* __restrict__ Vp, const float* __restrict__ PVp, int n,
@@ -224,10 +242,8 @@ __device__ __forceinline__ void project_and_bin_body(
   if (valid && !banded && !precomp) {
     // whole frame: the four input streams are requested together (one trip to memory on the kernel's latency chain)
     const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
-    const float sc[3] = {scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
-    const float4 q4 = reinterpret_cast<const float4*>(rotations)[gid];
-    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-    op = opacities[gid];
+    float sc[3], q[4];
+    load_activations(cs.raw_act != 0u, gid, opacities, scales, rotations, op, sc, q);
     vis = project_splat(cam, mean, sc, q, op, sp, aux);
     radii[gid] = vis ? sp.radius : 0;
     // the geometry record is stored NOW, whole (two dwordx4): carrying the centre's float32 remainder to a store behind the
@@ -240,11 +256,17 @@ __device__ __forceinline__ void project_and_bin_body(
     // before the rotation / opacity loads and the covariance algebra -- 7/8 of them at 8 ranks.  It reports radius 0 on this
     // rank: radii are complete as the MAXIMUM over the ranks.  The survivors pay a second trip to memory.
     const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
-    const float sc[3] = {scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
+    float sc[3];
+    if (cs.raw_act) { sc[0] = sc[1] = sc[2] = __expf(scales[gid]); }
+    else { sc[0] = scales[3 * gid]; sc[1] = scales[3 * gid + 1]; sc[2] = scales[3 * gid + 2]; }
     if (!outside_tile_rows(cam, mean, sc, cam.row8_begin / 2, (cam.row8_end + 1) / 2)) {
-      const float4 q4 = reinterpret_cast<const float4*>(rotations)[gid];
-      const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-      op = opacities[gid];
+      float q[4] = {1.f, 0.f, 0.f, 0.f};
+      if (cs.raw_act) { op = 1.f / (1.f + __expf(-opacities[gid])); }
+      else {
+        const float4 q4 = reinterpret_cast<const float4*>(rotations)[gid];
+        q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+        op = opacities[gid];
+      }
       vis = project_splat(cam, mean, sc, q, op, sp, aux);
       if (vis) store_geom(geom + gid, sp, op);
     }

@@ -1382,12 +1382,25 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
     mean[0] = means3D[3 * gid]; mean[1] = means3D[3 * gid + 1]; mean[2] = means3D[3 * gid + 2];
     if constexpr (COV3D) {
       for (int i = 0; i < 6; ++i) c6[i] = scales[6 * gid + i];
+      op = opacities[gid];
+    } else if (FRAME && cs.raw_act) {
+      // the forward's VTGS_FORWARD_RAW_ACTIVATIONS (kernel-uniform): parameters in, activations here; the Gaussian's rotation
+      // is read only when somebody wants its gradient (frame flag 1) -- the covariance s^2 I does not depend on it
+      sc[0] = sc[1] = sc[2] = __expf(scales[gid]);
+      op = 1.f / (1.f + __expf(-opacities[gid]));
+      if constexpr (FRAME) {
+        if (fe.flags & 1u) {
+          const float4 u = reinterpret_cast<const float4*>(fe.unnorm_rot)[gid];
+          const float un = rsqrtf(fmaxf(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w, 1e-24f));
+          q[0] = u.x * un; q[1] = u.y * un; q[2] = u.z * un; q[3] = u.w * un;
+        }
+      }
     } else {
       sc[0] = scales[3 * gid]; sc[1] = scales[3 * gid + 1]; sc[2] = scales[3 * gid + 2];
       const float4 q4 = reinterpret_cast<const float4*>(rotations)[gid];
       q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+      op = opacities[gid];
     }
-    op = opacities[gid];
     pixel_centre(cam, mean[0], mean[1], mean[2], cu, cv, culo, cvlo);
     if (!big) {
 #pragma unroll
@@ -1507,9 +1520,10 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
                                                                        (g.rot[2] - r[2] * dot) * un, (g.rot[3] - r[3] * dot) * un);
       }
       if (fe.flags & 4u) {
-        const float o = opacities[gid];                                        // = sigmoid(logit), the forward's value
-        fe.g_logit[row] = g.opacity * o * (1.f - o);
-        fe.g_log_scales[row] = scales[3 * gid] * (g.scale[0] + g.scale[1] + g.scale[2]);
+        // (op, sc[0] = sigmoid(logit), exp(log-scale): the forward's values, loaded or formed above; a Gaussian without
+        //  instances never loaded them and has zero gradients)
+        fe.g_logit[row] = g.opacity * op * (1.f - op);
+        fe.g_log_scales[row] = sc[0] * (g.scale[0] + g.scale[1] + g.scale[2]);
         fe.g_rgb[3 * row] = g.color[0]; fe.g_rgb[3 * row + 1] = g.color[1]; fe.g_rgb[3 * row + 2] = g.color[2];
       }
       if (fe.flags & 2u) {

@@ -35,12 +35,14 @@ __global__ __launch_bounds__(256) void prepare_frame_kernel(
   const float cy = P.R[3] * x + P.R[4] * y + P.R[5] * z + P.t[1];
   const float cz = P.R[6] * x + P.R[7] * y + P.R[8] * z + P.t[2];
   means_cam[3 * i] = cx; means_cam[3 * i + 1] = cy; means_cam[3 * i + 2] = cz;
-  opac[i] = 1.f / (1.f + __expf(-logit_op[row]));
-  const float s = __expf(log_scales[row]);
-  scales[3 * i] = s; scales[3 * i + 1] = s; scales[3 * i + 2] = s;
-  const float4 u = reinterpret_cast<const float4*>(unnorm_rot)[row];
-  const float un = rsqrtf(fmaxf(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w, 1e-24f));
-  reinterpret_cast<float4*>(rot)[i] = make_float4(u.x * un, u.y * un, u.z * un, u.w * un);
+  if (opac) {                      // (NULL, kernel-uniform: the render applies the activations itself, VTGS_FORWARD_RAW_ACTIVATIONS)
+    opac[i] = 1.f / (1.f + __expf(-logit_op[row]));
+    const float s = __expf(log_scales[row]);
+    scales[3 * i] = s; scales[3 * i + 1] = s; scales[3 * i + 2] = s;
+    const float4 u = reinterpret_cast<const float4*>(unnorm_rot)[row];
+    const float un = rsqrtf(fmaxf(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w, 1e-24f));
+    reinterpret_cast<float4*>(rot)[i] = make_float4(u.x * un, u.y * un, u.z * un, u.w * un);
+  }
   const float zz = P.zr[0] * cx + P.zr[1] * cy + P.zr[2] * cz + P.zr[3];
   dcol[3 * i] = zz; dcol[3 * i + 1] = 1.f; dcol[3 * i + 2] = zz * zz;
   if (rgb_out) { rgb_out[3 * i] = rgb[3 * row]; rgb_out[3 * i + 1] = rgb[3 * row + 1]; rgb_out[3 * i + 2] = rgb[3 * row + 2]; }
@@ -326,8 +328,9 @@ int vtgs_prepare_frame_slot(int32_t n, const float* means3D, const float* logit_
     return VTGS_ERR_INVALID_ARGUMENT;
   if (n == 0)                                                  // an empty map: the pose still has to reach the caller's seven floats
     return vtgs_pose_slot_gather(cam_unnorm_rots, cam_trans, frames, t, out_pose7, stream);
-  if (!means3D || !logit_opacities || !log_scales || !unnorm_rotations || !out_means_cam || !out_opacities || !out_scales ||
-      !out_rotations || !out_depth_colors)
+  const bool lite = !out_opacities && !out_scales && !out_rotations;      // means_cam + depth colours only
+  if (!means3D || !out_means_cam || !out_depth_colors) return VTGS_ERR_INVALID_ARGUMENT;
+  if (!lite && (!logit_opacities || !log_scales || !unnorm_rotations || !out_opacities || !out_scales || !out_rotations))
     return VTGS_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(prepare_frame_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, (const int32_t*)nullptr,
                      means3D, logit_opacities, log_scales, unnorm_rotations, (const float*)nullptr, cam_unnorm_rots + t, cam_trans + t,

@@ -144,6 +144,8 @@ struct CamScalars {
   uint32_t scratch_records;       // backward: gradient records the caller's scratch holds.  An instance id at or beyond it is
                                   // neither written (composite) nor read (gather: that Gaussian's gradient is zero): a scratch
                                   // sized from a wrong or stale count gives wrong numbers, not an out-of-bounds access
+  uint32_t raw_act;               // round 6 (VTGS_FORWARD_RAW_ACTIVATIONS / frame flag 16): `opacities` are logits, `scales` log-scales [N]
+                                  // (isotropic), `rotations` is not read -- project_and_bin and gather_splat_grads apply the activations
 #ifdef VTGS_Q_STAMPS
   uint32_t* dbg_proj;             // diagnostic build: 8 words of stamps per workgroup of project_and_bin
 #endif

@@ -73,6 +73,9 @@ inline int64_t counted_instances(int status, int64_t fwd_flags, int64_t slot_ptr
 // overflow mark the record as reported (complete = 2: the Python bookkeeping that follows at the next forward raises the
 // capacities and stays silent) and throw -- or, with deferral on (N-rank loops, partition.phase_overflows), count it.
 std::atomic<bool> g_check_in_backward{true}, g_defer_overflow{false};
+// RenderFrame without an owned list: the render applies the activations itself (VTGS_FORWARD_RAW_ACTIVATIONS, round 6) and
+// vtgs_prepare_frame_slot writes the camera-frame means and the depth colours only.  VTGS_FRAME_RAW=0: the full prepare.
+std::atomic<bool> g_frame_raw{true};
 std::atomic<int64_t> g_deferred{0};
 
 // The records are handed out round-robin (64 per device and stream) and a record is settled and handed on 64 forwards later: a
@@ -276,10 +279,14 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
     const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
     void* st_ = reinterpret_cast<void*>(stream);
     // one block for the render variables: means_cam 3, opacities 1, scales 3, rotations 4, depth colours 3 (+ compact colours 3)
+    // raw: means_cam 3 + depth colours 3 -- the kernels read logits / log-scales themselves (isotropic map: no rotation)
+    const bool raw = !owned && g_frame_raw.load();
+    if (raw) { fwd_flags |= (int64_t)VTGS_FORWARD_RAW_ACTIVATIONS; frame_flags |= 16; }
     const int64_t np = pad4(n);                                   // segment stride (rot is read as float4)
-    at::Tensor vars = at::empty({std::max<int64_t>(np, 4) * (owned ? 17 : 14)}, f32);
+    at::Tensor vars = at::empty({std::max<int64_t>(np, 4) * (owned ? 17 : raw ? 6 : 14)}, f32);
     float* v = vars.data_ptr<float>();
     float *means_cam = v, *opac = v + 3 * np, *scales = v + 4 * np, *rot = v + 7 * np, *dcol = v + 11 * np, *rgb_c = v + 14 * np;
+    if (raw) { dcol = v + 3 * np; opac = logit_op.data_ptr<float>(); scales = log_scales.data_ptr<float>(); rot = nullptr; }
     at::Tensor pose7 = at::empty({7}, f32);
     at::Tensor cam_q = pose7.narrow(0, 0, 4), cam_t = pose7.narrow(0, 4, 3);
     int rc;
@@ -300,8 +307,8 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
     } else {
       rc = vtgs_prepare_frame_slot((int32_t)n, means3D.data_ptr<float>(), logit_op.data_ptr<float>(), log_scales.data_ptr<float>(),
                                    unnorm_rot.data_ptr<float>(), cam_rots.data_ptr<float>(), cam_trans.data_ptr<float>(),
-                                   (int32_t)frames, (int32_t)t_idx, depth_w2c.data_ptr<float>(), means_cam, opac, scales, rot, dcol,
-                                   pose7.data_ptr<float>(), st_);
+                                   (int32_t)frames, (int32_t)t_idx, depth_w2c.data_ptr<float>(), means_cam, raw ? nullptr : opac,
+                                   raw ? nullptr : scales, raw ? nullptr : rot, dcol, pose7.data_ptr<float>(), st_);
     }
     TORCH_CHECK(rc == VTGS_OK, "vtgs_prepare_frame failed: ", vtgs_strerror(rc), " (", vtgs_last_hip_error(), ")");
     const float* colors_a = owned ? rgb_c : rgb.data_ptr<float>();
@@ -325,7 +332,7 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
       radii = at::zeros({n_map}, f32.dtype(at::kInt)).index_copy_(0, *owned_idx64, radii);
     at::Tensor idx_saved = owned ? *owned_idx : at::Tensor();
     ctx->save_for_backward({means3D, rgb, unnorm_rot, cam_q, cam_t, depth_w2c, vars, images, workspace, cam_bytes, bg, view, proj,
-                            idx_saved});
+                            idx_saved, logit_op, log_scales});
     ctx->saved_data["instances"] = counted_instances(st, fwd_flags, slot_ptr);
     ctx->saved_data["slot_ptr"] = slot_ptr;
     ctx->saved_data["slot_gen"] = slot_generation(slot_ptr);
@@ -382,6 +389,7 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
       const float* v = vars.data_ptr<float>();
       const int64_t np = pad4(n);
       const float *means_cam = v, *opac = v + 3 * np, *scales = v + 4 * np, *rot = v + 7 * np, *dcol = v + 11 * np, *rgb_c = v + 14 * np;
+      if (flags & 16) { dcol = v + 3 * np; opac = saved[14].data_ptr<float>(); scales = saved[15].data_ptr<float>(); rot = nullptr; }   // (raw activations)
       const int64_t counted = ctx->saved_data["instances"].toInt();   // (see Rasterize::backward)
       const size_t sbytes = vtgs_backward_dual_scratch_bytes((int32_t)n, (uint64_t)(counted > 0 ? counted : capacity));
       at::Tensor scratch = at::empty({alloc_bytes(sbytes)}, f32.dtype(at::kByte));
@@ -431,5 +439,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("set_poison", [](bool on) { g_poison = on; });
   m.def("set_check_in_backward", [](bool on) { g_check_in_backward = on; });
   m.def("set_defer_overflow", [](bool on) { g_defer_overflow = on; });
+  m.def("set_frame_raw", [](bool on) { g_frame_raw = on; });
   m.def("take_deferred_overflows", []() { return g_deferred.exchange(0); });
 }

@@ -463,6 +463,18 @@ if _EXT_CHECKS_IN_BACKWARD:
     _ext.set_check_in_backward(_SETTLE_IN_BACKWARD)
 
 
+def set_frame_raw(on: bool = True) -> None:
+    """fused.render_frame through the C++ node, no owned list: the render kernels apply sigmoid / exp themselves and skip the
+    rotation of the isotropic map (VTGS_FORWARD_RAW_ACTIVATIONS; `vtgs_prepare_frame_slot` then writes 36 instead of 92 bytes
+    per Gaussian).  Default on; VTGS_FRAME_RAW=0 or set_frame_raw(False): the full prepare step (the cross-check of
+    tests/test_gpu_fused_frame.py)."""
+    if _ext is not None and hasattr(_ext, "set_frame_raw"):
+        _ext.set_frame_raw(bool(on))
+
+
+set_frame_raw(os.environ.get("VTGS_FRAME_RAW", "1") != "0")
+
+
 def _settle_after_backward(out: torch.Tensor, fs) -> None:
     """C++ nodes: the verdict of a run-ahead forward inside `backward()`.  The node reads the pinned record itself
     (csrc/vtgs_torch.cpp check_run_ahead: no interpreter in the backward, ~14 us less host time per iteration than the
