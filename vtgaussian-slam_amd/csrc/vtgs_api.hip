@@ -352,10 +352,10 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
     // the run-aggregated global-atomic walk is faster again (5 M splats at 1752x1168: 488 us vs 525 us with a 128 KB
     // table and one workgroup per CU).
     const size_t table_bytes = (size_t)(r8e - r8b) * (size_t)((cam->image_width + kSubTile - 1) / kSubTile) * 4;
-    bool lds_bins = table_bytes <= (79u << 10) && option(OPT_BIN_IMPL) == 1;
+    bool lds_bins = table_bytes <= (79u << 10) && option(OPT_BIN_IMPL) == 1;   // (VTGS_BIN_IMPL = 2: the windowed table at every size)
     // a larger frame (1752x1168: 32 K tiles): the windowed table (VTGS_BIN_IMPL = 1, default) -- not for the cov3D form,
     // which has no windowed instantiation; VTGS_BIN_IMPL = 0: global atomics everywhere (cross-check)
-    const bool win_bins = !lds_bins && option(OPT_BIN_IMPL) == 1 && !cov3d &&
+    const bool win_bins = !lds_bins && option(OPT_BIN_IMPL) >= 1 && !cov3d &&
                           (uint32_t)((cam->image_width + kSubTile - 1) / kSubTile) <= 16384u;
     if (lds_bins && table_bytes > (64u << 10)) {
       static bool raised[64] = {false};                       // the attribute sticks to the function, per DEVICE

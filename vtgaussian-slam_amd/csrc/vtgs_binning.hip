@@ -418,12 +418,17 @@ __device__ __forceinline__ void project_and_bin_body(
     for (int k = 0; k < kWaves; ++k) { wy0 = min(wy0, s_wy0[k]); wy1 = max(wy1, s_wy1[k]); }
     const int win_rows = max(1, (int)(kWinEntries / (uint32_t)cam.gx8));
     const int cwd = max(w.cw, 1);
+    // row of candidate i without an integer division (two of them per reached tile and loop were ~50 instructions each):
+    // i < 64 and cwd <= 64, so (i * ceil(2^16 / cwd)) >> 16 is exact (the error i * (ceil - 2^16 / cwd) < 64 <= 2^16 / cwd); the
+    // hardware reciprocal is exact for the powers of two, the only widths whose quotient is an integer
+    const uint32_t row_magic = (uint32_t)ceilf(65536.f * __builtin_amdgcn_rcpf((float)cwd));
+    auto row_of = [&](int i) { return (int)(((uint32_t)i * row_magic) >> 16); };
     for (int py = wy0; py < wy1; py += win_rows) {                 // (workgroup-uniform bounds)
       const int rows = min(win_rows, wy1 - py), entries = rows * cam.gx8, t0 = py * cam.gx8;
       for (int i = (int)threadIdx.x; i < entries; i += kProjBlock) lds_tile[i] = 0u;
       __syncthreads();
       for (unsigned long long m = reach_mask; m; m &= m - 1ull) {  // histogram of this pass's tiles
-        const int i = __builtin_ctzll(m), tty = w.cy0 + i / cwd, ttx = w.cx0 + (i - (i / cwd) * cwd);
+        const int i = __builtin_ctzll(m), ry = row_of(i), tty = w.cy0 + ry, ttx = w.cx0 + (i - ry * cwd);
         if (tty >= py && tty < py + rows) atomicAdd(&lds_tile[tty * cam.gx8 + ttx - t0], 1u);
       }
       __syncthreads();
@@ -433,7 +438,7 @@ __device__ __forceinline__ void project_and_bin_body(
       }
       __syncthreads();
       for (unsigned long long m = reach_mask; m; m &= m - 1ull) {
-        const int i = __builtin_ctzll(m), tty = w.cy0 + i / cwd, ttx = w.cx0 + (i - (i / cwd) * cwd);
+        const int i = __builtin_ctzll(m), ry = row_of(i), tty = w.cy0 + ry, ttx = w.cx0 + (i - ry * cwd);
         if (tty >= py && tty < py + rows) {
           const int tile = tty * cam.gx8 + ttx;
           const uint32_t slot = atomicAdd(&lds_tile[tile - t0], 1u);

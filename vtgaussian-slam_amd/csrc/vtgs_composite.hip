@@ -1502,10 +1502,8 @@ __global__ __launch_bounds__(256) void gather_splat_grads(
       const FramePose P = load_pose(fe.cam_q, fe.cam_t, fe.depth_w2c);
       const int row = fe.idx ? fe.idx[gid] : gid;                              // owned sets: the Gaussian's row in the map
       const float x = fe.means3D_world[3 * row], y = fe.means3D_world[3 * row + 1], z = fe.means3D_world[3 * row + 2];
-      const float cx = P.R[0] * x + P.R[1] * y + P.R[2] * z + P.t[0];
-      const float cy = P.R[3] * x + P.R[4] * y + P.R[5] * z + P.t[1];
-      const float cz = P.R[6] * x + P.R[7] * y + P.R[8] * z + P.t[2];
-      const float zz = P.zr[0] * cx + P.zr[1] * cy + P.zr[2] * cz + P.zr[3];
+      float cx, cy, cz, zz;
+      pose_apply(P, x, y, z, cx, cy, cz, zz);
       const float dz = cb0 + 2.f * zz * cb2;                                   // colours of the second render: [z, 1, z^2]
       const float g0 = g.mean3D[0] + dz * P.zr[0], g1 = g.mean3D[1] + dz * P.zr[1], g2 = g.mean3D[2] + dz * P.zr[2];
       if (fe.flags & 1u) {

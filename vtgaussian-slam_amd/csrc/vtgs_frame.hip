@@ -31,9 +31,8 @@ __global__ __launch_bounds__(256) void prepare_frame_kernel(
   if (i >= n) return;
   const int row = idx ? idx[i] : i;
   const float x = means3D[3 * row], y = means3D[3 * row + 1], z = means3D[3 * row + 2];
-  const float cx = P.R[0] * x + P.R[1] * y + P.R[2] * z + P.t[0];
-  const float cy = P.R[3] * x + P.R[4] * y + P.R[5] * z + P.t[1];
-  const float cz = P.R[6] * x + P.R[7] * y + P.R[8] * z + P.t[2];
+  float cx, cy, cz, zz;
+  pose_apply(P, x, y, z, cx, cy, cz, zz);
   means_cam[3 * i] = cx; means_cam[3 * i + 1] = cy; means_cam[3 * i + 2] = cz;
   if (opac) {                      // (NULL, kernel-uniform: the render applies the activations itself, VTGS_FORWARD_RAW_ACTIVATIONS)
     opac[i] = 1.f / (1.f + __expf(-logit_op[row]));
@@ -43,9 +42,48 @@ __global__ __launch_bounds__(256) void prepare_frame_kernel(
     const float un = rsqrtf(fmaxf(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w, 1e-24f));
     reinterpret_cast<float4*>(rot)[i] = make_float4(u.x * un, u.y * un, u.z * un, u.w * un);
   }
-  const float zz = P.zr[0] * cx + P.zr[1] * cy + P.zr[2] * cz + P.zr[3];
   dcol[3 * i] = zz; dcol[3 * i + 1] = 1.f; dcol[3 * i + 2] = zz * zz;
   if (rgb_out) { rgb_out[3 * i] = rgb[3 * row]; rgb_out[3 * i + 1] = rgb[3 * row + 1]; rgb_out[3 * i + 2] = rgb[3 * row + 2]; }
+}
+
+// The pose-dependent half alone (round 6, VTGS_FORWARD_RAW_ACTIVATIONS: the render kernels apply the activations themselves):
+// camera-frame means and depth colours, 36 bytes per Gaussian.  One Gaussian per thread is bound by its own chain (load ->
+// transform -> store: 3 KB in flight per workgroup, 13.9 us for 1.12 M Gaussians = 2.9 TB/s -- the same through an LDS
+// transposition with 16-byte accesses, 13.7 us: not the access pattern).  Here a thread owns FOUR consecutive Gaussians:
+// twelve floats = three 16-byte loads in flight, six 16-byte stores.
+__global__ __launch_bounds__(256) void prepare_frame_pose_kernel(
+    int n, const float* __restrict__ means3D, const float* __restrict__ cam_q, const float* __restrict__ cam_t,
+    const float* __restrict__ depth_w2c, float* __restrict__ means_cam, float* __restrict__ dcol, int pose_stride,
+    float* __restrict__ pose7_out) {
+  const float qs[4] = {cam_q[0], cam_q[pose_stride], cam_q[2 * pose_stride], cam_q[3 * pose_stride]};
+  const float ts[3] = {cam_t[0], cam_t[pose_stride], cam_t[2 * pose_stride]};
+  const FramePose P = load_pose(qs, ts, depth_w2c);
+  if (pose7_out && blockIdx.x == 0 && threadIdx.x < 7) pose7_out[threadIdx.x] = threadIdx.x < 4 ? qs[threadIdx.x] : ts[threadIdx.x - 4];
+  const int g0 = 4 * (int)(blockIdx.x * 256u + threadIdx.x);      // the thread's first Gaussian
+  if (g0 >= n) return;
+  if (g0 + 4 <= n) {
+    const float4* __restrict__ in = reinterpret_cast<const float4*>(means3D + 3 * (size_t)g0);
+    const float4 a = in[0], b = in[1], c = in[2];
+    const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+    float m[12], d[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float zz;
+      pose_apply(P, v[3 * k], v[3 * k + 1], v[3 * k + 2], m[3 * k], m[3 * k + 1], m[3 * k + 2], zz);
+      d[3 * k] = zz; d[3 * k + 1] = 1.f; d[3 * k + 2] = zz * zz;
+    }
+    float4* __restrict__ om = reinterpret_cast<float4*>(means_cam + 3 * (size_t)g0);
+    float4* __restrict__ od = reinterpret_cast<float4*>(dcol + 3 * (size_t)g0);
+    om[0] = make_float4(m[0], m[1], m[2], m[3]); om[1] = make_float4(m[4], m[5], m[6], m[7]); om[2] = make_float4(m[8], m[9], m[10], m[11]);
+    od[0] = make_float4(d[0], d[1], d[2], d[3]); od[1] = make_float4(d[4], d[5], d[6], d[7]); od[2] = make_float4(d[8], d[9], d[10], d[11]);
+  } else {
+    for (int g = g0; g < n; ++g) {                                 // the map's last (up to three) Gaussians
+      float cx, cy, cz, zz;
+      pose_apply(P, means3D[3 * g], means3D[3 * g + 1], means3D[3 * g + 2], cx, cy, cz, zz);
+      means_cam[3 * g] = cx; means_cam[3 * g + 1] = cy; means_cam[3 * g + 2] = cz;
+      dcol[3 * g] = zz; dcol[3 * g + 1] = 1.f; dcol[3 * g + 2] = zz * zz;
+    }
+  }
 }
 
 // Owned sets of the tile-row partition: which Gaussians of the map can meet this rank's rows?  The test is the one
@@ -110,10 +148,8 @@ __global__ __launch_bounds__(256) void prepare_frame_backward_kernel(
   for (int k = 0; k < 12; ++k) acc[k] = 0.f;
   if (i < n) {
     const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
-    const float cx = P.R[0] * x + P.R[1] * y + P.R[2] * z + P.t[0];
-    const float cy = P.R[3] * x + P.R[4] * y + P.R[5] * z + P.t[1];
-    const float cz = P.R[6] * x + P.R[7] * y + P.R[8] * z + P.t[2];
-    const float zz = P.zr[0] * cx + P.zr[1] * cy + P.zr[2] * cz + P.zr[3];
+    float cx, cy, cz, zz;
+    pose_apply(P, x, y, z, cx, cy, cz, zz);
     const float dz = g_dcol[3 * i] + 2.f * zz * g_dcol[3 * i + 2];
     const bool hb = gm_b != nullptr;          // second set of rasterizer gradients (absent after a dual backward)
     const float g0 = gm_a[3 * i] + (hb ? gm_b[3 * i] : 0.f) + dz * P.zr[0];
@@ -332,6 +368,10 @@ int vtgs_prepare_frame_slot(int32_t n, const float* means3D, const float* logit_
   if (!means3D || !out_means_cam || !out_depth_colors) return VTGS_ERR_INVALID_ARGUMENT;
   if (!lite && (!logit_opacities || !log_scales || !unnorm_rotations || !out_opacities || !out_scales || !out_rotations))
     return VTGS_ERR_INVALID_ARGUMENT;
+  if (lite && !(((uintptr_t)means3D | (uintptr_t)out_means_cam | (uintptr_t)out_depth_colors) & 15u))   // (16-byte rows of the LDS form)
+    hipLaunchKernelGGL(prepare_frame_pose_kernel, dim3((n + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, n, means3D,
+                       cam_unnorm_rots + t, cam_trans + t, depth_w2c, out_means_cam, out_depth_colors, (int)frames, out_pose7);
+  else
   hipLaunchKernelGGL(prepare_frame_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, (const int32_t*)nullptr,
                      means3D, logit_opacities, log_scales, unnorm_rotations, (const float*)nullptr, cam_unnorm_rots + t, cam_trans + t,
                      depth_w2c, out_means_cam, out_opacities, out_scales, out_rotations, out_depth_colors, (float*)nullptr,

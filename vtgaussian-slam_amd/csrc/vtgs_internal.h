@@ -369,13 +369,28 @@ struct FramePose { float R[9]; float t[3]; float zr[4]; };   // rotation from th
 
 __device__ __forceinline__ FramePose load_pose(const float* __restrict__ q, const float* __restrict__ t,
                                                const float* __restrict__ w2c) {
+  // (multiply-adds spelled out, like pose_apply below: every kernel that loads the pose gets the same nine floats -- left to the
+  //  compiler, a * b + c is contracted differently from kernel to kernel and two routes to one image differ in the last bit)
   FramePose p;
-  const float n = rsqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  const float qq[4] = {q[0] * n, q[1] * n, q[2] * n, q[3] * n};
-  quat_to_R(qq, p.R);
+  const float n = rsqrtf(fmaf(q[3], q[3], fmaf(q[2], q[2], fmaf(q[1], q[1], q[0] * q[0]))));
+  const float r = q[0] * n, x = q[1] * n, y = q[2] * n, z = q[3] * n;
+  p.R[0] = fmaf(-2.f, fmaf(y, y, z * z), 1.f); p.R[1] = 2.f * fmaf(x, y, -(r * z));       p.R[2] = 2.f * fmaf(x, z, r * y);
+  p.R[3] = 2.f * fmaf(x, y, r * z);            p.R[4] = fmaf(-2.f, fmaf(x, x, z * z), 1.f); p.R[5] = 2.f * fmaf(y, z, -(r * x));
+  p.R[6] = 2.f * fmaf(x, z, -(r * y));         p.R[7] = 2.f * fmaf(y, z, r * x);           p.R[8] = fmaf(-2.f, fmaf(x, x, y * y), 1.f);
   p.t[0] = t[0]; p.t[1] = t[1]; p.t[2] = t[2];
   p.zr[0] = w2c[8]; p.zr[1] = w2c[9]; p.zr[2] = w2c[10]; p.zr[3] = w2c[11];    // row 2 of the row-major 4x4
   return p;
+}
+
+// The transform itself, with the multiply-adds spelled out: three kernels evaluate it (prepare_frame_kernel,
+// prepare_frame_pose_kernel, the epilogue of gather_splat_grads) and the compiler contracts a * b + c differently from one
+// kernel to the next -- the camera-frame means of two routes then differ in the last bit, and tests that compare routes
+// bit for bit (tests/test_gpu_fused_frame.py) see it.
+__device__ __forceinline__ void pose_apply(const FramePose& P, float x, float y, float z, float& cx, float& cy, float& cz, float& zz) {
+  cx = fmaf(P.R[2], z, fmaf(P.R[1], y, fmaf(P.R[0], x, P.t[0])));
+  cy = fmaf(P.R[5], z, fmaf(P.R[4], y, fmaf(P.R[3], x, P.t[1])));
+  cz = fmaf(P.R[8], z, fmaf(P.R[7], y, fmaf(P.R[6], x, P.t[2])));
+  zz = fmaf(P.zr[2], cz, fmaf(P.zr[1], cy, fmaf(P.zr[0], cx, P.zr[3])));
 }
 
 // What vtgs_prepare_frame_backward needs besides the operator gradients, for the backward that runs it in the gather
