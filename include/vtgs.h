@@ -139,6 +139,10 @@ int vtgs_bin_plan_uniform(int32_t width, int32_t height, uint32_t slots_per_bin,
                                 /* vtgs_prepare_frame_slot then still has to write is means_cam and the depth colours          */
                                 /* (its other three outputs NULL): 36 instead of 92 bytes per Gaussian and iteration.          */
                                 /* The matching backward is vtgs_backward_dual_frame with flags bit 4 (16).                     */
+#define VTGS_FORWARD_WORKSPACE_CLEARED 32u /* OR-ed to one of the modes: the caller has ZEROED the first vtgs_workspace_clear_bytes()   */
+                                /* bytes of `workspace` (the counters block and the per-tile list lengths) on this stream --    */
+                                /* vtgs_prepare_frame_slot does it in its own launch -- so the forward issues no fill command   */
+                                /* (~5 us of a SLAM iteration: every command costs the queue that much).                        */
 #define VTGS_FORWARD_MODE_MASK 3u
 
 uint32_t    vtgs_abi_version(void);
@@ -162,6 +166,9 @@ const char* vtgs_last_hip_error(void);   /* message of the last failed HIP call 
  * reports the exact needs (instances_needed, max_tile_list) on overflow.                               */
 size_t vtgs_workspace_bytes(int32_t n, int32_t width, int32_t height, uint64_t instance_capacity,
                             uint32_t tile_capacity);
+/* The head of the workspace a forward needs zeroed before it runs (counters + per-tile list lengths): the forward clears it
+ * itself unless the caller says VTGS_FORWARD_WORKSPACE_CLEARED. */
+size_t vtgs_workspace_clear_bytes(int32_t image_width, int32_t image_height);
 
 /* Bytes of backward scratch for a forward that binned `instances` instances.  When the count is not known
  * yet (asynchronous forward), pass its instance_capacity: the scratch is indexed by instance id < capacity.
@@ -307,12 +314,15 @@ uint32_t vtgs_pose_partial_rows(int32_t n);
  *                               and out_pose7 (device, 7 floats: q, t) receives it contiguous for the backward's entry points;
  *                               out_opacities, out_scales and out_rotations may be NULL TOGETHER (the caller renders with
  *                               VTGS_FORWARD_RAW_ACTIVATIONS): only means_cam and the depth colours are written;
+ *                               clear / clear_bytes (may be NULL / 0; 16-byte aligned, a multiple of 16): that many bytes are
+ *                               zeroed on the stream as well -- the head of the forward's workspace, see
+ *                               VTGS_FORWARD_WORKSPACE_CLEARED and vtgs_workspace_clear_bytes;
  *   vtgs_pose_gradient_slot   = vtgs_pose_gradient + vtgs_pose_slot_scatter in ONE launch: writes the FULL-SIZE gradients
  *                               (4 T and 3 T floats, zero except column t); cam_q = the contiguous q of out_pose7.             */
 int vtgs_prepare_frame_slot(int32_t n, const float* means3D, const float* logit_opacities, const float* log_scales,
                             const float* unnorm_rotations, const float* cam_unnorm_rots, const float* cam_trans, int32_t frames,
                             int32_t t, const float* depth_w2c, float* out_means_cam, float* out_opacities, float* out_scales,
-                            float* out_rotations, float* out_depth_colors, float* out_pose7, void* stream);
+                            float* out_rotations, float* out_depth_colors, float* out_pose7, void* clear, size_t clear_bytes, void* stream);
 int vtgs_pose_gradient_slot(const float* pose_partials, uint32_t rows, const float* cam_q, int32_t frames, int32_t t,
                             float* g_cam_unnorm_rots, float* g_cam_trans, void* stream);
 /* The pose of frame t out of the reference's camera tensors, cam_unnorm_rots [1,4,frames] and cam_trans [1,3,frames]

@@ -194,6 +194,12 @@ size_t vtgs_workspace_bytes(int32_t n, int32_t width, int32_t height, uint64_t i
   return make_layout(n, width, height, instance_capacity, tile_capacity).total;
 }
 
+size_t vtgs_workspace_clear_bytes(int32_t image_width, int32_t image_height) {
+  if (image_width <= 0 || image_height <= 0) return 0;
+  const size_t tiles8 = (size_t)((image_width + kSubTile - 1) / kSubTile) * (size_t)((image_height + kSubTile - 1) / kSubTile);
+  return 256 + align256((tiles8 + 1) * 4);       // WsLayout: counters at byte 0, tile_cnt behind them
+}
+
 size_t vtgs_backward_scratch_bytes(int32_t n, uint64_t instances) {
   (void)n;
   return align256((size_t)(instances ? instances : 1) * kGradRec * sizeof(float));
@@ -337,7 +343,9 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
   // counters + per-tile list lengths in one fill (adjacent in the layout, padded to 256 B).  (Round 5, measured and dropped:
   // clearing inside project_and_bin under a token costs +27 us -- the check sits on every workgroup's latency chain -- and a
   // clear kernel of this library takes the same 4.6-5 us as the runtime's fill; profiles/r5_negative_results.md)
-  VTGS_HIP(hipMemsetAsync(ws + L.counters, 0, 256 + align256(((size_t)L.tiles8 + 1) * 4), st));
+  // VTGS_FORWARD_WORKSPACE_CLEARED (round 6): the caller did it (vtgs_prepare_frame_slot, in the launch it makes anyway)
+  if (!(flags & VTGS_FORWARD_WORKSPACE_CLEARED))
+    VTGS_HIP(hipMemsetAsync(ws + L.counters, 0, 256 + align256(((size_t)L.tiles8 + 1) * 4), st));
   if (rows16 * kBinTile < cam->image_height || cam->tile_row_begin != 0) {
     // band mode: pixels outside the band are written as zero (include/vtgs.h); the caller keeps only
     // its own rows when it assembles the bands

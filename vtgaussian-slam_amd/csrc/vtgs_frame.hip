@@ -54,7 +54,10 @@ __global__ __launch_bounds__(256) void prepare_frame_kernel(
 __global__ __launch_bounds__(256) void prepare_frame_pose_kernel(
     int n, const float* __restrict__ means3D, const float* __restrict__ cam_q, const float* __restrict__ cam_t,
     const float* __restrict__ depth_w2c, float* __restrict__ means_cam, float* __restrict__ dcol, int pose_stride,
-    float* __restrict__ pose7_out) {
+    float* __restrict__ pose7_out, uint4* __restrict__ clear, uint32_t clear_words16) {
+  // `clear`: the head of the forward's workspace (counters, per-tile list lengths), zeroed here instead of by a fill command of
+  // its own in front of project_and_bin -- every command costs the queue ~4.6 us, whatever it does
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < clear_words16; i += gridDim.x * 256u) clear[i] = make_uint4(0u, 0u, 0u, 0u);
   const float qs[4] = {cam_q[0], cam_q[pose_stride], cam_q[2 * pose_stride], cam_q[3 * pose_stride]};
   const float ts[3] = {cam_t[0], cam_t[pose_stride], cam_t[2 * pose_stride]};
   const FramePose P = load_pose(qs, ts, depth_w2c);
@@ -359,19 +362,27 @@ uint32_t vtgs_pose_partial_rows(int32_t n) { return n > 0 ? (uint32_t)((n + 255)
 int vtgs_prepare_frame_slot(int32_t n, const float* means3D, const float* logit_opacities, const float* log_scales,
                             const float* unnorm_rotations, const float* cam_unnorm_rots, const float* cam_trans, int32_t frames,
                             int32_t t, const float* depth_w2c, float* out_means_cam, float* out_opacities, float* out_scales,
-                            float* out_rotations, float* out_depth_colors, float* out_pose7, void* stream) {
+                            float* out_rotations, float* out_depth_colors, float* out_pose7, void* clear, size_t clear_bytes,
+                            void* stream) {
   if (n < 0 || !cam_unnorm_rots || !cam_trans || !depth_w2c || !out_pose7 || frames <= 0 || t < 0 || t >= frames)
     return VTGS_ERR_INVALID_ARGUMENT;
-  if (n == 0)                                                  // an empty map: the pose still has to reach the caller's seven floats
+  if ((clear_bytes && !clear) || ((uintptr_t)clear & 15u) || (clear_bytes & 15u) || clear_bytes > (1ull << 32))
+    return VTGS_ERR_INVALID_ARGUMENT;
+  if (n == 0) {                                                // an empty map: the pose still has to reach the caller's seven floats
+    if (clear_bytes && hipMemsetAsync(clear, 0, clear_bytes, (hipStream_t)stream) != hipSuccess) return VTGS_ERR_HIP;
     return vtgs_pose_slot_gather(cam_unnorm_rots, cam_trans, frames, t, out_pose7, stream);
+  }
   const bool lite = !out_opacities && !out_scales && !out_rotations;      // means_cam + depth colours only
   if (!means3D || !out_means_cam || !out_depth_colors) return VTGS_ERR_INVALID_ARGUMENT;
   if (!lite && (!logit_opacities || !log_scales || !unnorm_rotations || !out_opacities || !out_scales || !out_rotations))
     return VTGS_ERR_INVALID_ARGUMENT;
-  if (lite && !(((uintptr_t)means3D | (uintptr_t)out_means_cam | (uintptr_t)out_depth_colors) & 15u))   // (16-byte rows of the LDS form)
+  if (lite && !(((uintptr_t)means3D | (uintptr_t)out_means_cam | (uintptr_t)out_depth_colors) & 15u)) {   // (16-byte accesses)
     hipLaunchKernelGGL(prepare_frame_pose_kernel, dim3((n + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, n, means3D,
-                       cam_unnorm_rots + t, cam_trans + t, depth_w2c, out_means_cam, out_depth_colors, (int)frames, out_pose7);
-  else
+                       cam_unnorm_rots + t, cam_trans + t, depth_w2c, out_means_cam, out_depth_colors, (int)frames, out_pose7,
+                       (uint4*)clear, (uint32_t)(clear_bytes / 16));
+    return hipGetLastError() == hipSuccess ? VTGS_OK : VTGS_ERR_HIP;
+  }
+  if (clear_bytes && hipMemsetAsync(clear, 0, clear_bytes, (hipStream_t)stream) != hipSuccess) return VTGS_ERR_HIP;
   hipLaunchKernelGGL(prepare_frame_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, (const int32_t*)nullptr,
                      means3D, logit_opacities, log_scales, unnorm_rotations, (const float*)nullptr, cam_unnorm_rots + t, cam_trans + t,
                      depth_w2c, out_means_cam, out_opacities, out_scales, out_rotations, out_depth_colors, (float*)nullptr,

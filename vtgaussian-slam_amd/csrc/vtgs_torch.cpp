@@ -289,6 +289,13 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
     if (raw) { dcol = v + 3 * np; opac = logit_op.data_ptr<float>(); scales = log_scales.data_ptr<float>(); rot = nullptr; }
     at::Tensor pose7 = at::empty({7}, f32);
     at::Tensor cam_q = pose7.narrow(0, 0, 4), cam_t = pose7.narrow(0, 4, 3);
+    // the forward's workspace, ahead of the prepare step: its head (counters, list lengths) is zeroed by that launch
+    const size_t nbytes = vtgs_workspace_bytes((int32_t)n, (int32_t)W, (int32_t)H, (uint64_t)capacity, (uint32_t)tile_cap);
+    at::Tensor workspace = at::empty({alloc_bytes(nbytes)}, f32.dtype(at::kByte));
+    at::Tensor images = at::empty({6, H, W}, f32);
+    if (g_poison) { workspace.fill_(0xFF); images.fill_(std::nanf("")); }
+    const size_t clear_bytes = owned ? 0 : vtgs_workspace_clear_bytes((int32_t)W, (int32_t)H);
+    if (clear_bytes) fwd_flags |= (int64_t)VTGS_FORWARD_WORKSPACE_CLEARED;
     int rc;
     if (owned) {
       rc = vtgs_pose_slot_gather(cam_rots.data_ptr<float>(), cam_trans.data_ptr<float>(), (int32_t)frames, (int32_t)t_idx,
@@ -308,16 +315,13 @@ struct RenderFrame : public torch::autograd::Function<RenderFrame> {
       rc = vtgs_prepare_frame_slot((int32_t)n, means3D.data_ptr<float>(), logit_op.data_ptr<float>(), log_scales.data_ptr<float>(),
                                    unnorm_rot.data_ptr<float>(), cam_rots.data_ptr<float>(), cam_trans.data_ptr<float>(),
                                    (int32_t)frames, (int32_t)t_idx, depth_w2c.data_ptr<float>(), means_cam, raw ? nullptr : opac,
-                                   raw ? nullptr : scales, raw ? nullptr : rot, dcol, pose7.data_ptr<float>(), st_);
+                                   raw ? nullptr : scales, raw ? nullptr : rot, dcol, pose7.data_ptr<float>(),
+                                   clear_bytes ? workspace.data_ptr() : nullptr, clear_bytes, st_);
     }
     TORCH_CHECK(rc == VTGS_OK, "vtgs_prepare_frame failed: ", vtgs_strerror(rc), " (", vtgs_last_hip_error(), ")");
     const float* colors_a = owned ? rgb_c : rgb.data_ptr<float>();
-    at::Tensor images = at::empty({6, H, W}, f32);
     at::Tensor im = images.narrow(0, 0, 3), depth_sil = images.narrow(0, 3, 3);
     at::Tensor radii = at::empty({n}, f32.dtype(at::kInt));
-    const size_t nbytes = vtgs_workspace_bytes((int32_t)n, (int32_t)W, (int32_t)H, (uint64_t)capacity, (uint32_t)tile_cap);
-    at::Tensor workspace = at::empty({alloc_bytes(nbytes)}, f32.dtype(at::kByte));
-    if (g_poison) { workspace.fill_(0xFF); images.fill_(std::nanf("")); }
     const int st = bin_plan
         ? vtgs_forward_dual_planned(&cam.c, (int32_t)n, means_cam, colors_a, dcol, opac, scales, rot, im.data_ptr<float>(),
                                     depth_sil.data_ptr<float>(), radii.data_ptr<int32_t>(), workspace.data_ptr(), nbytes,
