@@ -46,6 +46,13 @@ def test_version_strings_and_sizes(lib):
     assert b - a >= 80 * 60 * 256 * 20                                   # 20 bytes per bin slot, 80x60 tiles
     assert lib.vtgs_workspace_bytes(-1, 640, 480, 8, 64) == 0 and lib.vtgs_workspace_bytes(10, 0, 480, 8, 64) == 0
     assert lib.vtgs_workspace_bytes(10, 640, 480, 8, 0) == 0
+    # the head of the workspace a forward needs zeroed (VTGS_FORWARD_WORKSPACE_CLEARED): the 256-byte counters block + one
+    # list length per 8x8 tile (+ 1), padded to 256 -- and it lies inside every workspace
+    lib.vtgs_workspace_clear_bytes.restype = ctypes.c_size_t
+    lib.vtgs_workspace_clear_bytes.argtypes = [ctypes.c_int32] * 2
+    assert lib.vtgs_workspace_clear_bytes(1200, 680) == 256 + (((150 * 85 + 1) * 4 + 255) // 256) * 256
+    assert lib.vtgs_workspace_clear_bytes(640, 480) < lib.vtgs_workspace_bytes(0, 640, 480, 8, 64)
+    assert lib.vtgs_workspace_clear_bytes(0, 480) == 0 and lib.vtgs_workspace_clear_bytes(640, -1) == 0
     lib.vtgs_backward_scratch_bytes.restype = ctypes.c_size_t
     lib.vtgs_backward_scratch_bytes.argtypes = [ctypes.c_int32, ctypes.c_uint64]
     assert lib.vtgs_backward_scratch_bytes(10, 100) >= 100 * 40                 # 10-float records
