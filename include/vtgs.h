@@ -143,6 +143,14 @@ int vtgs_bin_plan_uniform(int32_t width, int32_t height, uint32_t slots_per_bin,
                                 /* bytes of `workspace` (the counters block and the per-tile list lengths) on this stream --    */
                                 /* vtgs_prepare_frame_slot does it in its own launch -- so the forward issues no fill command   */
                                 /* (~5 us of a SLAM iteration: every command costs the queue that much).                        */
+#define VTGS_FORWARD_EXPECT_NO_DEFERRED 64u /* hint, OR-ed to one of the modes: the caller expects no splat beyond nine candidate      */
+                                /* 8x8 tiles (its last forward of this view handed out exactly as many ids as it binned           */
+                                /* instances: instances_needed == instances).  The projection then bins every splat itself --      */
+                                /* a lane up to 64 candidates, its wavefront beyond -- and the second kernel (an empty launch   */
+                                /* on such a map: ~5 us of queue time) is not launched.  Any map renders correctly with the       */
+                                /* hint, a heavy-tailed one slowly; a workgroup that meets such a splat takes ONE     */
+                                /* unused id, so instances_needed > instances tells the caller to drop the hint.  Whole frame,     */
+                                /* uniform bins only (ignored for a band, planned bins, cov3D).                                    */
 #define VTGS_FORWARD_MODE_MASK 3u
 
 uint32_t    vtgs_abi_version(void);

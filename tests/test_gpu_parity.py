@@ -265,7 +265,7 @@ def test_capacity_overflow_is_answered_inside_the_forward(gpu_device):
     dev = gpu_device
     leaves = {k: v.to(dev).requires_grad_(True) for k, v in scene.items()}
     st = to_settings(cam, dev)
-    dgr._capacity_hint.clear(); dgr._caps_in_use.clear(); dgr._tile_cap_hint.clear()
+    dgr._capacity_hint.clear(); dgr._caps_in_use.clear(); dgr._tile_cap_hint.clear(); dgr._no_deferred.clear(); dgr._no_defer_cooldown.clear()
     c, r, d = dgr.GaussianRasterizer(raster_settings=st)(**leaves)             # first call of the shape: grows and re-runs
     info = dgr.last_forward_info()
     assert info["instances"] > 8 * n + 65536 or info["instances"] > 4 * n + 4096
@@ -420,11 +420,29 @@ def test_scalar_and_matrix_core_kernels_agree(gpu_device, monkeypatch):
     c0, r0, d0, g0 = run_hip(scene, cam, gpu_device, grad_color)
     assert torch.equal(r0, r1)
     _check_images(c0.double(), d0.double(), c1, d1)
-    _check_grads({k: v.double() for k, v in g0.items()}, g1)
+    # The two implementations form their exponents differently, so a pair on the alpha >= 1/255 threshold -- or a pixel on the
+    # T < 1e-4 stop -- may fall on different sides (round 6: a codegen change of the projection moved the geometry by one ulp and
+    # ONE pixel of this scene did: depth off by 7e-5, the gradients of the Gaussians behind it by 1e-5 of the largest, p99.9
+    # 3e-4 -> 1.3e-3; tools/xcheck_stat.py prints it).  As in the oracle comparisons, the Gaussians of the 8x8 tiles that hold
+    # such a pixel are held to 2e-2 instead; at most a handful of pixels may do that.
+    import diff_gaussian_rasterization as dgr
+    from parity_util import to_settings
+    bad = ((c0 - c1).abs().amax(0) > IMG_TOL * c0.abs().max()) | ((d0 - d1).abs().reshape(c0.shape[1:]) > IMG_TOL * d0.abs().max())
+    assert int(bad.sum()) <= 4, int(bad.sum())
+    rast = dgr.GaussianRasterizer(raster_settings=to_settings(cam, gpu_device))
+    with torch.no_grad():
+        rast(**{k: v.to(gpu_device) for k, v in scene.items()})
+    offs, gid, _ = dgr.debug_tile_lists(rast)
+    offs, gid = offs.cpu(), gid.cpu().long()
+    taint = torch.zeros(scene["means3D"].shape[0], dtype=torch.bool)
+    for y, x in torch.nonzero(bad.cpu()).tolist():
+        t = (y // 8) * ((cam.image_width + 7) // 8) + x // 8
+        taint[gid[offs[t]:offs[t + 1]]] = True
+    _check_grads({k: v.double() for k, v in g0.items()}, g1, taint)
     # mixed: matrix-core forward state feeding the scalar backward (the saved per-pixel state is interchangeable)
     _opt("VTGS_FWD_IMPL", "1"); _opt("VTGS_BWD_IMPL", "0")
     _, _, _, gm = run_hip(scene, cam, gpu_device, grad_color)
-    _check_grads({k: v.double() for k, v in g0.items()}, gm)
+    _check_grads({k: v.double() for k, v in g0.items()}, gm, taint)
 
 
 def test_mfma_register_layout_assumptions(gpu_device, tmp_path):
@@ -644,7 +662,7 @@ def test_forward_runs_ahead_of_its_record_and_settles_after_the_backward(gpu_dev
     st = to_settings(cam, dev)
     g = torch.Generator().manual_seed(3)
     grad_color = (torch.rand(3, 96, 160, generator=g) * 2 - 1).to(dev)
-    dgr._capacity_hint.clear(); dgr._caps_in_use.clear(); dgr._tile_cap_hint.clear(); dgr._async_ok.clear(); dgr._need_hist.clear()
+    dgr._capacity_hint.clear(); dgr._caps_in_use.clear(); dgr._tile_cap_hint.clear(); dgr._no_deferred.clear(); dgr._no_defer_cooldown.clear(); dgr._async_ok.clear(); dgr._need_hist.clear()
 
     def step(sc, mode):
         dgr._FORWARD_MODE = mode
@@ -707,7 +725,7 @@ def test_run_ahead_forward_follows_a_growing_scene(gpu_device):
     st = to_settings(cam, dev)
     g = torch.Generator().manual_seed(3)
     grad_color = (torch.rand(3, 96, 160, generator=g) * 2 - 1).to(dev)
-    dgr._capacity_hint.clear(); dgr._caps_in_use.clear(); dgr._tile_cap_hint.clear(); dgr._async_ok.clear(); dgr._need_hist.clear()
+    dgr._capacity_hint.clear(); dgr._caps_in_use.clear(); dgr._tile_cap_hint.clear(); dgr._no_deferred.clear(); dgr._no_defer_cooldown.clear(); dgr._async_ok.clear(); dgr._need_hist.clear()
     leaves = {k: v.to(dev).requires_grad_(True) for k, v in scene.items()}
     ran_ahead = 0
     try:

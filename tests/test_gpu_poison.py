@@ -32,7 +32,8 @@ def _short_list_scene(seed=5, W=200, H=136):
 
 
 def _clear_policy(dgr):
-    for d in (dgr._capacity_hint, dgr._caps_in_use, dgr._tile_cap_hint, dgr._async_ok, dgr._need_hist, dgr._slots_hint):
+    for d in (dgr._capacity_hint, dgr._caps_in_use, dgr._tile_cap_hint, dgr._async_ok, dgr._need_hist, dgr._slots_hint,
+              dgr._no_deferred, dgr._no_defer_cooldown):
         d.clear()
 
 

@@ -165,6 +165,7 @@ static CamScalars scalars_of(const VtgsCamera* cam, int row8_begin, int row8_end
   cs.bwd_flags = 0u;
   cs.scratch_records = 0xFFFFFFFFu;
   cs.raw_act = 0u;
+  cs.no_defer = 0u;
 #ifdef VTGS_Q_STAMPS
   cs.dbg_proj = nullptr;
 #endif
@@ -354,6 +355,7 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
     if (dual) VTGS_HIP(hipMemsetAsync(out_color_b, 0, 3 * P * sizeof(float), st));
     else VTGS_HIP(hipMemsetAsync(out_depth, 0, P * sizeof(float), st));
   }
+  bool no_defer = false;                                        // VTGS_FORWARD_EXPECT_NO_DEFERRED honoured: no second binning launch
   if (n > 0) {
     // LDS-binned form while the per-tile table (4 B per 8x8 tile of this call's band) leaves room for two workgroups
     // per CU: 79 KB = 20 K tiles (1200x680: 12.7 K; 1296x968: 19.6 K; a band of 1752x1168 on >= 2 GPUs).  Beyond that
@@ -383,6 +385,7 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
     {
       ProfScope ps__("project_and_bin", st);
       const int mode = ((r8b > 0 || r8e < (cam->image_height + kSubTile - 1) / kSubTile) ? 1 : 0) | (L.planned ? 2 : 0) | (cov3d ? 4 : 0);
+      if (mode == 0 && (flags & VTGS_FORWARD_EXPECT_NO_DEFERRED)) { cs.no_defer = 1u; no_defer = true; }   // (the hint: whole frame, uniform bins)
 #define VTGS_LAUNCH_PROJECT(LDS, MODE, SHMEM)                                                                          \
       hipLaunchKernelGGL((VTGS_PROJECT_KERNEL(LDS, MODE)), dim3((n + 1023) / 1024), dim3(1024), SHMEM, st, cs,             \
                          cam->viewmatrix, cam->projmatrix, n, means3D, opacities, scales, rotations, out_radii,         \
@@ -426,7 +429,7 @@ static int forward_impl(const VtgsCamera* cam, int32_t n, const float* means3D, 
 #undef VTGS_LAUNCH_PROJECT
     }
     VTGS_HIP(hipGetLastError());
-    {
+    if (!no_defer) {
       // the splats project_and_bin left aside (more than kDeferArea candidate tiles): binned here.  The lists' lengths are on the
       // device, so the grid is what lists of N / 8 small and N / 256 large entries need (longer lists: more rounds per
       // workgroup); with empty lists every workgroup leaves after one load.  The large list's workgroups come first.

@@ -177,6 +177,26 @@ constexpr int kBigArea = kDeferArea;          // (the name the body of project_a
 // budget: either feature alone cost that case 13 us of 54 through s_load re-materialisation, batch P of round 3):
 //   bit 0  a band of the tile-row partition (row cull before the projection, early exit of workgroups with nothing in the band)
 //   bit 1  planned bins (bin t = [plan[t], plan[t+1]), include/vtgs.h)
+// CamScalars::no_defer (VTGS_FORWARD_EXPECT_NO_DEFERRED): nothing is deferred -- a lane walks up to 64 candidates itself and a larger splat is
+// walked by its wavefront at the end of the kernel, every lane a tile, with an instance-range atomic of its own (the kernel of
+// rounds 2-5).  Correct for every map, fast for the maps the hint is given for (none of these splats), and no second launch.
+struct BigWalk {            // wave-uniform copy of one lane's walk and reach test
+  TileWalk w; Splat sp; ReachForm rf; float tau; int area;
+};
+__device__ __forceinline__ BigWalk broadcast_walk(const TileWalk& w, const Splat& sp, const ReachForm& rf, float tau, int area,
+                                                  int src) {
+  BigWalk b;
+  auto bi = [&](int v) { return __builtin_amdgcn_readlane(v, src); };
+  auto bf = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+  b.w.cx0 = bi(w.cx0); b.w.cy0 = bi(w.cy0); b.w.cw = bi(w.cw); b.w.ch = bi(w.ch);
+  b.sp = Splat{};
+  b.sp.u = bf(sp.u); b.sp.v = bf(sp.v); b.sp.A = bf(sp.A); b.sp.B = bf(sp.B); b.sp.C = bf(sp.C);
+  b.rf.hA = bf(rf.hA); b.rf.B = bf(rf.B); b.rf.hC = bf(rf.hC); b.rf.kx = bf(rf.kx); b.rf.ky = bf(rf.ky);
+  b.rf.regular = bi(rf.regular ? 1 : 0) != 0;
+  b.tau = bf(tau); b.area = bi(area);
+  return b;
+}
+
 // The per-Gaussian inputs of the projection besides the mean.  raw (CamScalars::raw_act, kernel-uniform): the fused caller chain's
 // isotropic map as its PARAMETERS -- logit, log-scale -- with the activations of utils/slam_helpers.py:127-160 applied here
 // (sigmoid, exp on all three axes) and the rotation left at the identity: the covariance s^2 I does not depend on it.
@@ -227,6 +247,9 @@ __device__ __forceinline__ void project_and_bin_body(
   constexpr bool banded = (MODE & 1) != 0;                      // a rank of the tile-row partition
   constexpr bool planned = (MODE & 2) != 0;
   constexpr bool precomp = (MODE & 4) != 0;                     // `scales` holds cov3D_precomp [N,6], `rotations` is not read
+  // (a RUN-TIME fact, not a template parameter: two instantiations contract the projection's multiply-adds differently, and the
+  //  first forward of a shape -- no hint yet -- and the later ones would differ in the last bit of their images)
+  const bool defer = cs.no_defer == 0u;                         // kernel-uniform; no_defer: no deferred list (see BigWalk)
   if constexpr (precomp) {
     if (valid) {                                                // (no row cull ahead of the projection: it is built on the scales)
       const float mean[3] = {means3D[3 * gid], means3D[3 * gid + 1], means3D[3 * gid + 2]};
@@ -307,7 +330,7 @@ __device__ __forceinline__ void project_and_bin_body(
   }
   VTGS_P_STAMP(1)                                                // inputs arrived, projection + walk set up
   const int area_all = w.cw * w.ch;
-  const bool big = area_all > kBigArea;                        // deferred: listed for bin_deferred_splats, not walked here
+  const bool big = area_all > (defer ? kBigArea : 64);         // deferred: listed for bin_deferred_splats, not walked here (no-defer form: by the wavefront, below)
   const int area = big ? 0 : area_all;
 
   // the per-tile table is cleared only now: the input loads above are in flight while it happens, and the workgroups of a
@@ -335,13 +358,14 @@ __device__ __forceinline__ void project_and_bin_body(
   __shared__ uint32_t s_wave_lrg[kWaves], s_lrg_base;              // ... those beyond kGroupArea candidates: the list's other end
   const int wv = (int)(threadIdx.x >> 6);
   // a deferred splat takes its instance ids here too: one per candidate tile, an upper bound (DeferRec::inst_base)
-  const uint32_t cnt_ids = big ? (uint32_t)area_all : cnt;
+  const uint32_t cnt_ids = (defer && big) ? (uint32_t)area_all : cnt;   // (no-defer form: a big splat takes its ids itself, cnt = 0 here)
   const uint32_t incl = wave_incl_scan(cnt_ids);
   const uint32_t r16 = vis ? (uint32_t)((sp.x1 - sp.x0) * (sp.y1 - sp.y0)) : 0u;
   const uint32_t r16_incl = wave_incl_scan(r16);
   const unsigned long long vb = __ballot(vis);
-  const bool large = area_all > kGroupArea;                        // (implies big)
-  const unsigned long long def_b = __ballot(big && !large), lrg_b = __ballot(large);
+  const bool large = defer && area_all > kGroupArea;               // (implies big)
+  // (no-defer form: def_b counts the splats the deferring form WOULD list -- see the phantom id below)
+  const unsigned long long def_b = __ballot(defer ? (big && !large) : (area_all > kBigArea)), lrg_b = __ballot(large);
   if (l == 63) {
     s_wave_cnt[wv] = incl; s_wave_vis[wv] = (uint32_t)__popcll(vb); s_wave_r16[wv] = r16_incl;
     s_wave_def[wv] = (uint32_t)__popcll(def_b); s_wave_lrg[wv] = (uint32_t)__popcll(lrg_b);
@@ -353,6 +377,12 @@ __device__ __forceinline__ void project_and_bin_body(
     //  the second workgroup per CU gone -- with three arrays, until round 5, the same loop just fitted under 64)
 #pragma unroll 4
     for (int k = 0; k < kWaves; ++k) { tot += s_wave_cnt[k]; v += s_wave_vis[k]; r += s_wave_r16[k]; nd += s_wave_def[k]; nl += s_wave_lrg[k]; }
+    if (!defer) {
+      // The caller expected no splat beyond kDeferArea candidates and this workgroup holds one: ONE id that nobody uses, so that
+      // the record's instances_needed exceeds its instances -- the only sign the host needs to drop the hint (the ids handed
+      // out are an upper bound in the deferring form too)
+      tot += nd ? 1u : 0u; nd = 0u;
+    }
     // the instance range and the stretch of the deferred list with ONE atomic (Counters: the 64-bit pair)
     const unsigned long long old = (tot | nd) ? atomicAdd(reinterpret_cast<unsigned long long*>(ctr), ((unsigned long long)tot << 32) | (unsigned long long)nd) : 0ull;
     // (the large ones are rare -- none in a fresh view-tied map: their counter is touched only by the workgroups that hold one;
@@ -376,7 +406,7 @@ __device__ __forceinline__ void project_and_bin_body(
   for (int k = 0; k < wv; ++k) wave_base += s_wave_cnt[k];
   const uint32_t inst_base = wave_base + incl - cnt_ids;
 
-  if (big) {
+  if (defer && big) {
     // listed for bin_deferred_splats, with everything it needs (DeferRec).  HERE, between the passes: the splat is still in registers.
     // (up to kGroupArea candidates: from the front of the list; larger: from its end, position n - 1 - index)
     uint32_t pos = (large ? s_lrg_base : s_def_base) + (uint32_t)__popcll((large ? lrg_b : def_b) & ((1ull << l) - 1ull));
@@ -535,6 +565,46 @@ __device__ __forceinline__ void project_and_bin_body(
     o[5] = (uint32_t)prt0; o[6] = (uint32_t)__builtin_amdgcn_s_memrealtime(); o[7] = (uint32_t)area_all;
   }
 #endif
+  if (!defer) {
+    // ---- the big splats of this wavefront, one after the other, every lane a tile -------------------------------------------
+    for (unsigned long long rest = __ballot(big); rest; rest &= rest - 1ull) {      // wave-uniform
+      const int src = __builtin_ctzll(rest);
+      const BigWalk b = broadcast_walk(w, sp, rf, tau, area_all, src);
+      uint32_t total = 0;
+      for (int i0 = 0; i0 < b.area; i0 += 64) {
+        const int i = i0 + l;
+        const int ty = i / b.w.cw, tx = i - ty * b.w.cw;
+        const bool hit = i < b.area && tile_reached(cam, b.sp, b.rf, b.tau, b.w.cx0 + tx, b.w.cy0 + ty);
+        total += (uint32_t)__builtin_popcountll(__ballot(hit));
+      }
+      unsigned long long got = 0ull;                               // (the 64-bit pair of Counters: the instance total is its high word)
+      if (l == src && total) got = atomicAdd(reinterpret_cast<unsigned long long*>(ctr), (unsigned long long)total << 32);
+      const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(got >> 32), src);
+      const unsigned long long key_src = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), src) << 32) |
+                                         (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, src);
+      uint32_t done = 0;
+      for (int i0 = 0; i0 < b.area; i0 += 64) {
+        const int i = i0 + l;
+        const int ty = i / b.w.cw, tx = i - ty * b.w.cw;
+        const bool hit = i < b.area && tile_reached(cam, b.sp, b.rf, b.tau, b.w.cx0 + tx, b.w.cy0 + ty);
+        const unsigned long long hb = __ballot(hit);
+        if (hit) {
+          const int tile = (b.w.cy0 + ty) * cam.gx8 + b.w.cx0 + tx;
+          const uint32_t slot = atomicAdd(&tile_cnt[tile], 1u);
+          const uint32_t rank = (uint32_t)__builtin_popcountll(hb & ((1ull << l) - 1ull));
+          const unsigned long long id = (unsigned long long)base + done + rank;            // raster order of the walk
+          const BinRange br = planned ? bin_range(cs, (uint32_t)tile, tile_cap) : BinRange{(uint32_t)tile * tile_cap, tile_cap};
+          if (id < capacity && slot < br.cap) {
+            const size_t pos = (size_t)br.s + slot;
+            keys[pos] = key_src;
+            vals[pos] = (uint32_t)id;
+          }
+        }
+        done += (uint32_t)__builtin_popcountll(hb);
+      }
+      if (l == src) gaux[gid] = GaussAux{base, total};
+    }
+  }
 }
 
 

@@ -146,6 +146,8 @@ struct CamScalars {
                                   // sized from a wrong or stale count gives wrong numbers, not an out-of-bounds access
   uint32_t raw_act;               // round 6 (VTGS_FORWARD_RAW_ACTIVATIONS / frame flag 16): `opacities` are logits, `scales` log-scales [N]
                                   // (isotropic), `rotations` is not read -- project_and_bin and gather_splat_grads apply the activations
+  uint32_t no_defer;              // project_and_bin: VTGS_FORWARD_EXPECT_NO_DEFERRED honoured (whole frame, uniform bins): nothing is listed for
+                                  // bin_deferred_splats, which is then not launched
 #ifdef VTGS_Q_STAMPS
   uint32_t* dbg_proj;             // diagnostic build: 8 words of stamps per workgroup of project_and_bin
 #endif

@@ -55,6 +55,7 @@ VTGS_OK, VTGS_ERR_INSTANCE_OVERFLOW = 0, 3
 ABI_VERSION = 16
 VTGS_FORWARD_SYNC, VTGS_FORWARD_ASYNC, VTGS_FORWARD_CHECKED = 0, 1, 2
 VTGS_FORWARD_EXPECT_SHORT_LISTS = 4        # hint: no list beyond 512 entries expected (skips the pre-sort pass for bins <= 1024)
+VTGS_FORWARD_EXPECT_NO_DEFERRED = 64       # hint: no splat beyond nine candidate tiles expected (no second binning launch; include/vtgs.h)
 VTGS_FORWARD_SECOND_IS_DEPTH = 8           # dual render consumed as get_loss consumes it (include/vtgs.h): the single render's kernel
 _P, _U64, _I32, _SZ = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
 
@@ -701,11 +702,27 @@ def _looks_steady(key) -> bool:
     return max(a) <= 1.1 * max(1, min(a)) and max(b) <= 1.1 * max(1, min(b))
 
 
+# Round 6: a splat of more than nine candidate tiles is binned by a second kernel -- an EMPTY launch on a fresh view-tied map, and
+# every command costs the queue ~5 us (1.3 % of the headline step, 6 % of a 10 k-Gaussian one).  When the last forward of a shape
+# handed out exactly as many instance ids as it binned instances (no splat reserved ids by candidate count: none was deferred),
+# the next one is launched with VTGS_FORWARD_EXPECT_NO_DEFERRED: the projection bins everything itself and the second kernel is
+# not launched.  The hint is never wrong, only slow: a workgroup that meets such a splat under the hint takes one unused id, so
+# the record shows instances_needed > instances and the hint is dropped -- for _NO_DEFER_COOLDOWN forwards, so that a map whose
+# few large splats happen to reach all their candidates does not flip between the two kernels every forward.
+_no_deferred = {}            # key -> the next forward of this shape may carry the hint
+_no_defer_cooldown = {}      # key -> forwards left before the hint may come back
+_NO_DEFER_COOLDOWN = 16
+_NO_DEFER_HINT = os.environ.get("VTGS_NO_DEFER_HINT", "1") != "0"
+
+
 def _forward_hints(key, tile_cap: int) -> int:
     """Flag bits OR-ed to the mode of the next forward of `key`."""
+    flags = 0
     if not (tile_cap & PLANNED) and tile_cap <= _RUN_AHEAD_MAX_BIN and 0 < _tile_cap_hint.get(key, 0) <= _SHORT_LIST_HINT:
-        return VTGS_FORWARD_EXPECT_SHORT_LISTS
-    return 0
+        flags |= VTGS_FORWARD_EXPECT_SHORT_LISTS
+    if _NO_DEFER_HINT and _no_deferred.get(key):
+        flags |= VTGS_FORWARD_EXPECT_NO_DEFERRED
+    return flags
 
 
 def _grow_after_overflow(key, n, device, info, capacity, tile_cap, workspace):
@@ -737,7 +754,7 @@ def _evict_policy_keys() -> None:
     first (dicts keep insertion order); _caps_in_use / _async_ok entries of an evicted shape go with it."""
     while len(_capacity_hint) > _POLICY_KEYS_MAX:
         old = next(iter(_capacity_hint))
-        for d in (_capacity_hint, _tile_cap_hint, _slots_hint, _caps_in_use, _async_ok, _need_hist):
+        for d in (_capacity_hint, _tile_cap_hint, _slots_hint, _caps_in_use, _async_ok, _need_hist, _no_deferred, _no_defer_cooldown):
             d.pop(old, None)
         for pk in [pk for pk in _bin_plans if pk[0] == old]:
             del _bin_plans[pk]
@@ -751,6 +768,16 @@ def _record_info(key, n, W, H, capacity, info):
     _capacity_hint[key] = need_i or 1
     _tile_cap_hint[key] = need_t or 1
     _slots_hint[key] = need_s or 1
+    binned = int(info.instances)
+    if binned > 0 and binned == need_i:            # every id was used: nothing was deferred (see _no_deferred)
+        cd = _no_defer_cooldown.get(key, 0)
+        if cd > 0:
+            _no_defer_cooldown[key] = cd - 1
+        _no_deferred[key] = cd <= 0
+    else:
+        if _no_deferred.get(key):                  # the hint was on and the map has grown a large splat
+            _no_defer_cooldown[key] = _NO_DEFER_COOLDOWN
+        _no_deferred[key] = False
     _last_shape[(key[0], key[2], key[3], key[4])] = (n, need_i, need_t, need_s)
     cap, tcap = _caps_in_use.get(key, (0, 0))                  # the capacities this forward ran with
     # Run-ahead is for STEADY loops (tracking, mapping on one frame): the last three forwards of this shape must have needed
